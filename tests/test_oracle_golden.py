@@ -1,0 +1,168 @@
+"""Pin the CPU oracle (oracle/) against the fixtures generated from the imported reference
+(tools/gen_golden.py).  CPU only.  Tolerances: 1e-12 relative (the reference's BLAS-internal
+summation order is not reproducible bit for bit; see oracle/brov2_oracle.c header)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from oracle import controls, edmdc_numpy as ek, fossen_c as fc
+
+TOL = 1e-12
+
+
+def test_constants_and_discretisation():
+    g = load_golden("fossen_constants.npz")
+    c = fc.constants()
+    assert rel_err(c["Minv"], np.diag(g["Minv"])) < 1e-15
+    assert rel_err(c["alloc"], g["alloc"]) < 1e-15
+    assert rel_err(c["thr_r"], g["thr_r"]) < 1e-15
+    assert rel_err(c["thr_dir"], g["thr_dir"]) < 1e-15
+    for dt in g["dts"]:
+        Ad, Bd = fc.discretise_lag(float(dt))
+        assert rel_err(Ad, g[f"Ad_{dt}"]) < 1e-14
+        assert rel_err(Bd, g[f"Bd_{dt}"]) < 1e-14
+
+
+@pytest.mark.parametrize("tag", ["thr", "thr_cur"])
+def test_thruster_rhs_three_stateful_calls(tag):
+    g = load_golden("fossen_rhs_kat.npz")
+    X, U, dt, cur = g[f"{tag}_X"], g[f"{tag}_U"], float(g[f"{tag}_dt"]), g[f"{tag}_cur"]
+    lag = None
+    for c in range(3):
+        xd, lag = fc.rhs(fc.MODEL_THRUSTER_EULER, X, U, dt, lag=lag, current=cur)
+        ref = g[f"{tag}_XDOT"][c]
+        fin = np.isfinite(ref)
+        # rows 0,1 are the theta = +-pi/2 clamp cases: tan ~ 1e7 amplifies the last ulp of cos
+        assert np.array_equal(np.isfinite(xd), fin)
+        assert rel_err(xd[2:], ref[2:]) < TOL
+        assert np.max(np.abs(xd[:2] - ref[:2]) / np.maximum(1.0, np.abs(ref[:2]))) < 1e-9
+        assert rel_err(lag, g[f"{tag}_LAG"][c]) < TOL
+    tau, _ = fc.thruster_forces(U, dt)
+    assert rel_err(tau, g[f"{tag}_TAU1"]) < TOL
+
+
+@pytest.mark.parametrize("tag,model", [("we", fc.MODEL_WRENCH_EULER), ("we_cur", fc.MODEL_WRENCH_EULER),
+                                       ("wq", fc.MODEL_WRENCH_QUAT), ("wq_cur", fc.MODEL_WRENCH_QUAT)])
+def test_wrench_rhs(tag, model):
+    g = load_golden("fossen_rhs_kat.npz")
+    xd, _ = fc.rhs(model, g[f"{tag}_X"], g[f"{tag}_U"], 0.02, current=g[f"{tag}_cur"])
+    ref = g[f"{tag}_XDOT"]
+    lo = 2 if model == fc.MODEL_WRENCH_EULER else 0
+    assert rel_err(xd[lo:], ref[lo:]) < TOL
+    assert np.max(np.abs(xd[:lo] - ref[:lo]) / np.maximum(1.0, np.abs(ref[:lo])), initial=0.0) < 1e-9
+
+
+def test_survey_kats():
+    """Compact KATs quoted in SURVEY.md section 8(a)."""
+    x = np.array([0.3, -0.2, 1.0, 0.1, -0.2, 0.7, 0.4, -0.3, 0.2, 0.05, -0.1, 0.2])
+    tau = np.array([10, -5, 3, 0.5, -0.4, 0.8])
+    xd, _ = fc.rhs(fc.MODEL_WRENCH_EULER, x, tau)
+    ref = [0.47931379506139227, -0.01266340763915013, 0.24514877925621098, 0.01168425760838594,
+           -0.11946709985716822, 0.19286188883949557, -0.9284243059999626, 0.6478701364644579,
+           -0.33335869293622805, 2.375088715763591, 2.556589038374261, 1.403344594594595]
+    assert rel_err(xd[0], ref) < 1e-14
+    u = np.array([0.1, -0.2, 0.3, -0.4, 0.5, -0.6, 0.7, -0.8])
+    xd1, lag = fc.rhs(fc.MODEL_THRUSTER_EULER, x, u, 0.02)
+    xd2, _ = fc.rhs(fc.MODEL_THRUSTER_EULER, x, u, 0.02, lag=lag)
+    assert rel_err(xd1[0, 6:], [-1.3696415288010468, 0.41406407349169017, -0.27971576990592095,
+                                -24.803789487103767, 3.42884851717307, 2.8145185134400537]) < 1e-13
+    assert rel_err(xd2[0, 6:], [-1.3336320564242452, 0.13880134287327764, -0.19483573957649727,
+                                -39.867757441222288, 3.2996050336711238, 4.4110704113983985]) < 1e-13
+
+
+def test_cfg2_rollouts_rk4_and_euler():
+    g = load_golden("fossen_rollouts.npz")
+    T, dt, sub, seed = int(g["cfg2_T"]), float(g["cfg2_dt"]), int(g["cfg2_sub"]), int(g["cfg2_seed"])
+    U = controls.controls_iid(seed, 0, 8, T)
+    assert np.array_equal(U[:, :4, :], g["cfg2_U_head"])
+    x0 = np.tile(g["cfg2_x0"], (8, 1))
+    r = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_RK4, x0, U, dt, sub=sub, nthreads=8)
+    assert rel_err(r["traj"], g["cfg2_rk4"]) < 1e-10
+    assert rel_err(r["lag"], g["cfg2_rk4_lag_end"]) < 1e-10
+    e = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_EULER, x0, U, dt, sub=sub, nthreads=8)
+    assert rel_err(e["traj"], g["cfg2_euler"]) < 1e-10
+    assert rel_err(e["lag"], g["cfg2_euler_lag_end"]) < 1e-10
+    assert rel_err(e["xT"], g["cfg2_euler"][:, -1]) < 1e-10
+
+
+def test_ar1_wrench_quat_and_cfg1_rollouts():
+    g = load_golden("fossen_rollouts.npz")
+    dt, sub = float(g["ar1_dt"]), int(g["ar1_sub"])
+    for integ, key in ((fc.INTEG_RK4, "ar1_rk4"), (fc.INTEG_EULER, "ar1_euler")):
+        r = fc.rollout(fc.MODEL_THRUSTER_EULER, integ, g["ar1_X0"], g["ar1_U"], dt, sub=sub)
+        assert rel_err(r["traj"], g[key]) < 1e-10
+    dt, sub = float(g["w_dt"]), int(g["w_sub"])
+    for model, integ, x0k, key in ((fc.MODEL_WRENCH_EULER, fc.INTEG_EULER, "we_X0", "we_euler"),
+                                   (fc.MODEL_WRENCH_EULER, fc.INTEG_RK4, "we_X0", "we_rk4"),
+                                   (fc.MODEL_WRENCH_QUAT, fc.INTEG_EULER, "wq_X0", "wq_euler"),
+                                   (fc.MODEL_WRENCH_QUAT, fc.INTEG_RK4, "wq_X0", "wq_rk4_ext")):
+        r = fc.rollout(model, integ, g[x0k], g["w_TAU"], dt, sub=sub)
+        assert rel_err(r["traj"], g[key]) < 1e-10, key
+    x0 = np.zeros((1, 12))
+    x0[0, 2] = 5.0
+    U = np.tile(g["cfg1_u"], (1, 1000, 1))
+    r = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_EULER, x0, U, 0.02, sub=10)
+    assert rel_err(r["traj"][0], g["cfg1_euler"]) < 1e-11
+
+
+def test_window_rmse_carried_lag():
+    g = load_golden("windows.npz")
+    X, U, TAU, Xq, dt = g["X"], g["U"], g["TAU"], g["Xq"], float(g["dt"])
+    for i, H in enumerate(g["H"]):
+        H = int(H)
+        assert abs(fc.window_rmse(fc.MODEL_THRUSTER_EULER, fc.INTEG_EULER, X, U, H, dt) - g["thr_euler_rmse"][i]) < 1e-12
+        assert abs(fc.window_rmse(fc.MODEL_THRUSTER_EULER, fc.INTEG_RK4, X, U, H, dt) - g["thr_rk4_rmse"][i]) < 1e-12
+        assert abs(fc.window_rmse(fc.MODEL_WRENCH_EULER, fc.INTEG_EULER, X, TAU, H, dt) - g["we_euler_rmse"][i]) < 1e-12
+        assert abs(fc.window_rmse(fc.MODEL_WRENCH_QUAT, fc.INTEG_EULER, Xq, TAU, H, dt) - g["wq_euler_rmse"][i]) < 1e-12
+    # quirk Q2 is real: a fresh lag per window gives a different number
+    fresh = fc.window_rmse(fc.MODEL_THRUSTER_EULER, fc.INTEG_EULER, X, U, 10, dt, carry_lag=False)
+    assert abs(fresh - g["thr_euler_rmse"][1]) > 1e-6
+
+
+def test_edmdc_lift_gram_fit_scores():
+    g = load_golden("edmdc.npz")
+    X, U, C = g["X"], g["U"], g["centers"]
+    nt, gamma, ridge = int(g["n_train"]), float(g["gamma"]), float(g["ridge"])
+    assert rel_err(ek.lift(X[:64], C, gamma), g["lift64"]) < 1e-13
+    assert rel_err(ek.lift(X[7], C, gamma), g["lift1"]) < 1e-13
+    assert rel_err(ek.rbf_mat(np.array([[0.3, -0.2, 1.0, 0.1, -0.2, 0.7, 0.4, -0.3, 0.2, 0.05, -0.1, 0.2]]),
+                              np.array([[0.0] * 12, [0.1] * 12]), 3.0), g["rbf_kat"]) < 1e-15
+    GtG, GtY, n = ek.gram([X[:nt]], [U[:nt]], C, gamma)
+    assert n == nt - 1
+    assert np.linalg.norm(GtG - g["GtG"]) / np.linalg.norm(g["GtG"]) < 1e-13
+    assert np.linalg.norm(GtY - g["GtY"]) / np.linalg.norm(g["GtY"]) < 1e-13
+    A, B = ek.solve_AB(GtG, GtY, ridge, 12 + C.shape[0])
+    # fit() evaluates (pinv @ G.T) @ Y, fit_multi/our form pinv @ (G.T @ Y): equal to conditioning
+    assert rel_err(A, g["A"]) < 1e-7 and rel_err(B, g["B"]) < 1e-7
+    Xt, Ut = X[nt:], U[nt:]
+    assert abs(ek.evaluate(Xt, Ut, C, gamma, A, B) - g["eval_rmse"]) < 1e-9
+    for i, H in enumerate((1, 10, 100)):
+        assert abs(ek.multistep_rmse(Xt, Ut, C, gamma, A, B, H) - g["ms_rmse"][i]) < 1e-8
+        # with the reference's own A,B the restated propagation is exact to rounding
+        assert abs(ek.multistep_rmse(Xt, Ut, C, gamma, g["A"], g["B"], H) - g["ms_rmse"][i]) < 1e-12
+    assert rel_err(ek.simulate(Xt[0], Ut[:50], C, gamma, g["A"], g["B"]), g["sim50"]) < 1e-12
+
+
+def test_edmdc_fit_multi_and_gamma3():
+    g = load_golden("edmdc.npz")
+    X, U = g["X"], g["U"]
+    cuts = g["multi_cuts"]
+    A, B = ek.fit([X[a:b] for a, b in cuts], [U[a:b] for a, b in cuts], g["multi_centers"], float(g["gamma"]), float(g["ridge"]))
+    assert rel_err(A, g["multi_A"]) < 1e-9 and rel_err(B, g["multi_B"]) < 1e-9
+    Xt, Ut = X[int(g["n_train"]):], U[int(g["n_train"]):]
+    for i, H in enumerate((1, 10, 100)):
+        assert abs(ek.multistep_rmse(Xt, Ut, g["multi_centers"], float(g["gamma"]), A, B, H) - g["multi_ms_rmse"][i]) < 1e-9
+    nt = int(g["n_train"])
+    A3, B3 = ek.fit([X[:nt]], [U[:nt]], g["g3_centers"], 3.0, 1e-1)
+    assert rel_err(A3, g["g3_A"]) < 1e-8
+    for i, H in enumerate((1, 10, 100)):
+        assert abs(ek.multistep_rmse(Xt, Ut, g["g3_centers"], 3.0, A3, B3, H) - g["g3_ms_rmse"][i]) < 1e-9
+
+
+def test_controls_stream_properties():
+    u = controls.controls_iid(0x5EED, 3, 2, 5000, t0=100, nt=7)
+    full = controls.controls_iid(0x5EED, 0, 5, 5000)
+    assert np.array_equal(u, full[3:5, 100:107])
+    assert full.min() >= -1.0 and full.max() < 1.0 and abs(full.mean()) < 5e-3
+    a = controls.controls_ar1(1, 0, 2, 300)
+    assert np.all(np.abs(a) <= 1.0) and np.abs(np.diff(a, axis=1)).max() < 0.15

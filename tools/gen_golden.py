@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference.
+
+Runs only in the build container (needs /root/reference).  Nothing from the
+reference is copied: the fixtures hold inputs and the reference's outputs only.
+
+    PYTHONDONTWRITEBYTECODE=1 MPLBACKEND=Agg python tools/gen_golden.py [--only NAME]
+
+Fixtures (all float64):
+  fossen_constants.npz  Minv, allocation matrix, thruster geometry, ZOH (Ad,Bd) at 3 dt
+  fossen_rhs_kat.npz    single/two-call RHS vectors for the 3 model variants (+edge cases)
+  fossen_rollouts.npz   config-2 stream, first 8 trajectories, 5000 RK4 / Euler steps
+                        (every 50th state) + wrench / quaternion rollouts
+  windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
+  edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
+"""
+import argparse
+import os
+import sys
+import time
+import warnings
+
+os.environ.setdefault("MPLBACKEND", "Agg")
+sys.dont_write_bytecode = True
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("BROV2_REFERENCE", "/root/reference")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+sys.path.insert(0, os.path.join(REF, "training"))
+warnings.filterwarnings("ignore")
+
+import numpy as np  # noqa: E402
+
+from oracle.controls import controls_ar1, controls_iid  # noqa: E402
+
+from fossen.BlueROV2 import BlueROV2 as RefThruster, ThrusterLag  # noqa: E402
+from fossen.BlueROV2_thrust import BlueROV2 as RefWrenchEuler  # noqa: E402
+from fossen.BlueROV2_wrench import BlueROV2 as RefWrenchQuat  # noqa: E402
+import fossen.BlueROV2_wrench as refquat  # noqa: E402
+from Koopman.koopmanEDMDc import KoopmanEDMDc as RefKoopman  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+SEED_CFG2 = 0x5EED
+T_CFG2 = 5000
+
+
+def versions():
+    import scipy
+    import sklearn
+    return np.array([f"numpy={np.__version__}", f"scipy={scipy.__version__}",
+                     f"sklearn={sklearn.__version__}", f"python={sys.version.split()[0]}"])
+
+
+# --------------------------------------------------------------------------- constants
+def gen_constants():
+    rov = RefThruster()
+    T = np.zeros((6, 8))
+    rr = np.zeros((8, 3))
+    dd = np.zeros((8, 3))
+    for i, th in enumerate(rov.thrusters_r):
+        rr[i], dd[i] = th["r"], th["dir"]
+        T[:3, i] = th["dir"]
+        T[3:, i] = np.cross(th["r"], th["dir"])
+    out = dict(Minv=rov.Minv, M=rov.M, W=rov.W, B=rov.B, alloc=T, thr_r=rr, thr_dir=dd,
+               Ac=ThrusterLag._Ac, Bc=ThrusterLag._Bc, Cc=ThrusterLag._Cc)
+    for dt in (0.01, 0.02, 0.05):
+        Ad, Bd = ThrusterLag._discretise(ThrusterLag._Ac, ThrusterLag._Bc, ThrusterLag._Cc,
+                                         ThrusterLag._Dc, dt)
+        out[f"Ad_{dt}"] = Ad
+        out[f"Bd_{dt}"] = Bd[:, 0]
+    out["dts"] = np.array([0.01, 0.02, 0.05])
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "fossen_constants.npz"), **out)
+
+
+# --------------------------------------------------------------------------- RHS KATs
+def _rand_states(rng, n, quat=False):
+    pos = rng.uniform(-3, 3, (n, 3))
+    ang = np.stack([rng.uniform(-1.2, 1.2, n), rng.uniform(-1.2, 1.2, n), rng.uniform(-6, 6, n)], 1)
+    nu = np.concatenate([rng.uniform(-1.5, 1.5, (n, 3)), rng.uniform(-1, 1, (n, 3))], 1)
+    if not quat:
+        return np.concatenate([pos, ang, nu], 1)
+    q = np.stack([refquat.euler_to_quat(*a) for a in ang])
+    q *= rng.uniform(0.8, 1.2, (n, 1))  # un-normalised on purpose (dynamics() normalises)
+    return np.concatenate([pos, q, nu], 1)
+
+
+def gen_rhs_kat():
+    rng = np.random.default_rng(20251003)
+    n = 48
+    out = {}
+    # --- thruster model: fresh object per sample, 3 consecutive calls with the same (x,u)
+    X = _rand_states(rng, n)
+    # edge cases: theta = +-pi/2 (cos clamp, fossen/BlueROV2.py:52-54), large yaw, zero state
+    X[0, 3:6] = [0.3, np.pi / 2, 0.2]
+    X[1, 3:6] = [-0.4, -np.pi / 2, 1.0]
+    X[2, 3:6] = [0.1, 0.2, 300.0]
+    X[3] = 0.0
+    U = rng.uniform(-1, 1, (n, 8))
+    U[4] = [1, -1, 1, -1, 1, -1, 1, -1]
+    U[5] = 0.0
+    for tag, cur, dt in (("thr", np.zeros(3), 0.02), ("thr_cur", np.array([0.3, -0.2, 0.1]), 0.05)):
+        D = np.zeros((3, n, 12))
+        LAG = np.zeros((3, n, 8, 3))
+        TAU = np.zeros((n, 6))
+        for i in range(n):
+            rov = RefThruster(current_speed=cur.copy())
+            for c in range(3):
+                D[c, i] = rov.dynamics(X[i], U[i], dt)
+                LAG[c, i] = np.stack([l._x for l in rov.thruster_lags])
+            rov2 = RefThruster()
+            TAU[i] = rov2.compute_thruster_forces(U[i], dt)
+        out[f"{tag}_X"], out[f"{tag}_U"], out[f"{tag}_dt"] = X, U, np.float64(dt)
+        out[f"{tag}_cur"], out[f"{tag}_XDOT"], out[f"{tag}_LAG"] = cur, D, LAG
+        out[f"{tag}_TAU1"] = TAU
+    # --- wrench, Euler angles
+    Xw = X.copy()
+    TAUW = rng.uniform(-1, 1, (n, 6)) * np.array([40, 40, 40, 4, 4, 4.0])
+    for tag, cur in (("we", np.zeros(3)), ("we_cur", np.array([0.3, -0.2, 0.1]))):
+        rov = RefWrenchEuler(current_speed=cur.copy())
+        out[f"{tag}_X"], out[f"{tag}_U"], out[f"{tag}_cur"] = Xw, TAUW, cur
+        out[f"{tag}_XDOT"] = np.stack([rov.dynamics(Xw[i], TAUW[i]) for i in range(n)])
+    # --- wrench, quaternion
+    Xq = _rand_states(rng, n, quat=True)
+    Xq[0, 3:7] = 0.0  # degenerate quaternion -> identity fallback (BlueROV2_wrench.py:33-35)
+    Xq[1, 3:7] = [1e-13, 0, 0, 0]
+    for tag, cur in (("wq", np.zeros(3)), ("wq_cur", np.array([0.3, -0.2, 0.1]))):
+        rov = RefWrenchQuat(current_speed=cur.copy())
+        out[f"{tag}_X"], out[f"{tag}_U"], out[f"{tag}_cur"] = Xq, TAUW, cur
+        out[f"{tag}_XDOT"] = np.stack([rov.dynamics(Xq[i], TAUW[i]) for i in range(n)])
+    # --- quaternion helpers
+    ang = np.stack([rng.uniform(-3, 3, 16), rng.uniform(-1.5, 1.5, 16), rng.uniform(-3, 3, 16)], 1)
+    Q = np.stack([refquat.euler_to_quat(*a) for a in ang])
+    out["q_euler_in"] = ang
+    out["q_from_euler"] = Q
+    out["q_to_euler"] = np.stack([np.array(refquat.quat_to_euler(q)) for q in Q])
+    out["q_to_yaw"] = np.array([refquat.quat_to_yaw(q) for q in Q])
+    out["q_to_R"] = np.stack([refquat.quat_to_rotation_matrix(q) for q in Q])
+    out["q_mul"] = np.stack([refquat.quat_multiply(Q[i], Q[(i + 1) % 16]) for i in range(16)])
+    out["q_deriv"] = np.stack([refquat.quat_derivative(Q[i], ang[i]) for i in range(16)])
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "fossen_rhs_kat.npz"), **out)
+
+
+# --------------------------------------------------------------------------- rollouts
+def _euler(rov, x0, U, dt, quat=False):
+    # loop of training/train_tank_brov2_full_comparison.py:453-466 (quat: ..._wrench_quat.py:249-266)
+    x = x0.copy()
+    traj = [x.copy()]
+    for k in range(len(U)):
+        x = x + dt * rov.dynamics(x, U[k], dt)
+        if quat:
+            x[3:7] = refquat.quat_normalize(x[3:7])
+        traj.append(x.copy())
+    return np.array(traj)
+
+
+def _rk4(rov, x0, U, dt, quat=False):
+    # loop of training/train_tank_brov2_rk4.py:375-396.  quat=True (renormalise after the
+    # full step) is OUR extension: the reference has no RK4 loop for the quaternion model.
+    x = x0.copy()
+    traj = [x.copy()]
+    for k in range(len(U)):
+        u = U[k]
+        k1 = rov.dynamics(x, u, dt)
+        k2 = rov.dynamics(x + 0.5 * dt * k1, u, dt)
+        k3 = rov.dynamics(x + 0.5 * dt * k2, u, dt)
+        k4 = rov.dynamics(x + dt * k3, u, dt)
+        x = x + (dt / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        if quat:
+            x[3:7] = refquat.quat_normalize(x[3:7])
+        traj.append(x.copy())
+    return np.array(traj)
+
+
+def gen_rollouts():
+    import train_tank_brov2_rk4 as ref_rk4
+    import train_tank_brov2_full_comparison as ref_eul
+    out = {}
+    nb, T, dt, sub = 8, T_CFG2, 0.02, 50
+    U = controls_iid(SEED_CFG2, 0, nb, T)
+    x0 = np.zeros(12)
+    x0[2] = 5.0
+    t0 = time.time()
+    R = np.zeros((nb, T // sub + 1, 12))
+    E = np.zeros_like(R)
+    LR = np.zeros((nb, 8, 3))
+    LE = np.zeros((nb, 8, 3))
+    for b in range(nb):
+        rov = RefThruster(dt=dt)
+        R[b] = ref_rk4.simulate_physics(x0, U[b], dt, rov)[::sub]
+        LR[b] = np.stack([l._x for l in rov.thruster_lags])
+        rov = RefThruster(dt=dt)
+        E[b] = ref_eul.simulate_physics(x0, U[b], dt, rov)[::sub]
+        LE[b] = np.stack([l._x for l in rov.thruster_lags])
+        print(f"  cfg2 traj {b} done ({time.time()-t0:.0f}s)", flush=True)
+    out.update(cfg2_seed=np.uint64(SEED_CFG2), cfg2_T=np.int64(T), cfg2_dt=np.float64(dt),
+               cfg2_sub=np.int64(sub), cfg2_x0=x0, cfg2_rk4=R, cfg2_euler=E,
+               cfg2_rk4_lag_end=LR, cfg2_euler_lag_end=LE, cfg2_U_head=U[:, :4, :])
+    # AR(1) inputs (sim-script template), T=1000, dt=0.05, nonzero start, RK4 + Euler
+    nb2, T2, dt2 = 4, 1000, 0.05
+    U2 = controls_ar1(777, 0, nb2, T2)
+    rng = np.random.default_rng(5)
+    X02 = _rand_states(rng, nb2)
+    X02[:, 3:5] *= 0.3
+    R2 = np.zeros((nb2, T2 // 20 + 1, 12))
+    E2 = np.zeros_like(R2)
+    for b in range(nb2):
+        R2[b] = ref_rk4.simulate_physics(X02[b], U2[b], dt2, RefThruster(dt=dt2))[::20]
+        E2[b] = ref_eul.simulate_physics(X02[b], U2[b], dt2, RefThruster(dt=dt2))[::20]
+    out.update(ar1_U=U2, ar1_X0=X02, ar1_dt=np.float64(dt2), ar1_sub=np.int64(20), ar1_rk4=R2, ar1_euler=E2)
+    # wrench models, T=600, dt=0.02
+    nb3, T3, dt3 = 4, 600, 0.02
+    TAU = controls_iid(99, 0, nb3, T3, nu=6) * np.array([30, 30, 30, 3, 3, 3.0])
+    Xw0 = _rand_states(rng, nb3)
+    Xw0[:, 3:5] *= 0.3
+    Xq0 = np.concatenate([Xw0[:, :3], np.stack([refquat.euler_to_quat(*a) for a in Xw0[:, 3:6]]), Xw0[:, 6:]], 1)
+    out.update(w_TAU=TAU, w_dt=np.float64(dt3), w_sub=np.int64(20), we_X0=Xw0, wq_X0=Xq0)
+    out["we_euler"] = np.stack([_euler(RefWrenchEuler(), Xw0[b], TAU[b], dt3)[::20] for b in range(nb3)])
+    out["we_rk4"] = np.stack([_rk4(RefWrenchEuler(), Xw0[b], TAU[b], dt3)[::20] for b in range(nb3)])
+    out["wq_euler"] = np.stack([_euler(RefWrenchQuat(), Xq0[b], TAU[b], dt3, quat=True)[::20] for b in range(nb3)])
+    out["wq_rk4_ext"] = np.stack([_rk4(RefWrenchQuat(), Xq0[b], TAU[b], dt3, quat=True)[::20] for b in range(nb3)])
+    # config 1: fossen/test_euler.py set-up at dt=0.02, 1000 Euler steps (SURVEY 8(d) cfg 1)
+    u1 = np.array([0.1, 0.1, 0.1, 0.0, 0.5, 0.5, 0.5, 0.5])
+    out["cfg1_u"] = u1
+    out["cfg1_euler"] = ref_eul.simulate_physics(x0, np.tile(u1, (1000, 1)), 0.02, RefThruster())[::10]
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "fossen_rollouts.npz"), **out)
+
+
+# --------------------------------------------------------------------------- windows
+def _sim_dataset(N, dt, seed, noise=True):
+    """Data set in the style of training/train_sim_brov2_koopmanEDMDc.py:153-197 (reference
+    dynamics, AR(1) thruster commands, sensor noise)."""
+    rng = np.random.default_rng(seed)
+    rov = RefThruster(dt=dt)
+    x = np.zeros(12)
+    up = np.zeros(8)
+    X = np.zeros((N, 12))
+    U = np.zeros((N, 8))
+    sig = np.array([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3)
+    for k in range(N):
+        u = np.clip(0.98 * up + 0.02 * rng.standard_normal(8), -1, 1)
+        x = x + dt * rov.dynamics(x, u, dt)
+        X[k] = x + (sig * rng.standard_normal(12) if noise else 0.0)
+        U[k] = u
+        up = u
+    return X, U
+
+
+def gen_windows():
+    import train_tank_brov2_rk4 as ref_rk4
+    import train_tank_brov2_full_comparison as ref_eul
+    import train_tank_brov2_wrench_comp as ref_we
+    import train_tank_brov2_wrench_quat as ref_wq
+    out = {}
+    N, dt = 400, 0.02
+    X, U = _sim_dataset(N, dt, seed=11)
+    out.update(X=X, U=U, dt=np.float64(dt), H=np.array([1, 10, 100]))
+    out["thr_euler_rmse"] = np.array([ref_eul.multistep_rmse_endpoint_physics(X, U, H, dt) for H in (1, 10, 100)])
+    out["thr_rk4_rmse"] = np.array([ref_rk4.multistep_rmse_endpoint_physics(X, U, H, dt) for H in (1, 10, 100)])
+    # wrench data: tau = alloc @ (static thrust curve) -- any 6-D input is fine for the KAT
+    rng = np.random.default_rng(3)
+    TAU = np.cumsum(rng.standard_normal((N, 6)), 0) * np.array([2, 2, 2, .2, .2, .2])
+    out["TAU"] = TAU
+    out["we_euler_rmse"] = np.array([ref_we.multistep_rmse_endpoint_physics(X, TAU, H, dt) for H in (1, 10, 100)])
+    Xq = np.concatenate([X[:, :3], np.stack([refquat.euler_to_quat(*a) for a in X[:, 3:6]]), X[:, 6:]], 1)
+    out["Xq"] = Xq
+    out["wq_euler_rmse"] = np.array([ref_wq.multistep_rmse_endpoint_physics(Xq, TAU, H, dt) for H in (1, 10, 100)])
+    out["wq_onestep_rmse"] = np.float64(ref_wq.one_step_rmse_physics(Xq, TAU, dt))
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "windows.npz"), **out)
+
+
+# --------------------------------------------------------------------------- EDMDc
+def gen_edmdc():
+    out = {}
+    N, dt = 2000, 0.05
+    X, U = _sim_dataset(N, dt, seed=42)
+    k, gamma, ridge = 48, 1.0, 1e-3
+    m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge)
+    m.fit(X[:1600], U[:1600])
+    Z = m._lift(X[:1599])
+    Zp = m._lift(X[1:1600])
+    G = np.hstack([Z, U[:1599]])
+    out.update(X=X, U=U, n_train=np.int64(1600), k=np.int64(k), gamma=np.float64(gamma), ridge=np.float64(ridge),
+               centers=m.centers_, lift64=m._lift(X[:64]), lift1=m._lift(X[7]),
+               GtG=G.T @ G, GtY=G.T @ Zp, A=m.A_, B=m.B_)
+    Xt, Ut = X[1600:], U[1600:]
+    out["eval_rmse"] = np.float64(m.evaluate(Xt, Ut))
+    out["ms_rmse"] = np.array([m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)])
+    out["sim50"] = m.simulate(Xt[0], Ut[:50])
+    # fit_multi on 3 unequal bags (no cross-bag pairs, Koopman/koopmanEDMDc.py:113-152)
+    cuts = [(0, 500), (500, 1300), (1300, 1600)]
+    m2 = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge)
+    m2.fit_multi([X[a:b] for a, b in cuts], [U[a:b] for a, b in cuts])
+    out.update(multi_cuts=np.array(cuts), multi_centers=m2.centers_, multi_A=m2.A_, multi_B=m2.B_,
+               multi_ms_rmse=np.array([m2.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)]))
+    # gamma=3 / ridge=0.1 (config of training/train_tank_brov2_full_comparison.py:42-44)
+    m3 = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=3.0, ridge=1e-1)
+    m3.fit(X[:1600], U[:1600])
+    out.update(g3_centers=m3.centers_, g3_A=m3.A_, g3_B=m3.B_,
+               g3_ms_rmse=np.array([m3.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)]))
+    out["rbf_kat"] = __import__("Koopman.koopmanEDMDc", fromlist=["_rbf_mat"])._rbf_mat(
+        np.array([[0.3, -0.2, 1.0, 0.1, -0.2, 0.7, 0.4, -0.3, 0.2, 0.05, -0.1, 0.2]]),
+        np.array([[0.0] * 12, [0.1] * 12]), 3.0)
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "edmdc.npz"), **out)
+
+
+GENS = dict(constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None, choices=list(GENS))
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    for name, fn in GENS.items():
+        if a.only and a.only != name:
+            continue
+        t0 = time.time()
+        fn()
+        print(f"[ok] {name} ({time.time()-t0:.1f}s)", flush=True)
