@@ -1,0 +1,249 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): RK4 rollout steps/s (batch x horizon) on MI355X, fp64,
+plus the EDMDc Gram build samples/s, each against its roofline, with the CPU oracle timed beside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch = ONE launch of the rollout kernel over
+65 536 trajectories x 5 000 RK4 steps (BASELINE config 2: thruster model, dt = 0.02, iid U(-1,1)
+commands from the counter-based stream, every state stored).  Inputs are resident in HBM before the
+timed region.  With N GPUs every rank runs its own 65 536-trajectory shard (weak scaling, no
+collective on the rollout path); the EDMDc leg all-reduces the per-rank Gram blocks over RCCL.
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+# algorithmic work per unit
+ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory
+ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
+EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
+EDMDC_BYTES_PER_SAMPLE = 256.0
+# /opt/skills/guides/MI355X_MICROARCH.md (HBM) and gfx950 datasheet (fp64): SURVEY.md 8(d)
+PEAK_HBM_GBS = 8000.0
+PEAK_FP64_VALU_TFLOPS = 78.6
+PEAK_FP64_MFMA_TFLOPS = 78.6
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
+    ap.add_argument("--horizon", type=int, default=5000)
+    ap.add_argument("--layout", default="tub", choices=["tub", "btu"])
+    ap.add_argument("--no-store", action="store_true", help="endpoint only (64 B/step algorithmic)")
+    ap.add_argument("--integrator", default="rk4", choices=["rk4", "euler"])
+    ap.add_argument("--edmdc-samples", type=int, default=10_000_000, help="(x,u,x+) pairs per GPU for the Gram leg")
+    ap.add_argument("--edmdc-steps", type=int, default=2)
+    ap.add_argument("--no-edmdc", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline_rollout(budget_s, integrator):
+    """C oracle (oracle/brov2_oracle.c), all host cores, same stream / model / integrator."""
+    from oracle import controls, fossen_c as fc
+    cores = os.cpu_count() or 1
+    T = 5000
+    integ = fc.INTEG_RK4 if integrator == "rk4" else fc.INTEG_EULER
+    x0 = np.zeros((cores, 12))
+    x0[:, 2] = 5.0
+    U = controls.controls_iid(0x5EED, 0, cores, T)
+    t0 = time.perf_counter()
+    fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)
+    probe = time.perf_counter() - t0
+    reps = max(1, min(64, int(budget_s / max(probe, 1e-3))))
+    nb = cores * reps
+    x0 = np.zeros((nb, 12))
+    x0[:, 2] = 5.0
+    U = controls.controls_iid(0x5EED, 0, nb, T)
+    t0 = time.perf_counter()
+    fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)
+    el = time.perf_counter() - t0
+    return {"value": nb * T / el, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{nb} trajectories x {T} {integrator} steps of the config-2 stream, C oracle with {cores} OpenMP threads, {el:.1f} s"}
+
+
+def cpu_baseline_gram(C, gamma, n_pairs=200_000):
+    """NumPy restatement of the reference's lift + G^T G + G^T Y (BLAS threads as configured on the box)."""
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(0)
+    X = rng.normal(0, 0.5, (n_pairs + 1, 12))
+    U = rng.uniform(-1, 1, (n_pairs + 1, 8))
+    t0 = time.perf_counter()
+    ek.gram([X], [U], C, gamma)
+    el = time.perf_counter() - t0
+    return {"value": n_pairs / el, "unit": "samples/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"{n_pairs} pairs, k={C.shape[0]}, NumPy/BLAS lift + Gram, {el:.1f} s"}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from bluerov2_dynamics_amd import _lib, engine
+    ctx = _lib.default_context(local)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def max_over_ranks(x):
+        if world == 1:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ------------------------------------------------------------------ rollout leg
+    B, T, dt = a.batch, a.horizon, 0.02
+    nu, nx = 8, 12
+    lay = a.layout
+    U = torch.empty((T, nu, B) if lay == "tub" else (B, T, nu), dtype=torch.float64, device=dev)
+    engine.fill_controls_dev(U, lay, "iid", seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)
+    x0 = torch.zeros((B, nx), dtype=torch.float64, device=dev)
+    x0[:, 2] = 5.0
+    traj = None
+    if not a.no_store:
+        traj = torch.empty((T + 1, nx, B) if lay == "tub" else (B, T + 1, nx), dtype=torch.float64, device=dev)
+    xT = torch.empty((B, nx), dtype=torch.float64, device=dev)
+
+    def step():
+        engine.rollout_dev(_lib.THRUSTER_EULER, a.integrator, x0, U, dt, traj=traj, xT=xT, layout=lay, stride=1, ctx=ctx)
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record()
+    for i in range(a.steps):
+        step()
+        ev[i + 1].record()       # same stream as the kernel (ctx uses torch's current stream)
+    barrier()
+    wall = max_over_ranks(time.perf_counter() - t0)
+    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
+    kern_s = float(np.mean(kern_ms)) * 1e-3
+    steps_total = world * B * T * a.steps
+    value = steps_total / wall
+    bytes_per_step = ROLLOUT_BYTES_PER_STEP if not a.no_store else 64.0
+    flop_rate = B * T * ROLLOUT_FLOP_PER_STEP / kern_s / 1e12
+    byte_rate = B * T * bytes_per_step / kern_s / 1e9
+    assert torch.isfinite(xT).all()
+
+    out = {
+        "metric": "rk4_rollout_steps_per_s" if a.integrator == "rk4" else "euler_rollout_steps_per_s",
+        "value": value, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"BASELINE config 2: {B} trajectories/GPU x {T} {a.integrator.upper()} steps, thruster model, dt=0.02, "
+                               f"iid U(-1,1) commands (splitmix64 stream 0x5EED), layout {lay}, "
+                               + ("all states stored" if traj is not None else "endpoint only"),
+                   "trajectories_per_gpu": B, "horizon": T, "parallelism": f"{world} x independent shards, no collective"},
+        "roofline": {"kernel": "rollout_kernel<THRUSTER_EULER,RK4>", "bound": "valu_fp64", "achieved": flop_rate,
+                     "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
+                     "kernel_ms": kern_s * 1e3, "flop_per_step": ROLLOUT_FLOP_PER_STEP,
+                     "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
+                             "bytes_per_step": bytes_per_step},
+                     "traffic": None},
+    }
+
+    # ------------------------------------------------------------------ EDMDc leg
+    del traj
+    if not a.no_edmdc:
+        torch.cuda.empty_cache()
+        n, r, k, gamma, ridge = 12, 8, 512, 1.0, 1e-3
+        L = 500
+        nb = max(1, a.edmdc_samples // L)
+        Ue = torch.empty((nb, L, r), dtype=torch.float64, device=dev)
+        engine.fill_controls_dev(Ue, "btu", "ar1", seed=0xED3D, b0=rank * nb, T_total=L, ctx=ctx)
+        Xe = torch.empty((nb, L + 1, n), dtype=torch.float64, device=dev)
+        xe0 = torch.zeros((nb, n), dtype=torch.float64, device=dev)
+        engine.rollout_dev(_lib.THRUSTER_EULER, "euler", xe0, Ue, dt, traj=Xe, layout="btu", stride=1, ctx=ctx)
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        sig = torch.tensor([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3, dtype=torch.float64, device=dev)
+        Xe += torch.randn(Xe.shape, generator=g, dtype=torch.float64, device=dev) * sig   # sensor noise of train_sim...:174-192
+        torch.cuda.synchronize()
+        # centres: sklearn KMeans on a seeded 1e5-row subsample of rank 0 (host, outside the timed region), broadcast
+        Cc = torch.empty((k, n), dtype=torch.float64, device=dev)
+        if rank == 0:
+            from sklearn.cluster import KMeans
+            idx = torch.randperm(nb * (L + 1), generator=torch.Generator().manual_seed(0))[:100_000].to(dev)
+            sub = Xe.reshape(-1, n)[idx].cpu().numpy()
+            Cc.copy_(torch.from_numpy(KMeans(n_clusters=k, n_init="auto", random_state=0).fit(sub).cluster_centers_))
+        if world > 1:
+            dist.broadcast(Cc, 0)
+        p, d = n + k + r, n + k
+        GG = torch.zeros((p * p + p * d,), dtype=torch.float64, device=dev)   # one buffer -> one all-reduce
+        GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+
+        def estep():
+            engine.gram_dev(Xe.view(-1, n), Ue.view(-1, r), Cc, gamma, nb, L, L + 1, L, GtG, GtY, ctx=ctx)
+            if world > 1:
+                dist.all_reduce(GG, op=dist.ReduceOp.SUM)
+
+        estep()
+        barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(a.edmdc_steps):
+            estep()
+        e1.record()
+        barrier()
+        ewall = max_over_ranks(time.perf_counter() - t0)
+        ekern_s = e0.elapsed_time(e1) * 1e-3 / a.edmdc_steps
+        pairs = nb * L
+        t1 = time.perf_counter()
+        A_, B_ = engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge * 1.0, d)
+        solve_s = time.perf_counter() - t1
+        eflops = pairs * EDMDC_FLOP_PER_SAMPLE / ekern_s / 1e12
+        out["edmdc"] = {
+            "metric": "edmdc_gram_samples_per_s", "value": world * pairs * a.edmdc_steps / ewall, "unit": "samples/s",
+            "pairs_per_gpu": pairs, "ms_per_fit_gram": ewall / a.edmdc_steps * 1e3, "host_pinv_solve_s": solve_s,
+            "end_to_end_fit_samples_per_s": world * pairs / (ewall / a.edmdc_steps + solve_s),
+            "config": {"workload": f"BASELINE config 3: {pairs} (x,u,x+) pairs/GPU from {nb} Euler rollouts x {L} steps, "
+                                   f"n=12 r=8 k=512 gamma={gamma}, lift + G^T[G|Y] on device, KMeans centres from a 1e5 subsample"},
+            "roofline": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": eflops,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": eflops / PEAK_FP64_MFMA_TFLOPS,
+                         "kernel_ms": ekern_s * 1e3, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE, "traffic": None},
+            "A_finite": bool(np.isfinite(A_).all() and np.isfinite(B_).all()),
+        }
+        if rank == 0 and not a.no_cpu:
+            out["edmdc"]["cpu_baseline"] = cpu_baseline_gram(Cc.cpu().numpy(), gamma)
+
+    if rank == 0 and not a.no_cpu:
+        out["cpu_baseline"] = cpu_baseline_rollout(a.cpu_seconds, a.integrator)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,106 @@
+"""EDMDc Koopman identification with an RBF dictionary -- drop-in for the reference's
+Koopman/koopmanEDMDc.py (class KoopmanEDMDc: fit, fit_multi, evaluate, multistep_rmse, simulate,
+_lift, _lift_inverse; dataclass fields state_dim, input_dim, n_rbfs, gamma, ridge, centers_, A_, B_,
+lift_dim_).
+
+What runs where:
+  * RBF centres: sklearn KMeans(n_clusters, n_init="auto", random_state=0) on the host, the very
+    call the reference makes (:85,126) -- a third-party dependency of both;
+  * lift phi(x) = [x, exp(-gamma(|x|^2+|c|^2-2x.c))] and the G^T[G|Y] normal-equation blocks:
+    HIP kernels (csrc/edmdc.hip, fp64 MFMA);
+  * the p x p ridge solve: NumPy pinv on the host, in fit_multi's association
+    M = pinv(G^T G + ridge I) (G^T Y) (:147).  The reference's fit() evaluates the same product as
+    (pinv G^T) Y (:97); the two agree to the conditioning of the Gram (tests quantify it);
+  * evaluate / multistep_rmse / simulate: H-step propagation Z <- Z A^T + U B^T as fp64 MFMA GEMMs
+    (csrc/propagate.hip).
+Unlike the reference, importing this module does not set OMP_NUM_THREADS / LOKY_MAX_CPU_COUNT.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from .. import engine
+
+
+def _kmeans_centers(X, n_rbfs):
+    from sklearn.cluster import KMeans
+    return KMeans(n_clusters=n_rbfs, n_init="auto", random_state=0).fit(X).cluster_centers_
+
+
+@dataclass
+class KoopmanEDMDc:
+    state_dim: int
+    input_dim: int
+    n_rbfs: int = 200
+    gamma: float = 1.0
+    ridge: float = 1e-8
+
+    centers_: np.ndarray = None
+    A_: np.ndarray = None
+    B_: np.ndarray = None
+    lift_dim_: int = None
+
+    # ------------------------------------------------------------------ fitting
+    def fit(self, X, U, centers=None) -> None:
+        """Learn (A, B) from one rollout X (N,n), U (N,r) (reference :72-103).
+        `centers` (k,n) overrides the KMeans step (extension, used for parity runs)."""
+        X = np.asarray(X, dtype=float)
+        U = np.asarray(U, dtype=float)
+        N, n = X.shape
+        assert U.shape[0] == N and U.shape[1] == self.input_dim
+        self.centers_ = _kmeans_centers(X, self.n_rbfs) if centers is None else np.asarray(centers, dtype=float)
+        self._solve([X], [U])
+
+    def fit_multi(self, X_list, U_list, centers=None) -> None:
+        """Fit from several independent trajectories without cross-bag transitions (reference :113-152)."""
+        assert len(X_list) == len(U_list) and len(X_list) > 0
+        for X, U in zip(X_list, U_list):
+            assert X.shape[1] == self.state_dim and U.shape[1] == self.input_dim
+        if centers is None:
+            X_all = np.vstack([X for X in X_list if len(X) > 0])
+            centers = _kmeans_centers(X_all, self.n_rbfs)
+        self.centers_ = np.asarray(centers, dtype=float)
+        self._solve(list(X_list), list(U_list))
+
+    def _solve(self, X_list, U_list):
+        GtG, GtY, _ = engine.gram(X_list, U_list, self.centers_, self.gamma)
+        d = self.state_dim + self.centers_.shape[0]
+        self.A_, self.B_ = engine.solve_AB(GtG, GtY, self.ridge, d)
+        self.lift_dim_ = d
+
+    # ------------------------------------------------------------------ scoring
+    def evaluate(self, X, U) -> float:
+        """One-step RMSE in state space (reference :157-170)."""
+        return self.multistep_rmse(X, U, H=1)
+
+    def multistep_rmse(self, X, U, H: int = 10) -> float:
+        """RMSE after H open-loop steps from every start index (reference :172-200)."""
+        X = np.asarray(X, dtype=float)
+        n_start = len(X) - H
+        if hasattr(self, "decoder_"):
+            raise NotImplementedError("decoder_ is never set by the reference's fit(); not supported")
+        se, _ = engine.multistep_se(X, U, self.centers_, self.gamma, self.A_, self.B_, H)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return float(np.sqrt(np.float64(se) / (n_start * X.shape[1]))) if n_start > 0 else float("nan")
+
+    def simulate(self, x0, U_seq) -> np.ndarray:
+        """Open-loop prediction (T+1, n) (reference :202-216)."""
+        x0 = np.asarray(x0, dtype=float)
+        U_seq = np.asarray(U_seq, dtype=float).reshape(-1, self.input_dim)
+        return engine.simulate_lifted(x0[None], U_seq[None], self.centers_, self.gamma, self.A_, self.B_)[0]
+
+    # ------------------------------------------------------------------ helpers
+    def _lift(self, x):
+        """phi(x) = [x, RBF_1(x) .. RBF_k(x)] for (n,) or (N,n) input (reference :221-236)."""
+        x = np.asarray(x, dtype=float)
+        if x.ndim == 1:
+            return engine.lift(x[None, :], self.centers_, self.gamma)[0]
+        if x.ndim == 2:
+            return engine.lift(x, self.centers_, self.gamma)
+        raise ValueError("x must have ndim 1 or 2")
+
+    def _lift_inverse(self, z):
+        """First n coordinates of the lifted state (reference :238-248)."""
+        if hasattr(self, "decoder_"):
+            return z @ self.decoder_.T
+        return z[..., :self.state_dim]

@@ -1,0 +1,230 @@
+"""ctypes binding of libbrov2.so (include/brov2.h).  There is NO CPU fallback: if the HIP
+library or a gfx950 device is missing, construction of a Context raises."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+from . import _build
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_void_p = ctypes.c_void_p
+i64 = ctypes.c_int64
+
+# enums of include/brov2.h
+THRUSTER_EULER, WRENCH_EULER, WRENCH_QUAT = 0, 1, 2
+EULER, RK4 = 0, 1
+LAG_PER_CALL, LAG_PER_STEP = 0, 1
+LAYOUT_BTU, LAYOUT_TUB = 0, 1
+DIST_IID_UNIFORM, DIST_AR1 = 0, 1
+NX = {THRUSTER_EULER: 12, WRENCH_EULER: 12, WRENCH_QUAT: 13}
+NU = {THRUSTER_EULER: 8, WRENCH_EULER: 6, WRENCH_QUAT: 6}
+STATUS = {0: "BROV_OK", -1: "BROV_ERR_ARG", -2: "BROV_ERR_HIP", -3: "BROV_ERR_NOMEM", -4: "BROV_ERR_NODEVICE"}
+
+
+class BrovParams(ctypes.Structure):
+    """struct brov_params (include/brov2.h)."""
+    _fields_ = [
+        ("rho", ctypes.c_double), ("g", ctypes.c_double), ("m", ctypes.c_double), ("volume", ctypes.c_double),
+        ("xb", ctypes.c_double), ("yb", ctypes.c_double), ("zb", ctypes.c_double),
+        ("Ix", ctypes.c_double), ("Iy", ctypes.c_double), ("Iz", ctypes.c_double),
+        ("added_mass", ctypes.c_double * 6), ("lin_damp", ctypes.c_double * 6), ("quad_damp", ctypes.c_double * 6),
+        ("current", ctypes.c_double * 3),
+        ("thr_r", (ctypes.c_double * 3) * 8), ("thr_dir", (ctypes.c_double * 3) * 8),
+        ("thrust_poly", ctypes.c_double * 5),
+        ("lag_Ac", ctypes.c_double * 9), ("lag_Bc", ctypes.c_double * 3), ("lag_Cc", ctypes.c_double * 3),
+    ]
+
+
+class BrovError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+# name -> (restype, argtypes); every symbol declared in include/brov2.h
+SIGNATURES = {
+    "brov_abi_version": (ctypes.c_int, []),
+    "brov_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_void_p)]),
+    "brov_destroy": (None, [c_void_p]),
+    "brov_last_error": (ctypes.c_char_p, [c_void_p]),
+    "brov_set_stream": (ctypes.c_int, [c_void_p, c_void_p]),
+    "brov_sync": (ctypes.c_int, [c_void_p]),
+    "brov_set_timing": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "brov_last_kernel_ms": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_float)]),
+    "brov_default_params": (None, [ctypes.POINTER(BrovParams)]),
+    "brov_set_params": (ctypes.c_int, [c_void_p, ctypes.POINTER(BrovParams)]),
+    "brov_get_params": (ctypes.c_int, [c_void_p, ctypes.POINTER(BrovParams)]),
+    "brov_get_derived": (ctypes.c_int, [ctypes.POINTER(BrovParams), c_double_p, c_double_p]),
+    "brov_discretise_lag": (ctypes.c_int, [ctypes.POINTER(BrovParams), ctypes.c_double, c_double_p, c_double_p]),
+    "brov_model_nx": (ctypes.c_int, [ctypes.c_int]),
+    "brov_model_nu": (ctypes.c_int, [ctypes.c_int]),
+    "brov_malloc": (ctypes.c_int, [c_void_p, ctypes.c_size_t, ctypes.POINTER(c_void_p)]),
+    "brov_free": (ctypes.c_int, [c_void_p, c_void_p]),
+    "brov_memcpy_h2d": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
+    "brov_memcpy_d2h": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
+    "brov_memset": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "brov_rhs": (ctypes.c_int, [c_void_p, ctypes.c_int, i64, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
+    "brov_thruster_forces": (ctypes.c_int, [c_void_p, i64, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
+    "brov_rollout": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
+                                    ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
+    "brov_rollout_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
+                                        ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
+    "brov_window_endpoint_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64, ctypes.c_double,
+                                               c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "brov_window_endpoint_se_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64, ctypes.c_double,
+                                                   c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "brov_fill_controls_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64, ctypes.c_int,
+                                              ctypes.c_uint64, i64, i64, c_void_p, c_void_p]),
+    "edmdc_lift": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p, c_void_p, c_void_p]),
+    "edmdc_gram": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                  i64, i64, i64, i64, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "edmdc_gram_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                      i64, i64, i64, i64, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "edmdc_set_chunk_rows": (ctypes.c_int, [c_void_p, i64]),
+    "edmdc_multistep_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                          c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edmdc_simulate": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                      c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def library_path():
+    return _build.LIB
+
+
+def load_library():
+    """dlopen libbrov2.so (needs libamdhip64; no GPU needed just to load) and bind every symbol."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        path = library_path()
+        if not os.path.exists(path):
+            raise BrovError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        lib = ctypes.CDLL(path)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)   # AttributeError = ABI mismatch, fail loudly
+            fn.restype = res
+            fn.argtypes = args
+        if lib.brov_abi_version() != 1:
+            raise BrovError("libbrov2.so ABI version mismatch")
+        _lib = lib
+        return lib
+
+
+def default_params() -> BrovParams:
+    p = BrovParams()
+    load_library().brov_default_params(ctypes.byref(p))
+    return p
+
+
+def discretise_lag(dt: float, params: BrovParams = None):
+    """ZOH (Ad, Bd) of the thruster lag -- host only (fossen/BlueROV2.py:490-496)."""
+    Ad = np.zeros((3, 3))
+    Bd = np.zeros(3)
+    rc = load_library().brov_discretise_lag(ctypes.byref(params) if params is not None else None, float(dt),
+                                            Ad.ctypes.data_as(c_double_p), Bd.ctypes.data_as(c_double_p))
+    if rc != 0:
+        raise BrovError(f"brov_discretise_lag failed: {STATUS.get(rc, rc)}")
+    return Ad, Bd
+
+
+def derived(params: BrovParams = None):
+    """(Minv diagonal [6], allocation matrix [6,8]) of a parameter set -- host only."""
+    Minv = np.zeros(6)
+    T = np.zeros((6, 8))
+    rc = load_library().brov_get_derived(ctypes.byref(params) if params is not None else None,
+                                         Minv.ctypes.data_as(c_double_p), T.ctypes.data_as(c_double_p))
+    if rc != 0:
+        raise BrovError(f"brov_get_derived failed: {STATUS.get(rc, rc)}")
+    return Minv, T
+
+
+def _hptr(a):
+    """host pointer of a C-contiguous float64 ndarray (or None)."""
+    if a is None:
+        return None
+    assert isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data
+
+
+def as_f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class Context:
+    """One brov_ctx = one device + one stream.  Not thread-safe (like the reference objects)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        h = c_void_p()
+        rc = self.lib.brov_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise BrovError(f"brov_create(device={device}) failed: {STATUS.get(rc, rc)} -- a gfx950 GPU is required, "
+                            "there is no CPU fallback")
+        self.h = h
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.brov_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc, what=""):
+        if rc != 0:
+            msg = self.lib.brov_last_error(self.h)
+            raise BrovError(f"{what}: {STATUS.get(rc, rc)}: {msg.decode() if msg else ''}")
+
+    # -- parameters
+    def get_params(self) -> BrovParams:
+        p = BrovParams()
+        self.check(self.lib.brov_get_params(self.h, ctypes.byref(p)), "brov_get_params")
+        return p
+
+    def set_params(self, p: BrovParams):
+        self.check(self.lib.brov_set_params(self.h, ctypes.byref(p)), "brov_set_params")
+
+    # -- stream / timing
+    def set_stream(self, stream_handle):
+        self.check(self.lib.brov_set_stream(self.h, c_void_p(stream_handle or 0)), "brov_set_stream")
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def sync(self):
+        self.check(self.lib.brov_sync(self.h), "brov_sync")
+
+    def set_timing(self, on: bool):
+        self.check(self.lib.brov_set_timing(self.h, int(bool(on))), "brov_set_timing")
+
+    def last_kernel_ms(self) -> float:
+        ms = ctypes.c_float(0.0)
+        self.check(self.lib.brov_last_kernel_ms(self.h, ctypes.byref(ms)), "brov_last_kernel_ms")
+        return float(ms.value)
+
+
+_default = {}
+
+
+def default_context(device: int = None) -> Context:
+    """Process-wide context per device (device defaults to $BROV2_DEVICE, then $LOCAL_RANK, then 0)."""
+    if device is None:
+        device = int(os.environ.get("BROV2_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

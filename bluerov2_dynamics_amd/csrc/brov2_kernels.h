@@ -1,0 +1,81 @@
+// brov2_kernels.h -- host-side launch entry points of the HIP kernels (internal; the public
+// boundary is include/brov2.h).  All pointers are device pointers; all launches are
+// asynchronous on `st`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "brov2_device.h"
+
+namespace brov {
+
+hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u,
+                      double* lag, double* xd);
+hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau);
+hipError_t launch_rollout(hipStream_t st, const DevParams& p, int model, int integ, int lag_mode, int layout, int64_t B,
+                          int64_t T, double dt, const double* x0, const double* U, double* lag, double* traj,
+                          int64_t stride, double* xT);
+hipError_t launch_window_endpoint(hipStream_t st, const DevParams& p, int model, int integ, int64_t N, int64_t H, double dt,
+                                  const double* X, const double* U, int carry_lag, const double* d_phi9,
+                                  double* d_resp, double* d_start, double* d_se, double* d_total);
+hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed,
+                                int64_t b0, int64_t T_total, const double* scale8, double* U);
+
+// ---- EDMDc -----------------------------------------------------------------------------
+// Lifted row layout (device native, "Z rows"): [rbf_0 .. rbf_{kp-1} | x_0..x_{n-1} u_0..u_{r-1} 0..]
+// with kp = k rounded up to 16 and the tail block (n + r) rounded up to 16; width = kp + tailp.
+struct EdmdcShape {
+    int n, r, k;
+    int kp;      // k padded to a multiple of 16
+    int tailp;   // (n + r) padded to a multiple of 16
+    int width;   // kp + tailp  (doubles per lifted row)
+    int d, p;    // n + k, n + k + r
+};
+inline EdmdcShape edmdc_shape(int n, int r, int k) {
+    EdmdcShape s;
+    s.n = n; s.r = r; s.k = k;
+    s.kp = (k + 15) / 16 * 16;
+    s.tailp = (n + r + 15) / 16 * 16;
+    s.width = s.kp + s.tailp;
+    s.d = n + k; s.p = n + k + r;
+    return s;
+}
+// Reference-order lift Z[N][n+k] = [x, rbf]  (edmdc_lift C entry point)
+hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z);
+// Device-native lifted rows for `rows` consecutive state rows starting at global row `row0`
+// (bag structure: state row index = b * xs + t, t in [0, L]; input row = b * us + t, t < L).
+// Rows >= total_rows (and gap rows t > L) are written as zeros with weight 0.
+hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double gamma, const double* C,
+                                  int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
+                                  const double* X, const double* U, double* Zrows, double* wrow);
+// Gram task table (device copy owned by the ctx) and sizes.
+// partial: [ntasks][nslab][24 tiles][64 lanes][4] doubles.
+size_t gram_partial_doubles(const EdmdcShape& s, int* ntasks_out, int* nslab_out);
+size_t gram_task_bytes();
+hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, void* d_tasks, size_t cap_bytes, int* ntasks);
+// Gram of one chunk: pairs (row, row+1) for row in [0, npairs) of Zrows (4*ceil(npairs/4)+1 rows lifted),
+// weight wrow[row]; accumulated into `partial` in place when `accumulate`.
+hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
+                                   const double* Zrows, const double* wrow, double* partial, int accumulate);
+// Sum partials over slabs (fixed order) and scatter into reference-order GtG [p][p], GtY [p][d].
+hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, const double* partial,
+                                    int accumulate_out, double* GtG, double* GtY);
+
+// ---- lifted propagation (propagate.hip) ---------------------------------------------------
+struct PropShape {
+    int n, r, k, d, p;
+    int dpad;      // d padded to 64 (feature rows of Zt / columns of ABt)
+    int ksteps;    // ceil(p / 4)
+    int ppad;      // 4 * ksteps (rows of ABt)
+    int64_t nw;    // windows (or simulated trajectories)
+    int64_t nwp;   // nw padded to 96
+};
+PropShape prop_shape(int n, int r, int k, int64_t nw);
+hipError_t launch_lift_t(hipStream_t st, const PropShape& s, double gamma, int64_t xstride, const double* X, const double* C, double* Zt);
+hipError_t launch_transpose(hipStream_t st, int64_t rows, int64_t cols, const double* src, int64_t lds_, double* dst, int64_t ldd);
+hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Ucur, int64_t ldu, double* Zout);
+hipError_t launch_endpoint_se(hipStream_t st, const PropShape& s, int64_t xstride, const double* Xref, const double* Zt, double* se, double* xhat);
+hipError_t launch_extract_state(hipStream_t st, const PropShape& s, int64_t T1, int64_t t, const double* Zt, double* Xp);
+hipError_t launch_useq_t(hipStream_t st, const PropShape& s, int64_t T, const double* Us, double* Ust);
+hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
+
+}  // namespace brov

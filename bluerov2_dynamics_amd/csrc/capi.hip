@@ -1,0 +1,866 @@
+// capi.hip -- the C ABI of libbrov2.so (include/brov2.h): context, parameters, host-side
+// ZOH discretisation, host<->device staging around the kernels of rollout.hip / edmdc.hip /
+// controls.hip / propagate.hip.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/brov2.h"
+#include "brov2_kernels.h"
+
+using namespace brov;
+
+// ------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------
+struct brov_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    brov_params params;
+    std::string err;
+    // timing
+    bool timing = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    // grow-only scratch arena (device)
+    char* scratch = nullptr;
+    size_t scratch_cap = 0;
+    // derived-parameter cache (per dt)
+    bool dp_valid = false;
+    double dp_dt = 0.0;
+    DevParams dp;
+    // EDMDc
+    int64_t chunk_rows = (int64_t)1 << 20;
+    void* d_tasks = nullptr;
+    EdmdcShape task_shape{};
+    int ntasks = 0;
+    // persistent EDMDc workspaces (separate from the per-call arena so that accumulate works across calls)
+    double* d_partial = nullptr;
+    size_t partial_cap = 0;
+};
+
+namespace {
+
+int fail(brov_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+int hip_fail(brov_ctx* c, hipError_t e, const char* what) {
+    return fail(c, e == hipErrorOutOfMemory ? BROV_ERR_NOMEM : BROV_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCK(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail((ctx), e__, #call); } while (0)
+
+struct DeviceGuard {
+    explicit DeviceGuard(const brov_ctx* c) { (void)hipSetDevice(c->device); }
+};
+
+// RAII: records the HIP events that bracket the kernels of one API call
+struct CallTimer {
+    brov_ctx* c;
+    explicit CallTimer(brov_ctx* ctx) : c(ctx) {
+        c->timed = false;
+        if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+    }
+    ~CallTimer() {
+        if (c->timing) { (void)hipEventRecord(c->ev1, c->stream); c->timed = true; }
+    }
+};
+
+// bump allocator over the ctx scratch arena; grows (after a stream sync) when too small
+struct Arena {
+    brov_ctx* c;
+    size_t off = 0;
+    std::vector<size_t> wants;
+    explicit Arena(brov_ctx* ctx) : c(ctx) {}
+    static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
+    int reserve(size_t total) {
+        total = al(total) + 4096;
+        if (total <= c->scratch_cap) return BROV_OK;
+        (void)hipStreamSynchronize(c->stream);
+        if (c->scratch) (void)hipFree(c->scratch);
+        c->scratch = nullptr;
+        c->scratch_cap = 0;
+        hipError_t e = hipMalloc((void**)&c->scratch, total);
+        if (e != hipSuccess) return hip_fail(c, e, "hipMalloc(scratch)");
+        c->scratch_cap = total;
+        return BROV_OK;
+    }
+    template <typename T> T* take(size_t count) {
+        T* p = reinterpret_cast<T*>(c->scratch + off);
+        off += al(count * sizeof(T));
+        return p;
+    }
+};
+
+// ---- small dense helpers (host, fp64) -------------------------------------------------------
+void matmul(int n, const double* A, const double* B, double* C) {
+    std::vector<double> t(n * n);
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double a = 0.0;
+            for (int k = 0; k < n; ++k) a += A[i * n + k] * B[k * n + j];
+            t[i * n + j] = a;
+        }
+    std::memcpy(C, t.data(), sizeof(double) * n * n);
+}
+// solve P X = Q (n x n), partial pivoting, in place on copies
+bool solve(int n, const double* P, const double* Q, double* X) {
+    std::vector<double> a(P, P + n * n), b(Q, Q + n * n);
+    for (int c = 0; c < n; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < n; ++r) if (std::fabs(a[r * n + c]) > std::fabs(a[piv * n + c])) piv = r;
+        if (a[piv * n + c] == 0.0) return false;
+        if (piv != c) for (int j = 0; j < n; ++j) { std::swap(a[c * n + j], a[piv * n + j]); std::swap(b[c * n + j], b[piv * n + j]); }
+        for (int r = c + 1; r < n; ++r) {
+            const double f = a[r * n + c] / a[c * n + c];
+            if (f == 0.0) continue;
+            for (int j = c; j < n; ++j) a[r * n + j] -= f * a[c * n + j];
+            for (int j = 0; j < n; ++j) b[r * n + j] -= f * b[c * n + j];
+        }
+    }
+    for (int j = 0; j < n; ++j)
+        for (int r = n - 1; r >= 0; --r) {
+            double s = b[r * n + j];
+            for (int k = r + 1; k < n; ++k) s -= a[r * n + k] * X[k * n + j];
+            X[r * n + j] = s / a[r * n + r];
+        }
+    return true;
+}
+// Matrix exponential, scaling and squaring with the [13/13] Pade approximant (Higham 2005).
+bool expm_pade13(int n, const double* Ain, double* E) {
+    static const double b[14] = {64764752532480000.0, 32382376266240000.0, 7771770303897600.0, 1187353796428800.0,
+                                 129060195264000.0, 10559470521600.0, 670442572800.0, 33522128640.0,
+                                 1323241920.0, 40840800.0, 960960.0, 16380.0, 182.0, 1.0};
+    const int nn = n * n;
+    std::vector<double> A(Ain, Ain + nn), A2(nn), A4(nn), A6(nn), U(nn), V(nn), T1(nn), T2(nn);
+    double norm1 = 0.0;
+    for (int j = 0; j < n; ++j) { double s = 0.0; for (int i = 0; i < n; ++i) s += std::fabs(A[i * n + j]); norm1 = std::fmax(norm1, s); }
+    int s = 0;
+    const double theta13 = 5.371920351148152;
+    if (norm1 > theta13) s = (int)std::ceil(std::log2(norm1 / theta13));
+    if (s < 0) s = 0;
+    const double sc = std::ldexp(1.0, -s);
+    for (auto& v : A) v *= sc;
+    matmul(n, A.data(), A.data(), A2.data());
+    matmul(n, A2.data(), A2.data(), A4.data());
+    matmul(n, A4.data(), A2.data(), A6.data());
+    for (int i = 0; i < nn; ++i) T1[i] = b[13] * A6[i] + b[11] * A4[i] + b[9] * A2[i];
+    matmul(n, A6.data(), T1.data(), T2.data());
+    for (int i = 0; i < nn; ++i) T2[i] += b[7] * A6[i] + b[5] * A4[i] + b[3] * A2[i];
+    for (int i = 0; i < n; ++i) T2[i * n + i] += b[1];
+    matmul(n, A.data(), T2.data(), U.data());
+    for (int i = 0; i < nn; ++i) T1[i] = b[12] * A6[i] + b[10] * A4[i] + b[8] * A2[i];
+    matmul(n, A6.data(), T1.data(), V.data());
+    for (int i = 0; i < nn; ++i) V[i] += b[6] * A6[i] + b[4] * A4[i] + b[2] * A2[i];
+    for (int i = 0; i < n; ++i) V[i * n + i] += b[0];
+    for (int i = 0; i < nn; ++i) { T1[i] = V[i] - U[i]; T2[i] = V[i] + U[i]; }
+    if (!solve(n, T1.data(), T2.data(), E)) return false;
+    for (int q = 0; q < s; ++q) matmul(n, E, E, E);
+    return true;
+}
+
+bool discretise(const brov_params& p, double dt, double Ad[9], double Bd[3]) {
+    // ZOH: expm(dt * [[Ac, Bc], [0, 0]]) -> top rows  (scipy.signal.cont2discrete(method="zoh"))
+    double M[16] = {0}, E[16];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) M[4 * i + j] = p.lag_Ac[3 * i + j] * dt; M[4 * i + 3] = p.lag_Bc[i] * dt; }
+    if (!expm_pade13(4, M, E)) return false;
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) Ad[3 * i + j] = E[4 * i + j]; Bd[i] = E[4 * i + 3]; }
+    return true;
+}
+
+void alloc_matrix(const brov_params& p, double T[6][8]) {
+    for (int i = 0; i < 8; ++i) {
+        const double* r = p.thr_r[i];
+        const double* d = p.thr_dir[i];
+        T[0][i] = d[0]; T[1][i] = d[1]; T[2][i] = d[2];
+        T[3][i] = r[1] * d[2] - r[2] * d[1];
+        T[4][i] = r[2] * d[0] - r[0] * d[2];
+        T[5][i] = r[0] * d[1] - r[1] * d[0];
+    }
+}
+
+bool derive(const brov_params& p, double dt, DevParams& o) {
+    std::memset(&o, 0, sizeof o);
+    const double md[6] = {p.m - p.added_mass[0], p.m - p.added_mass[1], p.m - p.added_mass[2],
+                          p.Ix - p.added_mass[3], p.Iy - p.added_mass[4], p.Iz - p.added_mass[5]};
+    for (int i = 0; i < 6; ++i) {
+        o.md[i] = md[i];
+        o.minv[i] = 1.0 / md[i];
+        o.dl[i] = -p.lin_damp[i] + 0.0;   // -(-0.0) = +0.0
+        o.dq[i] = -p.quad_damp[i];
+    }
+    const double W = p.m * p.g, B = p.rho * p.g * p.volume;
+    o.WmB = W - B;
+    o.xbB = p.xb * B; o.ybB = p.yb * B; o.zbB = p.zb * B;
+    o.has_current = 0;
+    for (int i = 0; i < 3; ++i) { o.cur[i] = p.current[i]; if (p.current[i] != 0.0) o.has_current = 1; }
+    alloc_matrix(p, o.alloc);
+    for (int i = 0; i < 5; ++i) o.poly[i] = p.thrust_poly[i];
+    double Ad[9], Bd[3];
+    if (!discretise(p, dt, Ad, Bd)) return false;
+    // powers: A^s, b_s = (I + A + ... + A^(s-1)) Bd, c_s = Cc A^s, d_s = Cc b_s
+    double As[9], bs[3];
+    std::memcpy(As, Ad, sizeof As);
+    std::memcpy(bs, Bd, sizeof bs);
+    for (int s = 0; s < 4; ++s) {
+        if (s > 0) {
+            double An[9], bn[3];
+            for (int i = 0; i < 3; ++i) {
+                for (int j = 0; j < 3; ++j) An[3 * i + j] = Ad[3 * i] * As[j] + Ad[3 * i + 1] * As[3 + j] + Ad[3 * i + 2] * As[6 + j];
+                bn[i] = Ad[3 * i] * bs[0] + Ad[3 * i + 1] * bs[1] + Ad[3 * i + 2] * bs[2] + Bd[i];
+            }
+            std::memcpy(As, An, sizeof As);
+            std::memcpy(bs, bn, sizeof bs);
+        }
+        for (int j = 0; j < 9; ++j) o.lag_A[s][j] = As[j];
+        for (int j = 0; j < 3; ++j) {
+            o.lag_b[s][j] = bs[j];
+            o.lag_c[s][j] = p.lag_Cc[0] * As[j] + p.lag_Cc[1] * As[3 + j] + p.lag_Cc[2] * As[6 + j];
+        }
+        o.lag_d[s] = p.lag_Cc[0] * bs[0] + p.lag_Cc[1] * bs[1] + p.lag_Cc[2] * bs[2];
+    }
+    return true;
+}
+
+int get_dp(brov_ctx* c, double dt, const DevParams** out) {
+    if (!(dt > 0.0) || !std::isfinite(dt)) return fail(c, BROV_ERR_ARG, "dt must be finite and > 0");
+    if (!c->dp_valid || c->dp_dt != dt) {
+        if (!derive(c->params, dt, c->dp)) return fail(c, BROV_ERR_ARG, "thruster-lag discretisation failed (singular Pade system)");
+        c->dp_dt = dt;
+        c->dp_valid = true;
+    }
+    *out = &c->dp;
+    return BROV_OK;
+}
+
+bool model_ok(int m) { return m == BROV_THRUSTER_EULER || m == BROV_WRENCH_EULER || m == BROV_WRENCH_QUAT; }
+int NX(int m) { return m == BROV_WRENCH_QUAT ? 13 : 12; }
+int NU(int m) { return m == BROV_THRUSTER_EULER ? 8 : 6; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+int brov_abi_version(void) { return BROV2_ABI_VERSION; }
+int brov_model_nx(int model) { return model_ok(model) ? NX(model) : BROV_ERR_ARG; }
+int brov_model_nu(int model) { return model_ok(model) ? NU(model) : BROV_ERR_ARG; }
+
+void brov_default_params(brov_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof *p);
+    // fossen/BlueROV2.py:81-99
+    p->rho = 1000.0; p->g = 9.82; p->m = 13.5; p->volume = 0.0134;
+    p->xb = 0.0; p->yb = 0.0; p->zb = -0.01;
+    p->Ix = 0.26; p->Iy = 0.23; p->Iz = 0.37;
+    // :111-116, :129-140
+    const double am[6] = {-6.36, -7.12, -18.68, -0.189, -0.135, -0.222};
+    const double dl[6] = {-13.7, -0.0, -33.0, -0.0, -0.8, -0.0};
+    const double dq[6] = {-141.0, -217.0, -190.0, -1.19, -0.47, -1.5};
+    for (int i = 0; i < 6; ++i) { p->added_mass[i] = am[i]; p->lin_damp[i] = dl[i]; p->quad_damp[i] = dq[i]; }
+    // :172-232 thruster geometry: r_i = Rz(a_i) r_base (angles as printed there), directions Rz(b_i) e or -z
+    const double r1234[3] = {0.156, 0.111, 0.085}, r5678[3] = {0.12, 0.218, 0.0};
+    const double e[3] = {1.0 / std::sqrt(2.0), -1.0 / std::sqrt(2.0), 0.0};
+    const double ar[8] = {0.0, 5.05, 1.91, M_PI, 0.0, 4.15, 1.01, M_PI};
+    const double ae[4] = {0.0, M_PI / 2, 3 * M_PI / 2, M_PI};
+    for (int i = 0; i < 8; ++i) {
+        const double* rb = i < 4 ? r1234 : r5678;
+        const double s = std::sin(ar[i]), c = std::cos(ar[i]);
+        p->thr_r[i][0] = c * rb[0] - s * rb[1];
+        p->thr_r[i][1] = s * rb[0] + c * rb[1];
+        p->thr_r[i][2] = rb[2];
+        if (i < 4) {
+            const double se = std::sin(ae[i]), ce = std::cos(ae[i]);
+            p->thr_dir[i][0] = ce * e[0] - se * e[1];
+            p->thr_dir[i][1] = se * e[0] + ce * e[1];
+            p->thr_dir[i][2] = 0.0;
+        } else {
+            p->thr_dir[i][0] = 0.0; p->thr_dir[i][1] = 0.0; p->thr_dir[i][2] = -1.0;
+        }
+    }
+    // :257 thrust curve, :476-480 lag
+    const double poly[5] = {8.9, 176.0, -404.1, 389.9, -140.3};
+    for (int i = 0; i < 5; ++i) p->thrust_poly[i] = poly[i];
+    const double Ac[9] = {-89.0, -72.33, -26.54, 128.0, 0.0, 0.0, 0.0, 32.0, 0.0};
+    const double Bc[3] = {8.0, 0.0, 0.0}, Cc[3] = {0.0, 5.992, 3.317};
+    for (int i = 0; i < 9; ++i) p->lag_Ac[i] = Ac[i];
+    for (int i = 0; i < 3; ++i) { p->lag_Bc[i] = Bc[i]; p->lag_Cc[i] = Cc[i]; }
+}
+
+int brov_create(int device_id, brov_ctx** out) {
+    if (!out) return BROV_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BROV_ERR_NODEVICE;
+    if (device_id < 0 || device_id >= ndev) return BROV_ERR_ARG;
+    brov_ctx* c = new (std::nothrow) brov_ctx();
+    if (!c) return BROV_ERR_NOMEM;
+    c->device = device_id;
+    brov_default_params(&c->params);
+    if (hipSetDevice(device_id) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+        delete c;
+        return BROV_ERR_HIP;
+    }
+    *out = c;
+    return BROV_OK;
+}
+
+void brov_destroy(brov_ctx* c) {
+    if (!c) return;
+    DeviceGuard g(c);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->d_tasks) (void)hipFree(c->d_tasks);
+    if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    delete c;
+}
+
+const char* brov_last_error(const brov_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
+
+int brov_set_stream(brov_ctx* c, void* s) {
+    if (!c) return BROV_ERR_ARG;
+    c->stream = reinterpret_cast<hipStream_t>(s);
+    return BROV_OK;
+}
+int brov_sync(brov_ctx* c) {
+    if (!c) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+int brov_set_timing(brov_ctx* c, int enabled) {
+    if (!c) return BROV_ERR_ARG;
+    c->timing = enabled != 0;
+    c->timed = false;
+    return BROV_OK;
+}
+int brov_last_kernel_ms(brov_ctx* c, float* ms) {
+    if (!c || !ms) return BROV_ERR_ARG;
+    if (!c->timed) return fail(c, BROV_ERR_ARG, "no timed call (brov_set_timing(ctx,1) first)");
+    DeviceGuard g(c);
+    HIPCK(c, hipEventSynchronize(c->ev1));
+    HIPCK(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return BROV_OK;
+}
+
+int brov_set_params(brov_ctx* c, const brov_params* p) {
+    if (!c || !p) return BROV_ERR_ARG;
+    const double md[6] = {p->m - p->added_mass[0], p->m - p->added_mass[1], p->m - p->added_mass[2],
+                          p->Ix - p->added_mass[3], p->Iy - p->added_mass[4], p->Iz - p->added_mass[5]};
+    for (int i = 0; i < 6; ++i)
+        if (!(md[i] != 0.0) || !std::isfinite(md[i])) return fail(c, BROV_ERR_ARG, "singular mass matrix");
+    c->params = *p;
+    c->dp_valid = false;
+    return BROV_OK;
+}
+int brov_get_params(const brov_ctx* c, brov_params* p) {
+    if (!c || !p) return BROV_ERR_ARG;
+    *p = c->params;
+    return BROV_OK;
+}
+int brov_get_derived(const brov_params* pp, double Minv6[6], double alloc6x8[48]) {
+    if (!Minv6 || !alloc6x8) return BROV_ERR_ARG;
+    brov_params def;
+    if (!pp) { brov_default_params(&def); pp = &def; }
+    const brov_params& p = *pp;
+    const double md[6] = {p.m - p.added_mass[0], p.m - p.added_mass[1], p.m - p.added_mass[2],
+                          p.Ix - p.added_mass[3], p.Iy - p.added_mass[4], p.Iz - p.added_mass[5]};
+    for (int i = 0; i < 6; ++i) Minv6[i] = 1.0 / md[i];
+    double T[6][8];
+    alloc_matrix(p, T);
+    std::memcpy(alloc6x8, T, sizeof T);
+    return BROV_OK;
+}
+int brov_discretise_lag(const brov_params* p, double dt, double Ad[9], double Bd[3]) {
+    if (!Ad || !Bd || !(dt > 0.0) || !std::isfinite(dt)) return BROV_ERR_ARG;
+    brov_params def;
+    if (!p) { brov_default_params(&def); p = &def; }
+    return discretise(*p, dt, Ad, Bd) ? BROV_OK : BROV_ERR_ARG;
+}
+
+// ---- device memory helpers ------------------------------------------------------------------
+int brov_malloc(brov_ctx* c, size_t bytes, void** dptr) {
+    if (!c || !dptr) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    *dptr = nullptr;
+    if (bytes == 0) return BROV_OK;
+    HIPCK(c, hipMalloc(dptr, bytes));
+    return BROV_OK;
+}
+int brov_free(brov_ctx* c, void* dptr) {
+    if (!c) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    if (dptr) HIPCK(c, hipFree(dptr));
+    return BROV_OK;
+}
+int brov_memcpy_h2d(brov_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+int brov_memcpy_d2h(brov_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+int brov_memset(brov_ctx* c, void* dst, int value, size_t bytes) {
+    if (!c || (bytes && !dst)) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    HIPCK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return BROV_OK;
+}
+
+// ---- RHS ---------------------------------------------------------------------------------------
+int brov_rhs(brov_ctx* c, int model, int64_t B, const double* x, const double* u, double dt, double* lag_io, double* xdot) {
+    if (!c || !model_ok(model) || B < 0 || (B && (!x || !u || !xdot))) return fail(c, BROV_ERR_ARG, "brov_rhs: bad argument");
+    if (B == 0) return BROV_OK;
+    DeviceGuard g(c);
+    const DevParams* dp;
+    int rc = get_dp(c, dt, &dp);
+    if (rc) return rc;
+    const int nx = NX(model), nu = NU(model);
+    const bool lag = lag_io && model == BROV_THRUSTER_EULER;
+    Arena a(c);
+    rc = a.reserve(Arena::al(B * nx * 8) * 2 + Arena::al(B * nu * 8) + Arena::al(B * 24 * 8));
+    if (rc) return rc;
+    double* dx = a.take<double>(B * nx);
+    double* du = a.take<double>(B * nu);
+    double* dxd = a.take<double>(B * nx);
+    double* dl = lag ? a.take<double>(B * 24) : nullptr;
+    HIPCK(c, hipMemcpyAsync(dx, x, B * nx * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(du, u, B * nu * 8, hipMemcpyHostToDevice, c->stream));
+    if (lag) HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_rhs(c->stream, *dp, model, B, dx, du, dl, dxd));
+    }
+    HIPCK(c, hipMemcpyAsync(xdot, dxd, B * nx * 8, hipMemcpyDeviceToHost, c->stream));
+    if (lag) HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+int brov_thruster_forces(brov_ctx* c, int64_t B, const double* u, double dt, double* lag_io, double* tau) {
+    if (!c || B < 0 || (B && (!u || !tau || !lag_io))) return fail(c, BROV_ERR_ARG, "brov_thruster_forces: bad argument");
+    if (B == 0) return BROV_OK;
+    DeviceGuard g(c);
+    const DevParams* dp;
+    int rc = get_dp(c, dt, &dp);
+    if (rc) return rc;
+    Arena a(c);
+    rc = a.reserve(Arena::al(B * 8 * 8) + Arena::al(B * 24 * 8) + Arena::al(B * 6 * 8));
+    if (rc) return rc;
+    double* du = a.take<double>(B * 8);
+    double* dl = a.take<double>(B * 24);
+    double* dt_ = a.take<double>(B * 6);
+    HIPCK(c, hipMemcpyAsync(du, u, B * 8 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_thruster_forces(c->stream, *dp, B, du, dl, dt_));
+    }
+    HIPCK(c, hipMemcpyAsync(tau, dt_, B * 6 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+// ---- rollout -------------------------------------------------------------------------------------
+static int rollout_args_ok(brov_ctx* c, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T, int64_t stride,
+                           const void* x0, const void* U, const void* traj) {
+    if (!c) return BROV_ERR_ARG;
+    if (!model_ok(model) || (integ != BROV_EULER && integ != BROV_RK4) || (lag_mode != BROV_LAG_PER_CALL && lag_mode != BROV_LAG_PER_STEP) ||
+        (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB) || B < 0 || T < 0)
+        return fail(c, BROV_ERR_ARG, "brov_rollout: bad enum or negative size");
+    if (B && (!x0 || (T && !U))) return fail(c, BROV_ERR_ARG, "brov_rollout: NULL input");
+    if (traj && stride < 1) return fail(c, BROV_ERR_ARG, "brov_rollout: traj_stride must be >= 1");
+    return BROV_OK;
+}
+
+int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T, double dt,
+                     const double* d_x0, const double* d_U, double* d_lag_io, double* d_traj, int64_t stride, double* d_xT) {
+    int rc = rollout_args_ok(c, model, integ, lag_mode, layout, B, T, stride, d_x0, d_U, d_traj);
+    if (rc) return rc;
+    if (B == 0) return BROV_OK;
+    DeviceGuard g(c);
+    const DevParams* dp;
+    rc = get_dp(c, dt, &dp);
+    if (rc) return rc;
+    CallTimer t(c);
+    HIPCK(c, launch_rollout(c->stream, *dp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U, d_lag_io, d_traj,
+                            d_traj ? stride : 1, d_xT));
+    return BROV_OK;
+}
+
+int brov_rollout(brov_ctx* c, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T, double dt,
+                 const double* x0, const double* U, double* lag_io, double* traj, int64_t stride, double* xT) {
+    int rc = rollout_args_ok(c, model, integ, lag_mode, layout, B, T, stride, x0, U, traj);
+    if (rc) return rc;
+    if (B == 0) return BROV_OK;
+    DeviceGuard g(c);
+    const int nx = NX(model), nu = NU(model);
+    const bool lag = lag_io && model == BROV_THRUSTER_EULER;
+    const int64_t rows = traj ? T / stride + 1 : 0;
+    Arena a(c);
+    rc = a.reserve(Arena::al(B * nx * 8) * 2 + Arena::al((size_t)B * T * nu * 8) + Arena::al(B * 24 * 8) + Arena::al((size_t)B * rows * nx * 8));
+    if (rc) return rc;
+    double* dx0 = a.take<double>(B * nx);
+    double* dU = a.take<double>((size_t)B * T * nu);
+    double* dxT = a.take<double>(B * nx);
+    double* dl = lag ? a.take<double>(B * 24) : nullptr;
+    double* dtr = traj ? a.take<double>((size_t)B * rows * nx) : nullptr;
+    HIPCK(c, hipMemcpyAsync(dx0, x0, B * nx * 8, hipMemcpyHostToDevice, c->stream));
+    if (T) HIPCK(c, hipMemcpyAsync(dU, U, (size_t)B * T * nu * 8, hipMemcpyHostToDevice, c->stream));
+    if (lag) HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    rc = brov_rollout_dev(c, model, integ, lag_mode, layout, B, T, dt, dx0, dU, dl, dtr, stride, dxT);
+    if (rc) return rc;
+    if (xT) HIPCK(c, hipMemcpyAsync(xT, dxT, B * nx * 8, hipMemcpyDeviceToHost, c->stream));
+    if (lag) HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
+    if (traj) HIPCK(c, hipMemcpyAsync(traj, dtr, (size_t)B * rows * nx * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+// ---- sliding-window endpoint error ----------------------------------------------------------------
+// Phi = Ad^(samples per window), by repeated squaring on the host
+static void lag_window_phi(const DevParams& dp, int64_t samples, double Phi[9]) {
+    double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, Bq[9];
+    std::memcpy(Bq, dp.lag_A[0], sizeof Bq);
+    while (samples > 0) {
+        if (samples & 1) matmul(3, R, Bq, R);
+        matmul(3, Bq, Bq, Bq);
+        samples >>= 1;
+    }
+    std::memcpy(Phi, R, sizeof R);
+}
+
+static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t H, double dt, const double* dX, const double* dU,
+                           int carry, double* d_total, double* d_se, Arena& a) {
+    const DevParams* dp;
+    int rc = get_dp(c, dt, &dp);
+    if (rc) return rc;
+    const int64_t nwin = N - H;
+    double *d_resp = nullptr, *d_start = nullptr, *d_phi = nullptr;
+    if (model == BROV_THRUSTER_EULER && carry) {
+        d_resp = a.take<double>(nwin * 24);
+        d_start = a.take<double>(nwin * 24);
+        d_phi = a.take<double>(16);
+        double Phi[9];
+        lag_window_phi(*dp, H * (integ == BROV_RK4 ? 4 : 1), Phi);
+        HIPCK(c, hipMemcpyAsync(d_phi, Phi, sizeof Phi, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));   // Phi is a stack temporary
+    }
+    CallTimer t(c);
+    HIPCK(c, launch_window_endpoint(c->stream, *dp, model, integ, N, H, dt, dX, dU, carry, d_phi, d_resp, d_start, d_se, d_total));
+    return BROV_OK;
+}
+
+int brov_window_endpoint_se_dev(brov_ctx* c, int model, int integ, int64_t N, int64_t H, double dt, const double* d_X,
+                                const double* d_U, int carry_lag, double* d_se_total, double* d_per_window) {
+    if (!c || !model_ok(model) || (integ != BROV_EULER && integ != BROV_RK4) || N < 0 || H < 0 || !d_se_total)
+        return fail(c, BROV_ERR_ARG, "brov_window_endpoint_se_dev: bad argument");
+    DeviceGuard g(c);
+    const int64_t nwin = N - H;
+    if (nwin <= 0) { HIPCK(c, hipMemsetAsync(d_se_total, 0, 8, c->stream)); return BROV_OK; }
+    if (!d_X || !d_U || !d_per_window) return fail(c, BROV_ERR_ARG, "brov_window_endpoint_se_dev: NULL array");
+    Arena a(c);
+    int rc = a.reserve(Arena::al(nwin * 24 * 8) * 2 + 1024);
+    if (rc) return rc;
+    return window_dev_impl(c, model, integ, N, H, dt, d_X, d_U, carry_lag, d_se_total, d_per_window, a);
+}
+
+int brov_window_endpoint_se(brov_ctx* c, int model, int integ, int64_t N, int64_t H, double dt, const double* X, const double* U,
+                            int carry_lag, double* se_total, double* per_window) {
+    if (!c || !model_ok(model) || (integ != BROV_EULER && integ != BROV_RK4) || N < 0 || H < 0 || !se_total)
+        return fail(c, BROV_ERR_ARG, "brov_window_endpoint_se: bad argument");
+    const int64_t nwin = N - H;
+    if (nwin <= 0) { *se_total = 0.0; return BROV_OK; }
+    if (!X || !U) return fail(c, BROV_ERR_ARG, "brov_window_endpoint_se: NULL array");
+    DeviceGuard g(c);
+    const int nx = NX(model), nu = NU(model);
+    Arena a(c);
+    int rc = a.reserve(Arena::al(N * nx * 8) + Arena::al(N * nu * 8) + Arena::al(nwin * 8) + Arena::al(nwin * 24 * 8) * 2 + 2048);
+    if (rc) return rc;
+    double* dX = a.take<double>(N * nx);
+    double* dU = a.take<double>(N * nu);
+    double* dse = a.take<double>(nwin);
+    double* dtot = a.take<double>(8);
+    HIPCK(c, hipMemcpyAsync(dX, X, N * nx * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(dU, U, N * nu * 8, hipMemcpyHostToDevice, c->stream));
+    rc = window_dev_impl(c, model, integ, N, H, dt, dX, dU, carry_lag, dtot, dse, a);
+    if (rc) return rc;
+    HIPCK(c, hipMemcpyAsync(se_total, dtot, 8, hipMemcpyDeviceToHost, c->stream));
+    if (per_window) HIPCK(c, hipMemcpyAsync(per_window, dse, nwin * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+// ---- synthetic controls -------------------------------------------------------------------------------
+int brov_fill_controls_dev(brov_ctx* c, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed, int64_t b0,
+                           int64_t T_total, const double* scale_host, double* d_U) {
+    if (!c || (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB) || (dist != BROV_DIST_IID_UNIFORM && dist != BROV_DIST_AR1) ||
+        B < 0 || T < 0 || nu < 1 || nu > 8 || b0 < 0 || T_total < T || (B && T && !d_U))
+        return fail(c, BROV_ERR_ARG, "brov_fill_controls_dev: bad argument");
+    DeviceGuard g(c);
+    CallTimer t(c);
+    double sc[8];
+    for (int j = 0; j < 8; ++j) sc[j] = (scale_host && j < nu) ? scale_host[j] : 1.0;
+    HIPCK(c, launch_fill_controls(c->stream, layout, dist, B, T, nu, seed, b0, T_total, sc, d_U));
+    return BROV_OK;
+}
+
+// ---- EDMDc -------------------------------------------------------------------------------------------
+int edmdc_set_chunk_rows(brov_ctx* c, int64_t rows) {
+    if (!c || rows < 64) return fail(c, BROV_ERR_ARG, "edmdc_set_chunk_rows: rows must be >= 64");
+    c->chunk_rows = (rows + 3) / 4 * 4;
+    return BROV_OK;
+}
+
+static int edmdc_shape_ok(brov_ctx* c, int n, int r, int k) {
+    if (!c) return BROV_ERR_ARG;
+    if (n < 1 || n > 16 || r < 0 || r > 64 || k < 1 || k > 65535 * 16 || ((n + r + 15) / 16 * 16) > 256)
+        return fail(c, BROV_ERR_ARG, "edmdc: unsupported shape (need 1<=n<=16, 0<=r<=64, k>=1)");
+    return BROV_OK;
+}
+
+int edmdc_lift(brov_ctx* c, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z) {
+    int rc = edmdc_shape_ok(c, n, 0, k);
+    if (rc) return rc;
+    if (N < 0 || (N && (!X || !Z)) || !C) return fail(c, BROV_ERR_ARG, "edmdc_lift: bad argument");
+    if (N == 0) return BROV_OK;
+    DeviceGuard g(c);
+    Arena a(c);
+    rc = a.reserve(Arena::al(N * n * 8) + Arena::al((size_t)k * n * 8) + Arena::al((size_t)N * (n + k) * 8));
+    if (rc) return rc;
+    double* dX = a.take<double>(N * n);
+    double* dC = a.take<double>((size_t)k * n);
+    double* dZ = a.take<double>((size_t)N * (n + k));
+    HIPCK(c, hipMemcpyAsync(dX, X, N * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_lift_ref(c->stream, N, n, k, gamma, dX, dC, dZ));
+    }
+    HIPCK(c, hipMemcpyAsync(Z, dZ, (size_t)N * (n + k) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+static int ensure_tasks(brov_ctx* c, const EdmdcShape& s) {
+    if (!c->d_tasks) HIPCK(c, hipMalloc(&c->d_tasks, gram_task_bytes()));
+    if (c->ntasks == 0 || c->task_shape.n != s.n || c->task_shape.r != s.r || c->task_shape.k != s.k) {
+        int nt = 0;
+        hipError_t e = upload_gram_tasks(c->stream, s, c->d_tasks, gram_task_bytes(), &nt);
+        if (e != hipSuccess) return hip_fail(c, e, "upload_gram_tasks (too many tasks for this shape?)");
+        HIPCK(c, hipStreamSynchronize(c->stream));   // source vector is a temporary
+        c->ntasks = nt;
+        c->task_shape = s;
+    }
+    return BROV_OK;
+}
+
+int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
+                   int64_t xs, int64_t us, const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !d_C || !d_GtG || !d_GtY || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_gram_dev: bad argument");
+    DeviceGuard g(c);
+    const EdmdcShape s = edmdc_shape(n, r, k);
+    rc = ensure_tasks(c, s);
+    if (rc) return rc;
+    if (nbags <= 1) { xs = L + 1; us = L; }
+    const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;   // rows that can start a pair
+    int nslab = 0, ntasks = 0;
+    const size_t pdoubles = gram_partial_doubles(s, &ntasks, &nslab);
+    if (pdoubles * 8 > c->partial_cap) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->d_partial) (void)hipFree(c->d_partial);
+        c->d_partial = nullptr; c->partial_cap = 0;
+        HIPCK(c, hipMalloc((void**)&c->d_partial, pdoubles * 8));
+        c->partial_cap = pdoubles * 8;
+    }
+    int64_t chunk = c->chunk_rows;
+    if (chunk > (total_pairs_rows + 3) / 4 * 4) chunk = (total_pairs_rows + 3) / 4 * 4;
+    if (chunk < 4) chunk = 4;
+    Arena a(c);
+    rc = a.reserve(Arena::al((size_t)(chunk + 8) * s.width * 8) + Arena::al((chunk + 8) * 8));
+    if (rc) return rc;
+    double* dZ = a.take<double>((size_t)(chunk + 8) * s.width);
+    double* dw = a.take<double>(chunk + 8);
+    CallTimer t(c);
+    if (total_pairs_rows == 0) {
+        HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
+    }
+    int first = 1;
+    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk) {
+        const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
+        const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
+        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks, c->d_tasks, npairs, dZ, dw, c->d_partial, first ? 0 : 1));
+        first = 0;
+    }
+    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks, c->d_tasks, c->d_partial, accumulate, d_GtG, d_GtY));
+    return BROV_OK;
+}
+
+int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
+               const double* X, const double* U, int accumulate, double* GtG, double* GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !C || !GtG || !GtY || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_gram: bad argument");
+    DeviceGuard g(c);
+    if (nbags <= 1) { xs = L + 1; us = L; }
+    const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
+    const int d = n + k, p = d + r;
+    // inputs live in plain device allocations (the arena is used by edmdc_gram_dev itself)
+    double *dX = nullptr, *dU = nullptr, *dC = nullptr, *dG = nullptr, *dY = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dC); (void)hipFree(dG); (void)hipFree(dY); };
+#define HIPCK_CLEAN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(c, e__, #call); } } while (0)
+    HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)(xrows > 0 ? xrows : 1) * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dU, (size_t)(urows > 0 ? urows : 1) * (r > 0 ? r : 1) * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dG, (size_t)p * p * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dY, (size_t)p * d * 8));
+    if (xrows) HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)xrows * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (urows && r) HIPCK_CLEAN(hipMemcpyAsync(dU, U, (size_t)urows * r * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK_CLEAN(hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (accumulate) {
+        HIPCK_CLEAN(hipMemcpyAsync(dG, GtG, (size_t)p * p * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK_CLEAN(hipMemcpyAsync(dY, GtY, (size_t)p * d * 8, hipMemcpyHostToDevice, c->stream));
+    } else {
+        HIPCK_CLEAN(hipMemsetAsync(dG, 0, (size_t)p * p * 8, c->stream));
+        HIPCK_CLEAN(hipMemsetAsync(dY, 0, (size_t)p * d * 8, c->stream));
+    }
+    rc = edmdc_gram_dev(c, n, r, k, gamma, dC, nbags, L, xs, us, dX, dU, accumulate, dG, dY);
+    if (rc) { cleanup(); return rc; }
+    HIPCK_CLEAN(hipMemcpyAsync(GtG, dG, (size_t)p * p * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(hipMemcpyAsync(GtY, dY, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(hipStreamSynchronize(c->stream));
+    cleanup();
+    return BROV_OK;
+}
+
+// ---- lifted propagation: evaluate / multistep_rmse / simulate ---------------------------------------
+// builds ABt [ppad][dpad] = [A | B]^T (zero padded) from host A [d][d], B [d][r]
+static int upload_ABt(brov_ctx* c, const PropShape& s, const double* A, const double* B, double* dABt) {
+    std::vector<double> h((size_t)s.ppad * s.dpad, 0.0);
+    for (int i = 0; i < s.d; ++i) {
+        for (int j = 0; j < s.d; ++j) h[(size_t)j * s.dpad + i] = A[(size_t)i * s.d + j];
+        for (int j = 0; j < s.r; ++j) h[(size_t)(s.d + j) * s.dpad + i] = B[(size_t)i * s.r + j];
+    }
+    HIPCK(c, hipMemcpyAsync(dABt, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const double* A, const double* B,
+                       int64_t N, int64_t H, const double* X, const double* U, double* se_total, double* xhat_end) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (N < 0 || H < 0 || !C || !A || !B || !se_total || (N && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_multistep_se: bad argument");
+    const int64_t nw = N - H;
+    if (nw <= 0) { *se_total = 0.0; return BROV_OK; }
+    DeviceGuard g(c);
+    const PropShape s = prop_shape(n, r, k, nw);
+    const int rpad = s.ppad - s.d;
+    const int64_t NUt = s.nwp + H + 16;
+    Arena a(c);
+    rc = a.reserve(Arena::al(N * n * 8) + Arena::al(N * (r ? r : 1) * 8) + Arena::al((size_t)k * n * 8) + Arena::al((size_t)s.ppad * s.dpad * 8) +
+                   2 * Arena::al((size_t)s.dpad * s.nwp * 8) + Arena::al((size_t)rpad * NUt * 8) + Arena::al(nw * 8) + Arena::al(nw * n * 8) + 4096);
+    if (rc) return rc;
+    double* dX = a.take<double>(N * n);
+    double* dU = a.take<double>(N * (r ? r : 1));
+    double* dC = a.take<double>((size_t)k * n);
+    double* dABt = a.take<double>((size_t)s.ppad * s.dpad);
+    double* dZ0 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dZ1 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dUt = a.take<double>((size_t)rpad * NUt);
+    double* dse = a.take<double>(nw);
+    double* dxh = a.take<double>(nw * n);
+    double* dtot = a.take<double>(8);
+    HIPCK(c, hipMemcpyAsync(dX, X, N * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (r) HIPCK(c, hipMemcpyAsync(dU, U, N * r * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    rc = upload_ABt(c, s, A, B, dABt);
+    if (rc) return rc;
+    HIPCK(c, hipMemsetAsync(dUt, 0, (size_t)rpad * NUt * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.dpad * s.nwp * 8, c->stream));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_transpose(c->stream, N, r, dU, r, dUt, NUt));
+        HIPCK(c, launch_lift_t(c->stream, s, gamma, n, dX, dC, dZ0));
+        double *zin = dZ0, *zout = dZ1;
+        for (int64_t t = 0; t < H; ++t) {
+            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, dUt + t, NUt, zout));
+            std::swap(zin, zout);
+        }
+        HIPCK(c, launch_endpoint_se(c->stream, s, n, dX + H * n, zin, dse, xhat_end ? dxh : nullptr));
+        HIPCK(c, launch_sum(c->stream, nw, dse, dtot));
+    }
+    HIPCK(c, hipMemcpyAsync(se_total, dtot, 8, hipMemcpyDeviceToHost, c->stream));
+    if (xhat_end) HIPCK(c, hipMemcpyAsync(xhat_end, dxh, nw * n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const double* A, const double* B,
+                   int64_t nb, int64_t T, const double* x0, const double* U_seq, double* X_pred) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nb < 0 || T < 0 || !C || !A || !B || (nb && (!x0 || !X_pred || (T && r && !U_seq)))) return fail(c, BROV_ERR_ARG, "edmdc_simulate: bad argument");
+    if (nb == 0) return BROV_OK;
+    DeviceGuard g(c);
+    const PropShape s = prop_shape(n, r, k, nb);
+    const int rpad = s.ppad - s.d;
+    const int64_t ust_rows = (T > 0 ? T : 1) * (int64_t)rpad;   // [t][rpad][nbp]: step t uses rows t*r .. (reads up to rpad rows)
+    Arena a(c);
+    rc = a.reserve(Arena::al(nb * n * 8) + Arena::al((size_t)nb * T * (r ? r : 1) * 8 + 8) + Arena::al((size_t)k * n * 8) +
+                   Arena::al((size_t)s.ppad * s.dpad * 8) + 2 * Arena::al((size_t)s.dpad * s.nwp * 8) +
+                   Arena::al((size_t)(ust_rows + rpad) * s.nwp * 8) + Arena::al((size_t)nb * (T + 1) * n * 8) + 4096);
+    if (rc) return rc;
+    double* dx0 = a.take<double>(nb * n);
+    double* dUs = a.take<double>((size_t)nb * T * (r ? r : 1) + 1);
+    double* dC = a.take<double>((size_t)k * n);
+    double* dABt = a.take<double>((size_t)s.ppad * s.dpad);
+    double* dZ0 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dZ1 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dUst = a.take<double>((size_t)(ust_rows + rpad) * s.nwp);
+    double* dXp = a.take<double>((size_t)nb * (T + 1) * n);
+    HIPCK(c, hipMemcpyAsync(dx0, x0, nb * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (T && r) HIPCK(c, hipMemcpyAsync(dUs, U_seq, (size_t)nb * T * r * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    rc = upload_ABt(c, s, A, B, dABt);
+    if (rc) return rc;
+    HIPCK(c, hipMemsetAsync(dUst, 0, (size_t)(ust_rows + rpad) * s.nwp * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.dpad * s.nwp * 8, c->stream));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_useq_t(c->stream, s, T, dUs, dUst));
+        HIPCK(c, launch_lift_t(c->stream, s, gamma, n, dx0, dC, dZ0));
+        double *zin = dZ0, *zout = dZ1;
+        HIPCK(c, launch_extract_state(c->stream, s, T + 1, 0, zin, dXp));
+        for (int64_t t = 0; t < T; ++t) {
+            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, dUst + (size_t)t * r * s.nwp, s.nwp, zout));
+            std::swap(zin, zout);
+            HIPCK(c, launch_extract_state(c->stream, s, T + 1, t + 1, zin, dXp));
+        }
+    }
+    HIPCK(c, hipMemcpyAsync(X_pred, dXp, (size_t)nb * (T + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// controls.hip -- K7: synthetic control sequences generated on device.
+//
+// Counter-based (random access) splitmix64, so the value for (trajectory b, step t,
+// channel j) does not depend on the layout or on how trajectories are sharded over GPUs:
+//   counter = ((b0 + b) * T_total + t) * nu + j
+//   bits    = mix(seed + (counter + 1) * 0x9E3779B97F4A7C15)
+//   uniform = (bits >> 11) * 2^-53
+// dist A: u = 2 uniform - 1 (bit exact with oracle/controls.py).
+// dist B: AR(1) u_t = clip(0.98 u_{t-1} + 0.02 xi_t, -1, 1) with Box-Muller xi, the smooth
+// thruster command of training/train_sim_brov2_koopmanEDMDc.py:160-164.
+#include "brov2_kernels.h"
+
+namespace brov {
+
+__device__ __forceinline__ uint64_t splitmix64_at(uint64_t seed, uint64_t counter) {
+    uint64_t z = seed + (counter + 1ull) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ double uniform01_at(uint64_t seed, uint64_t counter) {
+    return (double)(splitmix64_at(seed, counter) >> 11) * 0x1.0p-53;
+}
+
+struct Scale8 { double s[8]; };
+
+// one thread per (b, t); TUB stores are coalesced over b, BTU stores are one 8*nu-byte row per thread
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) fill_iid_kernel(int64_t B, int64_t T, int nu, uint64_t seed, int64_t b0,
+                                                       int64_t T_total, Scale8 sc, double* __restrict__ U) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
+        const uint64_t c0 = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)t) * (uint64_t)nu;
+        for (int j = 0; j < nu; ++j) {
+            const double v = (2.0 * uniform01_at(seed, c0 + j) - 1.0) * sc.s[j];
+            if constexpr (LAYOUT == LAYOUT_BTU) U[(b * T + t) * nu + j] = v;
+            else U[(t * nu + j) * B + b] = v;
+        }
+    }
+}
+
+// one thread per (b, j), sequential in t
+template <int LAYOUT>
+__global__ void __launch_bounds__(256) fill_ar1_kernel(int64_t B, int64_t T, int nu, uint64_t seed, int64_t b0,
+                                                       int64_t T_total, Scale8 sc, double* __restrict__ U) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = blockIdx.y;
+    if (b >= B) return;
+    const uint64_t s2 = seed ^ 0xA5A5A5A5A5A5A5A5ull;
+    double prev = 0.0;
+    for (int64_t t = 0; t < T; ++t) {
+        const uint64_t c = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)t) * (uint64_t)nu + (uint64_t)j;
+        const double u1 = uniform01_at(s2, 2ull * c), u2 = uniform01_at(s2, 2ull * c + 1ull);
+        const double xi = sqrt(-2.0 * log1p(-u1)) * cos(6.283185307179586476925286766559 * u2);
+        prev = fmin(fmax(fma(0.98, prev, 0.02 * xi), -1.0), 1.0);
+        const double v = prev * sc.s[j];
+        if constexpr (LAYOUT == LAYOUT_BTU) U[(b * T + t) * nu + j] = v;
+        else U[(t * nu + j) * B + b] = v;
+    }
+}
+
+hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed,
+                                int64_t b0, int64_t T_total, const double* scale8, double* U) {
+    if (B <= 0 || T <= 0) return hipSuccess;
+    Scale8 sc;
+    for (int j = 0; j < 8; ++j) sc.s[j] = scale8 ? scale8[j] : 1.0;
+    const unsigned gx = (unsigned)((B + 255) / 256);
+    if (dist == 0) {
+        const unsigned gy = (unsigned)(T < 4096 ? T : 4096);
+        if (layout == LAYOUT_BTU)
+            hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_BTU>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+        else
+            hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_TUB>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+    } else {
+        if (layout == LAYOUT_BTU)
+            hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_BTU>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+        else
+            hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_TUB>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace brov

@@ -1,0 +1,317 @@
+// edmdc.hip -- Koopman EDMDc on gfx950: RBF lift (K4) and the G^T[G|Y] normal-equation
+// blocks as an fp64 MFMA split-K reduction (K5).  Reference: Koopman/koopmanEDMDc.py:41-48
+// (_rbf_mat), :221-236 (_lift), :89-97 / :129-147 (fit / fit_multi normal equations).
+//
+// Data flow per chunk of state rows (chunk sized by the host, default 2^20 rows):
+//   lift_rows_kernel : X,U  ->  Zrows[row][W]   (W = kp + tailp doubles, e.g. 544)
+//                               row = [ rbf_0..rbf_{kp-1} | x_0..x_{n-1} u_0..u_{r-1} 0.. ]
+//                               wrow[row] = 1 if (row, row+1) is a pair inside one bag else 0
+//   gram_kernel      : partial[task][slab] += sum_{row in slab} w[row] Z[row]^T [ Z[row] | Z[row+1] ]
+//   gram_finish      : fixed-order sum over slabs, scatter to reference feature order.
+// phi(x_{t+1}) of pair t is phi(x_t) of pair t+1, so every state is lifted once and the Y
+// operand of the Gram is simply the next row of Zrows.
+//
+// gram_kernel: one wave = one task = a 4x6 block of 16x16 output tiles (64x96 outputs,
+// 96 fp64 accumulators per lane = 192 VGPRs; the whole kernel stays under 256 VGPRs so the
+// MFMAs use their VGPR form -- with more accumulators hipcc shuttles them between AGPRs and
+// VGPRs every iteration) over one K-slab of rows.  v_mfma_f64_16x16x4_f64 consumes 4 rows per
+// instruction; per 4-row step a wave issues 10 operand loads (8 B per lane, 4 rows x 128 B per
+// wave-load) for 24 MFMAs, so operands are read once per wave and all reuse is in registers.
+// Two waves share a SIMD and cover each other's load latency.  Waves of one K-slab are placed on one XCD (blockIdx % 8) so the
+// slab's rows are fetched from HBM once and shared through that XCD's L2.
+#include <vector>
+#include "brov2_kernels.h"
+
+namespace brov {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int LIFT_NMAX = 16;   // max state dimension held in registers per centre
+constexpr int GRAM_TA = 4;      // A tiles (rows of the output block) per task
+constexpr int GRAM_TB = 6;      // B tiles (cols of the output block) per task
+
+// ---------------------------------------------------------------------------------------
+// K4: lift
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) center_norms_kernel(int n, int k, const double* __restrict__ C, double* __restrict__ c2) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= k) return;
+    double s = 0.0;
+    for (int j = 0; j < n; ++j) s += C[c * n + j] * C[c * n + j];   // np.sum(C**2, axis=1)
+    c2[c] = s;
+}
+hipError_t launch_center_norms(hipStream_t st, int n, int k, const double* C, double* c2) {
+    hipLaunchKernelGGL(center_norms_kernel, dim3((k + 255) / 256), dim3(256), 0, st, n, k, C, c2);
+    return hipGetLastError();
+}
+
+// rbf value for the centre held by this lane, state row read through wave-uniform loads
+__device__ __forceinline__ double rbf_one(int n, double gamma, const double* __restrict__ xrow, const double* c, double c2) {
+    double x2 = 0.0, dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < LIFT_NMAX; ++j) {
+        if (j < n) { const double xj = xrow[j]; x2 = fma(xj, xj, x2); dot = fma(xj, c[j], dot); }
+    }
+    return exp(-gamma * ((x2 + c2) - 2.0 * dot));
+}
+
+// Reference-order lift: Z[N][n+k] = [x, rbf].  Block = 256 lanes = 256 centres, tile of 64 rows.
+__global__ void __launch_bounds__(256) lift_ref_kernel(int64_t N, int n, int k, double gamma, const double* __restrict__ X,
+                                                       const double* __restrict__ C, double* __restrict__ Z) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int d = n + k;
+    double cc[LIFT_NMAX], c2 = 0.0;
+#pragma unroll
+    for (int j = 0; j < LIFT_NMAX; ++j) { cc[j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2 = fma(cc[j], cc[j], c2); }
+    for (int64_t r = r0; r < r0 + 64 && r < N; ++r) {
+        const double* xrow = X + r * n;
+        if (c < k) Z[r * d + n + c] = rbf_one(n, gamma, xrow, cc, c2);
+        if (blockIdx.y == 0 && (int)threadIdx.x < n) Z[r * d + threadIdx.x] = xrow[threadIdx.x];
+    }
+}
+hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z) {
+    if (N <= 0) return hipSuccess;
+    if (n > LIFT_NMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lift_ref_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((k + 255) / 256)), dim3(256), 0, st, N, n, k, gamma, X, C, Z);
+    return hipGetLastError();
+}
+
+// Device-native lifted rows.  grid.x = row tiles of 32, grid.y = groups of 256 centres (+1 block row for the tail).
+__global__ void __launch_bounds__(256) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
+                                                        int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
+                                                        const double* __restrict__ X, const double* __restrict__ U,
+                                                        double* __restrict__ Zrows, double* __restrict__ wrow) {
+    const int n = s.n, k = s.k, W = s.width;
+    const int64_t l0 = (int64_t)blockIdx.x * 32;       // local row index within the chunk buffer
+    const int ngroups = (s.kp + 255) / 256;
+    if ((int)blockIdx.y < ngroups) {
+        const int c = blockIdx.y * 256 + threadIdx.x;
+        double cc[LIFT_NMAX], c2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < LIFT_NMAX; ++j) { cc[j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2 = fma(cc[j], cc[j], c2); }
+        for (int64_t l = l0; l < l0 + 32 && l < rows; ++l) {
+            const int64_t g = row0 + l;                 // global state row
+            double z = 0.0;
+            if (g < total_rows && c < k) {
+                const int64_t t = g % xs;
+                if (t <= L) z = rbf_one(n, gamma, X + g * n, cc, c2);
+            }
+            if (c < s.kp) Zrows[l * W + c] = z;
+        }
+    } else {
+        // tail block: [x | u | 0], and the pair weight
+        const int j = threadIdx.x;
+        for (int64_t l = l0; l < l0 + 32 && l < rows; ++l) {
+            const int64_t g = row0 + l;
+            double v = 0.0, w = 0.0;
+            if (g < total_rows) {
+                const int64_t b = g / xs, t = g % xs;
+                if (t <= L) {
+                    if (j < n) v = X[g * n + j];
+                    else if (j < n + s.r && t < L) v = U[(b * us + t) * s.r + (j - n)];
+                }
+                if (t < L) w = 1.0;
+            }
+            if (j < s.tailp) Zrows[l * W + s.kp + j] = v;
+            if (j == 0) wrow[l] = w;
+        }
+    }
+}
+hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double gamma, const double* C,
+                                  int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
+                                  const double* X, const double* U, double* Zrows, double* wrow) {
+    if (rows <= 0) return hipSuccess;
+    if (s.n > LIFT_NMAX || s.tailp > 256) return hipErrorInvalidValue;
+    const int ngroups = (s.kp + 255) / 256;
+    hipLaunchKernelGGL(lift_rows_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)(ngroups + 1)), dim3(256), 0, st,
+                       s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
+// K5: Gram
+// ---------------------------------------------------------------------------------------
+// One task = GRAM_TA A-tiles x GRAM_TB B-tiles.  A tile ta: columns [16 ta, 16 ta + 16) of row t.
+// B tile: tb >= 0 -> columns [16 tb, ..) of row t (G^T G part); encoded (tb | 0x10000) -> row t+1
+// (G^T Y part).  -1 = empty slot.
+struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; };
+
+static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks) {
+    const int nt = s.width / 16;                     // G tiles
+    const int nty = s.kp / 16 + (s.n + 15) / 16;     // Y tiles: rbf block + the x part of the tail
+    tasks.clear();
+    for (int a0 = 0; a0 < nt; a0 += GRAM_TA) {
+        std::vector<int> bl;
+        for (int tb = a0; tb < nt; ++tb) bl.push_back(tb);              // upper triangle of G^T G (block granularity)
+        for (int tb = 0; tb < nty; ++tb) bl.push_back(tb | 0x10000);    // all of G^T Y
+        for (size_t o = 0; o < bl.size(); o += GRAM_TB) {
+            GramTask t;
+            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < nt) ? a0 + i : -1;
+            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (o + j < bl.size()) ? bl[o + j] : -1;
+            tasks.push_back(t);
+        }
+    }
+}
+
+constexpr int GRAM_NSLAB = 24;   // K-slabs per chunk (multiple of 8 XCDs); 81 tasks x 24 = 1944 waves <= 2048 slots (2 waves/SIMD)
+
+size_t gram_partial_doubles(const EdmdcShape& s, int* ntasks_out, int* nslab_out) {
+    std::vector<GramTask> tasks;
+    build_gram_tasks(s, tasks);
+    if (ntasks_out) *ntasks_out = (int)tasks.size();
+    if (nslab_out) *nslab_out = GRAM_NSLAB;
+    return tasks.size() * (size_t)GRAM_NSLAB * GRAM_TA * GRAM_TB * 256;
+}
+
+size_t gram_task_bytes() { return 256 * sizeof(GramTask); }
+
+// d_tasks: device copy of the task table (owned by the ctx, rebuilt when the shape changes)
+hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, void* d_tasks, size_t cap_bytes, int* ntasks) {
+    std::vector<GramTask> tasks;
+    build_gram_tasks(s, tasks);
+    *ntasks = (int)tasks.size();
+    if (tasks.size() * sizeof(GramTask) > cap_bytes) return hipErrorInvalidValue;
+    return hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(GramTask), hipMemcpyHostToDevice, st);
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gram_kernel(int W, int ntasks, int64_t ksteps_total, const GramTask* __restrict__ tasks,
+            const double* __restrict__ Z, const double* __restrict__ wrow, double* __restrict__ partial, int accumulate) {
+    // XCD-aware item mapping: blocks b and b+8 share an XCD (observed round-robin); keep a slab on one XCD.
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, i = bid >> 3;
+    const int slab = (i / ntasks) * 8 + xcd;
+    const int task = i % ntasks;
+    const int lane = threadIdx.x;
+    const int kq = lane >> 4, col = lane & 15;
+
+    const int64_t per = (ksteps_total + GRAM_NSLAB - 1) / GRAM_NSLAB;
+    const int64_t ks0 = (int64_t)slab * per;
+    int64_t ks1 = ks0 + per;
+    if (ks1 > ksteps_total) ks1 = ksteps_total;
+
+    // per-lane element offsets (doubles, 32-bit) relative to the first row of the current k-step
+    int aoff[GRAM_TA], boff[GRAM_TB];
+#pragma unroll
+    for (int a = 0; a < GRAM_TA; ++a) { const int ta = tasks[task].a[a]; aoff[a] = kq * W + (ta < 0 ? 0 : ta * 16) + col; }
+#pragma unroll
+    for (int b = 0; b < GRAM_TB; ++b) {
+        const int tbe = tasks[task].b[b];
+        const int tb = tbe < 0 ? 0 : tbe;
+        boff[b] = (kq + ((tb >> 16) & 1)) * W + (tb & 0xFFFF) * 16 + col;
+    }
+    v4d acc[GRAM_TA][GRAM_TB];
+#pragma unroll
+    for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+        for (int b = 0; b < GRAM_TB; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+
+    if (ks0 < ks1) {
+        const double* zp = Z + ks0 * 4 * W;       // wave-uniform base of the current 4 rows
+        const double* wp = wrow + ks0 * 4;
+        double an[GRAM_TA], bn[GRAM_TB], wn;
+        wn = wp[kq];
+#pragma unroll
+        for (int a = 0; a < GRAM_TA; ++a) an[a] = zp[aoff[a]];
+#pragma unroll
+        for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
+        for (int64_t ks = ks0; ks < ks1; ++ks) {
+            double av[GRAM_TA], bv[GRAM_TB];
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a) av[a] = an[a] * wn;
+#pragma unroll
+            for (int b = 0; b < GRAM_TB; ++b) bv[b] = bn[b];
+            // prefetch the next 4 rows while the 32 MFMAs below run (unconditional: the row buffer is
+            // padded by 8 rows, and what the last step prefetches is never consumed)
+            zp += 4 * W;
+            wp += 4;
+            wn = wp[kq];
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a) an[a] = zp[aoff[a]];
+#pragma unroll
+            for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+                for (int b = 0; b < GRAM_TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // partial[(task * NSLAB + slab)][tile = a * TB + b][lane][4]
+    double* out = partial + ((int64_t)task * GRAM_NSLAB + slab) * (GRAM_TA * GRAM_TB * 256) + lane * 4;
+    if (accumulate) {
+#pragma unroll
+        for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+            for (int b = 0; b < GRAM_TB; ++b) {
+                v4d* o = reinterpret_cast<v4d*>(out + (a * GRAM_TB + b) * 256);
+                *o = *o + acc[a][b];
+            }
+    } else {
+#pragma unroll
+        for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+            for (int b = 0; b < GRAM_TB; ++b) *reinterpret_cast<v4d*>(out + (a * GRAM_TB + b) * 256) = acc[a][b];
+    }
+}
+
+hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
+                                   const double* Zrows, const double* wrow, double* partial, int accumulate) {
+    const int64_t ksteps = (npairs + 3) / 4;
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(ntasks * GRAM_NSLAB)), dim3(64), 0, st, s.width, ntasks, ksteps,
+                       reinterpret_cast<const GramTask*>(d_tasks), Zrows, wrow, partial, accumulate);
+    return hipGetLastError();
+}
+
+// Finish: one thread per (task, tile, lane, reg); sums the slabs in index order and scatters to the
+// reference feature order: G = [x (n) | rbf (k) | u (r)], Y = [x (n) | rbf (k)].
+__device__ __forceinline__ int dev_to_ref_feature(const EdmdcShape& s, int f, bool is_y) {
+    if (f < s.k) return s.n + f;
+    if (f < s.kp) return -1;
+    const int j = f - s.kp;
+    if (j < s.n) return j;
+    if (j < s.n + s.r) return is_y ? -1 : s.d + (j - s.n);
+    return -1;
+}
+__global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntasks, const GramTask* __restrict__ tasks,
+                                                          const double* __restrict__ partial, int accumulate_out,
+                                                          double* __restrict__ GtG, double* __restrict__ GtY) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over ntasks * 32 tiles * 256
+    const int64_t total = (int64_t)ntasks * GRAM_TA * GRAM_TB * 256;
+    if (idx >= total) return;
+    const int e = (int)(idx & 255), tile = (int)((idx >> 8) % (GRAM_TA * GRAM_TB)), task = (int)(idx / (GRAM_TA * GRAM_TB * 256));
+    const int lane = e >> 2, reg = e & 3;
+    const int a = tile / GRAM_TB, b = tile % GRAM_TB;
+    const int ta = tasks[task].a[a], tbe = tasks[task].b[b];
+    if (ta < 0 || tbe < 0) return;
+    const bool is_y = (tbe >> 16) & 1;
+    const int tb = tbe & 0xFFFF;
+    if (!is_y && tb < ta) return;                       // redundant lower-triangle tile
+    const int fi = ta * 16 + (lane >> 4) + 4 * reg;     // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg
+    const int fj = tb * 16 + (lane & 15);               //                                          col = lane & 15
+    const int ri = dev_to_ref_feature(s, fi, false), rj = dev_to_ref_feature(s, fj, is_y);
+    if (ri < 0 || rj < 0) return;
+    double sum = 0.0;
+    const double* pp = partial + (int64_t)task * GRAM_NSLAB * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;
+    for (int sl = 0; sl < GRAM_NSLAB; ++sl) sum += pp[(int64_t)sl * (GRAM_TA * GRAM_TB * 256)];
+    if (is_y) {
+        double* o = GtY + (int64_t)ri * s.d + rj;
+        *o = accumulate_out ? *o + sum : sum;
+    } else {
+        if (tb == ta && fj < fi) return;                // diagonal tile: write the upper half, mirror below
+        double* o = GtG + (int64_t)ri * s.p + rj;
+        const double v = accumulate_out ? *o + sum : sum;
+        *o = v;
+        if (ri != rj) GtG[(int64_t)rj * s.p + ri] = v;
+    }
+}
+hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, const double* partial,
+                                    int accumulate_out, double* GtG, double* GtY) {
+    const int64_t total = (int64_t)ntasks * GRAM_TA * GRAM_TB * 256;
+    hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, ntasks,
+                       reinterpret_cast<const GramTask*>(d_tasks), partial, accumulate_out, GtG, GtY);
+    return hipGetLastError();
+}
+
+}  // namespace brov

@@ -1,0 +1,407 @@
+// rollout.hip -- time-loop kernels: batched RHS, Euler/RK4 rollouts, sliding-window
+// endpoint error with the reference's carried thruster-lag state.
+//
+// Mapping: one wavefront lane = one trajectory (or one evaluation window).  256-thread
+// workgroups = 4 waves, one per SIMD of a CU.  All state lives in VGPRs; vehicle constants
+// arrive as a by-value kernel argument (scalar loads).  Control rows are prefetched one
+// step ahead so the HBM/L2 latency sits under the ~1.5k fp64 instructions of a step.
+#include "brov2_device.h"
+#include "brov2_kernels.h"
+
+namespace brov {
+
+// ---------------------------------------------------------------------------------------
+// global <-> register movement for one row of NX/NU doubles
+// ---------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void load_row(const double* __restrict__ src, double* r) {
+    if constexpr (N % 2 == 0) {
+        const double2* s2 = reinterpret_cast<const double2*>(src);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) { double2 v = s2[i]; r[2 * i] = v.x; r[2 * i + 1] = v.y; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) r[i] = src[i];
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_row(double* __restrict__ dst, const double* r) {
+    if constexpr (N % 2 == 0) {
+        double2* d2 = reinterpret_cast<double2*>(dst);
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) d2[i] = make_double2(r[2 * i], r[2 * i + 1]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) dst[i] = r[i];
+    }
+}
+template <int N>
+__device__ __forceinline__ void load_soa(const double* __restrict__ src, int64_t ld, double* r) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) r[i] = src[i * ld];
+}
+template <int N>
+__device__ __forceinline__ void store_soa(double* __restrict__ dst, int64_t ld, const double* r) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) dst[i * ld] = r[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// one integrator step (training/train_tank_brov2_full_comparison.py:462-465 Euler,
+// training/train_tank_brov2_rk4.py:385-394 RK4, ..._wrench_quat.py:258-263 renormalisation)
+// ---------------------------------------------------------------------------------------
+template <int MODEL, int INTEG, int LAGMODE>
+__device__ __forceinline__ void integrate_step(const DevParams& p, double dt, double* x, const double* u, LagBank& lag) {
+    constexpr int NX = Dims<MODEL>::NX;
+    constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
+    double fcmd[8], F[8], tau[6];
+    if constexpr (THR) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fcmd[i] = thrust_poly(p, u[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tau[i] = u[i];
+    }
+    if constexpr (INTEG == INTEG_EULER) {
+        double k[NX];
+        if constexpr (THR) { lag.forces_after(p, 1, fcmd, F); allocate(p, F, tau); }
+        rhs_state<MODEL>(p, x, tau, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
+        if constexpr (THR) lag.advance(p, 1, fcmd);
+    } else {
+        double k[NX], acc[NX], xs[NX];
+        const double h2 = 0.5 * dt;
+        if constexpr (THR) { lag.forces_after(p, 1, fcmd, F); allocate(p, F, tau); }
+        rhs_state<MODEL>(p, x, tau, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = fma(h2, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) { lag.forces_after(p, 2, fcmd, F); allocate(p, F, tau); }
+        rhs_state<MODEL>(p, xs, tau, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(h2, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) { lag.forces_after(p, 3, fcmd, F); allocate(p, F, tau); }
+        rhs_state<MODEL>(p, xs, tau, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(dt, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) { lag.forces_after(p, 4, fcmd, F); allocate(p, F, tau); }
+        rhs_state<MODEL>(p, xs, tau, k);
+        const double h6 = dt / 6.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = fma(h6, acc[i] + k[i], x[i]);
+        if constexpr (THR) lag.advance(p, LAGMODE == 0 ? 4 : 1, fcmd);
+    }
+    if constexpr (MODEL == MODEL_WRENCH_QUAT) quat_normalize(x + 3);
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: batched dynamics() -- one RHS evaluation per row, lag advanced one sample
+// ---------------------------------------------------------------------------------------
+template <int MODEL>
+__global__ void __launch_bounds__(256) rhs_kernel(DevParams p, int64_t B, const double* __restrict__ X,
+                                                  const double* __restrict__ U, double* __restrict__ lag_io,
+                                                  double* __restrict__ XD) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[NX], u[NU], xd[NX], tau[6];
+    load_row<NX>(X + b * NX, x);
+    load_row<NU>(U + b * NU, u);
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        LagBank lag;
+        if (lag_io) load_row<24>(lag_io + b * 24, &lag.x[0][0]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+        }
+        double fcmd[8], F[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fcmd[i] = thrust_poly(p, u[i]);
+        lag.forces_after(p, 1, fcmd, F);
+        allocate(p, F, tau);
+        lag.advance(p, 1, fcmd);
+        if (lag_io) store_row<24>(lag_io + b * 24, &lag.x[0][0]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) tau[i] = u[i];
+    }
+    rhs_state<MODEL>(p, x, tau, xd);
+    store_row<NX>(XD + b * NX, xd);
+}
+
+// compute_thruster_forces (fossen/BlueROV2.py:265-278), batched
+__global__ void __launch_bounds__(256) thruster_forces_kernel(DevParams p, int64_t B, const double* __restrict__ U,
+                                                              double* __restrict__ lag_io, double* __restrict__ TAU) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double u[8], fcmd[8], F[8], tau[6];
+    LagBank lag;
+    load_row<8>(U + b * 8, u);
+    load_row<24>(lag_io + b * 24, &lag.x[0][0]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) fcmd[i] = thrust_poly(p, u[i]);
+    lag.forces_after(p, 1, fcmd, F);
+    allocate(p, F, tau);
+    lag.advance(p, 1, fcmd);
+    store_row<24>(lag_io + b * 24, &lag.x[0][0]);
+    store_row<6>(TAU + b * 6, tau);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: rollout.  U / traj layouts: BTU = [B][T][nu] / [B][rows][nx]; TUB = [T][nu][B] / [rows][nx][B].
+// ---------------------------------------------------------------------------------------
+template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
+__global__ void __launch_bounds__(256) rollout_kernel(DevParams p, int64_t B, int64_t T, double dt,
+                                                      const double* __restrict__ X0, const double* __restrict__ U,
+                                                      double* __restrict__ lag_io, double* __restrict__ traj,
+                                                      int64_t stride, double* __restrict__ XT) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    double x[NX];
+    load_row<NX>(X0 + b * NX, x);
+    LagBank lag;
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        if (lag_io) load_row<24>(lag_io + b * 24, &lag.x[0][0]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+        }
+    }
+    const int64_t rows = traj ? T / stride + 1 : 0;
+    double* tp = nullptr;       // next trajectory row of this lane
+    int64_t tstep = 0;          // distance between rows
+    if (traj) {
+        if constexpr (LAYOUT == LAYOUT_BTU) { tp = traj + b * rows * NX; tstep = NX; store_row<NX>(tp, x); }
+        else { tp = traj + b; tstep = (int64_t)NX * B; store_soa<NX>(tp, B, x); }
+        tp += tstep;
+    }
+    const double* up;
+    int64_t ustep;
+    if constexpr (LAYOUT == LAYOUT_BTU) { up = U + b * T * NU; ustep = NU; }
+    else { up = U + b; ustep = (int64_t)NU * B; }
+
+    double un[NU];
+    if (T > 0) {
+        if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un); else load_soa<NU>(up, B, un);
+    }
+    int64_t countdown = stride;
+    for (int64_t t = 0; t < T; ++t) {
+        double u[NU];
+#pragma unroll
+        for (int i = 0; i < NU; ++i) u[i] = un[i];
+        if (t + 1 < T) {  // prefetch the next control row while this step computes
+            const double* nx_ = up + (t + 1) * ustep;
+            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(nx_, un); else load_soa<NU>(nx_, B, un);
+        }
+        integrate_step<MODEL, INTEG, LAGMODE>(p, dt, x, u, lag);
+        if (traj && --countdown == 0) {
+            countdown = stride;
+            if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x); else store_soa<NX>(tp, B, x);
+            tp += tstep;
+        }
+    }
+    if (XT) store_row<NX>(XT + b * NX, x);
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        if (lag_io) store_row<24>(lag_io + b * 24, &lag.x[0][0]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: sliding-window endpoint error (multistep_rmse_endpoint_physics,
+// training/train_tank_brov2_full_comparison.py:469-487).  Quirk Q2: the reference uses ONE
+// vehicle object for all windows, so window k starts from the lag state window k-1 left.
+// The lag bank is LTI and driven by the commands only, so:
+//   (A) zero-state response b_k of each window (parallel over windows),
+//   (B) x_{k+1} = Phi x_k + b_k, Phi = Ad^(samples per window)  (sequential, 8 lanes, 9 FMA/iter),
+//   (C) every window is an independent lane starting from its own x_k.
+// ---------------------------------------------------------------------------------------
+template <int NSUB>
+__global__ void __launch_bounds__(256) window_lag_response_kernel(DevParams p, int64_t nwin, int64_t H,
+                                                                  const double* __restrict__ U, double* __restrict__ resp) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nwin) return;
+    LagBank lag;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+    for (int64_t t = 0; t < H; ++t) {
+        double u[8], fcmd[8];
+        load_row<8>(U + (k + t) * 8, u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) fcmd[i] = thrust_poly(p, u[i]);
+        lag.advance(p, NSUB, fcmd);
+    }
+    store_row<24>(resp + k * 24, &lag.x[0][0]);
+}
+
+// start[k] = lag state at the beginning of window k; start[0] = lag0 (zeros in the reference).
+__global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const double* __restrict__ Phi9,
+                                                             const double* __restrict__ resp, double* __restrict__ start) {
+    const int i = threadIdx.x;  // thruster
+    if (i >= 8) return;
+    double P[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) P[j] = Phi9[j];
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    const double* r = resp + i * 3;
+    double* s = start + i * 3;
+    double b0 = 0, b1 = 0, b2 = 0;
+    if (nwin > 0) { b0 = r[0]; b1 = r[1]; b2 = r[2]; }
+    for (int64_t k = 0; k < nwin; ++k) {
+        s[k * 24 + 0] = x0; s[k * 24 + 1] = x1; s[k * 24 + 2] = x2;
+        double c0 = b0, c1 = b1, c2 = b2;
+        if (k + 1 < nwin) { b0 = r[(k + 1) * 24 + 0]; b1 = r[(k + 1) * 24 + 1]; b2 = r[(k + 1) * 24 + 2]; }
+        const double n0 = fma(P[2], x2, fma(P[1], x1, fma(P[0], x0, c0)));
+        const double n1 = fma(P[5], x2, fma(P[4], x1, fma(P[3], x0, c1)));
+        const double n2 = fma(P[8], x2, fma(P[7], x1, fma(P[6], x0, c2)));
+        x0 = n0; x1 = n1; x2 = n2;
+    }
+}
+
+template <int MODEL, int INTEG>
+__global__ void __launch_bounds__(256) window_endpoint_kernel(DevParams p, int64_t nwin, int64_t H, double dt,
+                                                              const double* __restrict__ X, const double* __restrict__ U,
+                                                              const double* __restrict__ lag_start, double* __restrict__ se) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= nwin) return;
+    double x[NX];
+    load_row<NX>(X + k * NX, x);
+    LagBank lag;
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        if (lag_start) load_row<24>(lag_start + k * 24, &lag.x[0][0]);
+        else {
+#pragma unroll
+            for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+        }
+    }
+    for (int64_t t = 0; t < H; ++t) {
+        double u[NU];
+        load_row<NU>(U + (k + t) * NU, u);   // lane k reads row k+t: coalesced across the wave
+        integrate_step<MODEL, INTEG, 0>(p, dt, x, u, lag);
+    }
+    double ref[NX], e = 0.0;
+    load_row<NX>(X + (k + H) * NX, ref);
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { const double d = x[i] - ref[i]; e = fma(d, d, e); }
+    se[k] = e;
+}
+
+// Deterministic sum of n doubles: fixed-shape tree, one block.  out[0] = sum.
+__global__ void __launch_bounds__(1024) sum_kernel(int64_t n, const double* __restrict__ v, double* __restrict__ out) {
+    __shared__ double sh[1024];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 1024) a += v[i];
+    sh[threadIdx.x] = a;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) sh[threadIdx.x] += sh[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// ---------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------
+hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out) {
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, n, v, out);
+    return hipGetLastError();
+}
+static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) / bs); }
+
+#define BROV_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
+
+template <int MODEL>
+static hipError_t launch_rhs_m(hipStream_t st, const DevParams& p, int64_t B, const double* x, const double* u, double* lag, double* xd) {
+    hipLaunchKernelGGL(rhs_kernel<MODEL>, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, x, u, lag, xd);
+    return hipGetLastError();
+}
+hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u, double* lag, double* xd) {
+    if (B <= 0) return hipSuccess;
+    switch (model) {
+        case MODEL_THRUSTER_EULER: return launch_rhs_m<MODEL_THRUSTER_EULER>(st, p, B, x, u, lag, xd);
+        case MODEL_WRENCH_EULER: return launch_rhs_m<MODEL_WRENCH_EULER>(st, p, B, x, u, lag, xd);
+        default: return launch_rhs_m<MODEL_WRENCH_QUAT>(st, p, B, x, u, lag, xd);
+    }
+}
+hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau) {
+    if (B <= 0) return hipSuccess;
+    hipLaunchKernelGGL(thruster_forces_kernel, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, u, lag, tau);
+    return hipGetLastError();
+}
+
+template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
+static hipError_t launch_rollout_t(hipStream_t st, const DevParams& p, int64_t B, int64_t T, double dt, const double* x0,
+                                   const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+    hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                       p, B, T, dt, x0, U, lag, traj, stride, xT);
+    return hipGetLastError();
+}
+template <int MODEL, int INTEG, int LAYOUT>
+static hipError_t launch_rollout_l(hipStream_t st, const DevParams& p, int lag_mode, int64_t B, int64_t T, double dt,
+                                   const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+    if constexpr (MODEL == MODEL_THRUSTER_EULER && INTEG == INTEG_RK4) {
+        if (lag_mode == 1) return launch_rollout_t<MODEL, INTEG, LAYOUT, 1>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
+    }
+    return launch_rollout_t<MODEL, INTEG, LAYOUT, 0>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
+}
+template <int MODEL>
+static hipError_t launch_rollout_m(hipStream_t st, const DevParams& p, int integ, int lag_mode, int layout, int64_t B, int64_t T,
+                                   double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+    if (integ == INTEG_EULER) {
+        if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+        return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+    }
+    if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+    return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+}
+hipError_t launch_rollout(hipStream_t st, const DevParams& p, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T,
+                          double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+    if (B <= 0) return hipSuccess;
+    switch (model) {
+        case MODEL_THRUSTER_EULER: return launch_rollout_m<MODEL_THRUSTER_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
+        case MODEL_WRENCH_EULER: return launch_rollout_m<MODEL_WRENCH_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
+        default: return launch_rollout_m<MODEL_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
+    }
+}
+
+template <int MODEL, int INTEG>
+static hipError_t launch_window_t(hipStream_t st, const DevParams& p, int64_t nwin, int64_t H, double dt, const double* X,
+                                  const double* U, const double* lag_start, double* se) {
+    hipLaunchKernelGGL((window_endpoint_kernel<MODEL, INTEG>), dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, dt, X, U, lag_start, se);
+    return hipGetLastError();
+}
+// scratch: resp [nwin][24], start [nwin][24], phi [9] (device) -- only used for the thruster model with carry_lag
+hipError_t launch_window_endpoint(hipStream_t st, const DevParams& p, int model, int integ, int64_t N, int64_t H, double dt,
+                                  const double* X, const double* U, int carry_lag, const double* d_phi9,
+                                  double* d_resp, double* d_start, double* d_se, double* d_total) {
+    const int64_t nwin = N - H;
+    if (nwin <= 0) return hipSuccess;
+    const double* lag_start = nullptr;
+    if (model == MODEL_THRUSTER_EULER && carry_lag) {
+        if (integ == INTEG_RK4)
+            hipLaunchKernelGGL(window_lag_response_kernel<4>, dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, U, d_resp);
+        else
+            hipLaunchKernelGGL(window_lag_response_kernel<1>, dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, U, d_resp);
+        BROV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(window_lag_scan_kernel, dim3(1), dim3(64), 0, st, nwin, d_phi9, d_resp, d_start);
+        BROV_LAUNCH_CHECK();
+        lag_start = d_start;
+    }
+    hipError_t e;
+    if (model == MODEL_THRUSTER_EULER)
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_THRUSTER_EULER, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_THRUSTER_EULER, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    else if (model == MODEL_WRENCH_EULER)
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_WRENCH_EULER, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_WRENCH_EULER, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    else
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_WRENCH_QUAT, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_WRENCH_QUAT, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, nwin, d_se, d_total);
+    return hipGetLastError();
+}
+
+}  // namespace brov

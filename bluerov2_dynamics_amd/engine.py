@@ -1,0 +1,244 @@
+"""Batched API over libbrov2.so: RHS, rollouts, sliding-window endpoint RMSE, EDMDc lift / Gram.
+
+Host path  : NumPy arrays in / out (the library stages them through HBM).
+Device path: torch CUDA tensors (fp64, contiguous) -- only their data_ptr() and the current
+             torch stream cross the C ABI; results stay in HBM.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TUB, THRUSTER_EULER, WRENCH_EULER,
+                   WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
+
+__all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "multistep_se", "simulate_lifted"]
+
+INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
+LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB}
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _dptr(t):
+    """device pointer of a contiguous fp64 CUDA tensor (or None)."""
+    if t is None:
+        return None
+    import torch
+    assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "need a contiguous fp64 CUDA tensor"
+    return t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------ host path
+def rhs(model, x, u, dt=0.02, lag=None, ctx=None):
+    """Batched dynamics().  Returns (xdot [B,nx], lag_after [B,8,3] or None)."""
+    ctx = ctx or default_context()
+    x = as_f64(x).reshape(-1, NX[model])
+    u = as_f64(u).reshape(-1, NU[model])
+    B = x.shape[0]
+    assert u.shape[0] == B
+    out = np.empty_like(x)
+    lag_io = None
+    if model == THRUSTER_EULER:
+        lag_io = np.zeros((B, 8, 3)) if lag is None else as_f64(lag).reshape(B, 8, 3).copy()
+    ctx.check(ctx.lib.brov_rhs(ctx.h, model, B, _hptr(x), _hptr(u), float(dt), _hptr(lag_io), _hptr(out)), "brov_rhs")
+    return out, lag_io
+
+
+def thruster_forces(u, dt=0.02, lag=None, ctx=None):
+    """Batched compute_thruster_forces().  Returns (tau [B,6], lag_after [B,8,3])."""
+    ctx = ctx or default_context()
+    u = as_f64(u).reshape(-1, 8)
+    B = u.shape[0]
+    lag_io = np.zeros((B, 8, 3)) if lag is None else as_f64(lag).reshape(B, 8, 3).copy()
+    tau = np.empty((B, 6))
+    ctx.check(ctx.lib.brov_thruster_forces(ctx.h, B, _hptr(u), float(dt), _hptr(lag_io), _hptr(tau)), "brov_thruster_forces")
+    return tau, lag_io
+
+
+def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layout="btu", stride=1, store=True, ctx=None):
+    """simulate_physics over a batch (host arrays).
+
+    x0 [B,nx]; U [B,T,nu] (layout "btu") or [T,nu,B] ("tub").
+    Returns dict(traj, xT [B,nx], lag [B,8,3] | None); traj is [B,T//stride+1,nx] or [T//stride+1,nx,B]."""
+    ctx = ctx or default_context()
+    integ, lay = INTEGRATORS[integrator], LAYOUTS[layout]
+    nx, nu = NX[model], NU[model]
+    U = as_f64(U)
+    if lay == LAYOUT_BTU:
+        B, T, nu_ = U.shape
+    else:
+        T, nu_, B = U.shape
+    assert nu_ == nu, f"U has {nu_} channels, model needs {nu}"
+    x0 = as_f64(x0).reshape(B, nx)
+    lag_io = None
+    if model == THRUSTER_EULER:
+        lag_io = np.zeros((B, 8, 3)) if lag is None else as_f64(lag).reshape(B, 8, 3).copy()
+    rows = T // stride + 1
+    traj = None
+    if store:
+        traj = np.empty((B, rows, nx) if lay == LAYOUT_BTU else (rows, nx, B))
+    xT = np.empty((B, nx))
+    ctx.check(ctx.lib.brov_rollout(ctx.h, model, integ, lag_mode, lay, B, T, float(dt), _hptr(x0), _hptr(U), _hptr(lag_io),
+                                   _hptr(traj), int(stride), _hptr(xT)), "brov_rollout")
+    return dict(traj=traj, xT=xT, lag=lag_io)
+
+
+def window_endpoint_se(model, integrator, X, U, H, dt, carry_lag=True, ctx=None):
+    """Sum of squared endpoint errors over all sliding windows; returns (se_total, per_window[N-H])."""
+    ctx = ctx or default_context()
+    X = as_f64(X).reshape(-1, NX[model])
+    U = as_f64(U).reshape(-1, NU[model])
+    N = X.shape[0]
+    assert U.shape[0] >= N, "U must be aligned with X"
+    per = np.zeros(max(N - H, 0))
+    se = ctypes.c_double(0.0)
+    ctx.check(ctx.lib.brov_window_endpoint_se(ctx.h, model, INTEGRATORS[integrator], N, int(H), float(dt), _hptr(X), _hptr(U),
+                                              int(bool(carry_lag)), ctypes.addressof(se), _hptr(per) if len(per) else None),
+              "brov_window_endpoint_se")
+    return se.value, per
+
+
+def window_rmse(model, integrator, X, U, H, dt, carry_lag=True, ctx=None):
+    """multistep_rmse_endpoint_physics (training/train_tank_brov2_full_comparison.py:469-487)."""
+    X = np.asarray(X)
+    n_start = len(X) - H
+    if n_start <= 0:
+        return float("nan")
+    se, _ = window_endpoint_se(model, integrator, X, U, H, dt, carry_lag, ctx)
+    return float(np.sqrt(se / (n_start * NX[model])))
+
+
+# ------------------------------------------------------------------------------------------ device path
+def rollout_dev(model, integrator, x0, U, dt, lag=None, traj=None, xT=None, lag_mode=LAG_PER_CALL, layout="tub", stride=1,
+                ctx=None):
+    """Asynchronous rollout on torch CUDA tensors (no copies).  Shapes as in rollout(); traj / xT / lag are
+    written in place when given."""
+    ctx = ctx or default_context(x0.device.index)
+    ctx.use_torch_stream()
+    lay = LAYOUTS[layout]
+    nu = NU[model]
+    if lay == LAYOUT_BTU:
+        B, T, nu_ = U.shape
+    else:
+        T, nu_, B = U.shape
+    assert nu_ == nu and tuple(x0.shape) == (B, NX[model])
+    if traj is not None:
+        rows = T // stride + 1
+        want = (B, rows, NX[model]) if lay == LAYOUT_BTU else (rows, NX[model], B)
+        assert tuple(traj.shape) == want, f"traj shape {tuple(traj.shape)} != {want}"
+    ctx.check(ctx.lib.brov_rollout_dev(ctx.h, model, INTEGRATORS[integrator], lag_mode, lay, B, T, float(dt), _dptr(x0), _dptr(U),
+                                       _dptr(lag), _dptr(traj), int(stride), _dptr(xT)), "brov_rollout_dev")
+
+
+def fill_controls_dev(U, layout, dist="iid", seed=0x5EED, b0=0, T_total=None, scale=None, ctx=None):
+    """Fill a torch CUDA tensor U ([B,T,nu] or [T,nu,B]) with the synthetic control stream."""
+    ctx = ctx or default_context(U.device.index)
+    ctx.use_torch_stream()
+    lay = LAYOUTS[layout]
+    if lay == LAYOUT_BTU:
+        B, T, nu = U.shape
+    else:
+        T, nu, B = U.shape
+    d = {"iid": DIST_IID_UNIFORM, "ar1": DIST_AR1}[dist]
+    sc = None if scale is None else as_f64(scale).reshape(nu)
+    ctx.check(ctx.lib.brov_fill_controls_dev(ctx.h, lay, d, B, T, nu, ctypes.c_uint64(seed), int(b0), int(T_total or T),
+                                             _hptr(sc), _dptr(U)), "brov_fill_controls_dev")
+
+
+def window_endpoint_se_dev(model, integrator, X, U, H, dt, se_total, per_window, carry_lag=True, ctx=None):
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    N = X.shape[0]
+    ctx.check(ctx.lib.brov_window_endpoint_se_dev(ctx.h, model, INTEGRATORS[integrator], N, int(H), float(dt), _dptr(X), _dptr(U),
+                                                  int(bool(carry_lag)), _dptr(se_total), _dptr(per_window)),
+              "brov_window_endpoint_se_dev")
+
+
+# ------------------------------------------------------------------------------------------ EDMDc
+def lift(X, C, gamma, ctx=None):
+    """phi(X) = [X, rbf(X)]  (KoopmanEDMDc._lift); X [N,n] -> [N,n+k]."""
+    ctx = ctx or default_context()
+    X = as_f64(X)
+    C = as_f64(C)
+    N, n = X.shape
+    k = C.shape[0]
+    Z = np.empty((N, n + k))
+    ctx.check(ctx.lib.edmdc_lift(ctx.h, N, n, k, float(gamma), _hptr(X), _hptr(C), _hptr(Z)), "edmdc_lift")
+    return Z
+
+
+def gram(X_list, U_list, C, gamma, ctx=None):
+    """G^T G [p,p] and G^T Y [p,d] over bags (no cross-bag pairs) -- fit / fit_multi normal equations."""
+    ctx = ctx or default_context()
+    C = as_f64(C)
+    k, n = C.shape
+    r = np.asarray(U_list[0]).shape[1]
+    d, p = n + k, n + k + r
+    GtG = np.zeros((p, p))
+    GtY = np.zeros((p, d))
+    npairs = 0
+    acc = 0
+    for X, U in zip(X_list, U_list):
+        if len(X) < 2:
+            continue
+        X = as_f64(X)
+        U = as_f64(U)[: len(X) - 1]
+        L = len(X) - 1
+        ctx.check(ctx.lib.edmdc_gram(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(np.ascontiguousarray(U)),
+                                     acc, _hptr(GtG), _hptr(GtY)), "edmdc_gram")
+        acc = 1
+        npairs += L
+    return GtG, GtY, npairs
+
+
+def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, accumulate=False, ctx=None):
+    """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h)."""
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
+    ctx.check(ctx.lib.edmdc_gram_dev(ctx.h, n, r, k, float(gamma), _dptr(C), int(nbags), int(L), int(x_bag_stride), int(u_bag_stride),
+                                     _dptr(X), _dptr(U), int(bool(accumulate)), _dptr(GtG), _dptr(GtY)), "edmdc_gram_dev")
+
+
+def solve_AB(GtG, GtY, ridge, d):
+    """Host solve of the ridge normal equations exactly as the reference does it
+    (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
+    M = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0])) @ GtY
+    M = M.T
+    return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
+
+
+def multistep_se(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
+    """H-step lifted propagation + endpoint squared error (KoopmanEDMDc.multistep_rmse / evaluate)."""
+    ctx = ctx or default_context()
+    X = as_f64(X)
+    U = as_f64(U)
+    C = as_f64(C)
+    A = as_f64(A)
+    B = as_f64(B)
+    N, n = X.shape
+    k, r = C.shape[0], U.shape[1]
+    ns = N - H
+    xhat = np.empty((max(ns, 0), n)) if want_xhat else None
+    se = ctypes.c_double(0.0)
+    ctx.check(ctx.lib.edmdc_multistep_se(ctx.h, n, r, k, float(gamma), _hptr(C), _hptr(A), _hptr(B), N, int(H), _hptr(X), _hptr(U),
+                                         ctypes.addressof(se), _hptr(xhat)), "edmdc_multistep_se")
+    return se.value, xhat
+
+
+def simulate_lifted(x0, U_seq, C, gamma, A, B, ctx=None):
+    """KoopmanEDMDc.simulate, batched: x0 [nb,n], U_seq [nb,T,r] -> [nb,T+1,n]."""
+    ctx = ctx or default_context()
+    x0 = as_f64(x0)
+    U_seq = as_f64(U_seq)
+    nb, n = x0.shape
+    T, r = U_seq.shape[1], U_seq.shape[2]
+    C = as_f64(C)
+    out = np.empty((nb, T + 1, n))
+    ctx.check(ctx.lib.edmdc_simulate(ctx.h, n, r, C.shape[0], float(gamma), _hptr(C), _hptr(as_f64(A)), _hptr(as_f64(B)), nb, T,
+                                     _hptr(x0), _hptr(U_seq), _hptr(out)), "edmdc_simulate")
+    return out

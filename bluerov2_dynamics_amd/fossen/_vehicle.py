@@ -1,0 +1,88 @@
+"""Shared host-side plumbing of the three drop-in vehicle classes: parameter struct <-> attributes,
+one brov_ctx per object, batched helpers."""
+import os
+
+import numpy as np
+
+from .. import _lib, engine
+
+_ATTR6 = ("Xu_dot", "Yv_dot", "Zw_dot", "Kp_dot", "Mq_dot", "Nr_dot")
+_LIN6 = ("Xu", "Yv", "Zw", "Kp", "Mq", "Nr")
+
+
+class VehicleBase:
+    """Holds the vehicle constants as plain attributes (same names as the reference objects,
+    fossen/BlueROV2.py:81-140) and mirrors them into the device context before each call."""
+    MODEL = None
+
+    def _init_common(self, rho, current_speed, device=None):
+        if device is None:
+            device = int(os.environ.get("BROV2_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        self._ctx = _lib.Context(device)
+        p = self._ctx.get_params()
+        self.rho = rho
+        self.g, self.m, self.volume = p.g, p.m, p.volume
+        self.W = self.m * self.g
+        self.B = self.rho * self.g * self.volume
+        self.xg = self.yg = self.zg = 0.0
+        self.xb, self.yb, self.zb = p.xb, p.yb, p.zb
+        self.Ix, self.Iy, self.Iz = p.Ix, p.Iy, p.Iz
+        for i, (a, l) in enumerate(zip(_ATTR6, _LIN6)):
+            setattr(self, a, p.added_mass[i])
+            setattr(self, l, p.lin_damp[i])
+            setattr(self, l + "_abs", p.quad_damp[i])
+        self.MRB = np.diag([self.m, self.m, self.m, self.Ix, self.Iy, self.Iz]).astype(float)
+        self.MA = np.diag([-getattr(self, a) for a in _ATTR6]).astype(float)
+        self.M = self.MRB + self.MA
+        self.Minv = np.linalg.inv(self.M)
+        self.current_speed = current_speed
+        self._pushed = None
+        self._params = p
+
+    def _sync_params(self):
+        """Push attribute values that differ from what the device context holds."""
+        cur = np.zeros(3) if self.current_speed is None else np.asarray(self.current_speed, dtype=float).reshape(3)
+        key = (float(self.rho), float(self.m), float(self.g), float(self.volume), float(self.zb), tuple(cur),
+               tuple(float(getattr(self, a)) for a in _ATTR6),
+               tuple(float(getattr(self, l)) for l in _LIN6), tuple(float(getattr(self, l + "_abs")) for l in _LIN6),
+               float(self.Ix), float(self.Iy), float(self.Iz), float(self.xb), float(self.yb))
+        if key == self._pushed:
+            return
+        p = self._params
+        p.rho, p.m, p.g, p.volume = self.rho, self.m, self.g, self.volume
+        p.xb, p.yb, p.zb = self.xb, self.yb, self.zb
+        p.Ix, p.Iy, p.Iz = self.Ix, self.Iy, self.Iz
+        for i, (a, l) in enumerate(zip(_ATTR6, _LIN6)):
+            p.added_mass[i] = getattr(self, a)
+            p.lin_damp[i] = getattr(self, l)
+            p.quad_damp[i] = getattr(self, l + "_abs")
+        for i in range(3):
+            p.current[i] = cur[i]
+        self._push_extra(p)
+        self._ctx.set_params(p)
+        self._pushed = key
+
+    def _push_extra(self, p):
+        pass
+
+    # ---- batched API (new; the reference only has the scalar dynamics()) --------------------
+    def rollout(self, x0, U, dt, integrator="euler", lag=None, stride=1, lag_mode=_lib.LAG_PER_CALL):
+        """simulate_physics for a batch: x0 [B,nx], U [B,T,nu] -> dict(traj [B,T//stride+1,nx], xT, lag)."""
+        self._sync_params()
+        return engine.rollout(self.MODEL, integrator, x0, U, dt, lag=lag, lag_mode=lag_mode, stride=stride, ctx=self._ctx)
+
+    def simulate(self, x0, U_seq, dt, integrator="euler"):
+        """One trajectory, the reference's simulate_physics signature: returns (len(U_seq)+1, nx).
+        Starts from this object's current thruster-lag state and leaves it advanced, like the reference."""
+        self._sync_params()
+        lag = getattr(self, "_lag", None)
+        r = engine.rollout(self.MODEL, integrator, np.asarray(x0, float)[None], np.asarray(U_seq, float)[None], dt,
+                           lag=None if lag is None else lag[None], ctx=self._ctx)
+        if lag is not None:
+            self._lag[...] = r["lag"][0]
+        return r["traj"][0]
+
+    def multistep_rmse_endpoint(self, X, U, H, dt, integrator="euler", carry_lag=True):
+        """multistep_rmse_endpoint_physics (training/train_tank_brov2_full_comparison.py:469-487)."""
+        self._sync_params()
+        return engine.window_rmse(self.MODEL, integrator, X, U, H, dt, carry_lag=carry_lag, ctx=self._ctx)

@@ -1,0 +1,196 @@
+/*
+ * brov2.h -- C ABI of libbrov2.so: MI355X (gfx950) batched BlueROV2 Fossen dynamics
+ * rollouts and Koopman-EDMDc lift / Gram build.
+ *
+ * The reference (ViktorNfa/bluerov2_dynamics) is pure Python and has no FFI layer; its
+ * boundary for this path is the Python object API that training scripts import.  Each
+ * entry point below names the reference interface it stands behind (paths relative to the
+ * reference checkout).  The Python classes in bluerov2_dynamics_amd/{fossen,Koopman}/ keep
+ * the reference's names/signatures and call these functions through ctypes
+ * (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *   - every array is IEEE fp64, C-contiguous; sizes are element counts, not bytes;
+ *   - functions return BROV_OK (0) or a negative brov_status; brov_last_error(ctx) gives
+ *     a message owned by the ctx.  Nothing aborts, NaN/inf propagate like in the reference;
+ *   - a ctx is bound to one device, is not thread-safe, and launches on one HIP stream
+ *     (brov_set_stream; default: the null stream);
+ *   - "_dev" functions take DEVICE pointers and are asynchronous on the ctx stream;
+ *     the others take HOST pointers, copy in/out and return when the result is on the host.
+ *
+ * Models (brov_model):
+ *   BROV_THRUSTER_EULER  nx=12 [x y z phi theta psi u v w p q r], nu=8 thruster commands
+ *                        in [-1,1], 8x3 thruster-lag state   (fossen/BlueROV2.py)
+ *   BROV_WRENCH_EULER    nx=12, nu=6 body wrench, no lag       (fossen/BlueROV2_thrust.py)
+ *   BROV_WRENCH_QUAT     nx=13 [x y z qw qx qy qz u v w p q r], nu=6; the quaternion is
+ *                        re-normalised after every integrator step (fossen/BlueROV2_wrench.py,
+ *                        training/train_tank_brov2_wrench_quat.py:258-263)
+ */
+#ifndef BROV2_H
+#define BROV2_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BROV2_ABI_VERSION 1
+
+#if defined(BROV2_BUILDING)
+#define BROV_API __attribute__((visibility("default")))
+#else
+#define BROV_API
+#endif
+
+typedef struct brov_ctx brov_ctx;
+
+typedef enum brov_status {
+    BROV_OK = 0,
+    BROV_ERR_ARG = -1,     /* bad argument (NULL, negative size, unknown enum) */
+    BROV_ERR_HIP = -2,     /* a HIP runtime call failed (message has hipGetErrorString) */
+    BROV_ERR_NOMEM = -3,   /* device or host allocation failed */
+    BROV_ERR_NODEVICE = -4 /* no gfx950 device visible */
+} brov_status;
+
+typedef enum brov_model { BROV_THRUSTER_EULER = 0, BROV_WRENCH_EULER = 1, BROV_WRENCH_QUAT = 2 } brov_model;
+typedef enum brov_integrator { BROV_EULER = 0, BROV_RK4 = 1 } brov_integrator;
+/* PER_CALL = the reference: the lag filters advance on every dynamics() call, i.e. 4x per RK4
+ * step (training/train_tank_brov2_rk4.py:386-391 calling fossen/BlueROV2.py:258).
+ * PER_STEP = lag advanced once per step, thrust frozen over the RK4 stages (not the reference). */
+typedef enum brov_lag_mode { BROV_LAG_PER_CALL = 0, BROV_LAG_PER_STEP = 1 } brov_lag_mode;
+/* BTU: U[B][T][nu], traj[B][T/stride+1][nx]  (what the reference's callers hold, row-major)
+ * TUB: U[T][nu][B], traj[T/stride+1][nx][B]  (time-major struct-of-arrays, device native) */
+typedef enum brov_layout { BROV_LAYOUT_BTU = 0, BROV_LAYOUT_TUB = 1 } brov_layout;
+typedef enum brov_dist { BROV_DIST_IID_UNIFORM = 0, BROV_DIST_AR1 = 1 } brov_dist;
+
+/* Vehicle parameters; brov_default_params() fills the reference's values
+ * (fossen/BlueROV2.py:79-140,172-232,245-257,476-480). Signs follow the reference's attributes. */
+typedef struct brov_params {
+    double rho, g, m, volume;
+    double xb, yb, zb;          /* centre of buoyancy (CG at origin) */
+    double Ix, Iy, Iz;
+    double added_mass[6];       /* Xu_dot Yv_dot Zw_dot Kp_dot Mq_dot Nr_dot (negative) */
+    double lin_damp[6];         /* Xu Yv Zw Kp Mq Nr (negative or -0.0) */
+    double quad_damp[6];        /* Xu_abs ... Nr_abs (negative) */
+    double current[3];          /* NED current speed, default 0 */
+    double thr_r[8][3];         /* thruster positions (body) */
+    double thr_dir[8][3];       /* thruster directions (body) */
+    double thrust_poly[5];      /* F_cmd = c0 V + c1 V^3 + c2 V^5 + c3 V^7 + c4 V^9 */
+    double lag_Ac[9], lag_Bc[3], lag_Cc[3]; /* continuous thruster lag (row-major) */
+} brov_params;
+
+/* ---- context ------------------------------------------------------------------------- */
+BROV_API int brov_abi_version(void);
+BROV_API int brov_create(int device_id, brov_ctx** out);
+BROV_API void brov_destroy(brov_ctx* ctx);
+BROV_API const char* brov_last_error(const brov_ctx* ctx);
+BROV_API int brov_set_stream(brov_ctx* ctx, void* hip_stream);     /* hipStream_t; NULL = null stream */
+BROV_API int brov_sync(brov_ctx* ctx);                             /* hipStreamSynchronize(ctx stream) */
+/* HIP-event timing of the kernels launched by the most recent call on this ctx
+ * (sum over its launches, ms).  Enable first; reading waits for the stop event. */
+BROV_API int brov_set_timing(brov_ctx* ctx, int enabled);
+BROV_API int brov_last_kernel_ms(brov_ctx* ctx, float* ms);
+
+/* ---- parameters  (replaces BlueROV2.__init__, fossen/BlueROV2.py:79-157) -------------- */
+BROV_API void brov_default_params(brov_params* p);
+BROV_API int brov_set_params(brov_ctx* ctx, const brov_params* p);
+BROV_API int brov_get_params(const brov_ctx* ctx, brov_params* p);
+/* Minv diagonal (6) and the 6x8 allocation matrix tau = T F  (fossen/BlueROV2.py:126,265-278).
+ * Host only; p = NULL means the default parameters. */
+BROV_API int brov_get_derived(const brov_params* p, double Minv6[6], double alloc6x8[48]);
+/* ZOH discretisation of the thruster lag: replaces ThrusterLag._discretise
+ * (fossen/BlueROV2.py:490-496 -> scipy.signal.cont2discrete(method="zoh")).  Host only. */
+BROV_API int brov_discretise_lag(const brov_params* p, double dt, double Ad[9], double Bd[3]);
+
+BROV_API int brov_model_nx(int model);
+BROV_API int brov_model_nu(int model);
+
+/* ---- device memory helpers (so that callers need no HIP/torch of their own) ----------- */
+BROV_API int brov_malloc(brov_ctx* ctx, size_t bytes, void** dptr);
+BROV_API int brov_free(brov_ctx* ctx, void* dptr);
+BROV_API int brov_memcpy_h2d(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
+BROV_API int brov_memcpy_d2h(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
+BROV_API int brov_memset(brov_ctx* ctx, void* dst, int value, size_t bytes);
+
+/* ---- Fossen RHS / rollouts ------------------------------------------------------------ */
+/* Batched dynamics(): xdot[b] = f(x[b], u[b]).  Replaces BlueROV2.dynamics
+ * (fossen/BlueROV2.py:357-400, BlueROV2_thrust.py:235-282, BlueROV2_wrench.py:322-367).
+ * lag_io [B][8][3] is advanced one sample in place (thruster model; the reference's side
+ * effect on self.thruster_lags); NULL = zero lag state, not returned. */
+BROV_API int brov_rhs(brov_ctx* ctx, int model, int64_t B, const double* x, const double* u, double dt,
+             double* lag_io, double* xdot);
+/* Replaces BlueROV2.compute_thruster_forces (fossen/BlueROV2.py:265-278): tau [B][6]. */
+BROV_API int brov_thruster_forces(brov_ctx* ctx, int64_t B, const double* u, double dt, double* lag_io, double* tau);
+
+/* simulate_physics over a batch: training/train_tank_brov2_full_comparison.py:453-466 (Euler),
+ * training/train_tank_brov2_rk4.py:375-396 (RK4), ..._wrench_quat.py:249-266 (quaternion).
+ * x0 [B][nx]; U and traj per `layout`; lag_io [B][8][3] in/out or NULL (zero start);
+ * traj holds every traj_stride-th state including x0 (T/stride+1 states) or is NULL;
+ * xT [B][nx] (final state) or NULL. */
+BROV_API int brov_rollout(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
+                 int64_t B, int64_t T, double dt, const double* x0, const double* U,
+                 double* lag_io, double* traj, int64_t traj_stride, double* xT);
+BROV_API int brov_rollout_dev(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
+                     int64_t B, int64_t T, double dt, const double* d_x0, const double* d_U,
+                     double* d_lag_io, double* d_traj, int64_t traj_stride, double* d_xT);
+
+/* multistep_rmse_endpoint_physics: training/train_tank_brov2_full_comparison.py:469-487,
+ * ..._rk4.py:399-417, ..._wrench_comp.py, ..._wrench_quat.py:279-297.
+ * X [N][nx], U [N][nu]; windows k = 0..N-H-1 start at X[k], apply U[k..k+H-1], and are scored
+ * against X[k+H].  carry_lag=1 is the reference: ONE vehicle object serves all windows, so the
+ * thruster-lag state left by window k-1 is the initial lag state of window k.
+ * se_total = sum_k |x_end - X[k+H]|^2 ; per_window [N-H] optional (NULL).
+ * rmse = sqrt(se_total / ((N-H) * nx)). */
+BROV_API int brov_window_endpoint_se(brov_ctx* ctx, int model, int integrator, int64_t N, int64_t H, double dt,
+                            const double* X, const double* U, int carry_lag,
+                            double* se_total, double* per_window);
+BROV_API int brov_window_endpoint_se_dev(brov_ctx* ctx, int model, int integrator, int64_t N, int64_t H, double dt,
+                                const double* d_X, const double* d_U, int carry_lag,
+                                double* d_se_total, double* d_per_window /* [N-H], required */);
+
+/* Synthetic control sequences on device (benchmarks):
+ * counter-based splitmix64 stream, value for (trajectory b0+b, step t, channel j) independent
+ * of layout and of how trajectories are sharded.  scale[nu] multiplies each channel (NULL = 1). */
+BROV_API int brov_fill_controls_dev(brov_ctx* ctx, int layout, int dist, int64_t B, int64_t T, int nu,
+                           uint64_t seed, int64_t b0, int64_t T_total, const double* scale_host,
+                           double* d_U);
+
+/* ---- Koopman EDMDc --------------------------------------------------------------------- */
+/* phi(x) = [x, exp(-gamma(|x|^2 + |c|^2 - 2 x.c))]: KoopmanEDMDc._lift / _rbf_mat
+ * (Koopman/koopmanEDMDc.py:41-48,221-236).  X [N][n], C [k][n] -> Z [N][n+k]. */
+BROV_API int edmdc_lift(brov_ctx* ctx, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z);
+
+/* Normal-equation blocks of fit / fit_multi (Koopman/koopmanEDMDc.py:89-97,129-147):
+ *   G = [phi(x_t), u_t], Y = phi(x_{t+1});  GtG [p][p] = G^T G, GtY [p][d] = G^T Y,
+ *   d = n + k, p = d + r, feature order exactly the reference's ([x, rbf..., u]).
+ * Data: nbags trajectories ("bags"); bag b holds states X[b*x_bag_stride + t], t = 0..L,
+ * and inputs U[b*u_bag_stride + t], t = 0..L-1, i.e. L pairs per bag and no pair crosses
+ * a bag.  fit(X,U) is nbags=1, L=N-1.  accumulate=1 adds to the GtG/GtY passed in. */
+BROV_API int edmdc_gram(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+               int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
+               const double* X, const double* U, int accumulate, double* GtG, double* GtY);
+BROV_API int edmdc_gram_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
+                   int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
+                   const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY);
+/* Rows lifted per chunk by edmdc_gram* (workspace = rows * padded_width * 8 bytes). */
+BROV_API int edmdc_set_chunk_rows(brov_ctx* ctx, int64_t rows);
+
+/* H-step propagation in lifted space + endpoint squared error: KoopmanEDMDc.multistep_rmse /
+ * evaluate (Koopman/koopmanEDMDc.py:157-200).  X [N][n], U [N][r], A [d][d], B [d][r];
+ * se_total = sum over k < N-H and the n state coordinates of (X[k+H] - x_hat)^2;
+ * rmse = sqrt(se_total / ((N-H) * n)).  xhat_end [N-H][n] optional (NULL). */
+BROV_API int edmdc_multistep_se(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+                       const double* A, const double* B, int64_t N, int64_t H,
+                       const double* X, const double* U, double* se_total, double* xhat_end);
+/* KoopmanEDMDc.simulate (Koopman/koopmanEDMDc.py:202-216), batched over nb start states:
+ * x0 [nb][n], U_seq [nb][T][r] -> X_pred [nb][T+1][n]. */
+BROV_API int edmdc_simulate(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+                   const double* A, const double* B, int64_t nb, int64_t T,
+                   const double* x0, const double* U_seq, double* X_pred);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BROV2_H */

@@ -1,0 +1,356 @@
+"""GPU parity: every hot-path entry point of the C ABI (through ctypes) against the CPU oracle on
+the same inputs and against the committed golden vectors of the reference.  Needs an MI355X.
+
+Tolerances (fp64): the north star asks for <= 1e-6 relative per step vs fossen/BlueROV2.py; the
+kernels differ from the reference only by operation order / FMA contraction / device libm, so the
+tests hold them to 1e-9 (whole 5000-step trajectories) and 1e-11..1e-12 (single calls), measured as
+max |a-b| / max(1,|b|)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL_CALL = 1e-11
+TOL_TRAJ = 1e-9
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from bluerov2_dynamics_amd import engine
+    return engine
+
+
+@pytest.fixture(scope="module")
+def fc():
+    from oracle import fossen_c
+    return fossen_c
+
+
+def test_extension_is_loaded_and_device_is_gfx950():
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    ctx = _lib.default_context(0)
+    assert ctx.h
+
+
+# ------------------------------------------------------------------------------------------ RHS
+@pytest.mark.parametrize("tag", ["thr", "thr_cur"])
+def test_thruster_rhs_matches_reference_fixture(eng, tag):
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
+    g = load_golden("fossen_rhs_kat.npz")
+    X, U, dt, cur = g[f"{tag}_X"], g[f"{tag}_U"], float(g[f"{tag}_dt"]), g[f"{tag}_cur"]
+    n = X.shape[0]
+    # drop-in object, one per sample, three stateful calls (fossen/BlueROV2.py:357-400)
+    for i in list(range(6)) + [17, n - 1]:
+        rov = BlueROV2(current_speed=cur.copy())
+        for c in range(3):
+            xd = rov.dynamics(X[i], U[i], dt)
+            ref = g[f"{tag}_XDOT"][c, i]
+            tol = 1e-8 if i < 2 else TOL_CALL      # rows 0,1: theta = +-pi/2, tan ~ 1e7
+            assert rel_err(xd / np.maximum(1.0, np.abs(ref)), ref / np.maximum(1.0, np.abs(ref))) < tol, (i, c)
+            assert rel_err(np.stack([l._x for l in rov.thruster_lags]), g[f"{tag}_LAG"][c, i]) < TOL_CALL
+        rov2 = BlueROV2()
+        assert rel_err(rov2.compute_thruster_forces(U[i], dt), g[f"{tag}_TAU1"][i]) < TOL_CALL
+    # batched, with explicit lag in/out
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.Context(0)
+    p = ctx.get_params()
+    for k in range(3):
+        p.current[k] = cur[k]
+    ctx.set_params(p)
+    lag = None
+    for c in range(3):
+        xd, lag = eng.rhs(_lib.THRUSTER_EULER, X, U, dt, lag=lag, ctx=ctx)
+        ref = g[f"{tag}_XDOT"][c]
+        assert rel_err(xd[2:], ref[2:]) < TOL_CALL
+        assert rel_err(lag, g[f"{tag}_LAG"][c]) < TOL_CALL
+
+
+@pytest.mark.parametrize("tag,mod", [("we", "BlueROV2_thrust"), ("we_cur", "BlueROV2_thrust"),
+                                     ("wq", "BlueROV2_wrench"), ("wq_cur", "BlueROV2_wrench")])
+def test_wrench_rhs_matches_reference_fixture(tag, mod):
+    import importlib
+    cls = importlib.import_module(f"bluerov2_dynamics_amd.fossen.{mod}").BlueROV2
+    g = load_golden("fossen_rhs_kat.npz")
+    X, U, ref = g[f"{tag}_X"], g[f"{tag}_U"], g[f"{tag}_XDOT"]
+    rov = cls(current_speed=g[f"{tag}_cur"].copy())
+    lo = 2 if mod == "BlueROV2_thrust" else 0
+    for i in range(X.shape[0]):
+        xd = rov.dynamics(X[i], U[i])
+        assert rel_err(xd, ref[i]) < (1e-8 if i < lo else TOL_CALL), i
+    with pytest.raises(ValueError):
+        rov.dynamics(np.zeros(5), U[0])
+
+
+def test_rhs_vs_oracle_random_batch(eng, fc):
+    rng = np.random.default_rng(0)
+    B = 5000
+    for model in (0, 1, 2):
+        nx, nu = fc.NX[model], fc.NU[model]
+        X = rng.uniform(-1.2, 1.2, (B, nx))
+        U = rng.uniform(-1, 1, (B, nu)) * (1.0 if model == 0 else 20.0)
+        lag0 = rng.uniform(-2, 2, (B, 8, 3))
+        xd, lag = eng.rhs(model, X, U, 0.05, lag=lag0 if model == 0 else None)
+        xo, lo = fc.rhs(model, X, U, 0.05, lag=lag0 if model == 0 else None)
+        assert rel_err(xd, xo) < TOL_CALL
+        if model == 0:
+            assert rel_err(lag, lo) < TOL_CALL
+
+
+# ------------------------------------------------------------------------------------------ rollouts
+def test_cfg2_first_8_trajectories_match_reference(eng):
+    """BASELINE config 2 stream (seed 0x5EED, T=5000, dt=0.02), trajectories 0..7, every 50th state,
+    against the states the reference produced (fixture) -- whole-trajectory relative error."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    g = load_golden("fossen_rollouts.npz")
+    T, dt, sub, seed = int(g["cfg2_T"]), float(g["cfg2_dt"]), int(g["cfg2_sub"]), int(g["cfg2_seed"])
+    B = 8
+    U = torch.empty((B, T, 8), dtype=torch.float64, device="cuda")
+    eng.fill_controls_dev(U, "btu", "iid", seed=seed, b0=0, T_total=T)
+    torch.cuda.synchronize()
+    Uh = U.cpu().numpy()
+    assert np.array_equal(Uh[:, :4, :], g["cfg2_U_head"])          # device stream is bit-exact
+    x0 = np.tile(g["cfg2_x0"], (B, 1))
+    for integ, key, lkey in (("rk4", "cfg2_rk4", "cfg2_rk4_lag_end"), ("euler", "cfg2_euler", "cfg2_euler_lag_end")):
+        r = eng.rollout(_lib.THRUSTER_EULER, integ, x0, Uh, dt, stride=sub)
+        assert rel_err(r["traj"], g[key]) < TOL_TRAJ, integ
+        assert rel_err(r["xT"], g[key][:, -1]) < TOL_TRAJ
+        assert rel_err(r["lag"], g[lkey]) < TOL_TRAJ
+        # time-major layout gives the same numbers
+        r2 = eng.rollout(_lib.THRUSTER_EULER, integ, x0, np.ascontiguousarray(Uh.transpose(1, 2, 0)), dt, stride=sub, layout="tub")
+        assert np.array_equal(r2["traj"].transpose(2, 0, 1), r["traj"])
+
+
+def test_ar1_wrench_quat_cfg1_rollouts_match_reference(eng):
+    from bluerov2_dynamics_amd import _lib
+    g = load_golden("fossen_rollouts.npz")
+    dt, sub = float(g["ar1_dt"]), int(g["ar1_sub"])
+    for integ, key in (("rk4", "ar1_rk4"), ("euler", "ar1_euler")):
+        r = eng.rollout(_lib.THRUSTER_EULER, integ, g["ar1_X0"], g["ar1_U"], dt, stride=sub)
+        assert rel_err(r["traj"], g[key]) < TOL_TRAJ, key
+    dt, sub = float(g["w_dt"]), int(g["w_sub"])
+    for model, integ, x0k, key in ((_lib.WRENCH_EULER, "euler", "we_X0", "we_euler"), (_lib.WRENCH_EULER, "rk4", "we_X0", "we_rk4"),
+                                   (_lib.WRENCH_QUAT, "euler", "wq_X0", "wq_euler"), (_lib.WRENCH_QUAT, "rk4", "wq_X0", "wq_rk4_ext")):
+        r = eng.rollout(model, integ, g[x0k], g["w_TAU"], dt, stride=sub)
+        assert rel_err(r["traj"], g[key]) < TOL_TRAJ, key
+    # config 1: fossen/test_euler.py set-up through the drop-in object
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
+    rov = BlueROV2()
+    x0 = np.zeros(12)
+    x0[2] = 5.0
+    traj = rov.simulate(x0, np.tile(g["cfg1_u"], (1000, 1)), 0.02, "euler")
+    assert rel_err(traj[::10], g["cfg1_euler"]) < TOL_TRAJ
+    # the object stays stateful: a python-level Euler loop over dynamics() continues from the advanced lag
+    x = traj[-1].copy()
+    for _ in range(3):
+        x = x + 0.02 * rov.dynamics(x, g["cfg1_u"], 0.02)
+    rov2 = BlueROV2()
+    traj2 = rov2.simulate(x0, np.tile(g["cfg1_u"], (1003, 1)), 0.02, "euler")
+    assert rel_err(x, traj2[-1]) < 1e-11
+
+
+def test_rollout_vs_oracle_all_models_layouts_modes(eng, fc):
+    rng = np.random.default_rng(1)
+    B, T, dt = 700, 64, 0.02          # ragged: not a multiple of the 256-lane workgroup
+    for model in (0, 1, 2):
+        nx, nu = fc.NX[model], fc.NU[model]
+        X0 = rng.uniform(-0.5, 0.5, (B, nx))
+        if model == 2:
+            X0[:, 3:7] /= np.linalg.norm(X0[:, 3:7], axis=1, keepdims=True)
+        U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 15.0)
+        lag0 = rng.uniform(-1, 1, (B, 8, 3)) if model == 0 else None
+        for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
+            for lag_mode in ((0, 1) if (model == 0 and integ == "rk4") else (0,)):
+                o = fc.rollout(model, oi, X0, U, dt, lag=lag0, lag_mode=lag_mode, sub=4, nthreads=8)
+                r = eng.rollout(model, integ, X0, U, dt, lag=lag0, lag_mode=lag_mode, stride=4)
+                assert rel_err(r["traj"], o["traj"]) < 1e-10, (model, integ, lag_mode)
+                assert rel_err(r["xT"], o["xT"]) < 1e-10
+                if model == 0:
+                    assert rel_err(r["lag"], o["lag"]) < 1e-10
+    # empty / degenerate sizes
+    r = eng.rollout(0, "rk4", np.zeros((0, 12)), np.zeros((0, 5, 8)), 0.02)
+    assert r["traj"].shape == (0, 6, 12)
+    r = eng.rollout(0, "rk4", np.ones((3, 12)) * 0.1, np.zeros((3, 0, 8)), 0.02)
+    assert np.array_equal(r["xT"], np.ones((3, 12)) * 0.1) and r["traj"].shape == (3, 1, 12)
+
+
+def test_fill_controls_layouts_and_ar1(eng):
+    import torch
+    from oracle import controls
+    B, T = 300, 97
+    for nu in (8, 6):
+        a = torch.empty((B, T, nu), dtype=torch.float64, device="cuda")
+        b = torch.empty((T, nu, B), dtype=torch.float64, device="cuda")
+        eng.fill_controls_dev(a, "btu", "iid", seed=7, b0=1000, T_total=500)
+        eng.fill_controls_dev(b, "tub", "iid", seed=7, b0=1000, T_total=500)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy(), controls.controls_iid(7, 1000, B, 500, nu=nu, nt=T))
+        assert torch.equal(a, b.permute(2, 0, 1))
+    a = torch.empty((B, T, 8), dtype=torch.float64, device="cuda")
+    eng.fill_controls_dev(a, "btu", "ar1", seed=9, b0=0, T_total=T, scale=[2.0] * 8)
+    torch.cuda.synchronize()
+    assert rel_err(a.cpu().numpy(), 2.0 * controls.controls_ar1(9, 0, B, T)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------ windows
+def test_window_rmse_matches_reference_fixture(eng):
+    from bluerov2_dynamics_amd import _lib
+    g = load_golden("windows.npz")
+    X, U, TAU, Xq, dt = g["X"], g["U"], g["TAU"], g["Xq"], float(g["dt"])
+    for i, H in enumerate(g["H"]):
+        H = int(H)
+        assert abs(eng.window_rmse(_lib.THRUSTER_EULER, "euler", X, U, H, dt) - g["thr_euler_rmse"][i]) < 1e-10
+        assert abs(eng.window_rmse(_lib.THRUSTER_EULER, "rk4", X, U, H, dt) - g["thr_rk4_rmse"][i]) < 1e-10
+        assert abs(eng.window_rmse(_lib.WRENCH_EULER, "euler", X, TAU, H, dt) - g["we_euler_rmse"][i]) < 1e-10
+        assert abs(eng.window_rmse(_lib.WRENCH_QUAT, "euler", Xq, TAU, H, dt) - g["wq_euler_rmse"][i]) < 1e-10
+    assert np.isnan(eng.window_rmse(_lib.THRUSTER_EULER, "euler", X[:5], U[:5], 10, dt))   # n_start <= 0 -> nan like the reference
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
+    assert abs(BlueROV2(dt=dt).multistep_rmse_endpoint(X, U, 10, dt) - g["thr_euler_rmse"][1]) < 1e-10
+
+
+def test_window_se_vs_oracle_larger(eng, fc):
+    rng = np.random.default_rng(2)
+    N = 3000
+    U = np.clip(np.cumsum(rng.normal(0, 0.05, (N, 8)), 0), -1, 1)
+    x0 = np.zeros((1, 12))
+    X = fc.rollout(0, fc.INTEG_EULER, x0, U[None], 0.02)["traj"][0][1:] + rng.normal(0, 1e-3, (N, 12))
+    for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
+        for H in (1, 7, 50):
+            for carry in (True, False):
+                se_o, per_o = fc.window_endpoint_se(0, oi, X, U, H, 0.02, carry_lag=carry)
+                se_g, per_g = eng.window_endpoint_se(0, integ, X, U, H, 0.02, carry_lag=carry)
+                assert rel_err(per_g, per_o) < 1e-9, (integ, H, carry)
+                assert abs(se_g - se_o) / se_o < 1e-10
+
+
+# ------------------------------------------------------------------------------------------ EDMDc
+def test_lift_and_gram_match_reference_fixture(eng):
+    from oracle import edmdc_numpy as ek
+    g = load_golden("edmdc.npz")
+    X, U, C = g["X"], g["U"], g["centers"]
+    nt, gamma, ridge = int(g["n_train"]), float(g["gamma"]), float(g["ridge"])
+    assert rel_err(eng.lift(X[:64], C, gamma), g["lift64"]) < 1e-13
+    assert rel_err(eng.lift(X[7:8], C, gamma)[0], g["lift1"]) < 1e-13
+    GtG, GtY, n = eng.gram([X[:nt]], [U[:nt]], C, gamma)
+    assert n == nt - 1
+    assert np.linalg.norm(GtG - g["GtG"]) / np.linalg.norm(g["GtG"]) < 1e-12
+    assert np.linalg.norm(GtY - g["GtY"]) / np.linalg.norm(g["GtY"]) < 1e-12
+    assert np.array_equal(GtG, GtG.T)
+    A, B = eng.solve_AB(GtG, GtY, ridge, 12 + C.shape[0])
+    Ao, Bo = ek.solve_AB(g["GtG"], g["GtY"], ridge, 12 + C.shape[0])
+    assert rel_err(A, Ao) < 1e-7 and rel_err(B, Bo) < 1e-7
+
+
+def test_koopman_dropin_scores_match_reference_fixture():
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    g = load_golden("edmdc.npz")
+    X, U = g["X"], g["U"]
+    nt = int(g["n_train"])
+    m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]))
+    m.fit(X[:nt], U[:nt], centers=g["centers"])
+    assert m.lift_dim_ == 12 + int(g["k"]) and m.A_.shape == (m.lift_dim_, m.lift_dim_) and m.B_.shape == (m.lift_dim_, 8)
+    Xt, Ut = X[nt:], U[nt:]
+    assert abs(m.evaluate(Xt, Ut) - g["eval_rmse"]) < 1e-8
+    ours = [m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)]
+    assert np.max(np.abs(np.array(ours) - g["ms_rmse"])) < 1e-7
+    # with the reference's own A, B the propagation kernels reproduce its numbers to rounding
+    m.A_, m.B_ = g["A"], g["B"]
+    for i, H in enumerate((1, 10, 100)):
+        assert abs(m.multistep_rmse(Xt, Ut, H) - g["ms_rmse"][i]) < 1e-11
+    assert rel_err(m.simulate(Xt[0], Ut[:50]), g["sim50"]) < 1e-11
+    assert rel_err(m._lift(Xt[:5])[:, :12], Xt[:5]) == 0.0
+    assert m._lift(Xt[3]).shape == (m.lift_dim_,)
+    with pytest.raises(ValueError):
+        m._lift(np.zeros((2, 2, 12)))
+    # fit_multi on unequal bags, and KMeans on the host picks the same centres as the reference did
+    cuts = g["multi_cuts"]
+    m2 = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]))
+    m2.fit_multi([X[a:b] for a, b in cuts], [U[a:b] for a, b in cuts])
+    if rel_err(m2.centers_, g["multi_centers"]) < 1e-9:         # sklearn is third party: same version -> same centres
+        assert np.max(np.abs(np.array([m2.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)]) - g["multi_ms_rmse"])) < 1e-7
+    m2.fit_multi([X[a:b] for a, b in cuts], [U[a:b] for a, b in cuts], centers=g["multi_centers"])
+    assert rel_err(m2.A_, g["multi_A"]) < 1e-8 and rel_err(m2.B_, g["multi_B"]) < 1e-8
+    with pytest.raises(AssertionError):
+        m2.fit(X[:10], U[:9])
+
+
+def test_gram_full_width_vs_oracle_chunked_and_bags(eng):
+    """k = 512 (p = 532, the benchmark shape), several chunks, bag boundaries inside chunks."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(3)
+    nb, L, n, r, k = 7, 301, 12, 8, 512
+    X = rng.normal(0, 0.6, (nb, L + 1, n))
+    U = rng.uniform(-1, 1, (nb, L, r))
+    C = rng.normal(0, 0.6, (k, n))
+    gamma = 0.7
+    GtG_o, GtY_o, npairs = ek.gram(list(X), list(U), C, gamma)
+    ctx = _lib.Context(0)
+    ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, 512), "chunk")
+    dX, dU, dC = (torch.tensor(a, device="cuda") for a in (X.reshape(-1, n), U.reshape(-1, r), C))
+    GtG = torch.zeros((n + k + r, n + k + r), dtype=torch.float64, device="cuda")
+    GtY = torch.zeros((n + k + r, n + k), dtype=torch.float64, device="cuda")
+    eng.gram_dev(dX, dU, dC, gamma, nb, L, L + 1, L, GtG, GtY, ctx=ctx)
+    torch.cuda.synchronize()
+    assert npairs == nb * L
+    assert np.linalg.norm(GtG.cpu().numpy() - GtG_o) / np.linalg.norm(GtG_o) < 1e-12
+    assert np.linalg.norm(GtY.cpu().numpy() - GtY_o) / np.linalg.norm(GtY_o) < 1e-12
+    # accumulate = sum of two halves; linearity in the data
+    G2 = torch.zeros_like(GtG)
+    Y2 = torch.zeros_like(GtY)
+    h = 3
+    eng.gram_dev(dX[: h * (L + 1)], dU[: h * L], dC, gamma, h, L, L + 1, L, G2, Y2, ctx=ctx)
+    eng.gram_dev(dX[h * (L + 1):], dU[h * L:], dC, gamma, nb - h, L, L + 1, L, G2, Y2, accumulate=True, ctx=ctx)
+    torch.cuda.synchronize()
+    assert torch.allclose(G2, GtG, rtol=1e-12, atol=1e-9) and torch.allclose(Y2, GtY, rtol=1e-12, atol=1e-9)
+
+
+def test_quaternion_state_koopman_shapes(eng):
+    """n = 13, r = 6 (training/train_tank_brov2_wrench_quat.py uses the 13-D state for EDMDc too)."""
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(4)
+    N, n, r, k = 500, 13, 6, 40
+    X = rng.normal(0, 0.5, (N, n))
+    U = rng.normal(0, 1.0, (N, r))
+    C = rng.normal(0, 0.5, (k, n))
+    GtG, GtY, _ = eng.gram([X], [U], C, 1.3)
+    Go, Yo, _ = ek.gram([X], [U], C, 1.3)
+    assert np.linalg.norm(GtG - Go) / np.linalg.norm(Go) < 1e-12 and np.linalg.norm(GtY - Yo) / np.linalg.norm(Yo) < 1e-12
+    A, B = ek.solve_AB(Go, Yo, 1e-3, n + k)
+    se, xh = eng.multistep_se(X, U, C, 1.3, A, B, 5, want_xhat=True)
+    ref = ek.multistep_rmse(X, U, C, 1.3, A, B, 5)
+    assert abs(np.sqrt(se / ((N - 5) * n)) - ref) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------ full size, property based
+def test_full_size_rollout_properties(eng):
+    """BASELINE config-2 sized batch (65 536 lanes; T shortened to keep the test short): trajectory b of
+    the big launch equals the same trajectory run alone, and the endpoint-only run equals the stored run."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    B, T, dt = 65536, 200, 0.02
+    U = torch.empty((T, 8, B), dtype=torch.float64, device="cuda")
+    eng.fill_controls_dev(U, "tub", "iid", seed=0x5EED, T_total=5000)
+    x0 = torch.zeros((B, 12), dtype=torch.float64, device="cuda")
+    x0[:, 2] = 5.0
+    traj = torch.empty((T // 50 + 1, 12, B), dtype=torch.float64, device="cuda")
+    xT = torch.empty((B, 12), dtype=torch.float64, device="cuda")
+    eng.rollout_dev(_lib.THRUSTER_EULER, "rk4", x0, U, dt, traj=traj, xT=xT, layout="tub", stride=50)
+    xT2 = torch.empty_like(xT)
+    eng.rollout_dev(_lib.THRUSTER_EULER, "rk4", x0, U, dt, xT=xT2, layout="tub")
+    torch.cuda.synchronize()
+    assert torch.equal(xT, xT2) and torch.equal(traj[-1].T.contiguous(), xT)
+    assert torch.isfinite(xT).all()
+    pick = [0, 1, 255, 256, 4097, 65535]
+    Uh = U[:, :, pick].permute(2, 0, 1).contiguous().cpu().numpy()
+    r = eng.rollout(_lib.THRUSTER_EULER, "rk4", np.tile(x0[0].cpu().numpy(), (len(pick), 1)), Uh, dt)
+    assert np.array_equal(r["xT"], xT[pick].cpu().numpy())
+    from oracle import controls
+    assert np.array_equal(Uh[0], controls.controls_iid(0x5EED, 0, 1, 5000, nt=T)[0])
+    assert np.array_equal(Uh[-1], controls.controls_iid(0x5EED, 65535, 1, 5000, nt=T)[0])
