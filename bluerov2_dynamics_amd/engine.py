@@ -186,9 +186,9 @@ def gram(X_list, U_list, C, gamma, ctx=None):
         if len(X) < 2:
             continue
         X = as_f64(X)
-        U = as_f64(U)[: len(X) - 1]
         L = len(X) - 1
-        ctx.check(ctx.lib.edmdc_gram(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(np.ascontiguousarray(U)),
+        Uc = as_f64(as_f64(U)[:L])           # keep a named reference: only its address crosses the ABI
+        ctx.check(ctx.lib.edmdc_gram(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(Uc),
                                      acc, _hptr(GtG), _hptr(GtY)), "edmdc_gram")
         acc = 1
         npairs += L
@@ -238,7 +238,9 @@ def simulate_lifted(x0, U_seq, C, gamma, A, B, ctx=None):
     nb, n = x0.shape
     T, r = U_seq.shape[1], U_seq.shape[2]
     C = as_f64(C)
+    A = as_f64(A)                            # named references: np.load can hand back Fortran-ordered arrays,
+    B = as_f64(B)                            # as_f64 then copies, and only the address crosses the ABI
     out = np.empty((nb, T + 1, n))
-    ctx.check(ctx.lib.edmdc_simulate(ctx.h, n, r, C.shape[0], float(gamma), _hptr(C), _hptr(as_f64(A)), _hptr(as_f64(B)), nb, T,
+    ctx.check(ctx.lib.edmdc_simulate(ctx.h, n, r, C.shape[0], float(gamma), _hptr(C), _hptr(A), _hptr(B), nb, T,
                                      _hptr(x0), _hptr(U_seq), _hptr(out)), "edmdc_simulate")
     return out
