@@ -1,0 +1,107 @@
+"""Multi-GPU layer: one process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI).
+
+The path shards naturally:
+  * rollouts  -- trajectories are independent: rank i owns the contiguous shard
+                 [shard_range(B, i, world)) and never talks to the others;
+  * EDMDc fit -- samples are independent: every rank builds its local G^T[G|Y] blocks on its GPU,
+                 ONE all-reduce (sum) of a single (p*p + p*d)-double buffer (4.5 MB at k = 512)
+                 combines them, then every rank solves the same p x p system on the host.
+No other exchange exists; centres are broadcast once.
+"""
+import numpy as np
+
+
+def shard_range(total: int, rank: int, world: int):
+    """Contiguous, balanced split of range(total): returns (start, stop) of `rank`."""
+    assert 0 <= rank < world
+    base, rem = divmod(int(total), int(world))
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def world_info():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def allreduce_gram_(GtG, GtY, group=None):
+    """In-place sum over ranks of both blocks with a single collective.  GtG/GtY: torch tensors
+    (CUDA for nccl, CPU for gloo).  Returns (GtG, GtY)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return GtG, GtY
+    p2, pd = GtG.numel(), GtY.numel()
+    buf = torch.empty(p2 + pd, dtype=GtG.dtype, device=GtG.device)
+    buf[:p2].copy_(GtG.reshape(-1))
+    buf[p2:].copy_(GtY.reshape(-1))
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    GtG.copy_(buf[:p2].view_as(GtG))
+    GtY.copy_(buf[p2:].view_as(GtY))
+    return GtG, GtY
+
+
+def broadcast_centers_(C, src=0, group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(C, src, group=group)
+    return C
+
+
+def _device_gram(X, U, C, gamma, nbags, L, xs, us):
+    """Local Gram on this rank's GPU (X, U, C: CUDA fp64 tensors) -> (GtG, GtY) CUDA tensors."""
+    import torch
+    from . import engine
+    n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
+    p, d = n + k + r, n + k
+    GtG = torch.zeros((p, p), dtype=torch.float64, device=X.device)
+    GtY = torch.zeros((p, d), dtype=torch.float64, device=X.device)
+    engine.gram_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, GtG, GtY)
+    return GtG, GtY
+
+
+def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None):
+    """EDMDc fit over trajectories sharded across ranks.
+
+    X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);
+    C [k, n] centres (identical on all ranks -- broadcast them first).
+    gram_fn(X, U, C, gamma, nbags, L, xs, us) -> (GtG, GtY) defaults to the HIP path; tests on CPU
+    inject a host implementation to exercise the collective + solve plumbing under gloo.
+    Returns (A [d,d], B [d,r]) as NumPy arrays, identical on every rank."""
+    from . import engine
+    nb, L1, n = X_local.shape
+    L = L1 - 1
+    assert U_local.shape[0] == nb and U_local.shape[1] == L
+    gram_fn = gram_fn or _device_gram
+    GtG, GtY = gram_fn(X_local, U_local, C, gamma, nb, L, L + 1, L)
+    allreduce_gram_(GtG, GtY, group)
+    d = n + C.shape[0]
+    return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d)
+
+
+def rollout_sharded(model, integrator, B_total, T, dt, seed=0x5EED, layout="tub", stride=None, device=None):
+    """Every rank rolls out its shard of a B_total-trajectory ensemble of the synthetic control stream
+    (values independent of the sharding).  Returns (b0, b1, xT [b1-b0, nx] CUDA tensor, traj or None)."""
+    import torch
+    from . import engine
+    from ._lib import NX, NU
+    rank, world = world_info()
+    b0, b1 = shard_range(B_total, rank, world)
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    B = b1 - b0
+    nu, nx = NU[model], NX[model]
+    U = torch.empty((T, nu, B) if layout == "tub" else (B, T, nu), dtype=torch.float64, device=dev)
+    engine.fill_controls_dev(U, layout, "iid", seed=seed, b0=b0, T_total=T)
+    x0 = torch.zeros((B, nx), dtype=torch.float64, device=dev)
+    x0[:, 2] = 5.0
+    if model == 2:
+        x0[:, 3] = 1.0
+    traj = None
+    if stride:
+        rows = T // stride + 1
+        traj = torch.empty((rows, nx, B) if layout == "tub" else (B, rows, nx), dtype=torch.float64, device=dev)
+    xT = torch.empty((B, nx), dtype=torch.float64, device=dev)
+    engine.rollout_dev(model, integrator, x0, U, dt, traj=traj, xT=xT, layout=layout, stride=stride or 1)
+    return b0, b1, xT, traj

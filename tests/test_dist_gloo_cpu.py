@@ -1,0 +1,68 @@
+"""world_size-2 `gloo` rehearsal of the multi-GPU EDMDc path on CPU: shard bags over ranks, local
+Gram (the oracle stands in for the HIP kernel -- there is no GPU here), ONE all-reduce of the packed
+[GtG | GtY] buffer, identical host solve on every rank == single-process fit."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import load_golden
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _oracle_gram(X, U, C, gamma, nbags, L, xs, us):
+    from oracle import edmdc_numpy as ek
+    Xn, Un, Cn = X.numpy(), U.numpy(), C.numpy()
+    GtG, GtY, _ = ek.gram(list(Xn), [np.vstack([u, np.zeros((1, u.shape[1]))]) for u in Un], Cn, gamma)
+    return torch.from_numpy(GtG), torch.from_numpy(GtY)
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from bluerov2_dynamics_amd import dist as bd
+    g = load_golden("edmdc.npz")
+    X, U = g["X"], g["U"]
+    nb, L = 8, 199
+    Xb = np.stack([X[i * 200:(i + 1) * 200] for i in range(nb)])
+    Ub = np.stack([U[i * 200:i * 200 + L] for i in range(nb)])
+    b0, b1 = bd.shard_range(nb, rank, world)
+    C = torch.from_numpy(g["centers"].copy()) if rank == 0 else torch.zeros(g["centers"].shape, dtype=torch.float64)
+    bd.broadcast_centers_(C)
+    A, B = bd.fit_sharded(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, 1e-3, gram_fn=_oracle_gram)
+    q.put((rank, A, B))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_fit_equals_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, A0, B0), (_, A1, B1) = res
+    assert np.array_equal(A0, A1) and np.array_equal(B0, B1)          # every rank solves the same reduced system
+    from oracle import edmdc_numpy as ek
+    g = load_golden("edmdc.npz")
+    X, U = g["X"], g["U"]
+    Xl = [X[i * 200:(i + 1) * 200] for i in range(8)]
+    Ul = [U[i * 200:(i + 1) * 200] for i in range(8)]
+    A, B = ek.fit(Xl, Ul, g["centers"], 1.0, 1e-3)
+    assert np.max(np.abs(A - A0)) < 1e-9 and np.max(np.abs(B - B0)) < 1e-9

@@ -1,0 +1,72 @@
+"""Host-side logic of the drop-in modules that needs no GPU: quaternion / rotation helpers, the
+stand-alone ThrusterLag filter, the ridge solve, argument checking, sharding arithmetic."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+
+def test_quaternion_helpers_match_reference_fixture():
+    from bluerov2_dynamics_amd.fossen import BlueROV2_wrench as qw
+    g = load_golden("fossen_rhs_kat.npz")
+    ang, Q = g["q_euler_in"], g["q_from_euler"]
+    for i in range(len(ang)):
+        assert rel_err(qw.euler_to_quat(*ang[i]), Q[i]) < 1e-15
+        assert rel_err(np.array(qw.quat_to_euler(Q[i])), g["q_to_euler"][i]) < 1e-14
+        assert abs(qw.quat_to_yaw(Q[i]) - g["q_to_yaw"][i]) < 1e-14
+        assert rel_err(qw.quat_to_rotation_matrix(Q[i]), g["q_to_R"][i]) < 1e-15
+        assert rel_err(qw.quat_multiply(Q[i], Q[(i + 1) % len(Q)]), g["q_mul"][i]) < 1e-15
+        assert rel_err(qw.quat_derivative(Q[i], ang[i]), g["q_deriv"][i]) < 1e-15
+    assert np.array_equal(qw.quat_normalize([0, 0, 0, 0]), [1, 0, 0, 0])
+    assert np.array_equal(qw.quat_normalize([1e-13, 0, 0, 0]), [1, 0, 0, 0])
+    with pytest.raises(ValueError):
+        qw.quat_normalize([1, 0, 0])
+
+
+def test_rotation_and_kinematics_helpers():
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import euler_kinematics_matrix, rotation_matrix
+    from bluerov2_dynamics_amd.fossen.BlueROV2_wrench import euler_to_quat, quat_to_rotation_matrix
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        a = rng.uniform(-1.4, 1.4, 3)
+        R = rotation_matrix(*a)
+        assert rel_err(R @ R.T, np.eye(3)) < 1e-14 and abs(np.linalg.det(R) - 1) < 1e-14
+        assert rel_err(R, quat_to_rotation_matrix(euler_to_quat(*a))) < 1e-14
+    J = euler_kinematics_matrix(0.3, np.pi / 2)        # clamp path: cos(theta) -> 1e-7
+    assert J[0, 1] == pytest.approx(np.sin(0.3) * 1e7, rel=1e-9)
+
+
+def test_thruster_lag_view_standalone_step():
+    """ThrusterLag.step on the host = first lag sample of the reference fixture (x <- Bd F, y = Cc x)."""
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import ThrusterLag
+    g = load_golden("fossen_rhs_kat.npz")
+    U, dt = g["thr_U"], float(g["thr_dt"])
+    store = np.zeros((8, 3))
+    lags = [ThrusterLag(store, i) for i in range(8)]
+    V = U[7]
+    F = -140.3 * V**9 + 389.9 * V**7 - 404.1 * V**5 + 176.0 * V**3 + 8.9 * V
+    y = [lags[i].step(F[i], dt) for i in range(8)]
+    assert rel_err(store, g["thr_LAG"][0, 7]) < 1e-13
+    assert rel_err(np.array(y), store @ np.array([0.0, 5.992, 3.317])) < 1e-15
+    lags[2]._x = [1.0, 2.0, 3.0]
+    assert np.array_equal(store[2], [1.0, 2.0, 3.0])
+
+
+def test_ridge_solve_matches_reference_fixture():
+    from bluerov2_dynamics_amd import engine
+    g = load_golden("edmdc.npz")
+    d = 12 + int(g["k"])
+    A, B = engine.solve_AB(g["GtG"], g["GtY"], float(g["ridge"]), d)
+    assert A.shape == (d, d) and B.shape == (d, 8) and A.flags["C_CONTIGUOUS"]
+    assert rel_err(A, g["A"]) < 1e-7 and rel_err(B, g["B"]) < 1e-7
+
+
+def test_shard_range_is_a_partition():
+    from bluerov2_dynamics_amd.dist import shard_range
+    for total in (0, 1, 7, 65536, 2**20, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
