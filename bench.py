@@ -24,7 +24,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 # algorithmic work per unit
-ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory
+ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (reference algebra)
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 946, "euler": 262}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0
@@ -150,7 +151,11 @@ def main():
     steps_total = world * B * T * a.steps
     value = steps_total / wall
     bytes_per_step = ROLLOUT_BYTES_PER_STEP if not a.no_store else 64.0
-    flop_rate = B * T * ROLLOUT_FLOP_PER_STEP / kern_s / 1e12
+    flop_per_step = ROLLOUT_FLOP_PER_STEP if a.integrator == "rk4" else ROLLOUT_FLOP_PER_STEP * 0.76 / 3.1
+    flop_rate = B * T * flop_per_step / kern_s / 1e12
+    # fraction of the SIMD fp64 issue slots the kernel actually fills: (fp64 instr/step x 4 cycles) / cycles per step
+    cyc_per_step = kern_s * 2.4e9 / T / max(1, -(-B // 65536))
+    valu_busy = ROLLOUT_EXEC_FP64_INSTR[a.integrator] * 4.0 / cyc_per_step
     byte_rate = B * T * bytes_per_step / kern_s / 1e9
     assert torch.isfinite(xT).all()
 
@@ -165,7 +170,8 @@ def main():
                    "trajectories_per_gpu": B, "horizon": T, "parallelism": f"{world} x independent shards, no collective"},
         "roofline": {"kernel": "rollout_kernel<THRUSTER_EULER,RK4>", "bound": "valu_fp64", "achieved": flop_rate,
                      "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
-                     "kernel_ms": kern_s * 1e3, "flop_per_step": ROLLOUT_FLOP_PER_STEP,
+                     "kernel_ms": kern_s * 1e3, "flop_per_step": flop_per_step,
+                     "executed_fp64_instr_per_step": ROLLOUT_EXEC_FP64_INSTR[a.integrator], "fp64_issue_slot_utilisation": valu_busy,
                      "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
                              "bytes_per_step": bytes_per_step},
                      "traffic": None},

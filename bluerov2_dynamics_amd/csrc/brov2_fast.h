@@ -1,0 +1,328 @@
+// brov2_fast.h -- the time-loop form of the Fossen model used by the rollout / window kernels.
+//
+// Same equations as brov2_device.h (which is the literal per-call form used by brov_rhs), re-arranged
+// so that one RK4 step costs ~1.1k fp64 instructions instead of ~3k:
+//
+//  * Minv is folded into everything: the kernels integrate nu_dot = a_thr - c(nu) - d(nu_r) - g(eta)
+//    with a_thr = Minv tau, c = Minv C(nu) nu written as 12 products with 12 pre-multiplied constants
+//    (the author's Coriolis sign fix, fossen/BlueROV2.py:293,297, is inside E30..E51), d = (da+db|nu_r|)nu_r,
+//    g = Minv g(eta).
+//  * The thruster lag is carried in "acceleration space": the eight filters share (Ad, Bd, Cc), so
+//    Z = (Minv T) X (6x3) obeys the same recurrence as the 8x3 per-thruster state X and
+//    Minv tau_s = Z c_s + (Minv T f_cmd) d_s for the s-th dynamics() call of a step (quirk Q1).
+//    That is 6 filters instead of 8 and one allocation product per step instead of four.  The
+//    per-thruster state is advanced alongside only when the caller wants it back (lag_io != NULL).
+//  * sin/cos: 3-term Cody-Waite reduction + the fdlibm kernel polynomials (~1 ulp for |x| < 3e9),
+//    instead of OCML's double-double reduction (fossen/BlueROV2.py:28-33,47-50,342-345 call
+//    np.sin/np.cos three times per call on the same angles; here once).
+//  * Per-stage constants live in VGPRs (uniform values, pinned with an empty asm) and once-per-step
+//    constants are re-read through a laundered kernarg pointer (scalar loads), so nothing spills:
+//    the first version kept all 150 constants live in SGPRs and paid ~1000 v_readlane per step.
+#pragma once
+#include "brov2_device.h"
+
+namespace brov {
+
+// ---- constants of the time loop (host: derive_fast() in capi.hip) ------------------------------
+struct FastParams {
+    // per-stage (hot): pinned in VGPRs
+    double E[12];      // Minv-folded Coriolis coefficients, see nu_dot_fast
+    double da[6], db[6];
+    double G[5];       // G0..G2 = minv_i (W-B), Z3 = minv3 zb B, Z4 = minv4 zb B
+    double lc[4][3];   // Cc Ad^s
+    double ld[4];      // Cc S_s Bd
+    // per-step (warm): scalar loads
+    double Tm[6][8];   // Minv T
+    double minv[6];    // wrench models: a_cmd = minv . tau
+    double poly[5];
+    double A1[9], b1[3];   // one lag sample
+    double A4[9], b4[3];   // four lag samples
+    // rare
+    double XY[4];      // Y3 = minv3 yb B, X4 = minv4 xb B, X5 = minv5 xb B, Y5 = minv5 yb B
+    double cur[3];
+    int has_current;
+    int has_xy;
+};
+
+// FastParams lives in a small device buffer owned by the ctx and is read through a CONSTANT
+// address-space pointer: uniform loads from it are scalar (s_load) by construction, whereas a
+// by-value kernel argument whose address is taken gets copied to scratch and read per lane.
+typedef const FastParams __attribute__((address_space(4)))* CFP;
+__device__ __forceinline__ CFP as_constant(const FastParams* g) { return (CFP)(unsigned long long)g; }
+
+struct HotConsts {
+    double E[12], da[6], db[6], G[5];
+};
+
+#define BROV_PIN_V(x) asm volatile("" : "+v"(x))
+
+// E, G, da stay uniform (SGPR operands: one scalar source per VALU instruction is free); db is pinned
+// in VGPRs because fma(db, |nu|, da) would otherwise need two scalar sources.
+__device__ __forceinline__ void load_hot(CFP pp, HotConsts& h) {
+    const auto& p = *pp;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { h.E[i] = p.E[i]; BROV_PIN_V(h.E[i]); }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { h.da[i] = p.da[i]; h.db[i] = p.db[i]; BROV_PIN_V(h.db[i]); }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) h.G[i] = p.G[i];
+}
+
+// pointer laundering: makes the compiler re-issue the (scalar) loads behind `p` at this point
+// instead of keeping 100+ SGPRs of loop-invariant constants alive (and spilling them)
+__device__ __forceinline__ CFP relaunder(CFP p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
+// ---- sin / cos --------------------------------------------------------------------------------
+// Valid (<= ~1 ulp) for |x| < 2^31 pi/2 ~ 3.4e9 rad; NaN/inf give NaN like np.sin/np.cos.  Beyond that
+// range the quadrant index saturates (a vehicle attitude angle never gets there).
+__device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
+    const double kf = rint(x * 6.36619772367581382433e-01);
+    double r = fma(-kf, 1.57079632673412561417e+00, x);      // pio2_1  (33 bits)
+    r = fma(-kf, 6.07710050630396597660e-11, r);             // pio2_2  (33 bits)
+    r = fma(-kf, 2.02226624879595063154e-21, r);             // pio2_2t
+    const int q = (int)kf;
+    const double z = r * r;
+    double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma(z, ps, 2.75573137070700676789e-06);
+    ps = fma(z, ps, -1.98412698298579493134e-04);
+    ps = fma(z, ps, 8.33333333332248946124e-03);
+    ps = fma(z, ps, -1.66666666666666324348e-01);
+    const double sr = fma(z * r, ps, r);
+    double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma(z, pc, -2.75573143513906633035e-07);
+    pc = fma(z, pc, 2.48015872894767294178e-05);
+    pc = fma(z, pc, -1.38888888888741095749e-03);
+    pc = fma(z, pc, 4.16666666666666019037e-02);
+    const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+    const bool swap = q & 1;
+    double so = swap ? cr : sr;
+    double co = swap ? sr : cr;
+    // sin negative in quadrants 2,3; cos negative in quadrants 1,2
+    const unsigned long long sbit = (unsigned long long)(q & 2) << 62;
+    const unsigned long long cbit = (unsigned long long)((q + 1) & 2) << 62;
+    s = __longlong_as_double(__double_as_longlong(so) ^ (long long)sbit);
+    c = __longlong_as_double(__double_as_longlong(co) ^ (long long)cbit);
+}
+
+// 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps
+__device__ __forceinline__ double recip_fast(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+// ---- nu_dot = a - Minv C nu - Minv D nu_r - Minv g --------------------------------------------
+// sth, ctsp, ctcp = sin(theta), cos(theta) sin(phi), cos(theta) cos(phi)  (or -R20, R21, R22)
+__device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const double R[9], const double nu[6],
+                                            const double a[6], double sth, double ctsp, double ctcp, double out[6]) {
+    const double u = nu[0], v = nu[1], w = nu[2], pp = nu[3], q = nu[4], r = nu[5];
+    double nr0 = u, nr1 = v, nr2 = w;
+    if (p->has_current) {   // wave-uniform, rare
+        nr0 -= fma(R[6], p->cur[2], fma(R[3], p->cur[1], R[0] * p->cur[0]));
+        nr1 -= fma(R[7], p->cur[2], fma(R[4], p->cur[1], R[1] * p->cur[0]));
+        nr2 -= fma(R[8], p->cur[2], fma(R[5], p->cur[1], R[2] * p->cur[0]));
+    }
+    double o0 = fma(-h.E[0], w * q, a[0]);  o0 = fma(h.E[1], v * r, o0);
+    double o1 = fma(-h.E[2], u * r, a[1]);  o1 = fma(h.E[3], w * pp, o1);
+    double o2 = fma(-h.E[4], v * pp, a[2]); o2 = fma(h.E[5], u * q, o2);
+    double o3 = fma(-h.E[6], v * w, a[3]);  o3 = fma(-h.E[7], q * r, o3);
+    double o4 = fma(-h.E[8], u * w, a[4]);  o4 = fma(-h.E[9], pp * r, o4);
+    double o5 = fma(-h.E[10], u * v, a[5]); o5 = fma(-h.E[11], pp * q, o5);
+    o0 = fma(-fma(h.db[0], fabs(nr0), h.da[0]), nr0, o0);
+    o1 = fma(-fma(h.db[1], fabs(nr1), h.da[1]), nr1, o1);
+    o2 = fma(-fma(h.db[2], fabs(nr2), h.da[2]), nr2, o2);
+    o3 = fma(-fma(h.db[3], fabs(pp), h.da[3]), pp, o3);
+    o4 = fma(-fma(h.db[4], fabs(q), h.da[4]), q, o4);
+    o5 = fma(-fma(h.db[5], fabs(r), h.da[5]), r, o5);
+    o0 = fma(-h.G[0], sth, o0);
+    o1 = fma(h.G[1], ctsp, o1);
+    o2 = fma(h.G[2], ctcp, o2);
+    o3 = fma(h.G[3], ctsp, o3);
+    o4 = fma(h.G[4], sth, o4);
+    if (p->has_xy) {        // xb, yb != 0: never for the reference's vehicle
+        o3 = fma(-p->XY[0], ctcp, o3);
+        o4 = fma(p->XY[1], ctcp, o4);
+        o5 = fma(-p->XY[2], ctsp, o5);
+        o5 = fma(-p->XY[3], sth, o5);
+    }
+    out[0] = o0; out[1] = o1; out[2] = o2; out[3] = o3; out[4] = o4; out[5] = o5;
+}
+
+// xdot for the Euler-angle state; a = Minv tau
+__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12]) {
+    double sphi, cphi, sth, cth, spsi, cpsi;
+    sincos_fast(x[3], sphi, cphi);
+    sincos_fast(x[4], sth, cth);
+    sincos_fast(x[5], spsi, cpsi);
+    double R[9];
+    const double ss = sth * sphi, sc = sth * cphi;
+    R[0] = cpsi * cth; R[1] = fma(cpsi, ss, -(spsi * cphi)); R[2] = fma(cpsi, sc, spsi * sphi);
+    R[3] = spsi * cth; R[4] = fma(spsi, ss, cpsi * cphi);    R[5] = fma(spsi, sc, -(cpsi * sphi));
+    R[6] = -sth;       R[7] = cth * sphi;                    R[8] = cth * cphi;
+    const double* nu = x + 6;
+    nu_dot_fast(h, p, R, nu, a, sth, R[7], R[8], xd + 6);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
+    double cc = cth;
+    if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));   // fossen/BlueROV2.py:52-54
+    const double ic = recip_fast(cc);
+    const double m = fma(sphi, nu[4], cphi * nu[5]);   // sin(phi) q + cos(phi) r
+    xd[3] = fma(sth * ic, m, nu[3]);
+    xd[4] = fma(cphi, nu[4], -(sphi * nu[5]));
+    xd[5] = ic * m;
+}
+
+__device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const double x[13], const double a[6], double xd[13]) {
+    double q[4] = {x[3], x[4], x[5], x[6]};
+    quat_normalize(q);
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    double R[9];
+    R[0] = 1.0 - 2.0 * fma(qy, qy, qz * qz); R[1] = 2.0 * fma(qx, qy, -(qz * qw));    R[2] = 2.0 * fma(qx, qz, qy * qw);
+    R[3] = 2.0 * fma(qx, qy, qz * qw);       R[4] = 1.0 - 2.0 * fma(qx, qx, qz * qz); R[5] = 2.0 * fma(qy, qz, -(qx * qw));
+    R[6] = 2.0 * fma(qx, qz, -(qy * qw));    R[7] = 2.0 * fma(qy, qz, qx * qw);       R[8] = 1.0 - 2.0 * fma(qx, qx, qy * qy);
+    const double* nu = x + 7;
+    nu_dot_fast(h, p, R, nu, a, -R[6], R[7], R[8], xd + 7);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
+    const double wx = nu[3], wy = nu[4], wz = nu[5];
+    xd[3] = 0.5 * (-(qx * wx) - qy * wy - qz * wz);
+    xd[4] = 0.5 * (qw * wx + qy * wz - qz * wy);
+    xd[5] = 0.5 * (qw * wy - qx * wz + qz * wx);
+    xd[6] = 0.5 * (qw * wz + qx * wy - qy * wx);
+}
+
+template <int MODEL>
+__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd) {
+    if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat(h, p, x, a, xd);
+    else rhs_fast_euler(h, p, x, a, xd);
+}
+
+// ---- thruster lag in acceleration space ---------------------------------------------------------
+struct LagZ {
+    double z[6][3];
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { z[k][0] = 0.0; z[k][1] = 0.0; z[k][2] = 0.0; }
+    }
+    // Z = (Minv T) X from the per-thruster state X [8][3]
+    __device__ __forceinline__ void from_thrusters(CFP p, const double X[8][3]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                double a = p->Tm[k][0] * X[0][j];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) a = fma(p->Tm[k][i], X[i][j], a);
+                z[k][j] = a;
+            }
+    }
+    // acceleration seen by the s-th dynamics() call after the last commit (s = 1..4)
+    __device__ __forceinline__ void accel_after(CFP p, int s, const double acmd[6], double a[6]) const {
+        const double c0 = p->lc[s - 1][0], c1 = p->lc[s - 1][1], c2 = p->lc[s - 1][2], d = p->ld[s - 1];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a[k] = fma(c2, z[k][2], fma(c1, z[k][1], fma(c0, z[k][0], d * acmd[k])));
+    }
+    __device__ __forceinline__ void advance(const double __attribute__((address_space(4)))* A, const double __attribute__((address_space(4)))* b, const double acmd[6]) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double a0 = z[k][0], a1 = z[k][1], a2 = z[k][2];
+            z[k][0] = fma(A[2], a2, fma(A[1], a1, fma(A[0], a0, b[0] * acmd[k])));
+            z[k][1] = fma(A[5], a2, fma(A[4], a1, fma(A[3], a0, b[1] * acmd[k])));
+            z[k][2] = fma(A[8], a2, fma(A[7], a1, fma(A[6], a0, b[2] * acmd[k])));
+        }
+    }
+};
+
+__device__ __forceinline__ void advance_thrusters(const double __attribute__((address_space(4)))* A, const double __attribute__((address_space(4)))* b, const double fcmd[8], double X[8][3]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double a0 = X[i][0], a1 = X[i][1], a2 = X[i][2];
+        X[i][0] = fma(A[2], a2, fma(A[1], a1, fma(A[0], a0, b[0] * fcmd[i])));
+        X[i][1] = fma(A[5], a2, fma(A[4], a1, fma(A[3], a0, b[1] * fcmd[i])));
+        X[i][2] = fma(A[8], a2, fma(A[7], a1, fma(A[6], a0, b[2] * fcmd[i])));
+    }
+}
+
+// commanded acceleration of one step: Minv T f(u) (thruster model) or Minv tau (wrench models)
+template <int MODEL>
+__device__ __forceinline__ void command_accel(CFP p, const double* u, double fcmd[8], double acmd[6]) {
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double V = u[i], V2 = V * V;
+            double hh = fma(V2, p->poly[4], p->poly[3]);
+            hh = fma(V2, hh, p->poly[2]);
+            hh = fma(V2, hh, p->poly[1]);
+            hh = fma(V2, hh, p->poly[0]);
+            fcmd[i] = V * hh;
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double a = p->Tm[k][0] * fcmd[0];
+#pragma unroll
+            for (int i = 1; i < 8; ++i) a = fma(p->Tm[k][i], fcmd[i], a);
+            acmd[k] = a;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) acmd[k] = p->minv[k] * u[k];
+    }
+}
+
+// One integrator step.  TRACK: also advance the per-thruster lag state X (for lag_io).
+template <int MODEL, int INTEG, int LAGMODE, bool TRACK>
+__device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt, double* x, const double* u,
+                                          LagZ& lz, double X[8][3]) {
+    constexpr int NX = Dims<MODEL>::NX;
+    constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
+    CFP p = relaunder(p0);
+    double fcmd[8], acmd[6], a[6];
+    command_accel<MODEL>(p, u, fcmd, acmd);
+    if constexpr (INTEG == INTEG_EULER) {
+        double k[NX];
+        if constexpr (THR) lz.accel_after(p, 1, acmd, a);
+        rhs_fast<MODEL>(h, p, x, THR ? a : acmd, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
+        if constexpr (THR) {
+            CFP pl = relaunder(p0);
+            lz.advance(pl->A1, pl->b1, acmd);
+            if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
+        }
+    } else {
+        double k[NX], acc[NX], xs[NX];
+        const double h2 = 0.5 * dt;
+        if constexpr (THR) lz.accel_after(p, 1, acmd, a);
+        rhs_fast<MODEL>(h, p, x, THR ? a : acmd, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = fma(h2, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 2, acmd, a);
+        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(h2, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 3, acmd, a);
+        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(dt, k[i], x[i]); }
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 4, acmd, a);
+        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
+        const double h6 = dt / 6.0;
+#pragma unroll
+        for (int i = 0; i < NX; ++i) x[i] = fma(h6, acc[i] + k[i], x[i]);
+        if constexpr (THR) {
+            CFP pl = relaunder(p0);
+            const double __attribute__((address_space(4)))* A = (LAGMODE == 0) ? pl->A4 : pl->A1;
+            const double __attribute__((address_space(4)))* b = (LAGMODE == 0) ? pl->b4 : pl->b1;
+            lz.advance(A, b, acmd);
+            if constexpr (TRACK) advance_thrusters(A, b, fcmd, X);
+        }
+    }
+    if constexpr (MODEL == MODEL_WRENCH_QUAT) quat_normalize(x + 3);
+}
+
+}  // namespace brov

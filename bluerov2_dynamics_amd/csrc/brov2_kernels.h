@@ -5,16 +5,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "brov2_device.h"
+#include "brov2_fast.h"
 
 namespace brov {
 
 hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u,
                       double* lag, double* xd);
 hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau);
-hipError_t launch_rollout(hipStream_t st, const DevParams& p, int model, int integ, int lag_mode, int layout, int64_t B,
+hipError_t launch_rollout(hipStream_t st, const FastParams* d_fp, int model, int integ, int lag_mode, int layout, int64_t B,
                           int64_t T, double dt, const double* x0, const double* U, double* lag, double* traj,
                           int64_t stride, double* xT);
-hipError_t launch_window_endpoint(hipStream_t st, const DevParams& p, int model, int integ, int64_t N, int64_t H, double dt,
+hipError_t launch_window_endpoint(hipStream_t st, const FastParams* d_fp, int model, int integ, int64_t N, int64_t H, double dt,
                                   const double* X, const double* U, int carry_lag, const double* d_phi9,
                                   double* d_resp, double* d_start, double* d_se, double* d_total);
 hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed,

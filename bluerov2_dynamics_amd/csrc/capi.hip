@@ -33,6 +33,8 @@ struct brov_ctx {
     bool dp_valid = false;
     double dp_dt = 0.0;
     DevParams dp;
+    FastParams fp;
+    FastParams* d_fp = nullptr;   // device copy read by the time-loop kernels through the constant address space
     // EDMDc
     int64_t chunk_rows = (int64_t)1 << 20;
     void* d_tasks = nullptr;
@@ -226,10 +228,41 @@ bool derive(const brov_params& p, double dt, DevParams& o) {
     return true;
 }
 
+// time-loop form of the constants (brov2_fast.h): everything pre-multiplied by Minv
+void derive_fast(const brov_params& p, const DevParams& d, FastParams& f) {
+    std::memset(&f, 0, sizeof f);
+    const double* md = d.md;
+    const double* mi = d.minv;
+    f.E[0] = mi[0] * md[2];  f.E[1] = mi[0] * md[1];
+    f.E[2] = mi[1] * md[0];  f.E[3] = mi[1] * md[2];
+    f.E[4] = mi[2] * md[1];  f.E[5] = mi[2] * md[0];
+    f.E[6] = mi[3] * (md[2] - md[1]);  f.E[7] = mi[3] * (md[5] - md[4]);
+    f.E[8] = mi[4] * (md[0] - md[2]);  f.E[9] = mi[4] * (md[3] - md[5]);
+    f.E[10] = mi[5] * (md[1] - md[0]); f.E[11] = mi[5] * (md[4] - md[3]);
+    for (int i = 0; i < 6; ++i) { f.da[i] = mi[i] * d.dl[i]; f.db[i] = mi[i] * d.dq[i]; f.minv[i] = mi[i]; }
+    f.G[0] = mi[0] * d.WmB; f.G[1] = mi[1] * d.WmB; f.G[2] = mi[2] * d.WmB;
+    f.G[3] = mi[3] * d.zbB; f.G[4] = mi[4] * d.zbB;
+    f.XY[0] = mi[3] * d.ybB; f.XY[1] = mi[4] * d.xbB; f.XY[2] = mi[5] * d.xbB; f.XY[3] = mi[5] * d.ybB;
+    f.has_xy = (p.xb != 0.0 || p.yb != 0.0) ? 1 : 0;
+    f.has_current = d.has_current;
+    for (int i = 0; i < 3; ++i) f.cur[i] = d.cur[i];
+    for (int k = 0; k < 6; ++k)
+        for (int i = 0; i < 8; ++i) f.Tm[k][i] = mi[k] * d.alloc[k][i];
+    for (int i = 0; i < 5; ++i) f.poly[i] = d.poly[i];
+    for (int s = 0; s < 4; ++s) { for (int j = 0; j < 3; ++j) f.lc[s][j] = d.lag_c[s][j]; f.ld[s] = d.lag_d[s]; }
+    for (int j = 0; j < 9; ++j) { f.A1[j] = d.lag_A[0][j]; f.A4[j] = d.lag_A[3][j]; }
+    for (int j = 0; j < 3; ++j) { f.b1[j] = d.lag_b[0][j]; f.b4[j] = d.lag_b[3][j]; }
+}
+
 int get_dp(brov_ctx* c, double dt, const DevParams** out) {
     if (!(dt > 0.0) || !std::isfinite(dt)) return fail(c, BROV_ERR_ARG, "dt must be finite and > 0");
     if (!c->dp_valid || c->dp_dt != dt) {
         if (!derive(c->params, dt, c->dp)) return fail(c, BROV_ERR_ARG, "thruster-lag discretisation failed (singular Pade system)");
+        derive_fast(c->params, c->dp, c->fp);
+        if (!c->d_fp) HIPCK(c, hipMalloc((void**)&c->d_fp, sizeof(FastParams)));
+        // stream ordered: kernels already queued keep the old constants; c->fp outlives the copy (sync below)
+        HIPCK(c, hipMemcpyAsync(c->d_fp, &c->fp, sizeof(FastParams), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
         c->dp_dt = dt;
         c->dp_valid = true;
     }
@@ -315,6 +348,7 @@ void brov_destroy(brov_ctx* c) {
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_tasks) (void)hipFree(c->d_tasks);
+    if (c->d_fp) (void)hipFree(c->d_fp);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -497,7 +531,7 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     rc = get_dp(c, dt, &dp);
     if (rc) return rc;
     CallTimer t(c);
-    HIPCK(c, launch_rollout(c->stream, *dp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U, d_lag_io, d_traj,
+    HIPCK(c, launch_rollout(c->stream, c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U, d_lag_io, d_traj,
                             d_traj ? stride : 1, d_xT));
     return BROV_OK;
 }
@@ -552,8 +586,8 @@ static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t
     const int64_t nwin = N - H;
     double *d_resp = nullptr, *d_start = nullptr, *d_phi = nullptr;
     if (model == BROV_THRUSTER_EULER && carry) {
-        d_resp = a.take<double>(nwin * 24);
-        d_start = a.take<double>(nwin * 24);
+        d_resp = a.take<double>(nwin * 18);
+        d_start = a.take<double>(nwin * 18);
         d_phi = a.take<double>(16);
         double Phi[9];
         lag_window_phi(*dp, H * (integ == BROV_RK4 ? 4 : 1), Phi);
@@ -561,7 +595,7 @@ static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t
         HIPCK(c, hipStreamSynchronize(c->stream));   // Phi is a stack temporary
     }
     CallTimer t(c);
-    HIPCK(c, launch_window_endpoint(c->stream, *dp, model, integ, N, H, dt, dX, dU, carry, d_phi, d_resp, d_start, d_se, d_total));
+    HIPCK(c, launch_window_endpoint(c->stream, c->d_fp, model, integ, N, H, dt, dX, dU, carry, d_phi, d_resp, d_start, d_se, d_total));
     return BROV_OK;
 }
 

@@ -6,6 +6,7 @@
 // arrive as a by-value kernel argument (scalar loads).  Control rows are prefetched one
 // step ahead so the HBM/L2 latency sits under the ~1.5k fp64 instructions of a step.
 #include "brov2_device.h"
+#include "brov2_fast.h"
 #include "brov2_kernels.h"
 
 namespace brov {
@@ -150,22 +151,27 @@ __global__ void __launch_bounds__(256) thruster_forces_kernel(DevParams p, int64
 // ---------------------------------------------------------------------------------------
 // K1: rollout.  U / traj layouts: BTU = [B][T][nu] / [B][rows][nx]; TUB = [T][nu][B] / [rows][nx][B].
 // ---------------------------------------------------------------------------------------
-template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
-__global__ void __launch_bounds__(256) rollout_kernel(DevParams p, int64_t B, int64_t T, double dt,
+template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK>
+__global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restrict__ pg, int64_t B, int64_t T, double dt,
                                                       const double* __restrict__ X0, const double* __restrict__ U,
                                                       double* __restrict__ lag_io, double* __restrict__ traj,
                                                       int64_t stride, double* __restrict__ XT) {
     constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const CFP p = as_constant(pg);
+    HotConsts h;
+    load_hot(p, h);
     double x[NX];
     load_row<NX>(X0 + b * NX, x);
-    LagBank lag;
+    LagZ lz;
+    double Xl[8][3];
     if constexpr (MODEL == MODEL_THRUSTER_EULER) {
-        if (lag_io) load_row<24>(lag_io + b * 24, &lag.x[0][0]);
-        else {
-#pragma unroll
-            for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+        if constexpr (TRACK) {
+            load_row<24>(lag_io + b * 24, &Xl[0][0]);
+            lz.from_thrusters(p, Xl);
+        } else {
+            lz.zero();
         }
     }
     const int64_t rows = traj ? T / stride + 1 : 0;
@@ -190,11 +196,11 @@ __global__ void __launch_bounds__(256) rollout_kernel(DevParams p, int64_t B, in
         double u[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = un[i];
+        up += ustep;
         if (t + 1 < T) {  // prefetch the next control row while this step computes
-            const double* nx_ = up + (t + 1) * ustep;
-            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(nx_, un); else load_soa<NU>(nx_, B, un);
+            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un); else load_soa<NU>(up, B, un);
         }
-        integrate_step<MODEL, INTEG, LAGMODE>(p, dt, x, u, lag);
+        step_fast<MODEL, INTEG, LAGMODE, TRACK>(h, p, dt, x, u, lz, Xl);
         if (traj && --countdown == 0) {
             countdown = stride;
             if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x); else store_soa<NX>(tp, B, x);
@@ -202,9 +208,7 @@ __global__ void __launch_bounds__(256) rollout_kernel(DevParams p, int64_t B, in
         }
     }
     if (XT) store_row<NX>(XT + b * NX, x);
-    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
-        if (lag_io) store_row<24>(lag_io + b * 24, &lag.x[0][0]);
-    }
+    if constexpr (MODEL == MODEL_THRUSTER_EULER && TRACK) store_row<24>(lag_io + b * 24, &Xl[0][0]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -217,28 +221,28 @@ __global__ void __launch_bounds__(256) rollout_kernel(DevParams p, int64_t B, in
 //   (C) every window is an independent lane starting from its own x_k.
 // ---------------------------------------------------------------------------------------
 template <int NSUB>
-__global__ void __launch_bounds__(256) window_lag_response_kernel(DevParams p, int64_t nwin, int64_t H,
+__global__ void __launch_bounds__(256) window_lag_response_kernel(const FastParams* __restrict__ pg, int64_t nwin, int64_t H,
                                                                   const double* __restrict__ U, double* __restrict__ resp) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nwin) return;
-    LagBank lag;
-#pragma unroll
-    for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
+    LagZ lz;
+    lz.zero();
     for (int64_t t = 0; t < H; ++t) {
-        double u[8], fcmd[8];
+        const CFP pp = relaunder(as_constant(pg));
+        double u[8], fcmd[8], acmd[6];
         load_row<8>(U + (k + t) * 8, u);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) fcmd[i] = thrust_poly(p, u[i]);
-        lag.advance(p, NSUB, fcmd);
+        command_accel<MODEL_THRUSTER_EULER>(pp, u, fcmd, acmd);
+        lz.advance(NSUB == 4 ? pp->A4 : pp->A1, NSUB == 4 ? pp->b4 : pp->b1, acmd);
     }
-    store_row<24>(resp + k * 24, &lag.x[0][0]);
+    store_row<18>(resp + k * 18, &lz.z[0][0]);
 }
 
-// start[k] = lag state at the beginning of window k; start[0] = lag0 (zeros in the reference).
+// start[k] = acceleration-space lag state at the beginning of window k; start[0] = 0 (fresh vehicle object).
+// One lane per wrench component; 9 FMA per window on the critical path.
 __global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const double* __restrict__ Phi9,
                                                              const double* __restrict__ resp, double* __restrict__ start) {
-    const int i = threadIdx.x;  // thruster
-    if (i >= 8) return;
+    const int i = threadIdx.x;  // wrench component
+    if (i >= 6) return;
     double P[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) P[j] = Phi9[j];
@@ -248,9 +252,9 @@ __global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const
     double b0 = 0, b1 = 0, b2 = 0;
     if (nwin > 0) { b0 = r[0]; b1 = r[1]; b2 = r[2]; }
     for (int64_t k = 0; k < nwin; ++k) {
-        s[k * 24 + 0] = x0; s[k * 24 + 1] = x1; s[k * 24 + 2] = x2;
+        s[k * 18 + 0] = x0; s[k * 18 + 1] = x1; s[k * 18 + 2] = x2;
         double c0 = b0, c1 = b1, c2 = b2;
-        if (k + 1 < nwin) { b0 = r[(k + 1) * 24 + 0]; b1 = r[(k + 1) * 24 + 1]; b2 = r[(k + 1) * 24 + 2]; }
+        if (k + 1 < nwin) { b0 = r[(k + 1) * 18 + 0]; b1 = r[(k + 1) * 18 + 1]; b2 = r[(k + 1) * 18 + 2]; }
         const double n0 = fma(P[2], x2, fma(P[1], x1, fma(P[0], x0, c0)));
         const double n1 = fma(P[5], x2, fma(P[4], x1, fma(P[3], x0, c1)));
         const double n2 = fma(P[8], x2, fma(P[7], x1, fma(P[6], x0, c2)));
@@ -259,26 +263,27 @@ __global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const
 }
 
 template <int MODEL, int INTEG>
-__global__ void __launch_bounds__(256) window_endpoint_kernel(DevParams p, int64_t nwin, int64_t H, double dt,
+__global__ void __launch_bounds__(256) window_endpoint_kernel(const FastParams* __restrict__ pg, int64_t nwin, int64_t H, double dt,
                                                               const double* __restrict__ X, const double* __restrict__ U,
                                                               const double* __restrict__ lag_start, double* __restrict__ se) {
     constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nwin) return;
+    const CFP p = as_constant(pg);
+    HotConsts h;
+    load_hot(p, h);
     double x[NX];
     load_row<NX>(X + k * NX, x);
-    LagBank lag;
+    LagZ lz;
+    double Xl[8][3];
     if constexpr (MODEL == MODEL_THRUSTER_EULER) {
-        if (lag_start) load_row<24>(lag_start + k * 24, &lag.x[0][0]);
-        else {
-#pragma unroll
-            for (int i = 0; i < 24; ++i) (&lag.x[0][0])[i] = 0.0;
-        }
+        if (lag_start) load_row<18>(lag_start + k * 18, &lz.z[0][0]);
+        else lz.zero();
     }
     for (int64_t t = 0; t < H; ++t) {
         double u[NU];
         load_row<NU>(U + (k + t) * NU, u);   // lane k reads row k+t: coalesced across the wave
-        integrate_step<MODEL, INTEG, 0>(p, dt, x, u, lag);
+        step_fast<MODEL, INTEG, 0, false>(h, p, dt, x, u, lz, Xl);
     }
     double ref[NX], e = 0.0;
     load_row<NX>(X + (k + H) * NX, ref);
@@ -332,14 +337,18 @@ hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B,
 }
 
 template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
-static hipError_t launch_rollout_t(hipStream_t st, const DevParams& p, int64_t B, int64_t T, double dt, const double* x0,
+static hipError_t launch_rollout_t(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
                                    const double* U, double* lag, double* traj, int64_t stride, double* xT) {
-    hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE>), dim3(nblk(B, 256)), dim3(256), 0, st,
-                       p, B, T, dt, x0, U, lag, traj, stride, xT);
+    if (MODEL == MODEL_THRUSTER_EULER && lag)
+        hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, true>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                           p, B, T, dt, x0, U, lag, traj, stride, xT);
+    else
+        hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, false>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                           p, B, T, dt, x0, U, lag, traj, stride, xT);
     return hipGetLastError();
 }
 template <int MODEL, int INTEG, int LAYOUT>
-static hipError_t launch_rollout_l(hipStream_t st, const DevParams& p, int lag_mode, int64_t B, int64_t T, double dt,
+static hipError_t launch_rollout_l(hipStream_t st, const FastParams* p, int lag_mode, int64_t B, int64_t T, double dt,
                                    const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
     if constexpr (MODEL == MODEL_THRUSTER_EULER && INTEG == INTEG_RK4) {
         if (lag_mode == 1) return launch_rollout_t<MODEL, INTEG, LAYOUT, 1>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
@@ -347,7 +356,7 @@ static hipError_t launch_rollout_l(hipStream_t st, const DevParams& p, int lag_m
     return launch_rollout_t<MODEL, INTEG, LAYOUT, 0>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
 }
 template <int MODEL>
-static hipError_t launch_rollout_m(hipStream_t st, const DevParams& p, int integ, int lag_mode, int layout, int64_t B, int64_t T,
+static hipError_t launch_rollout_m(hipStream_t st, const FastParams* p, int integ, int lag_mode, int layout, int64_t B, int64_t T,
                                    double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
     if (integ == INTEG_EULER) {
         if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
@@ -356,7 +365,7 @@ static hipError_t launch_rollout_m(hipStream_t st, const DevParams& p, int integ
     if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
     return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
 }
-hipError_t launch_rollout(hipStream_t st, const DevParams& p, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T,
+hipError_t launch_rollout(hipStream_t st, const FastParams* p, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T,
                           double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
     if (B <= 0) return hipSuccess;
     switch (model) {
@@ -367,13 +376,13 @@ hipError_t launch_rollout(hipStream_t st, const DevParams& p, int model, int int
 }
 
 template <int MODEL, int INTEG>
-static hipError_t launch_window_t(hipStream_t st, const DevParams& p, int64_t nwin, int64_t H, double dt, const double* X,
+static hipError_t launch_window_t(hipStream_t st, const FastParams* p, int64_t nwin, int64_t H, double dt, const double* X,
                                   const double* U, const double* lag_start, double* se) {
     hipLaunchKernelGGL((window_endpoint_kernel<MODEL, INTEG>), dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, dt, X, U, lag_start, se);
     return hipGetLastError();
 }
-// scratch: resp [nwin][24], start [nwin][24], phi [9] (device) -- only used for the thruster model with carry_lag
-hipError_t launch_window_endpoint(hipStream_t st, const DevParams& p, int model, int integ, int64_t N, int64_t H, double dt,
+// scratch: resp [nwin][18], start [nwin][18], phi [9] (device) -- only used for the thruster model with carry_lag
+hipError_t launch_window_endpoint(hipStream_t st, const FastParams* p, int model, int integ, int64_t N, int64_t H, double dt,
                                   const double* X, const double* U, int carry_lag, const double* d_phi9,
                                   double* d_resp, double* d_start, double* d_se, double* d_total) {
     const int64_t nwin = N - H;

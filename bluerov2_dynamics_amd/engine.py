@@ -59,11 +59,13 @@ def thruster_forces(u, dt=0.02, lag=None, ctx=None):
     return tau, lag_io
 
 
-def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layout="btu", stride=1, store=True, ctx=None):
+def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layout="btu", stride=1, store=True, ctx=None,
+            return_lag=True):
     """simulate_physics over a batch (host arrays).
 
     x0 [B,nx]; U [B,T,nu] (layout "btu") or [T,nu,B] ("tub").
-    Returns dict(traj, xT [B,nx], lag [B,8,3] | None); traj is [B,T//stride+1,nx] or [T//stride+1,nx,B]."""
+    Returns dict(traj, xT [B,nx], lag [B,8,3] | None); traj is [B,T//stride+1,nx] or [T//stride+1,nx,B].
+    return_lag=False with lag=None starts from a zero lag state and skips the per-thruster bookkeeping."""
     ctx = ctx or default_context()
     integ, lay = INTEGRATORS[integrator], LAYOUTS[layout]
     nx, nu = NX[model], NU[model]
@@ -75,7 +77,7 @@ def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layou
     assert nu_ == nu, f"U has {nu_} channels, model needs {nu}"
     x0 = as_f64(x0).reshape(B, nx)
     lag_io = None
-    if model == THRUSTER_EULER:
+    if model == THRUSTER_EULER and (lag is not None or return_lag):
         lag_io = np.zeros((B, 8, 3)) if lag is None else as_f64(lag).reshape(B, 8, 3).copy()
     rows = T // stride + 1
     traj = None

@@ -172,6 +172,13 @@ def test_rollout_vs_oracle_all_models_layouts_modes(eng, fc):
                 assert rel_err(r["xT"], o["xT"]) < 1e-10
                 if model == 0:
                     assert rel_err(r["lag"], o["lag"]) < 1e-10
+    # zero lag start without lag bookkeeping (the benchmark's kernel variant) == the tracked variant
+    U = rng.uniform(-1, 1, (B, T, 8))
+    X0 = rng.uniform(-0.5, 0.5, (B, 12))
+    for integ in ("euler", "rk4"):
+        a = eng.rollout(0, integ, X0, U, dt, return_lag=False)
+        b = eng.rollout(0, integ, X0, U, dt)
+        assert a["lag"] is None and np.array_equal(a["traj"], b["traj"])
     # empty / degenerate sizes
     r = eng.rollout(0, "rk4", np.zeros((0, 12)), np.zeros((0, 5, 8)), 0.02)
     assert r["traj"].shape == (0, 6, 12)
