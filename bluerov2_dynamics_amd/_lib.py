@@ -70,6 +70,7 @@ SIGNATURES = {
     "brov_thruster_forces": (ctypes.c_int, [c_void_p, i64, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
     "brov_rollout": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
                                     ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
+    "brov_set_btu_staging": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "brov_rollout_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
                                         ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
     "brov_window_endpoint_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64, ctypes.c_double,
@@ -205,6 +206,10 @@ class Context:
     def use_torch_stream(self):
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_btu_staging(self, mode: int):
+        """0 auto, 1 always stage BTU tiles through LDS, 2 never (see include/brov2.h)."""
+        self.check(self.lib.brov_set_btu_staging(self.h, int(mode)), "brov_set_btu_staging")
 
     def sync(self):
         self.check(self.lib.brov_sync(self.h), "brov_sync")

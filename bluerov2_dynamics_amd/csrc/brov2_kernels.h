@@ -14,7 +14,7 @@ hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, 
 hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau);
 hipError_t launch_rollout(hipStream_t st, const FastParams* d_fp, int model, int integ, int lag_mode, int layout, int64_t B,
                           int64_t T, double dt, const double* x0, const double* U, double* lag, double* traj,
-                          int64_t stride, double* xT);
+                          int64_t stride, double* xT, int btu_staging);
 hipError_t launch_window_endpoint(hipStream_t st, const FastParams* d_fp, int model, int integ, int64_t N, int64_t H, double dt,
                                   const double* X, const double* U, int carry_lag, const double* d_phi9,
                                   double* d_resp, double* d_start, double* d_se, double* d_total);

@@ -36,6 +36,7 @@ struct brov_ctx {
     FastParams fp;
     FastParams* d_fp = nullptr;   // device copy read by the time-loop kernels through the constant address space
     // EDMDc
+    int btu_staging = 0;
     int64_t chunk_rows = (int64_t)1 << 20;
     void* d_tasks = nullptr;
     EdmdcShape task_shape{};
@@ -521,6 +522,12 @@ static int rollout_args_ok(brov_ctx* c, int model, int integ, int lag_mode, int 
     return BROV_OK;
 }
 
+int brov_set_btu_staging(brov_ctx* c, int mode) {
+    if (!c || mode < 0 || mode > 2) return fail(c, BROV_ERR_ARG, "brov_set_btu_staging: mode must be 0, 1 or 2");
+    c->btu_staging = mode;
+    return BROV_OK;
+}
+
 int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T, double dt,
                      const double* d_x0, const double* d_U, double* d_lag_io, double* d_traj, int64_t stride, double* d_xT) {
     int rc = rollout_args_ok(c, model, integ, lag_mode, layout, B, T, stride, d_x0, d_U, d_traj);
@@ -532,7 +539,7 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     if (rc) return rc;
     CallTimer t(c);
     HIPCK(c, launch_rollout(c->stream, c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U, d_lag_io, d_traj,
-                            d_traj ? stride : 1, d_xT));
+                            d_traj ? stride : 1, d_xT, c->btu_staging));
     return BROV_OK;
 }
 

@@ -212,6 +212,123 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
 }
 
 // ---------------------------------------------------------------------------------------
+// K1b: rollout for the caller layout BTU (U[B][T][nu], traj[B][T+1][nx]) with LDS staging.
+//
+// Per trajectory the controls / states of consecutive steps are contiguous in memory but lanes
+// are T*nu*8 bytes apart, so a lane-per-row access touches 64 cache lines per instruction.  Here
+// each wave moves TILE steps at a time through its own LDS region:
+//   in : global_load_lds_dwordx4 (LDS-DMA, no VGPRs, asynchronous, double buffered): one
+//        wave-instruction copies 1 KiB = the next TILE*nu*8 contiguous bytes of 64/CH trajectories.
+//        The DMA writes LDS linearly (slot = i*64 + lane), so the bank-conflict-free image is
+//        obtained by permuting which 16-byte chunk of its trajectory a lane fetches
+//        (chunk = c ^ ((j>>1)&7) for nu = 8) and reading with the same permutation.
+//   out: every lane parks its state row in a padded LDS row; after TILE steps the wave writes the
+//        tile out with 16-byte stores whose lanes walk along the trajectory rows (TILE*nx*8
+//        contiguous bytes per trajectory).
+// Lane <-> trajectory, all state in VGPRs, exactly as rollout_kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int BTU_TILE = 2;
+
+template <int NU> __device__ __forceinline__ int in_swizzle(int d, int j) {
+    if constexpr (NU == 8) return d ^ ((j >> 1) & 7);   // conflict-free for ds_read_b128 (checked exhaustively)
+    else return d;                                       // nu = 6: 2-way at worst
+}
+
+template <int MODEL, int INTEG, int LAGMODE, bool TRACK>
+__global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* __restrict__ pg, int64_t B, int64_t T, double dt,
+                                                              const double* __restrict__ X0, const double* __restrict__ U,
+                                                              double* __restrict__ lag_io, double* __restrict__ traj,
+                                                              double* __restrict__ XT) {
+    constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    constexpr int CH = BTU_TILE * NU / 2;                 // 16-byte chunks per trajectory per input tile
+    constexpr int IN_SLOTS = 64 * CH;                     // per wave per buffer
+    constexpr int ORS = BTU_TILE * NX + 2;                // padded output row (doubles)
+    constexpr int OCB = (NX % 2 == 0) ? 2 : 1;            // doubles per output chunk (16 B when rows stay 16-B aligned)
+    constexpr int OCPR = BTU_TILE * NX / OCB;             // output chunks per trajectory per tile
+    __shared__ __attribute__((aligned(16))) double lds_in[4][2][IN_SLOTS * 2];
+    __shared__ __attribute__((aligned(16))) double lds_out[4][64 * ORS];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t b0w = (int64_t)blockIdx.x * 256 + wave * 64;     // first trajectory of this wave
+    const int64_t b_raw = b0w + lane;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;                        // dead lanes shadow the last trajectory, never store
+    const CFP p = as_constant(pg);
+    HotConsts h;
+    load_hot(p, h);
+    double x[NX];
+    load_row<NX>(X0 + b * NX, x);
+    LagZ lz;
+    double Xl[8][3];
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        if constexpr (TRACK) { load_row<24>(lag_io + b * 24, &Xl[0][0]); lz.from_thrusters(p, Xl); }
+        else lz.zero();
+    }
+    if (traj && live) store_row<NX>(traj + b * (T + 1) * NX, x);
+
+    // issue the LDS-DMA of input tile `k` into buffer k&1
+    auto issue_tile = [&](int64_t k) {
+        const int64_t t0 = k * BTU_TILE;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int g = i * 64 + lane;
+            const int j = g / CH, c = g % CH;
+            const int d = in_swizzle<NU>(c, j);                    // data chunk this lane fetches
+            int64_t bj = b0w + j;
+            if (bj >= B) bj = B - 1;
+            int64_t t = t0 + (2 * d) / NU;
+            if (t >= T) t = T - 1;                                 // stay inside the buffer; value is never used
+            const double* src = U + (bj * T + t) * NU + (2 * d) % NU;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(&lds_in[wave][k & 1][i * 128]), 16, 0, 0);
+        }
+    };
+
+    const int64_t ntiles = (T + BTU_TILE - 1) / BTU_TILE;
+    if (ntiles > 0) issue_tile(0);
+    for (int64_t k = 0; k < ntiles; ++k) {
+        __syncthreads();                     // tile k has landed (vmcnt(0)); last tile's LDS reads are finished
+        if (k + 1 < ntiles) issue_tile(k + 1);
+        const double* ib = &lds_in[wave][k & 1][0];
+        double* ob = &lds_out[wave][lane * ORS];
+        const int64_t t0 = k * BTU_TILE;
+#pragma unroll 1
+        for (int s = 0; s < BTU_TILE; ++s) {
+            if (t0 + s < T) {
+                double u[NU];
+#pragma unroll
+                for (int cc = 0; cc < NU / 2; ++cc) {
+                    const int d = s * (NU / 2) + cc;
+                    const double2 v = *reinterpret_cast<const double2*>(ib + (lane * CH + in_swizzle<NU>(d, lane)) * 2);
+                    u[2 * cc] = v.x; u[2 * cc + 1] = v.y;
+                }
+                step_fast<MODEL, INTEG, LAGMODE, TRACK>(h, p, dt, x, u, lz, Xl);
+                if (traj) store_row<NX>(ob + s * NX, x);
+            }
+        }
+        if (traj) {
+            __syncthreads();                 // the wave's output tile is complete
+            const double* ot = &lds_out[wave][0];
+#pragma unroll
+            for (int i = 0; i < (64 * OCPR + 63) / 64; ++i) {
+                const int g = i * 64 + lane;
+                const int j = g / OCPR, c = g % OCPR;
+                const int64_t bj = b0w + j;
+                const int64_t row = t0 + 1 + (c * OCB) / NX;       // trajectory row of this chunk
+                if (j < 64 && bj < B && row <= T) {
+                    double* dst = traj + (bj * (T + 1) + t0 + 1) * NX + c * OCB;
+                    const double* sp = ot + j * ORS + c * OCB;
+                    if constexpr (OCB == 2) *reinterpret_cast<double2*>(dst) = *reinterpret_cast<const double2*>(sp);
+                    else *dst = *sp;
+                }
+            }
+        }
+    }
+    if (XT && live) store_row<NX>(XT + b * NX, x);
+    if constexpr (MODEL == MODEL_THRUSTER_EULER && TRACK) { if (live) store_row<24>(lag_io + b * 24, &Xl[0][0]); }
+}
+
+// ---------------------------------------------------------------------------------------
 // K3: sliding-window endpoint error (multistep_rmse_endpoint_physics,
 // training/train_tank_brov2_full_comparison.py:469-487).  Quirk Q2: the reference uses ONE
 // vehicle object for all windows, so window k starts from the lag state window k-1 left.
@@ -338,7 +455,19 @@ hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B,
 
 template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
 static hipError_t launch_rollout_t(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
-                                   const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+                                   const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
+    // LDS staging pays where the kernel is memory-bound (Euler, wrench models); the thruster RK4 kernel is
+    // instruction-issue bound at one wave per SIMD and loses 14 % to the staging instructions
+    const bool want_lds = btu_staging == 1 || (btu_staging == 0 && (INTEG == INTEG_EULER || MODEL != MODEL_THRUSTER_EULER));
+    if (LAYOUT == LAYOUT_BTU && (!traj || stride == 1) && T > 0 && want_lds) {
+        if (MODEL == MODEL_THRUSTER_EULER && lag)
+            hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, true>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                               p, B, T, dt, x0, U, lag, traj, xT);
+        else
+            hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, false>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                               p, B, T, dt, x0, U, lag, traj, xT);
+        return hipGetLastError();
+    }
     if (MODEL == MODEL_THRUSTER_EULER && lag)
         hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, true>), dim3(nblk(B, 256)), dim3(256), 0, st,
                            p, B, T, dt, x0, U, lag, traj, stride, xT);
@@ -349,29 +478,29 @@ static hipError_t launch_rollout_t(hipStream_t st, const FastParams* p, int64_t 
 }
 template <int MODEL, int INTEG, int LAYOUT>
 static hipError_t launch_rollout_l(hipStream_t st, const FastParams* p, int lag_mode, int64_t B, int64_t T, double dt,
-                                   const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+                                   const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
     if constexpr (MODEL == MODEL_THRUSTER_EULER && INTEG == INTEG_RK4) {
-        if (lag_mode == 1) return launch_rollout_t<MODEL, INTEG, LAYOUT, 1>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
+        if (lag_mode == 1) return launch_rollout_t<MODEL, INTEG, LAYOUT, 1>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
     }
-    return launch_rollout_t<MODEL, INTEG, LAYOUT, 0>(st, p, B, T, dt, x0, U, lag, traj, stride, xT);
+    return launch_rollout_t<MODEL, INTEG, LAYOUT, 0>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
 }
 template <int MODEL>
 static hipError_t launch_rollout_m(hipStream_t st, const FastParams* p, int integ, int lag_mode, int layout, int64_t B, int64_t T,
-                                   double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+                                   double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
     if (integ == INTEG_EULER) {
-        if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
-        return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+        if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
     }
-    if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
-    return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT);
+    if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+    return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
 }
 hipError_t launch_rollout(hipStream_t st, const FastParams* p, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T,
-                          double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT) {
+                          double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
     if (B <= 0) return hipSuccess;
     switch (model) {
-        case MODEL_THRUSTER_EULER: return launch_rollout_m<MODEL_THRUSTER_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
-        case MODEL_WRENCH_EULER: return launch_rollout_m<MODEL_WRENCH_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
-        default: return launch_rollout_m<MODEL_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT);
+        case MODEL_THRUSTER_EULER: return launch_rollout_m<MODEL_THRUSTER_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        case MODEL_WRENCH_EULER: return launch_rollout_m<MODEL_WRENCH_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        default: return launch_rollout_m<MODEL_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
     }
 }
 

@@ -132,6 +132,10 @@ BROV_API int brov_thruster_forces(brov_ctx* ctx, int64_t B, const double* u, dou
 BROV_API int brov_rollout(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
                  int64_t B, int64_t T, double dt, const double* x0, const double* U,
                  double* lag_io, double* traj, int64_t traj_stride, double* xT);
+/* How BROV_LAYOUT_BTU rollouts (stride 1 or no trajectory) move data: 0 = auto (LDS-staged tiles
+ * for the memory-bound cases -- Euler, wrench models -- and lane-per-row accesses for the
+ * instruction-bound thruster RK4 kernel; measured in DESIGN.md), 1 = always LDS-staged, 2 = never. */
+BROV_API int brov_set_btu_staging(brov_ctx* ctx, int mode);
 BROV_API int brov_rollout_dev(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
                      int64_t B, int64_t T, double dt, const double* d_x0, const double* d_U,
                      double* d_lag_io, double* d_traj, int64_t traj_stride, double* d_xT);

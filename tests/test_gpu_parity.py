@@ -186,6 +186,35 @@ def test_rollout_vs_oracle_all_models_layouts_modes(eng, fc):
     assert np.array_equal(r["xT"], np.ones((3, 12)) * 0.1) and r["traj"].shape == (3, 1, 12)
 
 
+def test_btu_lds_staged_and_direct_paths_agree(eng, fc):
+    """BROV_LAYOUT_BTU has two data paths (LDS-staged tiles vs lane-per-row): both must equal the oracle
+    and each other bit for bit, for odd horizons (partial last tile) and ragged batches."""
+    from bluerov2_dynamics_amd import _lib
+    rng = np.random.default_rng(5)
+    B, dt = 300, 0.02
+    for model in (0, 1, 2):
+        nx, nu = fc.NX[model], fc.NU[model]
+        for T in (1, 2, 7):
+            X0 = rng.uniform(-0.5, 0.5, (B, nx))
+            U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 15.0)
+            lag0 = rng.uniform(-1, 1, (B, 8, 3)) if model == 0 else None
+            for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
+                o = fc.rollout(model, oi, X0, U, dt, lag=lag0, nthreads=8)
+                res = []
+                for mode in (1, 2):
+                    ctx = _lib.Context(0)
+                    ctx.set_btu_staging(mode)
+                    r = eng.rollout(model, integ, X0, U, dt, lag=lag0, ctx=ctx)
+                    assert rel_err(r["traj"], o["traj"]) < 1e-11, (model, T, integ, mode)
+                    assert rel_err(r["xT"], o["xT"]) < 1e-11
+                    r2 = eng.rollout(model, integ, X0, U, dt, lag=lag0, ctx=ctx, store=False)   # endpoint only
+                    assert np.array_equal(r2["xT"], r["xT"])
+                    res.append(r)
+                assert np.array_equal(res[0]["traj"], res[1]["traj"])
+                if model == 0:
+                    assert np.array_equal(res[0]["lag"], res[1]["lag"]) and rel_err(res[0]["lag"], o["lag"]) < 1e-11
+
+
 def test_fill_controls_layouts_and_ar1(eng):
     import torch
     from oracle import controls
