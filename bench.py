@@ -239,6 +239,23 @@ def main():
                          "kernel_ms": ekern_s * 1e3, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE, "traffic": None},
             "A_finite": bool(np.isfinite(A_).all() and np.isfinite(B_).all()),
         }
+        # f1: KoopmanEDMDc.multistep_rmse on the recorded-data size of the reference (45 823 samples, H = 100;
+        # training/best_results.txt:801 logs 41.19 s for it on the authors' CPU) -- rank 0 only, host arrays in/out
+        if rank == 0:
+            Nm, Hm = 45823, 100
+            Xm = Xe.view(-1, n)[: Nm].cpu().numpy()
+            Um = Ue.view(-1, r)[: Nm].cpu().numpy()      # timing only: alignment across bag ends is irrelevant
+            ctx.set_timing(True)
+            t1 = time.perf_counter()
+            se, _ = engine.multistep_se(Xm, Um, Cc.cpu().numpy(), gamma, A_, B_, Hm, ctx=ctx)
+            wall_ms = (time.perf_counter() - t1) * 1e3
+            kms = ctx.last_kernel_ms()
+            ctx.set_timing(False)
+            nw = Nm - Hm
+            out["edmdc"]["multistep_rmse_H100"] = {
+                "windows": nw, "H": Hm, "wall_ms_host_to_host": wall_ms, "kernel_ms": kms,
+                "tflops": 2.0 * nw * d * p * Hm / (kms * 1e-3) / 1e12, "finite": bool(np.isfinite(se)),
+                "note": "lift + 100 fp64 MFMA GEMM steps + endpoint error; reference CPU log: 41.19 s"}
         if rank == 0 and not a.no_cpu:
             out["edmdc"]["cpu_baseline"] = cpu_baseline_gram(Cc.cpu().numpy(), gamma)
 

@@ -45,17 +45,72 @@ hipError_t launch_center_norms(hipStream_t st, int n, int k, const double* C, do
     return hipGetLastError();
 }
 
-// rbf value for the centre held by this lane, state row read through wave-uniform loads
-__device__ __forceinline__ double rbf_one(int n, double gamma, const double* __restrict__ xrow, const double* c, double c2) {
-    double x2 = 0.0, dot = 0.0;
+// exp(x): k = rint(x / ln 2), r = x - k ln2 (two-constant Cody-Waite), degree-13 Taylor on |r| <= ln2/2
+// (truncation 4e-18), scaled by 2^k with v_ldexp_f64 (underflows to 0 like exp, NaN propagates).
+// ~20 instructions against ~35 for the OCML routine; <= 1 ulp on the range the RBF lift uses (x <= ~0).
+__device__ __forceinline__ double exp_fast(double x) {
+    const double kf = rint(x * 1.44269504088896338700e+00);
+    double r = fma(-kf, 6.93147180369123816490e-01, x);      // ln2_hi
+    r = fma(-kf, 1.90821492927058770002e-10, r);             // ln2_lo
+    double p = fma(r, 1.6059043836821614599e-10, 2.0876756987868098979e-09);   // 1/13!, 1/12!
+    p = fma(r, p, 2.5052108385441718775e-08);    // 1/11!
+    p = fma(r, p, 2.7557319223985890653e-07);    // 1/10!
+    p = fma(r, p, 2.7557319223985892511e-06);    // 1/9!
+    p = fma(r, p, 2.4801587301587301566e-05);    // 1/8!
+    p = fma(r, p, 1.9841269841269841253e-04);    // 1/7!
+    p = fma(r, p, 1.3888888888888889419e-03);    // 1/6!
+    p = fma(r, p, 8.3333333333333332177e-03);    // 1/5!
+    p = fma(r, p, 4.1666666666666664354e-02);    // 1/4!
+    p = fma(r, p, 1.6666666666666665741e-01);    // 1/3!
+    p = fma(r, p, 0.5);
+    p = fma(r, p, 1.0);
+    p = fma(r, p, 1.0);
+    double kc = fmin(fmax(kf, -2200.0), 2200.0);             // keep the int conversion in range; ldexp saturates
+    return ldexp(p, (int)kc);
+}
+
+// rbf value for the centre held by this lane, state row read through wave-uniform (scalar) loads.
+// NS > 0: compile-time state dimension (straight-line code, merged scalar loads); NS = 0: runtime n.
+// x2 = |x|^2 is the same for every lane; it is computed once per row and shared by the NC centres of a lane.
+template <int NS, int NC>
+__device__ __forceinline__ void rbf_row(int n, double gamma, const double* __restrict__ xrow, const double (*c)[LIFT_NMAX],
+                                        const double* c2, double* out) {
+    double x2 = 0.0, dot[NC];
 #pragma unroll
-    for (int j = 0; j < LIFT_NMAX; ++j) {
-        if (j < n) { const double xj = xrow[j]; x2 = fma(xj, xj, x2); dot = fma(xj, c[j], dot); }
+    for (int q = 0; q < NC; ++q) dot[q] = 0.0;
+    if constexpr (NS > 0) {
+        double xr[NS];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) xr[j] = xrow[j];
+#pragma unroll
+        for (int j = 0; j < NS; ++j) {
+            x2 = fma(xr[j], xr[j], x2);
+#pragma unroll
+            for (int q = 0; q < NC; ++q) dot[q] = fma(xr[j], c[q][j], dot[q]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < LIFT_NMAX; ++j) {
+            if (j < n) {
+                const double xj = xrow[j];
+                x2 = fma(xj, xj, x2);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) dot[q] = fma(xj, c[q][j], dot[q]);
+            }
+        }
     }
-    return exp(-gamma * ((x2 + c2) - 2.0 * dot));
+#pragma unroll
+    for (int q = 0; q < NC; ++q) out[q] = exp_fast(-gamma * ((x2 + c2[q]) - 2.0 * dot[q]));   // Koopman/koopmanEDMDc.py:46-48
+}
+template <int NS>
+__device__ __forceinline__ double rbf_one(int n, double gamma, const double* __restrict__ xrow, const double* c, double c2) {
+    double o;
+    rbf_row<NS, 1>(n, gamma, xrow, reinterpret_cast<const double (*)[LIFT_NMAX]>(c), &c2, &o);
+    return o;
 }
 
 // Reference-order lift: Z[N][n+k] = [x, rbf].  Block = 256 lanes = 256 centres, tile of 64 rows.
+template <int NS>
 __global__ void __launch_bounds__(256) lift_ref_kernel(int64_t N, int n, int k, double gamma, const double* __restrict__ X,
                                                        const double* __restrict__ C, double* __restrict__ Z) {
     const int c = blockIdx.y * 256 + threadIdx.x;
@@ -66,55 +121,80 @@ __global__ void __launch_bounds__(256) lift_ref_kernel(int64_t N, int n, int k, 
     for (int j = 0; j < LIFT_NMAX; ++j) { cc[j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2 = fma(cc[j], cc[j], c2); }
     for (int64_t r = r0; r < r0 + 64 && r < N; ++r) {
         const double* xrow = X + r * n;
-        if (c < k) Z[r * d + n + c] = rbf_one(n, gamma, xrow, cc, c2);
+        if (c < k) Z[r * d + n + c] = rbf_one<NS>(n, gamma, xrow, cc, c2);
         if (blockIdx.y == 0 && (int)threadIdx.x < n) Z[r * d + threadIdx.x] = xrow[threadIdx.x];
     }
 }
 hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z) {
     if (N <= 0) return hipSuccess;
     if (n > LIFT_NMAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lift_ref_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((k + 255) / 256)), dim3(256), 0, st, N, n, k, gamma, X, C, Z);
+    const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((k + 255) / 256));
+    if (n == 12) hipLaunchKernelGGL(lift_ref_kernel<12>, grid, dim3(256), 0, st, N, n, k, gamma, X, C, Z);
+    else if (n == 13) hipLaunchKernelGGL(lift_ref_kernel<13>, grid, dim3(256), 0, st, N, n, k, gamma, X, C, Z);
+    else hipLaunchKernelGGL(lift_ref_kernel<0>, grid, dim3(256), 0, st, N, n, k, gamma, X, C, Z);
     return hipGetLastError();
 }
 
-// Device-native lifted rows.  grid.x = row tiles of 32, grid.y = groups of 256 centres (+1 block row for the tail).
+// Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (+1 block row for the tail).
+template <int NS>
 __global__ void __launch_bounds__(256) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
                                                         int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
                                                         const double* __restrict__ X, const double* __restrict__ U,
                                                         double* __restrict__ Zrows, double* __restrict__ wrow) {
     const int n = s.n, k = s.k, W = s.width;
-    const int64_t l0 = (int64_t)blockIdx.x * 32;       // local row index within the chunk buffer
-    const int ngroups = (s.kp + 255) / 256;
+    constexpr int RT = 64;                             // rows per block
+    constexpr int NC = 2;                              // centres per lane: block covers 512 centres
+    const int64_t l0 = (int64_t)blockIdx.x * RT;       // local row index within the chunk buffer
+    const int ngroups = (s.kp + 256 * NC - 1) / (256 * NC);
+    // (bag, step) of the first row: one 64-bit division per block, then incremental (a division per row
+    // costs ~130 scalar instructions, three times the useful work of a row)
+    const int64_t g0 = row0 + l0;
+    int64_t bag = g0 / xs, t = g0 - bag * xs;
+    const int64_t lend = (l0 + RT < rows) ? l0 + RT : rows;
     if ((int)blockIdx.y < ngroups) {
-        const int c = blockIdx.y * 256 + threadIdx.x;
-        double cc[LIFT_NMAX], c2 = 0.0;
+        // lane holds centres c0 and c0 + 256 (both store streams stay 512 contiguous bytes per wave)
+        const int c0 = blockIdx.y * 256 * NC + threadIdx.x;
+        double cc[NC][LIFT_NMAX], c2[NC];
 #pragma unroll
-        for (int j = 0; j < LIFT_NMAX; ++j) { cc[j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2 = fma(cc[j], cc[j], c2); }
-        for (int64_t l = l0; l < l0 + 32 && l < rows; ++l) {
-            const int64_t g = row0 + l;                 // global state row
-            double z = 0.0;
-            if (g < total_rows && c < k) {
-                const int64_t t = g % xs;
-                if (t <= L) z = rbf_one(n, gamma, X + g * n, cc, c2);
+        for (int q = 0; q < NC; ++q) {
+            const int c = c0 + 256 * q;
+            c2[q] = 0.0;
+#pragma unroll
+            for (int j = 0; j < LIFT_NMAX; ++j) { cc[q][j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2[q] = fma(cc[q][j], cc[q][j], c2[q]); }
+        }
+        const double* xp = X + (g0 < total_rows ? g0 : total_rows - 1) * n;
+        double* zp = Zrows + l0 * W + c0;
+#pragma unroll 1
+        for (int64_t l = l0; l < lend; ++l) {
+            const int64_t g = row0 + l;
+            double z[NC];
+            rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
+            const bool valid = g < total_rows && t <= L;                     // wave-uniform
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                const int c = c0 + 256 * q;
+                if (c < s.kp) zp[256 * q] = (valid && c < k) ? z[q] : 0.0;
             }
-            if (c < s.kp) Zrows[l * W + c] = z;
+            zp += W;
+            if (g + 1 < total_rows) xp += n;                                 // clamp: rows past the end are masked
+            if (++t == xs) { t = 0; ++bag; }
         }
     } else {
         // tail block: [x | u | 0], and the pair weight
         const int j = threadIdx.x;
-        for (int64_t l = l0; l < l0 + 32 && l < rows; ++l) {
+        for (int64_t l = l0; l < lend; ++l) {
             const int64_t g = row0 + l;
             double v = 0.0, w = 0.0;
             if (g < total_rows) {
-                const int64_t b = g / xs, t = g % xs;
                 if (t <= L) {
                     if (j < n) v = X[g * n + j];
-                    else if (j < n + s.r && t < L) v = U[(b * us + t) * s.r + (j - n)];
+                    else if (j < n + s.r && t < L) v = U[(bag * us + t) * s.r + (j - n)];
                 }
                 if (t < L) w = 1.0;
             }
             if (j < s.tailp) Zrows[l * W + s.kp + j] = v;
             if (j == 0) wrow[l] = w;
+            if (++t == xs) { t = 0; ++bag; }
         }
     }
 }
@@ -122,10 +202,12 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
                                   int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
                                   const double* X, const double* U, double* Zrows, double* wrow) {
     if (rows <= 0) return hipSuccess;
-    if (s.n > LIFT_NMAX || s.tailp > 256) return hipErrorInvalidValue;
-    const int ngroups = (s.kp + 255) / 256;
-    hipLaunchKernelGGL(lift_rows_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)(ngroups + 1)), dim3(256), 0, st,
-                       s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    if (s.n > LIFT_NMAX || s.tailp > 256 || xs < 2 || total_rows < 1) return hipErrorInvalidValue;
+    const int ngroups = (s.kp + 511) / 512;
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(ngroups + 1));
+    if (s.n == 12) hipLaunchKernelGGL(lift_rows_kernel<12>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    else if (s.n == 13) hipLaunchKernelGGL(lift_rows_kernel<13>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    else hipLaunchKernelGGL(lift_rows_kernel<0>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     return hipGetLastError();
 }
 
@@ -154,14 +236,23 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks) 
     }
 }
 
-constexpr int GRAM_NSLAB = 24;   // K-slabs per chunk (multiple of 8 XCDs); 81 tasks x 24 = 1944 waves <= 2048 slots (2 waves/SIMD)
+// K-slabs per chunk: as many as keep tasks x slabs within the 2048 wave slots of the chip at 2 waves/SIMD
+// (k = 512: 81 tasks x 25 slabs = 2025 waves, one resident round, 98.9 % of the slots busy)
+constexpr int GRAM_WAVE_SLOTS = 2048;
+static int gram_nslab(int ntasks) {
+    int ns = GRAM_WAVE_SLOTS / (ntasks > 0 ? ntasks : 1);
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    return ns;
+}
 
 size_t gram_partial_doubles(const EdmdcShape& s, int* ntasks_out, int* nslab_out) {
     std::vector<GramTask> tasks;
     build_gram_tasks(s, tasks);
     if (ntasks_out) *ntasks_out = (int)tasks.size();
-    if (nslab_out) *nslab_out = GRAM_NSLAB;
-    return tasks.size() * (size_t)GRAM_NSLAB * GRAM_TA * GRAM_TB * 256;
+    const int ns = gram_nslab((int)tasks.size());
+    if (nslab_out) *nslab_out = ns;
+    return tasks.size() * (size_t)ns * GRAM_TA * GRAM_TB * 256;
 }
 
 size_t gram_task_bytes() { return 256 * sizeof(GramTask); }
@@ -176,17 +267,19 @@ hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, void* d_tasks,
 }
 
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
-gram_kernel(int W, int ntasks, int64_t ksteps_total, const GramTask* __restrict__ tasks,
+gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_total, const GramTask* __restrict__ tasks,
             const double* __restrict__ Z, const double* __restrict__ wrow, double* __restrict__ partial, int accumulate) {
-    // XCD-aware item mapping: blocks b and b+8 share an XCD (observed round-robin); keep a slab on one XCD.
+    // XCD-aware item mapping: blocks b and b+8 share an XCD (observed round-robin, speed only); items are
+    // ordered slab-major and each XCD takes a contiguous run, so the ~81 task-waves of a slab share one L2.
     const int bid = blockIdx.x;
-    const int xcd = bid & 7, i = bid >> 3;
-    const int slab = (i / ntasks) * 8 + xcd;
-    const int task = i % ntasks;
+    const int item = (bid & 7) * items_per_xcd + (bid >> 3);
+    if ((bid >> 3) >= items_per_xcd || item >= ntasks * nslab) return;
+    const int slab = item / ntasks;
+    const int task = item - slab * ntasks;
     const int lane = threadIdx.x;
     const int kq = lane >> 4, col = lane & 15;
 
-    const int64_t per = (ksteps_total + GRAM_NSLAB - 1) / GRAM_NSLAB;
+    const int64_t per = (ksteps_total + nslab - 1) / nslab;
     const int64_t ks0 = (int64_t)slab * per;
     int64_t ks1 = ks0 + per;
     if (ks1 > ksteps_total) ks1 = ksteps_total;
@@ -239,7 +332,7 @@ gram_kernel(int W, int ntasks, int64_t ksteps_total, const GramTask* __restrict_
         }
     }
     // partial[(task * NSLAB + slab)][tile = a * TB + b][lane][4]
-    double* out = partial + ((int64_t)task * GRAM_NSLAB + slab) * (GRAM_TA * GRAM_TB * 256) + lane * 4;
+    double* out = partial + ((int64_t)task * nslab + slab) * (GRAM_TA * GRAM_TB * 256) + lane * 4;
     if (accumulate) {
 #pragma unroll
         for (int a = 0; a < GRAM_TA; ++a)
@@ -259,7 +352,9 @@ gram_kernel(int W, int ntasks, int64_t ksteps_total, const GramTask* __restrict_
 hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
                                    const double* Zrows, const double* wrow, double* partial, int accumulate) {
     const int64_t ksteps = (npairs + 3) / 4;
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(ntasks * GRAM_NSLAB)), dim3(64), 0, st, s.width, ntasks, ksteps,
+    const int nslab = gram_nslab(ntasks);
+    const int per_xcd = (ntasks * nslab + 7) / 8;
+    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.width, ntasks, nslab, per_xcd, ksteps,
                        reinterpret_cast<const GramTask*>(d_tasks), Zrows, wrow, partial, accumulate);
     return hipGetLastError();
 }
@@ -274,7 +369,7 @@ __device__ __forceinline__ int dev_to_ref_feature(const EdmdcShape& s, int f, bo
     if (j < s.n + s.r) return is_y ? -1 : s.d + (j - s.n);
     return -1;
 }
-__global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntasks, const GramTask* __restrict__ tasks,
+__global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntasks, int nslab, const GramTask* __restrict__ tasks,
                                                           const double* __restrict__ partial, int accumulate_out,
                                                           double* __restrict__ GtG, double* __restrict__ GtY) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over ntasks * 32 tiles * 256
@@ -293,8 +388,8 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntas
     const int ri = dev_to_ref_feature(s, fi, false), rj = dev_to_ref_feature(s, fj, is_y);
     if (ri < 0 || rj < 0) return;
     double sum = 0.0;
-    const double* pp = partial + (int64_t)task * GRAM_NSLAB * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;
-    for (int sl = 0; sl < GRAM_NSLAB; ++sl) sum += pp[(int64_t)sl * (GRAM_TA * GRAM_TB * 256)];
+    const double* pp = partial + (int64_t)task * nslab * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;
+    for (int sl = 0; sl < nslab; ++sl) sum += pp[(int64_t)sl * (GRAM_TA * GRAM_TB * 256)];
     if (is_y) {
         double* o = GtY + (int64_t)ri * s.d + rj;
         *o = accumulate_out ? *o + sum : sum;
@@ -309,7 +404,7 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntas
 hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, const double* partial,
                                     int accumulate_out, double* GtG, double* GtY) {
     const int64_t total = (int64_t)ntasks * GRAM_TA * GRAM_TB * 256;
-    hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, ntasks,
+    hipLaunchKernelGGL(gram_finish_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, s, ntasks, gram_nslab(ntasks),
                        reinterpret_cast<const GramTask*>(d_tasks), partial, accumulate_out, GtG, GtY);
     return hipGetLastError();
 }
