@@ -4,8 +4,10 @@ _lift, _lift_inverse; dataclass fields state_dim, input_dim, n_rbfs, gamma, ridg
 lift_dim_).
 
 What runs where:
-  * RBF centres: sklearn KMeans(n_clusters, n_init="auto", random_state=0) on the host, the very
-    call the reference makes (:85,126) -- a third-party dependency of both;
+  * RBF centres: the reference calls sklearn KMeans(n_clusters, n_init="auto", random_state=0) (:85,126).
+    Here scikit-learn provides the seeded k-means++ initialisation and the Lloyd E/M loop runs on the GPU
+    (csrc/kmeans.hip) with scikit-learn's stopping rules: same centres to rounding, tested.  `kmeans="sklearn"`
+    calls scikit-learn for the whole thing instead;
   * lift phi(x) = [x, exp(-gamma(|x|^2+|c|^2-2x.c))] and the G^T[G|Y] normal-equation blocks:
     HIP kernels (csrc/edmdc.hip, fp64 MFMA);
   * the p x p ridge solve: NumPy pinv on the host, in fit_multi's association
@@ -22,9 +24,11 @@ import numpy as np
 from .. import engine
 
 
-def _kmeans_centers(X, n_rbfs):
-    from sklearn.cluster import KMeans
-    return KMeans(n_clusters=n_rbfs, n_init="auto", random_state=0).fit(X).cluster_centers_
+def _kmeans_centers(X, n_rbfs, backend="hip"):
+    if backend == "sklearn":
+        from sklearn.cluster import KMeans
+        return KMeans(n_clusters=n_rbfs, n_init="auto", random_state=0).fit(X).cluster_centers_
+    return engine.kmeans_centers(X, n_rbfs, random_state=0)
 
 
 @dataclass
@@ -39,6 +43,7 @@ class KoopmanEDMDc:
     A_: np.ndarray = None
     B_: np.ndarray = None
     lift_dim_: int = None
+    kmeans: str = "hip"                 # "hip" (GPU Lloyd, sklearn k-means++ init) or "sklearn"
 
     # ------------------------------------------------------------------ fitting
     def fit(self, X, U, centers=None) -> None:
@@ -48,7 +53,7 @@ class KoopmanEDMDc:
         U = np.asarray(U, dtype=float)
         N, n = X.shape
         assert U.shape[0] == N and U.shape[1] == self.input_dim
-        self.centers_ = _kmeans_centers(X, self.n_rbfs) if centers is None else np.asarray(centers, dtype=float)
+        self.centers_ = _kmeans_centers(X, self.n_rbfs, self.kmeans) if centers is None else np.asarray(centers, dtype=float)
         self._solve([X], [U])
 
     def fit_multi(self, X_list, U_list, centers=None) -> None:
@@ -58,7 +63,7 @@ class KoopmanEDMDc:
             assert X.shape[1] == self.state_dim and U.shape[1] == self.input_dim
         if centers is None:
             X_all = np.vstack([X for X in X_list if len(X) > 0])
-            centers = _kmeans_centers(X_all, self.n_rbfs)
+            centers = _kmeans_centers(X_all, self.n_rbfs, self.kmeans)
         self.centers_ = np.asarray(centers, dtype=float)
         self._solve(list(X_list), list(U_list))
 

@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libbrov2.so")
-SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "controls.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "kmeans.hip", "controls.hip"]
 HEADERS = ["brov2_device.h", "brov2_kernels.h", os.path.join("..", "..", "include", "brov2.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-DBROV2_BUILDING=1"]

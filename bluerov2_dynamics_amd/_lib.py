@@ -85,6 +85,10 @@ SIGNATURES = {
     "edmdc_gram_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                       i64, i64, i64, i64, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "edmdc_set_chunk_rows": (ctypes.c_int, [c_void_p, i64]),
+    "edmdc_kmeans_lloyd": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, ctypes.c_int,
+                                          ctypes.c_double, c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "edmdc_kmeans_lloyd_dev": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, ctypes.c_int,
+                                              ctypes.c_double, c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "edmdc_multistep_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                           c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_simulate": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,

@@ -79,4 +79,13 @@ hipError_t launch_extract_state(hipStream_t st, const PropShape& s, int64_t T1, 
 hipError_t launch_useq_t(hipStream_t st, const PropShape& s, int64_t T, const double* Us, double* Ust);
 hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 
+// ---- k-means (kmeans.hip) ------------------------------------------------------------------
+size_t kmeans_workspace_doubles(int n, int k);
+int kmeans_blocks(int64_t N);
+hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2);
+hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
+                                const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed);
+hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
+                                const int* block_changed, double* C, double* c2, double* stats);
+
 }  // namespace brov

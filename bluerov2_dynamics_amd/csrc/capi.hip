@@ -904,4 +904,74 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
     return BROV_OK;
 }
 
+// ---- k-means (Lloyd) --------------------------------------------------------------------------------------
+int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host,
+                           double* d_C, int max_iter, double tol_abs, int32_t* d_labels, double* inertia, int* n_iter) {
+    if (!c || N < 1 || n < 1 || n > 16 || k < 1 || !d_X || !d_C || !d_labels || max_iter < 1 || xstride < n || (size_t)k * (n + 1) * 8 > 150 * 1024)
+        return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd_dev: bad argument (need 1<=n<=16, k*(n+1)*8 <= 150 KiB of LDS)");
+    DeviceGuard g(c);
+    const int nb = kmeans_blocks(N);
+    Arena a(c);
+    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al(k * 8) + 4096);
+    if (rc) return rc;
+    double* partial = a.take<double>((size_t)nb * k * (n + 1));
+    double* binert = a.take<double>(nb);
+    int* bchg = a.take<int>(nb);
+    double* c2 = a.take<double>(k);
+    double* stats = a.take<double>(8);
+    double* dmean = a.take<double>(16);
+    if (mean_host) {
+        HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCK(c, hipMemsetAsync(d_labels, 0xFF, N * sizeof(int32_t), c->stream));
+    HIPCK(c, launch_kmeans_c2(c->stream, n, k, d_C, c2));
+    CallTimer t(c);
+    bool strict = false;
+    int it = 0;
+    double hs[3] = {0, 0, 0};
+    for (it = 1; it <= max_iter; ++it) {
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+        HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, d_C, c2, stats));
+        HIPCK(c, hipMemcpyAsync(hs, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
+        if (hs[0] <= tol_abs) break;
+    }
+    if (it > max_iter) it = max_iter;
+    double in = hs[1];
+    if (!strict) {   // labels / inertia consistent with the final centres
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+        std::vector<double> hb(nb);
+        HIPCK(c, hipMemcpyAsync(hb.data(), binert, nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        in = 0.0;
+        for (double v : hb) in += v;
+    }
+    if (inertia) *inertia = in;
+    if (n_iter) *n_iter = it;
+    return BROV_OK;
+}
+
+int edmdc_kmeans_lloyd(brov_ctx* c, int64_t N, int n, int k, const double* X, const double* mean, double* C_io, int max_iter,
+                       double tol_abs, int32_t* labels, double* inertia, int* n_iter) {
+    if (!c || N < 1 || n < 1 || k < 1 || !X || !C_io) return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: bad argument");
+    DeviceGuard g(c);
+    double *dX = nullptr, *dC = nullptr;
+    int32_t* dL = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dC); (void)hipFree(dL); };
+    HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)N * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dL, (size_t)N * 4));
+    HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)N * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK_CLEAN(hipMemcpyAsync(dC, C_io, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = edmdc_kmeans_lloyd_dev(c, N, n, k, dX, n, mean, dC, max_iter, tol_abs, dL, inertia, n_iter);
+    if (rc) { cleanup(); return rc; }
+    HIPCK_CLEAN(hipMemcpyAsync(C_io, dC, (size_t)k * n * 8, hipMemcpyDeviceToHost, c->stream));
+    if (labels) HIPCK_CLEAN(hipMemcpyAsync(labels, dL, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(hipStreamSynchronize(c->stream));
+    cleanup();
+    return BROV_OK;
+}
+
 }  // extern "C"

@@ -13,7 +13,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB}
@@ -204,6 +204,64 @@ def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, acc
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     ctx.check(ctx.lib.edmdc_gram_dev(ctx.h, n, r, k, float(gamma), _dptr(C), int(nbags), int(L), int(x_bag_stride), int(u_bag_stride),
                                      _dptr(X), _dptr(U), int(bool(accumulate)), _dptr(GtG), _dptr(GtY)), "edmdc_gram_dev")
+
+
+def kmeans_lloyd(X, C_init, max_iter=300, tol_abs=0.0, mean=None, ctx=None):
+    """Lloyd iterations on the GPU (edmdc_kmeans_lloyd): returns (centres [k,n] in the frame of X - mean,
+    labels [N] int32, inertia, n_iter)."""
+    ctx = ctx or default_context()
+    X = as_f64(X)
+    C = as_f64(C_init).copy()
+    N, n = X.shape
+    k = C.shape[0]
+    m = None if mean is None else as_f64(mean).reshape(n)
+    labels = np.empty(N, dtype=np.int32)
+    inertia = ctypes.c_double(0.0)
+    n_iter = ctypes.c_int(0)
+    ctx.check(ctx.lib.edmdc_kmeans_lloyd(ctx.h, N, n, k, _hptr(X), _hptr(m), _hptr(C), int(max_iter), float(tol_abs),
+                                         labels.ctypes.data, ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd")
+    return C, labels, inertia.value, n_iter.value
+
+
+def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init_rows=200_000, ctx=None):
+    """RBF centres the way KoopmanEDMDc.fit gets them (sklearn KMeans(k, n_init="auto", random_state=0),
+    Koopman/koopmanEDMDc.py:85): scikit-learn's seeded k-means++ initialisation on the host (on a seeded
+    subsample beyond `init_rows` rows), then Lloyd's E/M loop on the GPU with scikit-learn's stopping rules.
+    With the full data used for the initialisation the result equals sklearn's cluster_centers_ to rounding."""
+    from sklearn.cluster import kmeans_plusplus
+    X = as_f64(X)
+    mean = X.mean(axis=0)
+    Xi = X
+    if len(X) > init_rows:
+        Xi = X[np.random.RandomState(random_state).choice(len(X), init_rows, replace=False)]
+    C0, _ = kmeans_plusplus(Xi - mean, k, random_state=np.random.RandomState(random_state))
+    tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
+    C, _, _, _ = kmeans_lloyd(X, C0, max_iter=max_iter, tol_abs=tol_abs, mean=mean, ctx=ctx)
+    return C + mean
+
+
+def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init_rows=100_000, ctx=None):
+    """kmeans_centers for a device-resident X (torch CUDA tensor [N,n]): k-means++ on a seeded host subsample,
+    Lloyd on the full set in HBM.  Returns (centres CUDA tensor [k,n], inertia, n_iter)."""
+    import torch
+    from sklearn.cluster import kmeans_plusplus
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    N, n = X.shape
+    mean = X.mean(dim=0)
+    tol_abs = float(X.var(dim=0, unbiased=False).mean().item() * tol)
+    idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, min(N, init_rows), replace=False)).to(X.device)
+    Xi = (X[idx] - mean).cpu().numpy()
+    C0, _ = kmeans_plusplus(Xi, k, random_state=np.random.RandomState(random_state))
+    C = torch.from_numpy(np.ascontiguousarray(C0)).to(X.device)
+    labels = torch.empty(N, dtype=torch.int32, device=X.device)
+    mean_h = as_f64(mean.cpu().numpy())
+    inertia = ctypes.c_double(0.0)
+    n_iter = ctypes.c_int(0)
+    torch.cuda.current_stream(X.device).synchronize()
+    ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _dptr(X), n, _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
+                                             labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
+    return C + mean, inertia.value, n_iter.value
 
 
 def solve_AB(GtG, GtY, ridge, d):

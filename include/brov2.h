@@ -194,6 +194,19 @@ BROV_API int edmdc_simulate(brov_ctx* ctx, int n, int r, int k, double gamma, co
                    const double* A, const double* B, int64_t nb, int64_t T,
                    const double* x0, const double* U_seq, double* X_pred);
 
+/* Lloyd iterations of k-means on device: the E/M loop of scikit-learn's KMeans(algorithm="lloyd") that
+ * KoopmanEDMDc.fit / fit_multi run to place the RBF centres (Koopman/koopmanEDMDc.py:85,126).  The host layer
+ * obtains the k-means++ initialisation from scikit-learn and passes it in C_io; the final centres come back
+ * in C_io.  X [N][n] (row stride x_stride doubles), mean [n] = column means to subtract (NULL = none; centres
+ * are then in the centred frame), stop when no label changes, when the summed squared centre shift is
+ * <= tol_abs, or after max_iter iterations.  labels [N] int32 (host version: optional), inertia = sum of
+ * squared distances to the final centres, n_iter = iterations run.  Empty clusters keep their centre. */
+BROV_API int edmdc_kmeans_lloyd(brov_ctx* ctx, int64_t N, int n, int k, const double* X, const double* mean,
+                                double* C_io, int max_iter, double tol_abs, int32_t* labels, double* inertia, int* n_iter);
+BROV_API int edmdc_kmeans_lloyd_dev(brov_ctx* ctx, int64_t N, int n, int k, const double* d_X, int64_t x_stride,
+                                    const double* mean_host, double* d_C_io, int max_iter, double tol_abs,
+                                    int32_t* d_labels, double* inertia, int* n_iter);
+
 #ifdef __cplusplus
 }
 #endif

@@ -315,6 +315,28 @@ def test_koopman_dropin_scores_match_reference_fixture():
         m2.fit(X[:10], U[:9])
 
 
+def test_gpu_lloyd_kmeans_matches_sklearn(eng):
+    """Centres from the GPU Lloyd loop == sklearn KMeans(n_init="auto", random_state=0) (the reference's call),
+    on the fixture data (reference centres stored) and on a larger random set; labels / inertia consistent."""
+    from sklearn.cluster import KMeans
+    g = load_golden("edmdc.npz")
+    X = g["X"][: int(g["n_train"])]
+    C = eng.kmeans_centers(X, int(g["k"]))
+    assert rel_err(C, g["centers"]) < 1e-12
+    rng = np.random.default_rng(6)
+    X = np.concatenate([rng.normal(m, 0.3, (4000, 13)) for m in rng.uniform(-2, 2, (5, 13))])
+    ref = KMeans(n_clusters=64, n_init="auto", random_state=0).fit(X)
+    C = eng.kmeans_centers(X, 64)
+    assert rel_err(C, ref.cluster_centers_) < 1e-10
+    mean = X.mean(0)
+    # restart from sklearn's result with sklearn's tolerance: one more E/M step, same labels, tiny shift
+    tol_abs = 1e-4 * np.mean(np.var(X, axis=0))
+    C2, labels, inertia, n_iter = eng.kmeans_lloyd(X, ref.cluster_centers_ - mean, max_iter=5, tol_abs=tol_abs, mean=mean)
+    assert n_iter == 1 and np.mean(labels != ref.labels_) < 1e-3
+    assert abs(inertia - ref.inertia_) / ref.inertia_ < 1e-4
+    assert np.sum((C2 + mean - ref.cluster_centers_) ** 2) <= tol_abs
+
+
 def test_gram_full_width_vs_oracle_chunked_and_bags(eng):
     """k = 512 (p = 532, the benchmark shape), several chunks, bag boundaries inside chunks."""
     import torch
