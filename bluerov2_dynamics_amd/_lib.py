@@ -14,12 +14,13 @@ i64 = ctypes.c_int64
 
 # enums of include/brov2.h
 THRUSTER_EULER, WRENCH_EULER, WRENCH_QUAT = 0, 1, 2
+DI_THRUSTER_EULER, DI_WRENCH_EULER, DI_WRENCH_QUAT = 3, 4, 5
 EULER, RK4 = 0, 1
 LAG_PER_CALL, LAG_PER_STEP = 0, 1
 LAYOUT_BTU, LAYOUT_TUB = 0, 1
 DIST_IID_UNIFORM, DIST_AR1 = 0, 1
-NX = {THRUSTER_EULER: 12, WRENCH_EULER: 12, WRENCH_QUAT: 13}
-NU = {THRUSTER_EULER: 8, WRENCH_EULER: 6, WRENCH_QUAT: 6}
+NX = {THRUSTER_EULER: 12, WRENCH_EULER: 12, WRENCH_QUAT: 13, DI_THRUSTER_EULER: 12, DI_WRENCH_EULER: 12, DI_WRENCH_QUAT: 13}
+NU = {THRUSTER_EULER: 8, WRENCH_EULER: 6, WRENCH_QUAT: 6, DI_THRUSTER_EULER: 8, DI_WRENCH_EULER: 6, DI_WRENCH_QUAT: 6}
 STATUS = {0: "BROV_OK", -1: "BROV_ERR_ARG", -2: "BROV_ERR_HIP", -3: "BROV_ERR_NOMEM", -4: "BROV_ERR_NODEVICE"}
 
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "brov_rollout": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
                                     ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
     "brov_set_btu_staging": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "brov_set_di_gains": (ctypes.c_int, [c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "brov_rollout_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
                                         ctypes.c_double, c_void_p, c_void_p, c_void_p, c_void_p, i64, c_void_p]),
     "brov_window_endpoint_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64, ctypes.c_double,
@@ -210,6 +212,12 @@ class Context:
     def use_torch_stream(self):
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_di_gains(self, K_lin, K_ang):
+        """Gains [nu,3] of the double-integrator models (include/brov2.h: brov_set_di_gains)."""
+        K_lin, K_ang = as_f64(K_lin), as_f64(K_ang)
+        assert K_lin.shape == K_ang.shape and K_lin.shape[1] == 3
+        self.check(self.lib.brov_set_di_gains(self.h, int(K_lin.shape[0]), K_lin.ctypes.data, K_ang.ctypes.data), "brov_set_di_gains")
 
     def set_btu_staging(self, mode: int):
         """0 auto, 1 always stage BTU tiles through LDS, 2 never (see include/brov2.h)."""

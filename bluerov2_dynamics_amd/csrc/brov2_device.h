@@ -18,14 +18,21 @@ namespace brov {
 constexpr int MODEL_THRUSTER_EULER = 0;
 constexpr int MODEL_WRENCH_EULER = 1;
 constexpr int MODEL_WRENCH_QUAT = 2;
+// learned double-integrator baseline of the comparison scripts (training/train_tank_brov2_full_comparison.py:531-573,
+// ..._rk4.py:461-525, ..._wrench_comp.py:293-341, ..._wrench_quat.py:324-372): state-independent accelerations U K
+constexpr int MODEL_DI_THRUSTER_EULER = 3;
+constexpr int MODEL_DI_WRENCH_EULER = 4;
+constexpr int MODEL_DI_WRENCH_QUAT = 5;
+constexpr bool model_is_quat(int m) { return m == MODEL_WRENCH_QUAT || m == MODEL_DI_WRENCH_QUAT; }
+constexpr bool model_is_di(int m) { return m >= MODEL_DI_THRUSTER_EULER; }
 constexpr int INTEG_EULER = 0;
 constexpr int INTEG_RK4 = 1;
 constexpr int LAYOUT_BTU = 0;
 constexpr int LAYOUT_TUB = 1;
 
 template <int MODEL> struct Dims {
-    static constexpr int NX = (MODEL == MODEL_WRENCH_QUAT) ? 13 : 12;
-    static constexpr int NU = (MODEL == MODEL_THRUSTER_EULER) ? 8 : 6;
+    static constexpr int NX = model_is_quat(MODEL) ? 13 : 12;
+    static constexpr int NU = (MODEL == MODEL_THRUSTER_EULER || MODEL == MODEL_DI_THRUSTER_EULER) ? 8 : 6;
     static constexpr int NV = NX - 6;  // offset of nu inside x
 };
 

@@ -196,9 +196,50 @@ __device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const d
     xd[6] = 0.5 * (qw * wz + qx * wy - qy * wx);
 }
 
+// double integrator: dpos = R v, dang = w (Euler angles, "small-angle" in the reference) or q_dot, dnu = a
+__device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[6], double xd[12]) {
+    double sphi, cphi, sth, cth, spsi, cpsi;
+    sincos_fast(x[3], sphi, cphi);
+    sincos_fast(x[4], sth, cth);
+    sincos_fast(x[5], spsi, cpsi);
+    const double ss = sth * sphi, sc = sth * cphi;
+    const double R0 = cpsi * cth, R1 = fma(cpsi, ss, -(spsi * cphi)), R2 = fma(cpsi, sc, spsi * sphi);
+    const double R3 = spsi * cth, R4 = fma(spsi, ss, cpsi * cphi), R5 = fma(spsi, sc, -(cpsi * sphi));
+    const double R6 = -sth, R7 = cth * sphi, R8 = cth * cphi;
+    const double* v = x + 6;
+    xd[0] = fma(R2, v[2], fma(R1, v[1], R0 * v[0]));
+    xd[1] = fma(R5, v[2], fma(R4, v[1], R3 * v[0]));
+    xd[2] = fma(R8, v[2], fma(R7, v[1], R6 * v[0]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) xd[3 + i] = x[9 + i];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xd[6 + i] = a[i];
+}
+__device__ __forceinline__ void rhs_di_quat(const double x[13], const double a[6], double xd[13]) {
+    double q[4] = {x[3], x[4], x[5], x[6]};
+    quat_normalize(q);
+    const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
+    const double R0 = 1.0 - 2.0 * fma(qy, qy, qz * qz), R1 = 2.0 * fma(qx, qy, -(qz * qw)), R2 = 2.0 * fma(qx, qz, qy * qw);
+    const double R3 = 2.0 * fma(qx, qy, qz * qw), R4 = 1.0 - 2.0 * fma(qx, qx, qz * qz), R5 = 2.0 * fma(qy, qz, -(qx * qw));
+    const double R6 = 2.0 * fma(qx, qz, -(qy * qw)), R7 = 2.0 * fma(qy, qz, qx * qw), R8 = 1.0 - 2.0 * fma(qx, qx, qy * qy);
+    const double* v = x + 7;
+    xd[0] = fma(R2, v[2], fma(R1, v[1], R0 * v[0]));
+    xd[1] = fma(R5, v[2], fma(R4, v[1], R3 * v[0]));
+    xd[2] = fma(R8, v[2], fma(R7, v[1], R6 * v[0]));
+    const double wx = x[10], wy = x[11], wz = x[12];
+    xd[3] = 0.5 * (-(qx * wx) - qy * wy - qz * wz);
+    xd[4] = 0.5 * (qw * wx + qy * wz - qz * wy);
+    xd[5] = 0.5 * (qw * wy - qx * wz + qz * wx);
+    xd[6] = 0.5 * (qw * wz + qx * wy - qy * wx);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) xd[7 + i] = a[i];
+}
+
 template <int MODEL>
 __device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd) {
-    if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat(h, p, x, a, xd);
+    if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) rhs_di_quat(x, a, xd);
+    else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd);
+    else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat(h, p, x, a, xd);
     else rhs_fast_euler(h, p, x, a, xd);
 }
 
@@ -268,6 +309,16 @@ __device__ __forceinline__ void command_accel(CFP p, const double* u, double fcm
             for (int i = 1; i < 8; ++i) a = fma(p->Tm[k][i], fcmd[i], a);
             acmd[k] = a;
         }
+    } else if constexpr (model_is_di(MODEL)) {
+        // a = U K: the [nu][3] gains K_lin / K_ang are stored transposed in Tm (rows 0-2 / 3-5)
+        constexpr int NU = Dims<MODEL>::NU;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            double a = p->Tm[k][0] * u[0];
+#pragma unroll
+            for (int i = 1; i < NU; ++i) a = fma(p->Tm[k][i], u[i], a);
+            acmd[k] = a;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) acmd[k] = p->minv[k] * u[k];
@@ -282,6 +333,7 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
     constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
     CFP p = relaunder(p0);
     double fcmd[8], acmd[6], a[6];
+    if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) quat_normalize(x + 3);   // the reference normalises q before its update (wrench_quat.py:339)
     command_accel<MODEL>(p, u, fcmd, acmd);
     if constexpr (INTEG == INTEG_EULER) {
         double k[NX];
@@ -322,7 +374,7 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
             if constexpr (TRACK) advance_thrusters(A, b, fcmd, X);
         }
     }
-    if constexpr (MODEL == MODEL_WRENCH_QUAT) quat_normalize(x + 3);
+    if constexpr (model_is_quat(MODEL)) quat_normalize(x + 3);
 }
 
 }  // namespace brov

@@ -35,6 +35,8 @@ struct brov_ctx {
     DevParams dp;
     FastParams fp;
     FastParams* d_fp = nullptr;   // device copy read by the time-loop kernels through the constant address space
+    FastParams* d_fp_di = nullptr;    // same struct for the double-integrator models: Tm holds the gains [K_lin | K_ang]^T
+    bool di_set = false;
     // EDMDc
     int btu_staging = 0;
     int64_t chunk_rows = (int64_t)1 << 20;
@@ -271,9 +273,10 @@ int get_dp(brov_ctx* c, double dt, const DevParams** out) {
     return BROV_OK;
 }
 
-bool model_ok(int m) { return m == BROV_THRUSTER_EULER || m == BROV_WRENCH_EULER || m == BROV_WRENCH_QUAT; }
-int NX(int m) { return m == BROV_WRENCH_QUAT ? 13 : 12; }
-int NU(int m) { return m == BROV_THRUSTER_EULER ? 8 : 6; }
+bool model_ok(int m) { return m >= BROV_THRUSTER_EULER && m <= BROV_DI_WRENCH_QUAT; }
+bool model_is_di_h(int m) { return m >= BROV_DI_THRUSTER_EULER; }
+int NX(int m) { return (m == BROV_WRENCH_QUAT || m == BROV_DI_WRENCH_QUAT) ? 13 : 12; }
+int NU(int m) { return (m == BROV_THRUSTER_EULER || m == BROV_DI_THRUSTER_EULER) ? 8 : 6; }
 
 }  // namespace
 
@@ -350,6 +353,7 @@ void brov_destroy(brov_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_tasks) (void)hipFree(c->d_tasks);
     if (c->d_fp) (void)hipFree(c->d_fp);
+    if (c->d_fp_di) (void)hipFree(c->d_fp_di);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -457,7 +461,8 @@ int brov_memset(brov_ctx* c, void* dst, int value, size_t bytes) {
 
 // ---- RHS ---------------------------------------------------------------------------------------
 int brov_rhs(brov_ctx* c, int model, int64_t B, const double* x, const double* u, double dt, double* lag_io, double* xdot) {
-    if (!c || !model_ok(model) || B < 0 || (B && (!x || !u || !xdot))) return fail(c, BROV_ERR_ARG, "brov_rhs: bad argument");
+    if (!c || !model_ok(model) || model_is_di_h(model) || B < 0 || (B && (!x || !u || !xdot)))
+        return fail(c, BROV_ERR_ARG, "brov_rhs: bad argument (the double-integrator models have rollouts only)");
     if (B == 0) return BROV_OK;
     DeviceGuard g(c);
     const DevParams* dp;
@@ -522,6 +527,20 @@ static int rollout_args_ok(brov_ctx* c, int model, int integ, int lag_mode, int 
     return BROV_OK;
 }
 
+int brov_set_di_gains(brov_ctx* c, int nu, const double* K_lin, const double* K_ang) {
+    if (!c || (nu != 6 && nu != 8) || !K_lin || !K_ang) return fail(c, BROV_ERR_ARG, "brov_set_di_gains: nu must be 6 or 8");
+    DeviceGuard g(c);
+    FastParams f;
+    std::memset(&f, 0, sizeof f);
+    for (int i = 0; i < nu; ++i)
+        for (int k = 0; k < 3; ++k) { f.Tm[k][i] = K_lin[3 * i + k]; f.Tm[3 + k][i] = K_ang[3 * i + k]; }
+    if (!c->d_fp_di) HIPCK(c, hipMalloc((void**)&c->d_fp_di, sizeof(FastParams)));
+    HIPCK(c, hipMemcpyAsync(c->d_fp_di, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    c->di_set = true;
+    return BROV_OK;
+}
+
 int brov_set_btu_staging(brov_ctx* c, int mode) {
     if (!c || mode < 0 || mode > 2) return fail(c, BROV_ERR_ARG, "brov_set_btu_staging: mode must be 0, 1 or 2");
     c->btu_staging = mode;
@@ -537,9 +556,10 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     const DevParams* dp;
     rc = get_dp(c, dt, &dp);
     if (rc) return rc;
+    if (model_is_di_h(model) && !c->di_set) return fail(c, BROV_ERR_ARG, "double-integrator model: call brov_set_di_gains first");
     CallTimer t(c);
-    HIPCK(c, launch_rollout(c->stream, c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U, d_lag_io, d_traj,
-                            d_traj ? stride : 1, d_xT, c->btu_staging));
+    HIPCK(c, launch_rollout(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U,
+                            d_lag_io, d_traj, d_traj ? stride : 1, d_xT, c->btu_staging));
     return BROV_OK;
 }
 
@@ -601,8 +621,10 @@ static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t
         HIPCK(c, hipMemcpyAsync(d_phi, Phi, sizeof Phi, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));   // Phi is a stack temporary
     }
+    if (model_is_di_h(model) && !c->di_set) return fail(c, BROV_ERR_ARG, "double-integrator model: call brov_set_di_gains first");
     CallTimer t(c);
-    HIPCK(c, launch_window_endpoint(c->stream, c->d_fp, model, integ, N, H, dt, dX, dU, carry, d_phi, d_resp, d_start, d_se, d_total));
+    HIPCK(c, launch_window_endpoint(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, N, H, dt, dX, dU, carry, d_phi,
+                                    d_resp, d_start, d_se, d_total));
     return BROV_OK;
 }
 

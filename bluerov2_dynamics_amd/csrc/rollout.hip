@@ -500,7 +500,10 @@ hipError_t launch_rollout(hipStream_t st, const FastParams* p, int model, int in
     switch (model) {
         case MODEL_THRUSTER_EULER: return launch_rollout_m<MODEL_THRUSTER_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
         case MODEL_WRENCH_EULER: return launch_rollout_m<MODEL_WRENCH_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
-        default: return launch_rollout_m<MODEL_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        case MODEL_WRENCH_QUAT: return launch_rollout_m<MODEL_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        case MODEL_DI_THRUSTER_EULER: return launch_rollout_m<MODEL_DI_THRUSTER_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, nullptr, traj, stride, xT, btu_staging);
+        case MODEL_DI_WRENCH_EULER: return launch_rollout_m<MODEL_DI_WRENCH_EULER>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, nullptr, traj, stride, xT, btu_staging);
+        default: return launch_rollout_m<MODEL_DI_WRENCH_QUAT>(st, p, integ, lag_mode, layout, B, T, dt, x0, U, nullptr, traj, stride, xT, btu_staging);
     }
 }
 
@@ -534,9 +537,18 @@ hipError_t launch_window_endpoint(hipStream_t st, const FastParams* p, int model
     else if (model == MODEL_WRENCH_EULER)
         e = integ == INTEG_RK4 ? launch_window_t<MODEL_WRENCH_EULER, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
                                : launch_window_t<MODEL_WRENCH_EULER, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
-    else
+    else if (model == MODEL_WRENCH_QUAT)
         e = integ == INTEG_RK4 ? launch_window_t<MODEL_WRENCH_QUAT, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
                                : launch_window_t<MODEL_WRENCH_QUAT, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    else if (model == MODEL_DI_THRUSTER_EULER)
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_DI_THRUSTER_EULER, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_DI_THRUSTER_EULER, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    else if (model == MODEL_DI_WRENCH_EULER)
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_DI_WRENCH_EULER, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_DI_WRENCH_EULER, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
+    else
+        e = integ == INTEG_RK4 ? launch_window_t<MODEL_DI_WRENCH_QUAT, INTEG_RK4>(st, p, nwin, H, dt, X, U, lag_start, d_se)
+                               : launch_window_t<MODEL_DI_WRENCH_QUAT, INTEG_EULER>(st, p, nwin, H, dt, X, U, lag_start, d_se);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(1024), 0, st, nwin, d_se, d_total);
     return hipGetLastError();

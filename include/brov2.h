@@ -54,7 +54,12 @@ typedef enum brov_status {
     BROV_ERR_NODEVICE = -4 /* no gfx950 device visible */
 } brov_status;
 
-typedef enum brov_model { BROV_THRUSTER_EULER = 0, BROV_WRENCH_EULER = 1, BROV_WRENCH_QUAT = 2 } brov_model;
+typedef enum brov_model {
+    BROV_THRUSTER_EULER = 0, BROV_WRENCH_EULER = 1, BROV_WRENCH_QUAT = 2,
+    /* learned double-integrator baseline of the comparison scripts (gains from brov_set_di_gains):
+     * nx/nu = 12/8, 12/6, 13/6; rollouts and window errors only */
+    BROV_DI_THRUSTER_EULER = 3, BROV_DI_WRENCH_EULER = 4, BROV_DI_WRENCH_QUAT = 5
+} brov_model;
 typedef enum brov_integrator { BROV_EULER = 0, BROV_RK4 = 1 } brov_integrator;
 /* PER_CALL = the reference: the lag filters advance on every dynamics() call, i.e. 4x per RK4
  * step (training/train_tank_brov2_rk4.py:386-391 calling fossen/BlueROV2.py:258).
@@ -132,6 +137,10 @@ BROV_API int brov_thruster_forces(brov_ctx* ctx, int64_t B, const double* u, dou
 BROV_API int brov_rollout(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
                  int64_t B, int64_t T, double dt, const double* x0, const double* U,
                  double* lag_io, double* traj, int64_t traj_stride, double* xT);
+/* Gains of the double-integrator models: dv = u K_lin, dw = u K_ang with K_lin, K_ang [nu][3] row-major, nu = 8 or 6
+ * (estimate_di_gains + simulate_double_integrator, training/train_tank_brov2_full_comparison.py:510-573,
+ * RK4 form ..._rk4.py:461-525, wrench / quaternion forms ..._wrench_comp.py:293-341, ..._wrench_quat.py:324-372). */
+BROV_API int brov_set_di_gains(brov_ctx* ctx, int nu, const double* K_lin, const double* K_ang);
 /* How BROV_LAYOUT_BTU rollouts (stride 1 or no trajectory) move data: 0 = auto (LDS-staged tiles
  * for the memory-bound cases -- Euler, wrench models -- and lane-per-row accesses for the
  * instruction-bound thruster RK4 kernel; measured in DESIGN.md), 1 = always LDS-staged, 2 = never. */

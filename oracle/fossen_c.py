@@ -9,10 +9,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle.so")
 
 MODEL_THRUSTER_EULER, MODEL_WRENCH_EULER, MODEL_WRENCH_QUAT = 0, 1, 2
+MODEL_DI_THRUSTER_EULER, MODEL_DI_WRENCH_EULER, MODEL_DI_WRENCH_QUAT = 3, 4, 5
 INTEG_EULER, INTEG_RK4 = 0, 1
 LAG_PER_CALL, LAG_PER_STEP = 0, 1
-NX = {0: 12, 1: 12, 2: 13}
-NU = {0: 8, 1: 6, 2: 6}
+NX = {0: 12, 1: 12, 2: 13, 3: 12, 4: 12, 5: 13}
+NU = {0: 8, 1: 6, 2: 6, 3: 8, 4: 6, 5: 6}
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _lib = None
@@ -49,6 +50,24 @@ def _c(a, shape=None):
 
 def _cur(cur):
     return None if cur is None else _c(cur, (3,))
+
+
+def set_di_gains(K_lin, K_ang):
+    """Gains of the double-integrator models 3..5 (global in the oracle library): K_lin, K_ang [nu,3]."""
+    K_lin, K_ang = _c(K_lin), _c(K_ang)
+    lib().orc_set_di_gains(int(K_lin.shape[0]), _p(K_lin), _p(K_ang))
+
+
+def estimate_di_gains(X, U, dt, ridge=1e-3):
+    """estimate_di_gains (training/train_tank_brov2_full_comparison.py:510-528; velocity columns are the last six)."""
+    X, U = np.asarray(X, float), np.asarray(U, float)
+    V, W = X[:, -6:-3], X[:, -3:]
+    dV = (V[1:] - V[:-1]) / max(dt, 1e-9)
+    dW = (W[1:] - W[:-1]) / max(dt, 1e-9)
+    G = U[:-1]
+    GTG = G.T @ G
+    I = np.eye(GTG.shape[0])
+    return np.linalg.solve(GTG + ridge * I, G.T @ dV), np.linalg.solve(GTG + ridge * I, G.T @ dW)
 
 
 def constants():

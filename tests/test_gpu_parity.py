@@ -264,6 +264,38 @@ def test_window_se_vs_oracle_larger(eng, fc):
                 assert abs(se_g - se_o) / se_o < 1e-8      # sum of ~3000 terms each matched to 1e-9
 
 
+def test_double_integrator_baseline_matches_reference_fixture(fc):
+    from bluerov2_dynamics_amd.baselines import DoubleIntegrator, estimate_di_gains
+    g, w = load_golden("di.npz"), load_golden("windows.npz")
+    X, U, TAU, Xq, dt = w["X"], w["U"], w["TAU"], w["Xq"], float(w["dt"])
+    Kl, Ka = estimate_di_gains(X[:300], U[:300], dt)
+    assert rel_err(Kl, g["thr_Klin"]) < 1e-13 and rel_err(Ka, g["thr_Kang"]) < 1e-13
+    di = DoubleIntegrator(g["thr_Klin"], g["thr_Kang"])
+    assert rel_err(di.simulate(X[5], U[5:65], dt, "euler"), g["thr_sim_euler"]) < 1e-12
+    assert rel_err(di.simulate(X[5], U[5:65], dt, "rk4"), g["thr_sim_rk4"]) < 1e-12
+    for i, H in enumerate(g["H"]):
+        assert abs(di.multistep_rmse_endpoint(X, U, int(H), dt, "euler") - g["thr_euler_rmse"][i]) < 1e-11
+        assert abs(di.multistep_rmse_endpoint(X, U, int(H), dt, "rk4") - g["thr_rk4_rmse"][i]) < 1e-11
+    di6 = DoubleIntegrator(g["we_Klin"], g["we_Kang"])
+    assert rel_err(di6.simulate(X[5], TAU[5:65], dt), g["we_sim_euler"]) < 1e-12
+    diq = DoubleIntegrator.fit(Xq[:300], TAU[:300], dt, quaternion=True)
+    assert rel_err(diq.K_lin, g["wq_Klin"]) < 1e-13
+    assert rel_err(diq.simulate(Xq[5], TAU[5:65], dt), g["wq_sim_euler"]) < 1e-12
+    for i, H in enumerate(g["H"]):
+        assert abs(di6.multistep_rmse_endpoint(X, TAU, int(H), dt) - g["we_euler_rmse"][i]) < 1e-11
+        assert abs(diq.multistep_rmse_endpoint(Xq, TAU, int(H), dt) - g["wq_euler_rmse"][i]) < 1e-11
+    # batched vs oracle, both BTU data paths, RK4 on the quaternion variant (our extension)
+    rng = np.random.default_rng(8)
+    fc.set_di_gains(g["wq_Klin"], g["wq_Kang"])
+    X0 = rng.uniform(-0.5, 0.5, (200, 13))
+    Ub = rng.uniform(-10, 10, (200, 33, 6))
+    for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
+        o = fc.rollout(fc.MODEL_DI_WRENCH_QUAT, oi, X0, Ub, dt)
+        for mode in (1, 2):
+            diq._ctx.set_btu_staging(mode)
+            assert rel_err(diq.rollout(X0, Ub, dt, integ)["traj"], o["traj"]) < 1e-11
+
+
 # ------------------------------------------------------------------------------------------ EDMDc
 def test_lift_and_gram_match_reference_fixture(eng):
     from oracle import edmdc_numpy as ek

@@ -119,6 +119,25 @@ def test_window_rmse_carried_lag():
     assert abs(fresh - g["thr_euler_rmse"][1]) > 1e-6
 
 
+def test_double_integrator_baseline():
+    g, w = load_golden("di.npz"), load_golden("windows.npz")
+    X, U, TAU, Xq, dt = w["X"], w["U"], w["TAU"], w["Xq"], float(w["dt"])
+    Kl, Ka = fc.estimate_di_gains(X[:300], U[:300], dt)
+    assert rel_err(Kl, g["thr_Klin"]) < 1e-14 and rel_err(Ka, g["thr_Kang"]) < 1e-14
+    fc.set_di_gains(g["thr_Klin"], g["thr_Kang"])
+    assert rel_err(fc.rollout(fc.MODEL_DI_THRUSTER_EULER, fc.INTEG_EULER, X[5:6], U[None, 5:65], dt)["traj"][0], g["thr_sim_euler"]) < 1e-14
+    assert rel_err(fc.rollout(fc.MODEL_DI_THRUSTER_EULER, fc.INTEG_RK4, X[5:6], U[None, 5:65], dt)["traj"][0], g["thr_sim_rk4"]) < 1e-14
+    for i, H in enumerate(g["H"]):
+        assert abs(fc.window_rmse(fc.MODEL_DI_THRUSTER_EULER, fc.INTEG_EULER, X, U, int(H), dt) - g["thr_euler_rmse"][i]) < 1e-14
+        assert abs(fc.window_rmse(fc.MODEL_DI_THRUSTER_EULER, fc.INTEG_RK4, X, U, int(H), dt) - g["thr_rk4_rmse"][i]) < 1e-14
+    fc.set_di_gains(g["we_Klin"], g["we_Kang"])
+    assert rel_err(fc.rollout(fc.MODEL_DI_WRENCH_EULER, fc.INTEG_EULER, X[5:6], TAU[None, 5:65], dt)["traj"][0], g["we_sim_euler"]) < 1e-14
+    fc.set_di_gains(g["wq_Klin"], g["wq_Kang"])
+    assert rel_err(fc.rollout(fc.MODEL_DI_WRENCH_QUAT, fc.INTEG_EULER, Xq[5:6], TAU[None, 5:65], dt)["traj"][0], g["wq_sim_euler"]) < 1e-14
+    for i, H in enumerate(g["H"]):
+        assert abs(fc.window_rmse(fc.MODEL_DI_WRENCH_QUAT, fc.INTEG_EULER, Xq, TAU, int(H), dt) - g["wq_euler_rmse"][i]) < 1e-14
+
+
 def test_edmdc_lift_gram_fit_scores():
     g = load_golden("edmdc.npz")
     X, U, C = g["X"], g["U"], g["centers"]

@@ -13,6 +13,7 @@ Fixtures (all float64):
                         (every 50th state) + wrench / quaternion rollouts
   windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
+  di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
 """
 import argparse
 import os
@@ -308,7 +309,37 @@ def gen_edmdc():
     np.savez(os.path.join(OUT, "edmdc.npz"), **out)
 
 
-GENS = dict(constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+# --------------------------------------------------------------------------- double integrator
+def gen_di():
+    """Learned double-integrator baseline of the comparison scripts: estimate_di_gains,
+    simulate_double_integrator (Euler: full_comparison.py:531-573, wrench_comp.py:293-341, wrench_quat.py:324-372;
+    RK4: rk4.py:497-525) and multistep_rmse_endpoint_di, on the windows.npz data set."""
+    import train_tank_brov2_rk4 as ref_rk4
+    import train_tank_brov2_full_comparison as ref_eul
+    import train_tank_brov2_wrench_comp as ref_we
+    import train_tank_brov2_wrench_quat as ref_wq
+    w = np.load(os.path.join(OUT, "windows.npz"))
+    X, U, TAU, Xq, dt = w["X"], w["U"], w["TAU"], w["Xq"], float(w["dt"])
+    out = dict(dt=np.float64(dt), H=np.array([1, 10, 100]))
+    Kl, Ka = ref_eul.estimate_di_gains(X[:300], U[:300], dt)
+    out.update(thr_Klin=Kl, thr_Kang=Ka)
+    out["thr_sim_euler"] = ref_eul.simulate_double_integrator(X[5], U[5:65], dt, Kl, Ka)
+    out["thr_sim_rk4"] = ref_rk4.simulate_double_integrator(X[5], U[5:65], dt, Kl, Ka)
+    out["thr_euler_rmse"] = np.array([ref_eul.multistep_rmse_endpoint_di(X, U, H, dt, Kl, Ka) for H in (1, 10, 100)])
+    out["thr_rk4_rmse"] = np.array([ref_rk4.multistep_rmse_endpoint_di(X, U, H, dt, Kl, Ka) for H in (1, 10, 100)])
+    Kl6, Ka6 = ref_we.estimate_di_gains(X[:300], TAU[:300], dt)
+    out.update(we_Klin=Kl6, we_Kang=Ka6)
+    out["we_sim_euler"] = ref_we.simulate_double_integrator(X[5], TAU[5:65], dt, Kl6, Ka6)
+    out["we_euler_rmse"] = np.array([ref_we.multistep_rmse_endpoint_di(X, TAU, H, dt, Kl6, Ka6) for H in (1, 10, 100)])
+    Klq, Kaq = ref_wq.estimate_di_gains(Xq[:300], TAU[:300], dt)
+    out.update(wq_Klin=Klq, wq_Kang=Kaq)
+    out["wq_sim_euler"] = ref_wq.simulate_double_integrator(Xq[5], TAU[5:65], dt, Klq, Kaq)
+    out["wq_euler_rmse"] = np.array([ref_wq.multistep_rmse_endpoint_di(Xq, TAU, H, dt, Klq, Kaq) for H in (1, 10, 100)])
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "di.npz"), **out)
+
+
+GENS = dict(di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
