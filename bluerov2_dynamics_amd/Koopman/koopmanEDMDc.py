@@ -94,6 +94,19 @@ class KoopmanEDMDc:
         U_seq = np.asarray(U_seq, dtype=float).reshape(-1, self.input_dim)
         return engine.simulate_lifted(x0[None], U_seq[None], self.centers_, self.gamma, self.A_, self.B_)[0]
 
+    # ------------------------------------------------------------------ persistence (new: the reference never stores it)
+    def save(self, path) -> None:
+        np.savez(path, state_dim=self.state_dim, input_dim=self.input_dim, n_rbfs=self.n_rbfs, gamma=self.gamma, ridge=self.ridge,
+                 centers_=self.centers_, A_=self.A_, B_=self.B_, lift_dim_=self.lift_dim_)
+
+    @classmethod
+    def load(cls, path) -> "KoopmanEDMDc":
+        z = np.load(path, allow_pickle=False)
+        m = cls(state_dim=int(z["state_dim"]), input_dim=int(z["input_dim"]), n_rbfs=int(z["n_rbfs"]), gamma=float(z["gamma"]),
+                ridge=float(z["ridge"]))
+        m.centers_, m.A_, m.B_, m.lift_dim_ = z["centers_"], z["A_"], z["B_"], int(z["lift_dim_"])
+        return m
+
     # ------------------------------------------------------------------ helpers
     def _lift(self, x):
         """phi(x) = [x, RBF_1(x) .. RBF_k(x)] for (n,) or (N,n) input (reference :221-236)."""

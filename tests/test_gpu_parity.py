@@ -445,3 +445,32 @@ def test_full_size_rollout_properties(eng):
     from oracle import controls
     assert np.array_equal(Uh[0], controls.controls_iid(0x5EED, 0, 1, 5000, nt=T)[0])
     assert np.array_equal(Uh[-1], controls.controls_iid(0x5EED, 65535, 1, 5000, nt=T)[0])
+
+
+# ------------------------------------------------------------------------------------------ config 5: script level
+def test_full_comparison_script_matches_reference_table(tmp_path):
+    """examples/full_comparison.py on the CSV fixture == the table the reference's own functions produced for it
+    (Koopman given the reference's centres: <= 1e-6 as BASELINE config 5 asks; Fossen and DI: to rounding), same
+    ranking per horizon; with GPU k-means instead of given centres the Koopman row still agrees to 1e-6."""
+    import importlib.util
+    import os
+    from conftest import GOLDEN, REPO
+    spec = importlib.util.spec_from_file_location("full_comparison", os.path.join(REPO, "examples", "full_comparison.py"))
+    fcmp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fcmp)
+    g = load_golden("cfg5.npz")
+    csv = os.path.join(GOLDEN, "cfg5_dataset.csv.gz")
+    r = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]), centers=g["centers"], verbose=False)
+    assert r["split"] == int(g["split"]) and r["dt"] == float(g["dt"])
+    assert np.max(np.abs(r["table"][0] - g["table"][0])) < 1e-6
+    assert np.max(np.abs(r["table"][1:] - g["table"][1:])) < 1e-10
+    assert np.array_equal(np.argsort(r["table"], axis=0), np.argsort(g["table"], axis=0))
+    r2 = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]), verbose=False)
+    assert rel_err(r2["model"].centers_, g["centers"]) < 1e-10
+    assert np.max(np.abs(r2["table"][0] - g["table"][0])) < 1e-6
+    # persistence round trip
+    p = tmp_path / "koop.npz"
+    r2["model"].save(p)
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    m = KoopmanEDMDc.load(p)
+    assert abs(m.multistep_rmse(g["X"][int(g["split"]):], g["U"][int(g["split"]):], 10) - r2["table"][0, 1]) < 1e-15

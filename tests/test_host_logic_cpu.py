@@ -70,3 +70,26 @@ def test_shard_range_is_a_partition():
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
             sizes = [b - a for a, b in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_load_dataset_matches_reference_loader(tmp_path):
+    """The CSV fixture has shuffled rows, duplicate time stamps and an inf: the loader must return exactly what the
+    reference's load_dataset returned for it (fixture), and raise like the reference on missing columns."""
+    import os
+    import pandas as pd
+    from bluerov2_dynamics_amd.data import load_dataset, write_dataset
+    from conftest import GOLDEN
+    g = load_golden("cfg5.npz")
+    X, U, dt = load_dataset(os.path.join(GOLDEN, "cfg5_dataset.csv.gz"), verbose=False)
+    assert np.array_equal(X, g["X"]) and np.array_equal(U, g["U"]) and dt == float(g["dt"])
+    p = tmp_path / "d.csv"
+    write_dataset(p, np.arange(5) * 0.02, X[:5], U[:5, :3], input_cols=["u1", "u2", "u3"])
+    X2, U2, dt2 = load_dataset(p, verbose=False)                       # missing u4..u8 are zero-filled
+    assert U2.shape == (5, 8) and np.all(U2[:, 3:] == 0.0) and abs(dt2 - 0.02) < 1e-12
+    df = pd.read_csv(p)
+    df.drop(columns=["theta"]).to_csv(p, index=False)
+    with pytest.raises(ValueError, match="Missing state column"):
+        load_dataset(p, verbose=False)
+    df.drop(columns=["t"]).to_csv(p, index=False)
+    with pytest.raises(ValueError, match="'t' time column"):
+        load_dataset(p, verbose=False)

@@ -14,6 +14,7 @@ Fixtures (all float64):
   windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
+  cfg5_dataset.csv.gz + cfg5.npz   script-level run (loader, split, Koopman / Fossen / DI RMSE table)
 """
 import argparse
 import os
@@ -339,7 +340,45 @@ def gen_di():
     np.savez(os.path.join(OUT, "di.npz"), **out)
 
 
-GENS = dict(di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+# --------------------------------------------------------------------------- config 5 (script level)
+def gen_cfg5():
+    """BASELINE config 5 on synthetic data: a CSV with the reference's schema (rosbags/bag2csv.py:462-465) is run
+    through the reference's own load_dataset / KoopmanEDMDc / multistep_rmse_endpoint_physics / DI helpers
+    (training/train_tank_brov2_full_comparison.py:82-110, 910-912, 921-930, 982-992).  The recorded CSVs are absent
+    from the reference checkout, so the data come from the reference simulator + sensor noise; a few dirty rows
+    (duplicate time stamp, inf, shuffled order) exercise the loader."""
+    import pandas as pd
+    import train_tank_brov2_full_comparison as ref
+    N, dt = 2000, 0.02
+    X, U = _sim_dataset(N, dt, seed=2025)
+    t = np.arange(N) * dt
+    cols = ["t", "x", "y", "z", "phi", "theta", "psi", "u", "v", "w", "p", "q", "r"] + [f"u{i}" for i in range(1, 9)]
+    df = pd.DataFrame(np.column_stack([t, X, U]), columns=cols)
+    dirty = df.iloc[[100, 500]].copy()               # duplicated time stamps (dropped by the loader)
+    dirty.iloc[0, 1] += 1.0
+    bad = df.iloc[[700]].copy()
+    bad["z"] = np.inf                                 # inf -> NaN -> dropped
+    bad["t"] = 700.5 * dt
+    df = pd.concat([df, dirty, bad]).sample(frac=1.0, random_state=1).reset_index(drop=True)   # unsorted on disk
+    path = os.path.join(OUT, "cfg5_dataset.csv.gz")
+    df.to_csv(path, index=False, float_format="%.12g", compression="gzip")
+    Xl, Ul, dtl = ref.load_dataset(path)
+    split = int(ref.TRAIN_SPLIT * len(Xl))
+    Xtr, Utr, Xte, Ute = Xl[:split], Ul[:split], Xl[split:], Ul[split:]
+    k = 40
+    m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=ref.GAMMA, ridge=ref.RIDGE)
+    m.fit(Xtr, Utr)
+    Kl, Ka = ref.estimate_di_gains(Xtr, Utr, dtl, ridge=1e-3)
+    table = np.array([[m.multistep_rmse(Xte, Ute, H=H) for H in (1, 10, 100)],
+                      [ref.multistep_rmse_endpoint_physics(Xte, Ute, H=H, dt=dtl) for H in (1, 10, 100)],
+                      [ref.multistep_rmse_endpoint_di(Xte, Ute, H=H, dt=dtl, K_lin=Kl, K_ang=Ka) for H in (1, 10, 100)]])
+    np.savez(os.path.join(OUT, "cfg5.npz"), X=Xl, U=Ul, dt=np.float64(dtl), split=np.int64(split), k=np.int64(k),
+             gamma=np.float64(ref.GAMMA), ridge=np.float64(ref.RIDGE), centers=m.centers_, table=table,
+             rows=np.array(["Koopman", "Fossen (BlueROV2)", "Double Integrator"]), versions=versions())
+    print(table)
+
+
+GENS = dict(cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
