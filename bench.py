@@ -35,6 +35,17 @@ PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP64_MFMA_TFLOPS = 78.6
 
 
+def pmc_traffic(kernel, launches=1):
+    """HBM bytes per launch from the committed PMC run (profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this same command, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  PMC counters
+    cannot be read from inside the timed process, so this is the recorded figure, not a live one."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))[kernel]
+        return {"bytes": d["hbm_total_GB_per_launch"] * 1e9 * launches, "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc, recorded run)"}
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,7 +186,7 @@ def main():
                      "executed_fp64_instr_per_step": ROLLOUT_EXEC_FP64_INSTR[a.integrator], "fp64_issue_slot_utilisation": valu_busy,
                      "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
                              "bytes_per_step": bytes_per_step},
-                     "traffic": None},
+                     "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay == "tub" and B == 65536 and T == 5000) else None},
     }
 
     # ------------------------------------------------------------------ EDMDc leg
@@ -246,7 +257,8 @@ def main():
                                    f"n=12 r=8 k=512 gamma={gamma}, lift + G^T[G|Y] on device, centres from GPU Lloyd k-means over all states"},
             "roofline": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": eflops,
                          "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": eflops / PEAK_FP64_MFMA_TFLOPS,
-                         "kernel_ms": ekern_s * 1e3, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE, "traffic": None},
+                         "kernel_ms": ekern_s * 1e3, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE,
+                         "traffic": pmc_traffic("gram", launches=-(-(pairs + nb) // (1 << 20))) if pairs == 10_000_000 else None},
             "A_finite": bool(np.isfinite(A_).all() and np.isfinite(B_).all()),
             "kmeans": kmeans_info,
         }
