@@ -51,21 +51,20 @@ typedef const FastParams __attribute__((address_space(4)))* CFP;
 __device__ __forceinline__ CFP as_constant(const FastParams* g) { return (CFP)(unsigned long long)g; }
 
 struct HotConsts {
-    double E[12], da[6], db[6], G[5];
+    double E[12], db[6];
 };
 
 #define BROV_PIN_V(x) asm volatile("" : "+v"(x))
 
-// E, G, da stay uniform (SGPR operands: one scalar source per VALU instruction is free); db is pinned
-// in VGPRs because fma(db, |nu|, da) would otherwise need two scalar sources.
+// E and db are pinned in VGPRs for the whole launch (fma(db, |nu|, da) needs a non-scalar second constant
+// anyway); G and da are re-read through the per-stage laundered pointer as scalar operands, so that no
+// loop-invariant SGPRs have to be spilled around the sin/cos literals and the per-step scalar loads.
 __device__ __forceinline__ void load_hot(CFP pp, HotConsts& h) {
     const auto& p = *pp;
 #pragma unroll
     for (int i = 0; i < 12; ++i) { h.E[i] = p.E[i]; BROV_PIN_V(h.E[i]); }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) { h.da[i] = p.da[i]; h.db[i] = p.db[i]; BROV_PIN_V(h.db[i]); }
-#pragma unroll
-    for (int i = 0; i < 5; ++i) h.G[i] = p.G[i];
+    for (int i = 0; i < 6; ++i) { h.db[i] = p.db[i]; BROV_PIN_V(h.db[i]); }
 }
 
 // pointer laundering: makes the compiler re-issue the (scalar) loads behind `p` at this point
@@ -78,7 +77,7 @@ __device__ __forceinline__ CFP relaunder(CFP p) {
 // ---- sin / cos --------------------------------------------------------------------------------
 // Valid (<= ~1 ulp) for |x| < 2^31 pi/2 ~ 3.4e9 rad; NaN/inf give NaN like np.sin/np.cos.  Beyond that
 // range the quadrant index saturates (a vehicle attitude angle never gets there).
-__device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
+__device__ __forceinline__ void sincos_fast(double x, double& s, double& c, const double2* __restrict__ qt) {
     const double kf = rint(x * 6.36619772367581382433e-01);
     double r = fma(-kf, 1.57079632673412561417e+00, x);      // pio2_1  (33 bits)
     r = fma(-kf, 6.07710050630396597660e-11, r);             // pio2_2  (33 bits)
@@ -97,14 +96,20 @@ __device__ __forceinline__ void sincos_fast(double x, double& s, double& c) {
     pc = fma(z, pc, -1.38888888888741095749e-03);
     pc = fma(z, pc, 4.16666666666666019037e-02);
     const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
-    const bool swap = q & 1;
-    double so = swap ? cr : sr;
-    double co = swap ? sr : cr;
-    // sin negative in quadrants 2,3; cos negative in quadrants 1,2
-    const unsigned long long sbit = (unsigned long long)(q & 2) << 62;
-    const unsigned long long cbit = (unsigned long long)((q + 1) & 2) << 62;
-    s = __longlong_as_double(__double_as_longlong(so) ^ (long long)sbit);
-    c = __longlong_as_double(__double_as_longlong(co) ^ (long long)cbit);
+    // quadrant rotation: (sin x, cos x) = (sr cn + cr sn, cr cn - sr sn) with (cn, sn) = (cos, sin)(q pi/2) in
+    // {(1,0),(0,1),(-1,0),(0,-1)} read from a 4-entry LDS table: 3 integer/LDS + 4 fp64 instructions instead of
+    // the 12 of a select + sign-flip sequence; multiplications by 0 and +-1 are exact.
+    const double2 t = qt[q & 3];
+    s = fma(cr, t.y, sr * t.x);
+    c = fma(-sr, t.y, cr * t.x);
+}
+
+// the table lives in LDS: call from every thread of the block before the first sincos_fast, then __syncthreads()
+__device__ __forceinline__ void init_quadrant_table(double2* qt) {
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        qt[q] = make_double2(q == 0 ? 1.0 : (q == 2 ? -1.0 : 0.0), q == 1 ? 1.0 : (q == 3 ? -1.0 : 0.0));
+    }
 }
 
 // 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps
@@ -118,11 +123,15 @@ __device__ __forceinline__ double recip_fast(double x) {
 
 // ---- nu_dot = a - Minv C nu - Minv D nu_r - Minv g --------------------------------------------
 // sth, ctsp, ctcp = sin(theta), cos(theta) sin(phi), cos(theta) cos(phi)  (or -R20, R21, R22)
+// GENERIC = false is the reference's vehicle (no current, xb = yb = 0): one straight-line block per stage.  The
+// uniform branches of the generic form cost a scalar load + wait + branch each and stop the scheduler from
+// overlapping a stage's scalar constant loads with its sin/cos work.
+template <bool GENERIC>
 __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const double R[9], const double nu[6],
                                             const double a[6], double sth, double ctsp, double ctcp, double out[6]) {
     const double u = nu[0], v = nu[1], w = nu[2], pp = nu[3], q = nu[4], r = nu[5];
     double nr0 = u, nr1 = v, nr2 = w;
-    if (p->has_current) {   // wave-uniform, rare
+    if (GENERIC && p->has_current) {   // wave-uniform, rare
         nr0 -= fma(R[6], p->cur[2], fma(R[3], p->cur[1], R[0] * p->cur[0]));
         nr1 -= fma(R[7], p->cur[2], fma(R[4], p->cur[1], R[1] * p->cur[0]));
         nr2 -= fma(R[8], p->cur[2], fma(R[5], p->cur[1], R[2] * p->cur[0]));
@@ -133,18 +142,18 @@ __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const dou
     double o3 = fma(-h.E[6], v * w, a[3]);  o3 = fma(-h.E[7], q * r, o3);
     double o4 = fma(-h.E[8], u * w, a[4]);  o4 = fma(-h.E[9], pp * r, o4);
     double o5 = fma(-h.E[10], u * v, a[5]); o5 = fma(-h.E[11], pp * q, o5);
-    o0 = fma(-fma(h.db[0], fabs(nr0), h.da[0]), nr0, o0);
-    o1 = fma(-fma(h.db[1], fabs(nr1), h.da[1]), nr1, o1);
-    o2 = fma(-fma(h.db[2], fabs(nr2), h.da[2]), nr2, o2);
-    o3 = fma(-fma(h.db[3], fabs(pp), h.da[3]), pp, o3);
-    o4 = fma(-fma(h.db[4], fabs(q), h.da[4]), q, o4);
-    o5 = fma(-fma(h.db[5], fabs(r), h.da[5]), r, o5);
-    o0 = fma(-h.G[0], sth, o0);
-    o1 = fma(h.G[1], ctsp, o1);
-    o2 = fma(h.G[2], ctcp, o2);
-    o3 = fma(h.G[3], ctsp, o3);
-    o4 = fma(h.G[4], sth, o4);
-    if (p->has_xy) {        // xb, yb != 0: never for the reference's vehicle
+    o0 = fma(-fma(h.db[0], fabs(nr0), p->da[0]), nr0, o0);
+    o1 = fma(-fma(h.db[1], fabs(nr1), p->da[1]), nr1, o1);
+    o2 = fma(-fma(h.db[2], fabs(nr2), p->da[2]), nr2, o2);
+    o3 = fma(-fma(h.db[3], fabs(pp), p->da[3]), pp, o3);
+    o4 = fma(-fma(h.db[4], fabs(q), p->da[4]), q, o4);
+    o5 = fma(-fma(h.db[5], fabs(r), p->da[5]), r, o5);
+    o0 = fma(-p->G[0], sth, o0);
+    o1 = fma(p->G[1], ctsp, o1);
+    o2 = fma(p->G[2], ctcp, o2);
+    o3 = fma(p->G[3], ctsp, o3);
+    o4 = fma(p->G[4], sth, o4);
+    if (GENERIC && p->has_xy) {        // xb, yb != 0: never for the reference's vehicle
         o3 = fma(-p->XY[0], ctcp, o3);
         o4 = fma(p->XY[1], ctcp, o4);
         o5 = fma(-p->XY[2], ctsp, o5);
@@ -154,18 +163,19 @@ __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const dou
 }
 
 // xdot for the Euler-angle state; a = Minv tau
-__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12]) {
+template <bool GENERIC>
+__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12], const double2* qt) {
     double sphi, cphi, sth, cth, spsi, cpsi;
-    sincos_fast(x[3], sphi, cphi);
-    sincos_fast(x[4], sth, cth);
-    sincos_fast(x[5], spsi, cpsi);
+    sincos_fast(x[3], sphi, cphi, qt);
+    sincos_fast(x[4], sth, cth, qt);
+    sincos_fast(x[5], spsi, cpsi, qt);
     double R[9];
     const double ss = sth * sphi, sc = sth * cphi;
     R[0] = cpsi * cth; R[1] = fma(cpsi, ss, -(spsi * cphi)); R[2] = fma(cpsi, sc, spsi * sphi);
     R[3] = spsi * cth; R[4] = fma(spsi, ss, cpsi * cphi);    R[5] = fma(spsi, sc, -(cpsi * sphi));
     R[6] = -sth;       R[7] = cth * sphi;                    R[8] = cth * cphi;
     const double* nu = x + 6;
-    nu_dot_fast(h, p, R, nu, a, sth, R[7], R[8], xd + 6);
+    nu_dot_fast<GENERIC>(h, p, R, nu, a, sth, R[7], R[8], xd + 6);
 #pragma unroll
     for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
     double cc = cth;
@@ -177,6 +187,7 @@ __device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const 
     xd[5] = ic * m;
 }
 
+template <bool GENERIC>
 __device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const double x[13], const double a[6], double xd[13]) {
     double q[4] = {x[3], x[4], x[5], x[6]};
     quat_normalize(q);
@@ -186,7 +197,7 @@ __device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const d
     R[3] = 2.0 * fma(qx, qy, qz * qw);       R[4] = 1.0 - 2.0 * fma(qx, qx, qz * qz); R[5] = 2.0 * fma(qy, qz, -(qx * qw));
     R[6] = 2.0 * fma(qx, qz, -(qy * qw));    R[7] = 2.0 * fma(qy, qz, qx * qw);       R[8] = 1.0 - 2.0 * fma(qx, qx, qy * qy);
     const double* nu = x + 7;
-    nu_dot_fast(h, p, R, nu, a, -R[6], R[7], R[8], xd + 7);
+    nu_dot_fast<GENERIC>(h, p, R, nu, a, -R[6], R[7], R[8], xd + 7);
 #pragma unroll
     for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
     const double wx = nu[3], wy = nu[4], wz = nu[5];
@@ -197,11 +208,11 @@ __device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const d
 }
 
 // double integrator: dpos = R v, dang = w (Euler angles, "small-angle" in the reference) or q_dot, dnu = a
-__device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[6], double xd[12]) {
+__device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[6], double xd[12], const double2* qt) {
     double sphi, cphi, sth, cth, spsi, cpsi;
-    sincos_fast(x[3], sphi, cphi);
-    sincos_fast(x[4], sth, cth);
-    sincos_fast(x[5], spsi, cpsi);
+    sincos_fast(x[3], sphi, cphi, qt);
+    sincos_fast(x[4], sth, cth, qt);
+    sincos_fast(x[5], spsi, cpsi, qt);
     const double ss = sth * sphi, sc = sth * cphi;
     const double R0 = cpsi * cth, R1 = fma(cpsi, ss, -(spsi * cphi)), R2 = fma(cpsi, sc, spsi * sphi);
     const double R3 = spsi * cth, R4 = fma(spsi, ss, cpsi * cphi), R5 = fma(spsi, sc, -(cpsi * sphi));
@@ -235,12 +246,12 @@ __device__ __forceinline__ void rhs_di_quat(const double x[13], const double a[6
     for (int i = 0; i < 6; ++i) xd[7 + i] = a[i];
 }
 
-template <int MODEL>
-__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd) {
+template <int MODEL, bool GENERIC>
+__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd, const double2* qt) {
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) rhs_di_quat(x, a, xd);
-    else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd);
-    else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat(h, p, x, a, xd);
-    else rhs_fast_euler(h, p, x, a, xd);
+    else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd, qt);
+    else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat<GENERIC>(h, p, x, a, xd);
+    else rhs_fast_euler<GENERIC>(h, p, x, a, xd, qt);
 }
 
 // ---- thruster lag in acceleration space ---------------------------------------------------------
@@ -326,9 +337,11 @@ __device__ __forceinline__ void command_accel(CFP p, const double* u, double fcm
 }
 
 // One integrator step.  TRACK: also advance the per-thruster lag state X (for lag_io).
-template <int MODEL, int INTEG, int LAGMODE, bool TRACK>
+// RK4 is accumulated as xn = x + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (four FMAs per state instead of forming
+// k1 + 2 k2 + 2 k3 + k4 first; same value up to rounding, 24 instructions fewer per step).
+template <int MODEL, int INTEG, int LAGMODE, bool TRACK, bool GENERIC>
 __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt, double* x, const double* u,
-                                          LagZ& lz, double X[8][3]) {
+                                          LagZ& lz, double X[8][3], const double2* qt) {
     constexpr int NX = Dims<MODEL>::NX;
     constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
     CFP p = relaunder(p0);
@@ -338,7 +351,7 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
     if constexpr (INTEG == INTEG_EULER) {
         double k[NX];
         if constexpr (THR) lz.accel_after(p, 1, acmd, a);
-        rhs_fast<MODEL>(h, p, x, THR ? a : acmd, k);
+        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, qt);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
         if constexpr (THR) {
@@ -347,25 +360,27 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
             if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
         }
     } else {
-        double k[NX], acc[NX], xs[NX];
-        const double h2 = 0.5 * dt;
+        double k[NX], xn[NX], xs[NX];
+        const double h2 = 0.5 * dt, h6 = dt / 6.0, h3 = dt / 3.0;
         if constexpr (THR) lz.accel_after(p, 1, acmd, a);
-        rhs_fast<MODEL>(h, p, x, THR ? a : acmd, k);
+        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, qt);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = k[i]; xs[i] = fma(h2, k[i], x[i]); }
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 2, acmd, a);
-        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
+        for (int i = 0; i < NX; ++i) { xn[i] = fma(h6, k[i], x[i]); xs[i] = fma(h2, k[i], x[i]); }
+        CFP p2 = relaunder(p0);
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(p2, 2, acmd, a);
+        rhs_fast<MODEL, GENERIC>(h, p2, xs, THR ? a : acmd, k, qt);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(h2, k[i], x[i]); }
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 3, acmd, a);
-        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
+        for (int i = 0; i < NX; ++i) { xn[i] = fma(h3, k[i], xn[i]); xs[i] = fma(h2, k[i], x[i]); }
+        CFP p3 = relaunder(p0);
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(p3, 3, acmd, a);
+        rhs_fast<MODEL, GENERIC>(h, p3, xs, THR ? a : acmd, k, qt);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { acc[i] = fma(2.0, k[i], acc[i]); xs[i] = fma(dt, k[i], x[i]); }
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(relaunder(p0), 4, acmd, a);
-        rhs_fast<MODEL>(h, p, xs, THR ? a : acmd, k);
-        const double h6 = dt / 6.0;
+        for (int i = 0; i < NX; ++i) { xn[i] = fma(h3, k[i], xn[i]); xs[i] = fma(dt, k[i], x[i]); }
+        CFP p4 = relaunder(p0);
+        if constexpr (THR && LAGMODE == 0) lz.accel_after(p4, 4, acmd, a);
+        rhs_fast<MODEL, GENERIC>(h, p4, xs, THR ? a : acmd, k, qt);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = fma(h6, acc[i] + k[i], x[i]);
+        for (int i = 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
         if constexpr (THR) {
             CFP pl = relaunder(p0);
             const double __attribute__((address_space(4)))* A = (LAGMODE == 0) ? pl->A4 : pl->A1;

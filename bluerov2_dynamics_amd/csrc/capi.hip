@@ -559,7 +559,8 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     if (model_is_di_h(model) && !c->di_set) return fail(c, BROV_ERR_ARG, "double-integrator model: call brov_set_di_gains first");
     CallTimer t(c);
     HIPCK(c, launch_rollout(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U,
-                            d_lag_io, d_traj, d_traj ? stride : 1, d_xT, c->btu_staging));
+                            d_lag_io, d_traj, d_traj ? stride : 1, d_xT,
+                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy) ? 4 : 0)));
     return BROV_OK;
 }
 

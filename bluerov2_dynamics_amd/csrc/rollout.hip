@@ -151,12 +151,15 @@ __global__ void __launch_bounds__(256) thruster_forces_kernel(DevParams p, int64
 // ---------------------------------------------------------------------------------------
 // K1: rollout.  U / traj layouts: BTU = [B][T][nu] / [B][rows][nx]; TUB = [T][nu][B] / [rows][nx][B].
 // ---------------------------------------------------------------------------------------
-template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK>
+template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
 __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restrict__ pg, int64_t B, int64_t T, double dt,
                                                       const double* __restrict__ X0, const double* __restrict__ U,
                                                       double* __restrict__ lag_io, double* __restrict__ traj,
                                                       int64_t stride, double* __restrict__ XT) {
     constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    __shared__ double2 qt[4];
+    init_quadrant_table(qt);
+    __syncthreads();
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const CFP p = as_constant(pg);
@@ -200,7 +203,7 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
         if (t + 1 < T) {  // prefetch the next control row while this step computes
             if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un); else load_soa<NU>(up, B, un);
         }
-        step_fast<MODEL, INTEG, LAGMODE, TRACK>(h, p, dt, x, u, lz, Xl);
+        step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
         if (traj && --countdown == 0) {
             countdown = stride;
             if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x); else store_soa<NX>(tp, B, x);
@@ -234,7 +237,7 @@ template <int NU> __device__ __forceinline__ int in_swizzle(int d, int j) {
     else return d;                                       // nu = 6: 2-way at worst
 }
 
-template <int MODEL, int INTEG, int LAGMODE, bool TRACK>
+template <int MODEL, int INTEG, int LAGMODE, bool TRACK, bool GENERIC>
 __global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* __restrict__ pg, int64_t B, int64_t T, double dt,
                                                               const double* __restrict__ X0, const double* __restrict__ U,
                                                               double* __restrict__ lag_io, double* __restrict__ traj,
@@ -247,6 +250,9 @@ __global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* 
     constexpr int OCPR = BTU_TILE * NX / OCB;             // output chunks per trajectory per tile
     __shared__ __attribute__((aligned(16))) double lds_in[4][2][IN_SLOTS * 2];
     __shared__ __attribute__((aligned(16))) double lds_out[4][64 * ORS];
+    __shared__ double2 qt[4];
+    init_quadrant_table(qt);
+    __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t b0w = (int64_t)blockIdx.x * 256 + wave * 64;     // first trajectory of this wave
@@ -302,7 +308,7 @@ __global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* 
                     const double2 v = *reinterpret_cast<const double2*>(ib + (lane * CH + in_swizzle<NU>(d, lane)) * 2);
                     u[2 * cc] = v.x; u[2 * cc + 1] = v.y;
                 }
-                step_fast<MODEL, INTEG, LAGMODE, TRACK>(h, p, dt, x, u, lz, Xl);
+                step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
                 if (traj) store_row<NX>(ob + s * NX, x);
             }
         }
@@ -379,11 +385,14 @@ __global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const
     }
 }
 
-template <int MODEL, int INTEG>
+template <int MODEL, int INTEG, bool GENERIC>
 __global__ void __launch_bounds__(256) window_endpoint_kernel(const FastParams* __restrict__ pg, int64_t nwin, int64_t H, double dt,
                                                               const double* __restrict__ X, const double* __restrict__ U,
                                                               const double* __restrict__ lag_start, double* __restrict__ se) {
     constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
+    __shared__ double2 qt[4];
+    init_quadrant_table(qt);
+    __syncthreads();
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nwin) return;
     const CFP p = as_constant(pg);
@@ -400,7 +409,7 @@ __global__ void __launch_bounds__(256) window_endpoint_kernel(const FastParams* 
     for (int64_t t = 0; t < H; ++t) {
         double u[NU];
         load_row<NU>(U + (k + t) * NU, u);   // lane k reads row k+t: coalesced across the wave
-        step_fast<MODEL, INTEG, 0, false>(h, p, dt, x, u, lz, Xl);
+        step_fast<MODEL, INTEG, 0, false, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
     }
     double ref[NX], e = 0.0;
     load_row<NX>(X + (k + H) * NX, ref);
@@ -453,28 +462,33 @@ hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B,
     return hipGetLastError();
 }
 
+template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
+static hipError_t launch_rollout_g(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
+                                   const double* U, double* lag, double* traj, int64_t stride, double* xT, bool want_lds) {
+    if (LAYOUT == LAYOUT_BTU && (!traj || stride == 1) && T > 0 && want_lds)
+        hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, TRACK, GENERIC>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                           p, B, T, dt, x0, U, lag, traj, xT);
+    else
+        hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, TRACK, GENERIC>), dim3(nblk(B, 256)), dim3(256), 0, st,
+                           p, B, T, dt, x0, U, lag, traj, stride, xT);
+    return hipGetLastError();
+}
 template <int MODEL, int INTEG, int LAYOUT, int LAGMODE>
 static hipError_t launch_rollout_t(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
                                    const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
     // LDS staging pays where the kernel is memory-bound (Euler, wrench models); the thruster RK4 kernel is
     // instruction-issue bound at one wave per SIMD and loses 14 % to the staging instructions
-    const bool want_lds = btu_staging == 1 || (btu_staging == 0 && (INTEG == INTEG_EULER || MODEL != MODEL_THRUSTER_EULER));
-    if (LAYOUT == LAYOUT_BTU && (!traj || stride == 1) && T > 0 && want_lds) {
-        if (MODEL == MODEL_THRUSTER_EULER && lag)
-            hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, true>), dim3(nblk(B, 256)), dim3(256), 0, st,
-                               p, B, T, dt, x0, U, lag, traj, xT);
-        else
-            hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, false>), dim3(nblk(B, 256)), dim3(256), 0, st,
-                               p, B, T, dt, x0, U, lag, traj, xT);
-        return hipGetLastError();
+    const bool want_lds = (btu_staging & 3) == 1 || ((btu_staging & 3) == 0 && (INTEG == INTEG_EULER || MODEL != MODEL_THRUSTER_EULER));
+    const bool generic = (btu_staging & 4) != 0;      // bit 2: vehicle has a current or xb/yb != 0 (set by the C ABI layer)
+    constexpr bool DI = model_is_di(MODEL);
+    if (MODEL == MODEL_THRUSTER_EULER && lag) {
+        if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+            return generic ? launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds)
+                           : launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
+        }
     }
-    if (MODEL == MODEL_THRUSTER_EULER && lag)
-        hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, true>), dim3(nblk(B, 256)), dim3(256), 0, st,
-                           p, B, T, dt, x0, U, lag, traj, stride, xT);
-    else
-        hipLaunchKernelGGL((rollout_kernel<MODEL, INTEG, LAYOUT, LAGMODE, false>), dim3(nblk(B, 256)), dim3(256), 0, st,
-                           p, B, T, dt, x0, U, lag, traj, stride, xT);
-    return hipGetLastError();
+    if (generic && !DI) return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
+    return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
 }
 template <int MODEL, int INTEG, int LAYOUT>
 static hipError_t launch_rollout_l(hipStream_t st, const FastParams* p, int lag_mode, int64_t B, int64_t T, double dt,
@@ -510,7 +524,8 @@ hipError_t launch_rollout(hipStream_t st, const FastParams* p, int model, int in
 template <int MODEL, int INTEG>
 static hipError_t launch_window_t(hipStream_t st, const FastParams* p, int64_t nwin, int64_t H, double dt, const double* X,
                                   const double* U, const double* lag_start, double* se) {
-    hipLaunchKernelGGL((window_endpoint_kernel<MODEL, INTEG>), dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, dt, X, U, lag_start, se);
+    // the evaluator always uses the generic form (current / xb, yb branches): it is short-lived and not the benchmark path
+    hipLaunchKernelGGL((window_endpoint_kernel<MODEL, INTEG, true>), dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, dt, X, U, lag_start, se);
     return hipGetLastError();
 }
 // scratch: resp [nwin][18], start [nwin][18], phi [9] (device) -- only used for the thruster model with carry_lag

@@ -99,6 +99,14 @@ int main() {
         ms = time_ms([&] { hipLaunchKernelGGL(fma_kernel<2>, dim3(blocks), dim3(256), 0, 0, out, iters * 4, 1.0000001, 1e-9); });
         printf("v_fma_f64   %d waves/SIMD, 2 chains : %8.3f ms  %7.2f TFLOP/s\n", wps, ms, 2.0 * 2 * iters * 4 * 256.0 * blocks / ms * 1e-9);
     }
+    // half-populated waves: 32-thread blocks = one wave with lanes 32..63 masked off.  If the SIMD skipped the
+    // empty half, the same number of wave-instructions would take half the time.
+    for (int wps : {1, 2, 4}) {
+        const int blocks = cus * 4 * wps;
+        float ms = time_ms([&] { hipLaunchKernelGGL(fma_kernel<8>, dim3(blocks), dim3(32), 0, 0, out, iters, 1.0000001, 1e-9); });
+        printf("v_fma_f64   %d HALF waves/SIMD (32 lanes), 8 chains : %8.3f ms  (%.2f TFLOP/s of useful lanes)\n", wps, ms,
+               2.0 * 8 * iters * 32.0 * blocks / ms * 1e-9);
+    }
     for (int wps : {1, 2}) {
         const int blocks = cus * wps;
         float ms = time_ms([&] { hipLaunchKernelGGL(mfma_kernel<8>, dim3(blocks), dim3(256), 0, 0, out, iters / 4, 1.0000001, 1e-9); });
