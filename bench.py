@@ -25,7 +25,7 @@ sys.path.insert(0, REPO)
 
 # algorithmic work per unit
 ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (reference algebra)
-ROLLOUT_EXEC_FP64_INSTR = {"rk4": 946, "euler": 262}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 879, "euler": 327}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0
@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=65536, help="trajectories per GPU")
     ap.add_argument("--horizon", type=int, default=5000)
-    ap.add_argument("--layout", default="tub", choices=["tub", "btu"])
+    ap.add_argument("--layout", default="tpb", choices=["tpb", "tub", "btu"])
     ap.add_argument("--no-store", action="store_true", help="endpoint only (64 B/step algorithmic)")
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "euler"])
     ap.add_argument("--edmdc-samples", type=int, default=10_000_000, help="(x,u,x+) pairs per GPU for the Gram leg")
@@ -135,13 +135,14 @@ def main():
     B, T, dt = a.batch, a.horizon, 0.02
     nu, nx = 8, 12
     lay = a.layout
-    U = torch.empty((T, nu, B) if lay == "tub" else (B, T, nu), dtype=torch.float64, device=dev)
+    shape = {"tub": lambda r_, c_: (r_, c_, B), "btu": lambda r_, c_: (B, r_, c_), "tpb": lambda r_, c_: (r_, c_ // 2, B, 2)}[lay]
+    U = torch.empty(shape(T, nu), dtype=torch.float64, device=dev)
     engine.fill_controls_dev(U, lay, "iid", seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)
     x0 = torch.zeros((B, nx), dtype=torch.float64, device=dev)
     x0[:, 2] = 5.0
     traj = None
     if not a.no_store:
-        traj = torch.empty((T + 1, nx, B) if lay == "tub" else (B, T + 1, nx), dtype=torch.float64, device=dev)
+        traj = torch.empty(shape(T + 1, nx), dtype=torch.float64, device=dev)
     xT = torch.empty((B, nx), dtype=torch.float64, device=dev)
 
     def step():
@@ -186,7 +187,7 @@ def main():
                      "executed_fp64_instr_per_step": ROLLOUT_EXEC_FP64_INSTR[a.integrator], "fp64_issue_slot_utilisation": valu_busy,
                      "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
                              "bytes_per_step": bytes_per_step},
-                     "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay == "tub" and B == 65536 and T == 5000) else None},
+                     "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay != "btu" and B == 65536 and T == 5000) else None},
     }
 
     # ------------------------------------------------------------------ EDMDc leg

@@ -11,6 +11,6 @@ there is no CPU fallback.
 """
 from ._lib import (BrovError, BrovParams, Context, default_context, default_params, discretise_lag, load_library,
                    THRUSTER_EULER, WRENCH_EULER, WRENCH_QUAT, EULER, RK4, LAG_PER_CALL, LAG_PER_STEP,
-                   LAYOUT_BTU, LAYOUT_TUB)
+                   LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB)
 
 __version__ = "0.1.0"

@@ -17,7 +17,7 @@ THRUSTER_EULER, WRENCH_EULER, WRENCH_QUAT = 0, 1, 2
 DI_THRUSTER_EULER, DI_WRENCH_EULER, DI_WRENCH_QUAT = 3, 4, 5
 EULER, RK4 = 0, 1
 LAG_PER_CALL, LAG_PER_STEP = 0, 1
-LAYOUT_BTU, LAYOUT_TUB = 0, 1
+LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB = 0, 1, 2
 DIST_IID_UNIFORM, DIST_AR1 = 0, 1
 NX = {THRUSTER_EULER: 12, WRENCH_EULER: 12, WRENCH_QUAT: 13, DI_THRUSTER_EULER: 12, DI_WRENCH_EULER: 12, DI_WRENCH_QUAT: 13}
 NU = {THRUSTER_EULER: 8, WRENCH_EULER: 6, WRENCH_QUAT: 6, DI_THRUSTER_EULER: 8, DI_WRENCH_EULER: 6, DI_WRENCH_QUAT: 6}

@@ -29,6 +29,7 @@ constexpr int INTEG_EULER = 0;
 constexpr int INTEG_RK4 = 1;
 constexpr int LAYOUT_BTU = 0;
 constexpr int LAYOUT_TUB = 1;
+constexpr int LAYOUT_TPB = 2;   // time-major, channel PAIRS interleaved: [T][ceil(n/2)][B][2] -> 16-byte accesses per lane
 
 template <int MODEL> struct Dims {
     static constexpr int NX = model_is_quat(MODEL) ? 13 : 12;

@@ -42,6 +42,8 @@ struct FastParams {
     double cur[3];
     int has_current;
     int has_xy;
+    int tm_dense;      // allocation matrix does not have the reference's zero pattern
+    int pad1;
 };
 
 // FastParams lives in a small device buffer owned by the ctx and is read through a CONSTANT
@@ -169,15 +171,27 @@ __device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const 
     sincos_fast(x[3], sphi, cphi, qt);
     sincos_fast(x[4], sth, cth, qt);
     sincos_fast(x[5], spsi, cpsi, qt);
-    double R[9];
-    const double ss = sth * sphi, sc = sth * cphi;
-    R[0] = cpsi * cth; R[1] = fma(cpsi, ss, -(spsi * cphi)); R[2] = fma(cpsi, sc, spsi * sphi);
-    R[3] = spsi * cth; R[4] = fma(spsi, ss, cpsi * cphi);    R[5] = fma(spsi, sc, -(cpsi * sphi));
-    R[6] = -sth;       R[7] = cth * sphi;                    R[8] = cth * cphi;
     const double* nu = x + 6;
-    nu_dot_fast<GENERIC>(h, p, R, nu, a, sth, R[7], R[8], xd + 6);
+    const double ctsp = cth * sphi, ctcp = cth * cphi;         // R[7], R[8]
+    if constexpr (GENERIC) {
+        double R[9];
+        const double ss = sth * sphi, sc = sth * cphi;
+        R[0] = cpsi * cth; R[1] = fma(cpsi, ss, -(spsi * cphi)); R[2] = fma(cpsi, sc, spsi * sphi);
+        R[3] = spsi * cth; R[4] = fma(spsi, ss, cpsi * cphi);    R[5] = fma(spsi, sc, -(cpsi * sphi));
+        R[6] = -sth;       R[7] = ctsp;                          R[8] = ctcp;
+        nu_dot_fast<true>(h, p, R, nu, a, sth, ctsp, ctcp, xd + 6);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
+        for (int i = 0; i < 3; ++i) xd[i] = fma(R[3 * i + 2], nu[2], fma(R[3 * i + 1], nu[1], R[3 * i] * nu[0]));
+    } else {
+        nu_dot_fast<false>(h, p, nullptr, nu, a, sth, ctsp, ctcp, xd + 6);
+        // p_dot = Rz(psi) Ry(theta) Rx(phi) v applied as three plane rotations: 12 instructions instead of
+        // forming the nine entries of R (14) and a 3x3 product (9)
+        const double y1 = fma(cphi, nu[1], -(sphi * nu[2])), z1 = fma(sphi, nu[1], cphi * nu[2]);
+        const double x2 = fma(cth, nu[0], sth * z1), z2 = fma(cth, z1, -(sth * nu[0]));
+        xd[0] = fma(cpsi, x2, -(spsi * y1));
+        xd[1] = fma(spsi, x2, cpsi * y1);
+        xd[2] = z2;
+    }
     double cc = cth;
     if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));   // fossen/BlueROV2.py:52-54
     const double ic = recip_fast(cc);
@@ -213,14 +227,12 @@ __device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[
     sincos_fast(x[3], sphi, cphi, qt);
     sincos_fast(x[4], sth, cth, qt);
     sincos_fast(x[5], spsi, cpsi, qt);
-    const double ss = sth * sphi, sc = sth * cphi;
-    const double R0 = cpsi * cth, R1 = fma(cpsi, ss, -(spsi * cphi)), R2 = fma(cpsi, sc, spsi * sphi);
-    const double R3 = spsi * cth, R4 = fma(spsi, ss, cpsi * cphi), R5 = fma(spsi, sc, -(cpsi * sphi));
-    const double R6 = -sth, R7 = cth * sphi, R8 = cth * cphi;
     const double* v = x + 6;
-    xd[0] = fma(R2, v[2], fma(R1, v[1], R0 * v[0]));
-    xd[1] = fma(R5, v[2], fma(R4, v[1], R3 * v[0]));
-    xd[2] = fma(R8, v[2], fma(R7, v[1], R6 * v[0]));
+    const double y1 = fma(cphi, v[1], -(sphi * v[2])), z1 = fma(sphi, v[1], cphi * v[2]);
+    const double x2 = fma(cth, v[0], sth * z1);
+    xd[0] = fma(cpsi, x2, -(spsi * y1));
+    xd[1] = fma(spsi, x2, cpsi * y1);
+    xd[2] = fma(cth, z1, -(sth * v[0]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) xd[3 + i] = x[9 + i];
 #pragma unroll
@@ -301,7 +313,9 @@ __device__ __forceinline__ void advance_thrusters(const double __attribute__((ad
 }
 
 // commanded acceleration of one step: Minv T f(u) (thruster model) or Minv tau (wrench models)
-template <int MODEL>
+// SPARSE: the reference geometry -- horizontal thrusters 0..3 produce no heave, vertical thrusters 4..7 only heave,
+// roll and pitch -- so 16 of the 48 allocation products are zero (host-checked, capi.hip: derive_fast)
+template <int MODEL, bool SPARSE>
 __device__ __forceinline__ void command_accel(CFP p, const double* u, double fcmd[8], double acmd[6]) {
     if constexpr (MODEL == MODEL_THRUSTER_EULER) {
 #pragma unroll
@@ -313,12 +327,23 @@ __device__ __forceinline__ void command_accel(CFP p, const double* u, double fcm
             hh = fma(V2, hh, p->poly[0]);
             fcmd[i] = V * hh;
         }
+        if constexpr (SPARSE) {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            double a = p->Tm[k][0] * fcmd[0];
+            for (int k = 0; k < 6; ++k) {
+                const int i0 = (k == 2) ? 4 : 0, i1 = (k == 3 || k == 4) ? 8 : (k == 2 ? 8 : 4);
+                double a = p->Tm[k][i0] * fcmd[i0];
 #pragma unroll
-            for (int i = 1; i < 8; ++i) a = fma(p->Tm[k][i], fcmd[i], a);
-            acmd[k] = a;
+                for (int i = i0 + 1; i < i1; ++i) a = fma(p->Tm[k][i], fcmd[i], a);
+                acmd[k] = a;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                double a = p->Tm[k][0] * fcmd[0];
+#pragma unroll
+                for (int i = 1; i < 8; ++i) a = fma(p->Tm[k][i], fcmd[i], a);
+                acmd[k] = a;
+            }
         }
     } else if constexpr (model_is_di(MODEL)) {
         // a = U K: the [nu][3] gains K_lin / K_ang are stored transposed in Tm (rows 0-2 / 3-5)
@@ -347,7 +372,7 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
     CFP p = relaunder(p0);
     double fcmd[8], acmd[6], a[6];
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) quat_normalize(x + 3);   // the reference normalises q before its update (wrench_quat.py:339)
-    command_accel<MODEL>(p, u, fcmd, acmd);
+    command_accel<MODEL, !GENERIC>(p, u, fcmd, acmd);
     if constexpr (INTEG == INTEG_EULER) {
         double k[NX];
         if constexpr (THR) lz.accel_after(p, 1, acmd, a);

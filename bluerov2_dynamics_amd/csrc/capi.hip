@@ -249,8 +249,13 @@ void derive_fast(const brov_params& p, const DevParams& d, FastParams& f) {
     f.has_xy = (p.xb != 0.0 || p.yb != 0.0) ? 1 : 0;
     f.has_current = d.has_current;
     for (int i = 0; i < 3; ++i) f.cur[i] = d.cur[i];
+    f.tm_dense = 0;
     for (int k = 0; k < 6; ++k)
-        for (int i = 0; i < 8; ++i) f.Tm[k][i] = mi[k] * d.alloc[k][i];
+        for (int i = 0; i < 8; ++i) {
+            f.Tm[k][i] = mi[k] * d.alloc[k][i];
+            const bool expect_zero = (k == 2) ? (i < 4) : ((k == 0 || k == 1 || k == 5) ? (i >= 4) : false);
+            if (expect_zero && d.alloc[k][i] != 0.0) f.tm_dense = 1;
+        }
     for (int i = 0; i < 5; ++i) f.poly[i] = d.poly[i];
     for (int s = 0; s < 4; ++s) { for (int j = 0; j < 3; ++j) f.lc[s][j] = d.lag_c[s][j]; f.ld[s] = d.lag_d[s]; }
     for (int j = 0; j < 9; ++j) { f.A1[j] = d.lag_A[0][j]; f.A4[j] = d.lag_A[3][j]; }
@@ -520,7 +525,7 @@ static int rollout_args_ok(brov_ctx* c, int model, int integ, int lag_mode, int 
                            const void* x0, const void* U, const void* traj) {
     if (!c) return BROV_ERR_ARG;
     if (!model_ok(model) || (integ != BROV_EULER && integ != BROV_RK4) || (lag_mode != BROV_LAG_PER_CALL && lag_mode != BROV_LAG_PER_STEP) ||
-        (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB) || B < 0 || T < 0)
+        (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB && layout != BROV_LAYOUT_TPB) || B < 0 || T < 0)
         return fail(c, BROV_ERR_ARG, "brov_rollout: bad enum or negative size");
     if (B && (!x0 || (T && !U))) return fail(c, BROV_ERR_ARG, "brov_rollout: NULL input");
     if (traj && stride < 1) return fail(c, BROV_ERR_ARG, "brov_rollout: traj_stride must be >= 1");
@@ -560,7 +565,7 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     CallTimer t(c);
     HIPCK(c, launch_rollout(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U,
                             d_lag_io, d_traj, d_traj ? stride : 1, d_xT,
-                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy) ? 4 : 0)));
+                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy || c->fp.tm_dense) ? 4 : 0)));
     return BROV_OK;
 }
 
@@ -573,22 +578,24 @@ int brov_rollout(brov_ctx* c, int model, int integ, int lag_mode, int layout, in
     const int nx = NX(model), nu = NU(model);
     const bool lag = lag_io && model == BROV_THRUSTER_EULER;
     const int64_t rows = traj ? T / stride + 1 : 0;
+    const int nuw = layout == BROV_LAYOUT_TPB ? (nu + 1) / 2 * 2 : nu;     // TPB pads odd channel counts to pairs
+    const int nxw = layout == BROV_LAYOUT_TPB ? (nx + 1) / 2 * 2 : nx;
     Arena a(c);
-    rc = a.reserve(Arena::al(B * nx * 8) * 2 + Arena::al((size_t)B * T * nu * 8) + Arena::al(B * 24 * 8) + Arena::al((size_t)B * rows * nx * 8));
+    rc = a.reserve(Arena::al(B * nx * 8) * 2 + Arena::al((size_t)B * T * nuw * 8) + Arena::al(B * 24 * 8) + Arena::al((size_t)B * rows * nxw * 8));
     if (rc) return rc;
     double* dx0 = a.take<double>(B * nx);
-    double* dU = a.take<double>((size_t)B * T * nu);
+    double* dU = a.take<double>((size_t)B * T * nuw);
     double* dxT = a.take<double>(B * nx);
     double* dl = lag ? a.take<double>(B * 24) : nullptr;
-    double* dtr = traj ? a.take<double>((size_t)B * rows * nx) : nullptr;
+    double* dtr = traj ? a.take<double>((size_t)B * rows * nxw) : nullptr;
     HIPCK(c, hipMemcpyAsync(dx0, x0, B * nx * 8, hipMemcpyHostToDevice, c->stream));
-    if (T) HIPCK(c, hipMemcpyAsync(dU, U, (size_t)B * T * nu * 8, hipMemcpyHostToDevice, c->stream));
+    if (T) HIPCK(c, hipMemcpyAsync(dU, U, (size_t)B * T * nuw * 8, hipMemcpyHostToDevice, c->stream));
     if (lag) HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
     rc = brov_rollout_dev(c, model, integ, lag_mode, layout, B, T, dt, dx0, dU, dl, dtr, stride, dxT);
     if (rc) return rc;
     if (xT) HIPCK(c, hipMemcpyAsync(xT, dxT, B * nx * 8, hipMemcpyDeviceToHost, c->stream));
     if (lag) HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
-    if (traj) HIPCK(c, hipMemcpyAsync(traj, dtr, (size_t)B * rows * nx * 8, hipMemcpyDeviceToHost, c->stream));
+    if (traj) HIPCK(c, hipMemcpyAsync(traj, dtr, (size_t)B * rows * nxw * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -672,7 +679,7 @@ int brov_window_endpoint_se(brov_ctx* c, int model, int integ, int64_t N, int64_
 // ---- synthetic controls -------------------------------------------------------------------------------
 int brov_fill_controls_dev(brov_ctx* c, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed, int64_t b0,
                            int64_t T_total, const double* scale_host, double* d_U) {
-    if (!c || (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB) || (dist != BROV_DIST_IID_UNIFORM && dist != BROV_DIST_AR1) ||
+    if (!c || (layout != BROV_LAYOUT_BTU && layout != BROV_LAYOUT_TUB && layout != BROV_LAYOUT_TPB) || (dist != BROV_DIST_IID_UNIFORM && dist != BROV_DIST_AR1) ||
         B < 0 || T < 0 || nu < 1 || nu > 8 || b0 < 0 || T_total < T || (B && T && !d_U))
         return fail(c, BROV_ERR_ARG, "brov_fill_controls_dev: bad argument");
     DeviceGuard g(c);

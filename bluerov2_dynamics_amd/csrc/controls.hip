@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(256) fill_iid_kernel(int64_t B, int64_t T, int
         for (int j = 0; j < nu; ++j) {
             const double v = (2.0 * uniform01_at(seed, c0 + j) - 1.0) * sc.s[j];
             if constexpr (LAYOUT == LAYOUT_BTU) U[(b * T + t) * nu + j] = v;
-            else U[(t * nu + j) * B + b] = v;
+            else if constexpr (LAYOUT == LAYOUT_TUB) U[(t * nu + j) * B + b] = v;
+            else U[((t * ((nu + 1) / 2) + j / 2) * B + b) * 2 + (j & 1)] = v;
         }
     }
 }
@@ -56,7 +57,8 @@ __global__ void __launch_bounds__(256) fill_ar1_kernel(int64_t B, int64_t T, int
         prev = fmin(fmax(fma(0.98, prev, 0.02 * xi), -1.0), 1.0);
         const double v = prev * sc.s[j];
         if constexpr (LAYOUT == LAYOUT_BTU) U[(b * T + t) * nu + j] = v;
-        else U[(t * nu + j) * B + b] = v;
+        else if constexpr (LAYOUT == LAYOUT_TUB) U[(t * nu + j) * B + b] = v;
+        else U[((t * ((nu + 1) / 2) + j / 2) * B + b) * 2 + (j & 1)] = v;
     }
 }
 
@@ -70,13 +72,17 @@ hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B,
         const unsigned gy = (unsigned)(T < 4096 ? T : 4096);
         if (layout == LAYOUT_BTU)
             hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_BTU>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
-        else
+        else if (layout == LAYOUT_TUB)
             hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_TUB>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+        else
+            hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_TPB>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
     } else {
         if (layout == LAYOUT_BTU)
             hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_BTU>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
-        else
+        else if (layout == LAYOUT_TUB)
             hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_TUB>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+        else
+            hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_TPB>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
     }
     return hipGetLastError();
 }

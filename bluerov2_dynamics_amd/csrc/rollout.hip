@@ -46,6 +46,22 @@ __device__ __forceinline__ void store_soa(double* __restrict__ dst, int64_t ld, 
 #pragma unroll
     for (int i = 0; i < N; ++i) dst[i * ld] = r[i];
 }
+// paired struct-of-arrays: element pair i of lane b lives at base[(i * B + b) * 2 .. +1]; `p` points at pair 0 of this lane
+template <int N>
+__device__ __forceinline__ void load_pairs(const double* __restrict__ p, int64_t ld2, double* r) {
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        const double2 v = *reinterpret_cast<const double2*>(p + i * ld2);
+        r[2 * i] = v.x;
+        if (2 * i + 1 < N) r[2 * i + 1] = v.y;
+    }
+}
+template <int N>
+__device__ __forceinline__ void store_pairs(double* __restrict__ p, int64_t ld2, const double* r) {
+#pragma unroll
+    for (int i = 0; i < (N + 1) / 2; ++i)
+        *reinterpret_cast<double2*>(p + i * ld2) = make_double2(r[2 * i], (2 * i + 1 < N) ? r[2 * i + 1] : 0.0);
+}
 
 // ---------------------------------------------------------------------------------------
 // one integrator step (training/train_tank_brov2_full_comparison.py:462-465 Euler,
@@ -180,19 +196,24 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
     const int64_t rows = traj ? T / stride + 1 : 0;
     double* tp = nullptr;       // next trajectory row of this lane
     int64_t tstep = 0;          // distance between rows
+    constexpr int NXP = (NX + 1) / 2, NUP = (NU + 1) / 2;
     if (traj) {
         if constexpr (LAYOUT == LAYOUT_BTU) { tp = traj + b * rows * NX; tstep = NX; store_row<NX>(tp, x); }
-        else { tp = traj + b; tstep = (int64_t)NX * B; store_soa<NX>(tp, B, x); }
+        else if constexpr (LAYOUT == LAYOUT_TUB) { tp = traj + b; tstep = (int64_t)NX * B; store_soa<NX>(tp, B, x); }
+        else { tp = traj + 2 * b; tstep = (int64_t)NXP * 2 * B; store_pairs<NX>(tp, 2 * B, x); }
         tp += tstep;
     }
     const double* up;
     int64_t ustep;
     if constexpr (LAYOUT == LAYOUT_BTU) { up = U + b * T * NU; ustep = NU; }
-    else { up = U + b; ustep = (int64_t)NU * B; }
+    else if constexpr (LAYOUT == LAYOUT_TUB) { up = U + b; ustep = (int64_t)NU * B; }
+    else { up = U + 2 * b; ustep = (int64_t)NUP * 2 * B; }
 
     double un[NU];
     if (T > 0) {
-        if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un); else load_soa<NU>(up, B, un);
+        if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un);
+        else if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un);
+        else load_pairs<NU>(up, 2 * B, un);
     }
     int64_t countdown = stride;
     for (int64_t t = 0; t < T; ++t) {
@@ -201,12 +222,16 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
         for (int i = 0; i < NU; ++i) u[i] = un[i];
         up += ustep;
         if (t + 1 < T) {  // prefetch the next control row while this step computes
-            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un); else load_soa<NU>(up, B, un);
+            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un);
+            else if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un);
+            else load_pairs<NU>(up, 2 * B, un);
         }
         step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
         if (traj && --countdown == 0) {
             countdown = stride;
-            if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x); else store_soa<NX>(tp, B, x);
+            if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x);
+            else if constexpr (LAYOUT == LAYOUT_TUB) store_soa<NX>(tp, B, x);
+            else store_pairs<NX>(tp, 2 * B, x);
             tp += tstep;
         }
     }
@@ -354,7 +379,7 @@ __global__ void __launch_bounds__(256) window_lag_response_kernel(const FastPara
         const CFP pp = relaunder(as_constant(pg));
         double u[8], fcmd[8], acmd[6];
         load_row<8>(U + (k + t) * 8, u);
-        command_accel<MODEL_THRUSTER_EULER>(pp, u, fcmd, acmd);
+        command_accel<MODEL_THRUSTER_EULER, false>(pp, u, fcmd, acmd);
         lz.advance(NSUB == 4 ? pp->A4 : pp->A1, NSUB == 4 ? pp->b4 : pp->b1, acmd);
     }
     store_row<18>(resp + k * 18, &lz.z[0][0]);
@@ -503,10 +528,12 @@ static hipError_t launch_rollout_m(hipStream_t st, const FastParams* p, int inte
                                    double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {
     if (integ == INTEG_EULER) {
         if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
-        return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        if (layout == LAYOUT_TUB) return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+        return launch_rollout_l<MODEL, INTEG_EULER, LAYOUT_TPB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
     }
     if (layout == LAYOUT_BTU) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_BTU>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
-    return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+    if (layout == LAYOUT_TUB) return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TUB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
+    return launch_rollout_l<MODEL, INTEG_RK4, LAYOUT_TPB>(st, p, lag_mode, B, T, dt, x0, U, lag, traj, stride, xT, btu_staging);
 }
 hipError_t launch_rollout(hipStream_t st, const FastParams* p, int model, int integ, int lag_mode, int layout, int64_t B, int64_t T,
                           double dt, const double* x0, const double* U, double* lag, double* traj, int64_t stride, double* xT, int btu_staging) {

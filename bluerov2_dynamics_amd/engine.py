@@ -9,14 +9,31 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TUB, THRUSTER_EULER, WRENCH_EULER,
+from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB, THRUSTER_EULER, WRENCH_EULER,
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
            "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
-LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB}
+LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
+
+
+def _dims(U_shape, lay):
+    """(B, T, channels) of a control / trajectory array of the given layout ([B,T,c], [T,c,B] or [T,ceil(c/2),B,2])."""
+    if lay == LAYOUT_BTU:
+        return U_shape[0], U_shape[1], U_shape[2]
+    if lay == LAYOUT_TUB:
+        return U_shape[2], U_shape[0], U_shape[1]
+    return U_shape[2], U_shape[0], 2 * U_shape[1]
+
+
+def _shape(lay, B, rows, c):
+    if lay == LAYOUT_BTU:
+        return (B, rows, c)
+    if lay == LAYOUT_TUB:
+        return (rows, c, B)
+    return (rows, (c + 1) // 2, B, 2)
 
 
 def _is_torch(x):
@@ -70,11 +87,8 @@ def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layou
     integ, lay = INTEGRATORS[integrator], LAYOUTS[layout]
     nx, nu = NX[model], NU[model]
     U = as_f64(U)
-    if lay == LAYOUT_BTU:
-        B, T, nu_ = U.shape
-    else:
-        T, nu_, B = U.shape
-    assert nu_ == nu, f"U has {nu_} channels, model needs {nu}"
+    B, T, nu_ = _dims(U.shape, lay)
+    assert nu_ == (nu + 1) // 2 * 2 if lay == LAYOUT_TPB else nu_ == nu, f"U has {nu_} channels, model needs {nu}"
     x0 = as_f64(x0).reshape(B, nx)
     lag_io = None
     if model == THRUSTER_EULER and (lag is not None or return_lag):
@@ -82,7 +96,7 @@ def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layou
     rows = T // stride + 1
     traj = None
     if store:
-        traj = np.empty((B, rows, nx) if lay == LAYOUT_BTU else (rows, nx, B))
+        traj = np.empty(_shape(lay, B, rows, nx))
     xT = np.empty((B, nx))
     ctx.check(ctx.lib.brov_rollout(ctx.h, model, integ, lag_mode, lay, B, T, float(dt), _hptr(x0), _hptr(U), _hptr(lag_io),
                                    _hptr(traj), int(stride), _hptr(xT)), "brov_rollout")
@@ -123,14 +137,11 @@ def rollout_dev(model, integrator, x0, U, dt, lag=None, traj=None, xT=None, lag_
     ctx.use_torch_stream()
     lay = LAYOUTS[layout]
     nu = NU[model]
-    if lay == LAYOUT_BTU:
-        B, T, nu_ = U.shape
-    else:
-        T, nu_, B = U.shape
-    assert nu_ == nu and tuple(x0.shape) == (B, NX[model])
+    B, T, nu_ = _dims(tuple(U.shape), lay)
+    assert (nu_ == (nu + 1) // 2 * 2 if lay == LAYOUT_TPB else nu_ == nu) and tuple(x0.shape) == (B, NX[model])
     if traj is not None:
         rows = T // stride + 1
-        want = (B, rows, NX[model]) if lay == LAYOUT_BTU else (rows, NX[model], B)
+        want = _shape(lay, B, rows, NX[model])
         assert tuple(traj.shape) == want, f"traj shape {tuple(traj.shape)} != {want}"
     ctx.check(ctx.lib.brov_rollout_dev(ctx.h, model, INTEGRATORS[integrator], lag_mode, lay, B, T, float(dt), _dptr(x0), _dptr(U),
                                        _dptr(lag), _dptr(traj), int(stride), _dptr(xT)), "brov_rollout_dev")
@@ -141,10 +152,7 @@ def fill_controls_dev(U, layout, dist="iid", seed=0x5EED, b0=0, T_total=None, sc
     ctx = ctx or default_context(U.device.index)
     ctx.use_torch_stream()
     lay = LAYOUTS[layout]
-    if lay == LAYOUT_BTU:
-        B, T, nu = U.shape
-    else:
-        T, nu, B = U.shape
+    B, T, nu = _dims(tuple(U.shape), lay)
     d = {"iid": DIST_IID_UNIFORM, "ar1": DIST_AR1}[dist]
     sc = None if scale is None else as_f64(scale).reshape(nu)
     ctx.check(ctx.lib.brov_fill_controls_dev(ctx.h, lay, d, B, T, nu, ctypes.c_uint64(seed), int(b0), int(T_total or T),

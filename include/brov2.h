@@ -67,7 +67,9 @@ typedef enum brov_integrator { BROV_EULER = 0, BROV_RK4 = 1 } brov_integrator;
 typedef enum brov_lag_mode { BROV_LAG_PER_CALL = 0, BROV_LAG_PER_STEP = 1 } brov_lag_mode;
 /* BTU: U[B][T][nu], traj[B][T/stride+1][nx]  (what the reference's callers hold, row-major)
  * TUB: U[T][nu][B], traj[T/stride+1][nx][B]  (time-major struct-of-arrays, device native) */
-typedef enum brov_layout { BROV_LAYOUT_BTU = 0, BROV_LAYOUT_TUB = 1 } brov_layout;
+/* TPB: as TUB with channel PAIRS interleaved -- U[T][ceil(nu/2)][B][2], traj[T/stride+1][ceil(nx/2)][B][2] (an odd
+ *      channel count is padded with one unused element): 16-byte accesses per lane, the fastest rollout layout */
+typedef enum brov_layout { BROV_LAYOUT_BTU = 0, BROV_LAYOUT_TUB = 1, BROV_LAYOUT_TPB = 2 } brov_layout;
 typedef enum brov_dist { BROV_DIST_IID_UNIFORM = 0, BROV_DIST_AR1 = 1 } brov_dist;
 
 /* Vehicle parameters; brov_default_params() fills the reference's values

@@ -121,9 +121,12 @@ def test_cfg2_first_8_trajectories_match_reference(eng):
         assert rel_err(r["traj"], g[key]) < TOL_TRAJ, integ
         assert rel_err(r["xT"], g[key][:, -1]) < TOL_TRAJ
         assert rel_err(r["lag"], g[lkey]) < TOL_TRAJ
-        # time-major layout gives the same numbers
+        # the time-major layouts give the same numbers
         r2 = eng.rollout(_lib.THRUSTER_EULER, integ, x0, np.ascontiguousarray(Uh.transpose(1, 2, 0)), dt, stride=sub, layout="tub")
         assert np.array_equal(r2["traj"].transpose(2, 0, 1), r["traj"])
+        Up = np.ascontiguousarray(Uh.reshape(B, T, 4, 2).transpose(1, 2, 0, 3))           # [T][4][B][2]
+        r3 = eng.rollout(_lib.THRUSTER_EULER, integ, x0, Up, dt, stride=sub, layout="tpb")
+        assert np.array_equal(r3["traj"].transpose(2, 0, 1, 3).reshape(B, -1, 12), r["traj"])
 
 
 def test_ar1_wrench_quat_cfg1_rollouts_match_reference(eng):
@@ -179,6 +182,13 @@ def test_rollout_vs_oracle_all_models_layouts_modes(eng, fc):
         a = eng.rollout(0, integ, X0, U, dt, return_lag=False)
         b = eng.rollout(0, integ, X0, U, dt)
         assert a["lag"] is None and np.array_equal(a["traj"], b["traj"])
+    # paired layout with an odd state dimension (13 -> 7 pairs, last element unused)
+    Xq0 = rng.uniform(-0.5, 0.5, (B, 13))
+    Uq = rng.uniform(-10, 10, (B, T, 6))
+    a = eng.rollout(2, "rk4", Xq0, Uq, dt)
+    b = eng.rollout(2, "rk4", Xq0, np.ascontiguousarray(Uq.reshape(B, T, 3, 2).transpose(1, 2, 0, 3)), dt, layout="tpb")
+    assert b["traj"].shape == (T + 1, 7, B, 2)
+    assert np.array_equal(b["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 14)[:, :, :13], a["traj"])
     # empty / degenerate sizes
     r = eng.rollout(0, "rk4", np.zeros((0, 12)), np.zeros((0, 5, 8)), 0.02)
     assert r["traj"].shape == (0, 6, 12)
@@ -227,6 +237,10 @@ def test_fill_controls_layouts_and_ar1(eng):
         torch.cuda.synchronize()
         assert np.array_equal(a.cpu().numpy(), controls.controls_iid(7, 1000, B, 500, nu=nu, nt=T))
         assert torch.equal(a, b.permute(2, 0, 1))
+    c = torch.empty((T, 3, B, 2), dtype=torch.float64, device="cuda")                      # paired layout, nu = 6
+    eng.fill_controls_dev(c, "tpb", "iid", seed=7, b0=1000, T_total=500)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.permute(2, 0, 1, 3).reshape(B, T, 6).cpu().numpy(), controls.controls_iid(7, 1000, B, 500, nu=6, nt=T))
     a = torch.empty((B, T, 8), dtype=torch.float64, device="cuda")
     eng.fill_controls_dev(a, "btu", "ar1", seed=9, b0=0, T_total=T, scale=[2.0] * 8)
     torch.cuda.synchronize()
