@@ -25,7 +25,7 @@ sys.path.insert(0, REPO)
 
 # algorithmic work per unit
 ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (reference algebra)
-ROLLOUT_EXEC_FP64_INSTR = {"rk4": 879, "euler": 327}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 779, "euler": 284}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0

@@ -14,9 +14,12 @@
 //    per-thruster state is advanced alongside only when the caller wants it back (lag_io != NULL).
 //  * sin/cos: 3-term Cody-Waite reduction + the fdlibm kernel polynomials (~1 ulp for |x| < 3e9),
 //    instead of OCML's double-double reduction (fossen/BlueROV2.py:28-33,47-50,342-345 call
-//    np.sin/np.cos three times per call on the same angles; here once).
-//  * Per-stage constants live in VGPRs (uniform values, pinned with an empty asm) and once-per-step
-//    constants are re-read through a laundered kernarg pointer (scalar loads), so nothing spills:
+//    np.sin/np.cos three times per call on the same angles; here once).  RK4 stages 2-4 get theirs from the
+//    first stage's by the addition theorem on the small angle increment (trig_delta).
+//  * The lag bank is carried in the observer basis of its next three outputs (LagZ::to_observer): stages 1-3
+//    of a step read the thrust with one FMA per channel.
+//  * The hottest constants live in VGPRs (uniform values, pinned with an empty asm) and the rest is
+//    re-read once per step through a laundered constant pointer (scalar loads), so nothing spills to scratch:
 //    the first version kept all 150 constants live in SGPRs and paid ~1000 v_readlane per step.
 #pragma once
 #include "brov2_device.h"
@@ -37,13 +40,18 @@ struct FastParams {
     double poly[5];
     double A1[9], b1[3];   // one lag sample
     double A4[9], b4[3];   // four lag samples
+    // the same lag bank in the observer basis w = O z, rows of O = Cc Ad^1..3 (see LagZ): used by the GENERIC = false kernels
+    double Ob[9];          // O
+    double al4[3];         // Cc Ad^4 O^-1
+    double Aw4[9], bw4[3]; // O A4 O^-1, O b4
+    double g1[3];          // O Bd
     // rare
     double XY[4];      // Y3 = minv3 yb B, X4 = minv4 xb B, X5 = minv5 xb B, Y5 = minv5 yb B
     double cur[3];
     int has_current;
     int has_xy;
     int tm_dense;      // allocation matrix does not have the reference's zero pattern
-    int pad1;
+    int obs_bad;       // O is (nearly) singular: the observer form is not usable, host selects the GENERIC kernels
 };
 
 // FastParams lives in a small device buffer owned by the ctx and is read through a CONSTANT
@@ -59,7 +67,7 @@ struct HotConsts {
 #define BROV_PIN_V(x) asm volatile("" : "+v"(x))
 
 // E and db are pinned in VGPRs for the whole launch (fma(db, |nu|, da) needs a non-scalar second constant
-// anyway); G and da are re-read through the per-stage laundered pointer as scalar operands, so that no
+// anyway); G and da are re-read through the per-step laundered pointer as scalar operands, so that no
 // loop-invariant SGPRs have to be spilled around the sin/cos literals and the per-step scalar loads.
 __device__ __forceinline__ void load_hot(CFP pp, HotConsts& h) {
     const auto& p = *pp;
@@ -114,6 +122,68 @@ __device__ __forceinline__ void init_quadrant_table(double2* qt) {
     }
 }
 
+// sin/cos of the three attitude angles of one dynamics() call
+struct Trig { double sphi, cphi, sth, cth, spsi, cpsi; };
+
+__device__ __forceinline__ void trig_full(const double* ang, Trig& t, const double2* __restrict__ qt) {
+    sincos_fast(ang[0], t.sphi, t.cphi, qt);
+    sincos_fast(ang[1], t.sth, t.cth, qt);
+    sincos_fast(ang[2], t.spsi, t.cpsi, qt);
+}
+
+// RK4 stages 2-4 evaluate the RHS at angles a + d with a = the angles at the start of the step (whose sin/cos the
+// first stage computed) and d = c dt k_angle, a few hundredths of a radian: addition theorem on (sin d, cos d - 1) from
+// short Taylor-like kernels instead of three fresh range reductions (15 instructions per angle against 27).
+//   |d| <= 1/8 : the leading fdlibm coefficients of sincos_fast, truncated -- they differ from the Taylor ones by
+//                < 1e-16 relative in the result there, and sharing the literals keeps them in the same SGPRs.
+//   larger     : (3 % of the wave-steps of BASELINE config 2: near theta = +-pi/2 the Euler-angle rates blow up)
+//                d is halved k times into that range and (sin, cos - 1) doubled back k times, sin 2a = 2 sin a cos a,
+//                cos 2a - 1 = -2 sin^2 a: the rounding error doubles per level (|d| = 2 rad: 16 ulp), the code is a
+//                dozen instructions, and no second copy of the full evaluation sits in the time loop (the first
+//                version had one per stage: its literals cost 36 SGPR spill reloads and 40 AGPR moves per step).
+//   |d| >= 2^37 or not finite: NaN (np.sin gives NaN for inf/NaN; for finite arguments of that size the reference's
+//                values carry no information about the trajectory either).
+__device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Trig& t) {
+    double dd[3] = {d[0], d[1], d[2]};
+    int k = 0;
+    const double m = fmax(fmax(fabs(d[0]), fabs(d[1])), fabs(d[2]));
+    if (!(m <= 0.125)) {                                     // also NaN
+        int e;
+        (void)frexp(m, &e);                                  // m < 2^e
+        k = e + 3;
+        double sc = ldexp(1.0, -k);
+        if (!(m < 0x1p37)) { sc = __builtin_nan(""); k = 0; }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dd[i] *= sc;
+    }
+    double sd[3], cm[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const double z = dd[i] * dd[i];
+        double ps = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
+        ps = fma(z, ps, 8.33333333332248946124e-03);
+        ps = fma(z, ps, -1.66666666666666324348e-01);
+        sd[i] = fma(z * dd[i], ps, dd[i]);                   // sin d
+        double pc = fma(z, -2.75573143513906633035e-07, 2.48015872894767294178e-05);
+        pc = fma(z, pc, -1.38888888888741095749e-03);
+        pc = fma(z, pc, 4.16666666666666019037e-02);
+        pc = fma(z, pc, -0.5);
+        cm[i] = z * pc;                                      // cos d - 1
+    }
+    for (int j = 0; j < k; ++j) {                            // lane-varying trip count, almost always 0
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const double t2 = sd[i] + sd[i];
+            const double s2 = fma(t2, cm[i], t2);
+            cm[i] = -(t2 * sd[i]);
+            sd[i] = s2;
+        }
+    }
+    t.sphi = fma(b.cphi, sd[0], fma(b.sphi, cm[0], b.sphi)); t.cphi = fma(-b.sphi, sd[0], fma(b.cphi, cm[0], b.cphi));
+    t.sth = fma(b.cth, sd[1], fma(b.sth, cm[1], b.sth));     t.cth = fma(-b.sth, sd[1], fma(b.cth, cm[1], b.cth));
+    t.spsi = fma(b.cpsi, sd[2], fma(b.spsi, cm[2], b.spsi)); t.cpsi = fma(-b.spsi, sd[2], fma(b.cpsi, cm[2], b.cpsi));
+}
+
 // 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps
 __device__ __forceinline__ double recip_fast(double x) {
     double y = __builtin_amdgcn_rcp(x);
@@ -166,11 +236,8 @@ __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const dou
 
 // xdot for the Euler-angle state; a = Minv tau
 template <bool GENERIC>
-__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12], const double2* qt) {
-    double sphi, cphi, sth, cth, spsi, cpsi;
-    sincos_fast(x[3], sphi, cphi, qt);
-    sincos_fast(x[4], sth, cth, qt);
-    sincos_fast(x[5], spsi, cpsi, qt);
+__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12], const Trig& tg) {
+    const double sphi = tg.sphi, cphi = tg.cphi, sth = tg.sth, cth = tg.cth, spsi = tg.spsi, cpsi = tg.cpsi;   // x[3..5] enter only through these
     const double* nu = x + 6;
     const double ctsp = cth * sphi, ctcp = cth * cphi;         // R[7], R[8]
     if constexpr (GENERIC) {
@@ -222,11 +289,8 @@ __device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const d
 }
 
 // double integrator: dpos = R v, dang = w (Euler angles, "small-angle" in the reference) or q_dot, dnu = a
-__device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[6], double xd[12], const double2* qt) {
-    double sphi, cphi, sth, cth, spsi, cpsi;
-    sincos_fast(x[3], sphi, cphi, qt);
-    sincos_fast(x[4], sth, cth, qt);
-    sincos_fast(x[5], spsi, cpsi, qt);
+__device__ __forceinline__ void rhs_di_euler(const double x[12], const double a[6], double xd[12], const Trig& tg) {
+    const double sphi = tg.sphi, cphi = tg.cphi, sth = tg.sth, cth = tg.cth, spsi = tg.spsi, cpsi = tg.cpsi;
     const double* v = x + 6;
     const double y1 = fma(cphi, v[1], -(sphi * v[2])), z1 = fma(sphi, v[1], cphi * v[2]);
     const double x2 = fma(cth, v[0], sth * z1);
@@ -258,12 +322,13 @@ __device__ __forceinline__ void rhs_di_quat(const double x[13], const double a[6
     for (int i = 0; i < 6; ++i) xd[7 + i] = a[i];
 }
 
+// tg: sin/cos of x[3..5] for the Euler-angle models (ignored by the quaternion ones)
 template <int MODEL, bool GENERIC>
-__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd, const double2* qt) {
+__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd, const Trig& tg) {
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) rhs_di_quat(x, a, xd);
-    else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd, qt);
+    else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd, tg);
     else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat<GENERIC>(h, p, x, a, xd);
-    else rhs_fast_euler<GENERIC>(h, p, x, a, xd, qt);
+    else rhs_fast_euler<GENERIC>(h, p, x, a, xd, tg);
 }
 
 // ---- thruster lag in acceleration space ---------------------------------------------------------
@@ -290,6 +355,41 @@ struct LagZ {
         const double c0 = p->lc[s - 1][0], c1 = p->lc[s - 1][1], c2 = p->lc[s - 1][2], d = p->ld[s - 1];
 #pragma unroll
         for (int k = 0; k < 6; ++k) a[k] = fma(c2, z[k][2], fma(c1, z[k][1], fma(c0, z[k][0], d * acmd[k])));
+    }
+    // ---- observer basis (GENERIC = false kernels) ------------------------------------------------
+    // w = O z with rows of O = Cc Ad, Cc Ad^2, Cc Ad^3: the coordinates ARE the zero-input outputs the next three
+    // dynamics() calls will see, so stages 1-3 of an RK4 step cost one FMA per channel (w_s + d_s a_cmd), stage 4 four
+    // (Cc Ad^4 O^-1 . w), and a one-sample advance is a companion shift.  19 instead of 28 instructions per channel
+    // and RK4 step; cond(O) = 9.9 at dt = 0.02 (host refuses the form above 1e4 -> GENERIC kernels).
+    __device__ __forceinline__ void to_observer(CFP p) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double a0 = z[k][0], a1 = z[k][1], a2 = z[k][2];
+            z[k][0] = fma(p->Ob[2], a2, fma(p->Ob[1], a1, p->Ob[0] * a0));
+            z[k][1] = fma(p->Ob[5], a2, fma(p->Ob[4], a1, p->Ob[3] * a0));
+            z[k][2] = fma(p->Ob[8], a2, fma(p->Ob[7], a1, p->Ob[6] * a0));
+        }
+    }
+    __device__ __forceinline__ void obs_accel_after(CFP p, int s, const double acmd[6], double a[6]) const {
+        if (s <= 3) {
+            const double d = p->ld[s - 1];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = fma(d, acmd[k], z[k][s - 1]);
+        } else {
+            const double c0 = p->al4[0], c1 = p->al4[1], c2 = p->al4[2], d = p->ld[3];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = fma(c2, z[k][2], fma(c1, z[k][1], fma(c0, z[k][0], d * acmd[k])));
+        }
+    }
+    __device__ __forceinline__ void obs_advance1(CFP p, const double acmd[6]) {
+        const double c0 = p->al4[0], c1 = p->al4[1], c2 = p->al4[2], g0 = p->g1[0], g1 = p->g1[1], g2 = p->g1[2];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const double a0 = z[k][0], a1 = z[k][1], a2 = z[k][2];
+            z[k][0] = fma(g0, acmd[k], a1);
+            z[k][1] = fma(g1, acmd[k], a2);
+            z[k][2] = fma(c2, a2, fma(c1, a1, fma(c0, a0, g2 * acmd[k])));
+        }
     }
     __device__ __forceinline__ void advance(const double __attribute__((address_space(4)))* A, const double __attribute__((address_space(4)))* b, const double acmd[6]) {
 #pragma unroll
@@ -369,49 +469,69 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
                                           LagZ& lz, double X[8][3], const double2* qt) {
     constexpr int NX = Dims<MODEL>::NX;
     constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
+    constexpr bool OBS = !GENERIC;                       // lag state held in the observer basis (kernels call to_observer once)
+    constexpr bool ANG = !model_is_quat(MODEL);          // x[3..5] are Euler angles
     CFP p = relaunder(p0);
     double fcmd[8], acmd[6], a[6];
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) quat_normalize(x + 3);   // the reference normalises q before its update (wrench_quat.py:339)
     command_accel<MODEL, !GENERIC>(p, u, fcmd, acmd);
+    auto accel = [&](CFP pp, int s) {
+        if constexpr (THR) { if constexpr (OBS) lz.obs_accel_after(pp, s, acmd, a); else lz.accel_after(pp, s, acmd, a); }
+    };
+    Trig tb, ts;
+    if constexpr (ANG) trig_full(x + 3, tb, qt);
     if constexpr (INTEG == INTEG_EULER) {
         double k[NX];
-        if constexpr (THR) lz.accel_after(p, 1, acmd, a);
-        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, qt);
+        accel(p, 1);
+        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, tb);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
         if constexpr (THR) {
             CFP pl = relaunder(p0);
-            lz.advance(pl->A1, pl->b1, acmd);
+            if constexpr (OBS) lz.obs_advance1(pl, acmd); else lz.advance(pl->A1, pl->b1, acmd);
             if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
         }
     } else {
-        double k[NX], xn[NX], xs[NX];
+        double k[NX], xn[NX], xs[NX], dl[3];
         const double h2 = 0.5 * dt, h6 = dt / 6.0, h3 = dt / 3.0;
-        if constexpr (THR) lz.accel_after(p, 1, acmd, a);
-        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, qt);
+        // stage state xs = x + c k; for the Euler-angle models the angles enter the RHS only through their sin/cos,
+        // which come from the angle increments dl = c k[3..5] (trig_delta), so xs[3..5] is never formed
+        auto stage_state = [&](double c) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { xn[i] = fma(h6, k[i], x[i]); xs[i] = fma(h2, k[i], x[i]); }
-        CFP p2 = relaunder(p0);
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(p2, 2, acmd, a);
-        rhs_fast<MODEL, GENERIC>(h, p2, xs, THR ? a : acmd, k, qt);
+            for (int i = 0; i < NX; ++i) {
+                if (ANG && i >= 3 && i < 6) dl[i - 3] = c * k[i];
+                else xs[i] = fma(c, k[i], x[i]);
+            }
+            if constexpr (ANG) trig_delta(tb, dl, ts);
+        };
+        accel(p, 1);
+        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, tb);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { xn[i] = fma(h3, k[i], xn[i]); xs[i] = fma(h2, k[i], x[i]); }
-        CFP p3 = relaunder(p0);
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(p3, 3, acmd, a);
-        rhs_fast<MODEL, GENERIC>(h, p3, xs, THR ? a : acmd, k, qt);
+        for (int i = 0; i < NX; ++i) xn[i] = fma(h6, k[i], x[i]);
+        stage_state(h2);
+        if constexpr (LAGMODE == 0) accel(p, 2);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) { xn[i] = fma(h3, k[i], xn[i]); xs[i] = fma(dt, k[i], x[i]); }
-        CFP p4 = relaunder(p0);
-        if constexpr (THR && LAGMODE == 0) lz.accel_after(p4, 4, acmd, a);
-        rhs_fast<MODEL, GENERIC>(h, p4, xs, THR ? a : acmd, k, qt);
+        for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        stage_state(h2);
+        if constexpr (LAGMODE == 0) accel(p, 3);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        stage_state(dt);
+        if constexpr (LAGMODE == 0) accel(p, 4);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
 #pragma unroll
         for (int i = 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
         if constexpr (THR) {
             CFP pl = relaunder(p0);
-            const double __attribute__((address_space(4)))* A = (LAGMODE == 0) ? pl->A4 : pl->A1;
-            const double __attribute__((address_space(4)))* b = (LAGMODE == 0) ? pl->b4 : pl->b1;
-            lz.advance(A, b, acmd);
-            if constexpr (TRACK) advance_thrusters(A, b, fcmd, X);
+            if constexpr (LAGMODE == 0) {
+                if constexpr (OBS) lz.advance(pl->Aw4, pl->bw4, acmd); else lz.advance(pl->A4, pl->b4, acmd);
+                if constexpr (TRACK) advance_thrusters(pl->A4, pl->b4, fcmd, X);
+            } else {
+                if constexpr (OBS) lz.obs_advance1(pl, acmd); else lz.advance(pl->A1, pl->b1, acmd);
+                if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
+            }
         }
     }
     if constexpr (model_is_quat(MODEL)) quat_normalize(x + 3);

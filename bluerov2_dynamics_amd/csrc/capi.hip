@@ -260,6 +260,46 @@ void derive_fast(const brov_params& p, const DevParams& d, FastParams& f) {
     for (int s = 0; s < 4; ++s) { for (int j = 0; j < 3; ++j) f.lc[s][j] = d.lag_c[s][j]; f.ld[s] = d.lag_d[s]; }
     for (int j = 0; j < 9; ++j) { f.A1[j] = d.lag_A[0][j]; f.A4[j] = d.lag_A[3][j]; }
     for (int j = 0; j < 3; ++j) { f.b1[j] = d.lag_b[0][j]; f.b4[j] = d.lag_b[3][j]; }
+    // observer basis w = O z, rows of O = Cc Ad^1..3 (LagZ::to_observer): constants in long double, O^-1 by the adjugate
+    long double O[9], Oi[9];
+    for (int r = 0; r < 3; ++r) for (int j = 0; j < 3; ++j) O[3 * r + j] = d.lag_c[r][j];
+    const long double det = O[0] * (O[4] * O[8] - O[5] * O[7]) - O[1] * (O[3] * O[8] - O[5] * O[6]) + O[2] * (O[3] * O[7] - O[4] * O[6]);
+    long double nO = 0, nOi = 0;
+    f.obs_bad = 1;
+    if (det != 0.0L && std::isfinite((double)det)) {
+        Oi[0] = (O[4] * O[8] - O[5] * O[7]) / det; Oi[1] = (O[2] * O[7] - O[1] * O[8]) / det; Oi[2] = (O[1] * O[5] - O[2] * O[4]) / det;
+        Oi[3] = (O[5] * O[6] - O[3] * O[8]) / det; Oi[4] = (O[0] * O[8] - O[2] * O[6]) / det; Oi[5] = (O[2] * O[3] - O[0] * O[5]) / det;
+        Oi[6] = (O[3] * O[7] - O[4] * O[6]) / det; Oi[7] = (O[1] * O[6] - O[0] * O[7]) / det; Oi[8] = (O[0] * O[4] - O[1] * O[3]) / det;
+        for (int j = 0; j < 9; ++j) { nO += O[j] * O[j]; nOi += Oi[j] * Oi[j]; }
+        const long double cond = sqrtl(nO) * sqrtl(nOi);           // Frobenius condition number
+        if (std::isfinite((double)cond) && cond < 1.0e4L) {
+            f.obs_bad = 0;
+            long double OA[9];                                       // O A4
+            for (int r = 0; r < 3; ++r) for (int j = 0; j < 3; ++j) {
+                long double a = 0;
+                for (int m = 0; m < 3; ++m) a += O[3 * r + m] * (long double)d.lag_A[3][3 * m + j];
+                OA[3 * r + j] = a;
+            }
+            for (int r = 0; r < 3; ++r) {
+                long double b4 = 0, g = 0;
+                for (int j = 0; j < 3; ++j) {
+                    long double a = 0;
+                    for (int m = 0; m < 3; ++m) a += OA[3 * r + m] * Oi[3 * m + j];
+                    f.Aw4[3 * r + j] = (double)a;
+                    b4 += O[3 * r + j] * (long double)d.lag_b[3][j];
+                    g += O[3 * r + j] * (long double)d.lag_b[0][j];
+                }
+                f.bw4[r] = (double)b4;
+                f.g1[r] = (double)g;
+            }
+            for (int j = 0; j < 3; ++j) {
+                long double a = 0;
+                for (int m = 0; m < 3; ++m) a += (long double)d.lag_c[3][m] * Oi[3 * m + j];
+                f.al4[j] = (double)a;
+            }
+            for (int j = 0; j < 9; ++j) f.Ob[j] = (double)O[j];
+        }
+    }
 }
 
 int get_dp(brov_ctx* c, double dt, const DevParams** out) {
@@ -565,7 +605,7 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     CallTimer t(c);
     HIPCK(c, launch_rollout(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U,
                             d_lag_io, d_traj, d_traj ? stride : 1, d_xT,
-                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy || c->fp.tm_dense) ? 4 : 0)));
+                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy || c->fp.tm_dense || c->fp.obs_bad) ? 4 : 0)));
     return BROV_OK;
 }
 

@@ -196,6 +196,94 @@ def test_rollout_vs_oracle_all_models_layouts_modes(eng, fc):
     assert np.array_equal(r["xT"], np.ones((3, 12)) * 0.1) and r["traj"].shape == (3, 1, 12)
 
 
+def test_large_angle_increments_near_pitch_singularity(eng, fc):
+    """RK4 stages 2-4 take sin/cos from the addition theorem on the angle increment; increments above 1/8 rad go through
+    the halving/doubling branch (brov2_fast.h: trig_delta).  Near theta = +-pi/2 the Euler-angle rates blow up, which is
+    where BASELINE config 2 hits that branch; here every trajectory starts near it.  The problem is ill-conditioned
+    there (tan(theta) up to 1e3), so the yardstick is what a 1e-13 perturbation of the initial pitch does to the
+    oracle itself."""
+    rng = np.random.default_rng(7)
+    B, T, dt = 512, 40, 0.02
+    X0 = rng.uniform(-0.3, 0.3, (B, 12))
+    X0[:, 4] = rng.choice([-1.0, 1.0], B) * rng.uniform(1.2, 1.5, B)
+    X0[:, 9:12] = rng.uniform(-2.0, 2.0, (B, 3))
+    U = rng.uniform(-1, 1, (B, T, 8))
+    o = fc.rollout(0, fc.INTEG_RK4, X0, U, dt, nthreads=8)
+    inc = np.abs(np.diff(o["traj"][:, :, 3:6], axis=1))
+    assert (inc > 0.125).mean() > 0.01 and inc.max() > 4.0          # the branch is exercised, incl. several doublings
+    X1 = X0.copy()
+    X1[:, 4] += 1e-13
+    o1 = fc.rollout(0, fc.INTEG_RK4, X1, U, dt, nthreads=8)
+    scale = np.maximum(1.0, np.abs(o["traj"]))
+    sens = (np.abs(o1["traj"] - o["traj"]) / scale).max(axis=(1, 2))
+    r = eng.rollout(0, "rk4", X0, U, dt)
+    err = (np.abs(r["traj"] - o["traj"]) / scale).max(axis=(1, 2))
+    assert np.isfinite(err).all()
+    assert (err <= 1e-11 + 10.0 * sens).all(), float((err / (1e-11 + 10.0 * sens)).max())
+    assert np.median(err) < 1e-13
+    # non-finite increments give NaN like np.sin(inf), and only in the lane concerned
+    Xn = X0[:4].copy()
+    Xn[0, 10] = np.inf
+    rn = eng.rollout(0, "rk4", Xn, U[:4], dt)
+    assert np.isnan(rn["xT"][0]).any()
+    assert np.array_equal(rn["xT"][1:], r["xT"][1:4])
+
+
+def test_custom_vehicle_fast_path_equals_literal_rhs_loop(eng):
+    """brov_set_params with a vehicle outside the reference's structure (current, xb/yb, tilted thrusters, a lag
+    whose observer basis is singular) runs the GENERIC kernels: check the time-loop form (csrc/brov2_fast.h) against a
+    host loop over brov_rhs, the literal per-call form (csrc/brov2_device.h), which advances the lag per call (Q1)."""
+    from bluerov2_dynamics_amd import _lib
+    rng = np.random.default_rng(11)
+    for variant in ("tilted", "lag_unobservable", "reference"):
+        ctx = _lib.Context(0)
+        p = ctx.get_params()
+        if variant != "reference":
+            p.xb, p.yb = 0.01, -0.02
+            for k in range(3):
+                p.current[k] = (0.2, -0.1, 0.05)[k]
+            for i in range(6):
+                p.lin_damp[i] = -(3.0 + i)
+        if variant == "tilted":
+            for i in range(8):
+                d = np.array([p.thr_dir[i][j] for j in range(3)]) + rng.uniform(-0.2, 0.2, 3)
+                d /= np.linalg.norm(d)
+                for j in range(3):
+                    p.thr_dir[i][j] = d[j]
+        if variant == "lag_unobservable":
+            Ac = np.diag([-10.0, -20.0, -30.0])
+            for j in range(9):
+                p.lag_Ac[j] = Ac.ravel()[j]
+            for j in range(3):
+                p.lag_Bc[j] = (10.0, 0.0, 0.0)[j]
+                p.lag_Cc[j] = (1.0, 0.0, 0.0)[j]
+        ctx.set_params(p)
+        B, T, dt = 200, 12, 0.02
+        X0 = rng.uniform(-0.4, 0.4, (B, 12))
+        U = rng.uniform(-1, 1, (B, T, 8))
+        lag0 = rng.uniform(-1, 1, (B, 8, 3))
+        for integ in ("euler", "rk4"):
+            x, lag = X0.copy(), lag0.copy()
+            for t in range(T):
+                if integ == "euler":
+                    k1, lag = eng.rhs(0, x, U[:, t], dt, lag=lag, ctx=ctx)
+                    x = x + dt * k1
+                else:
+                    k1, lag = eng.rhs(0, x, U[:, t], dt, lag=lag, ctx=ctx)
+                    k2, lag = eng.rhs(0, x + 0.5 * dt * k1, U[:, t], dt, lag=lag, ctx=ctx)
+                    k3, lag = eng.rhs(0, x + 0.5 * dt * k2, U[:, t], dt, lag=lag, ctx=ctx)
+                    k4, lag = eng.rhs(0, x + dt * k3, U[:, t], dt, lag=lag, ctx=ctx)
+                    x = x + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+            for layout, Uin in (("btu", U), ("tub", np.ascontiguousarray(U.transpose(1, 2, 0)))):
+                r = eng.rollout(0, integ, X0, Uin, dt, lag=lag0, layout=layout, ctx=ctx)
+                assert rel_err(r["xT"], x) < 1e-11, (variant, integ, layout)
+                assert rel_err(r["lag"], lag) < 1e-11, (variant, integ, layout)
+            r0 = eng.rollout(0, integ, X0, U, dt, ctx=ctx)                        # zero lag, tracked
+            r1 = eng.rollout(0, integ, X0, U, dt, return_lag=False, ctx=ctx)      # zero lag, untracked kernel
+            assert np.array_equal(r0["xT"], r1["xT"])
+        ctx.close()
+
+
 def test_btu_lds_staged_and_direct_paths_agree(eng, fc):
     """BROV_LAYOUT_BTU has two data paths (LDS-staged tiles vs lane-per-row): both must equal the oracle
     and each other bit for bit, for odd horizons (partial last tile) and ragged batches."""
