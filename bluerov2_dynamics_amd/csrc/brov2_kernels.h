@@ -64,11 +64,11 @@ hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int nta
 // ---- lifted propagation (propagate.hip) ---------------------------------------------------
 struct PropShape {
     int n, r, k, d, p;
-    int dpad;      // d padded to 64 (feature rows of Zt / columns of ABt)
+    int dpad;      // d padded to 48 (feature rows of Zt / columns of ABt)
     int ksteps;    // ceil(p / 4)
     int ppad;      // 4 * ksteps (rows of ABt)
     int64_t nw;    // windows (or simulated trajectories)
-    int64_t nwp;   // nw padded to 96
+    int64_t nwp;   // nw padded to 128
 };
 PropShape prop_shape(int n, int r, int k, int64_t nw);
 hipError_t launch_lift_t(hipStream_t st, const PropShape& s, double gamma, int64_t xstride, const double* X, const double* C, double* Zt);

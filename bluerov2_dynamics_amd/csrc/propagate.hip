@@ -2,18 +2,21 @@
 // (Koopman/koopmanEDMDc.py:157-216):  Z <- A Z + B u_t, H times, for all start windows at once.
 //
 // Layout: feature-major.  Zt[i][w] = feature i (reference order [x | rbf]) of window w, leading
-// dimension nwp (windows padded to a multiple of 96).  One step is the fp64 GEMM
+// dimension nwp (windows padded to a multiple of 128).  One step is the fp64 GEMM
 //     Zout[d x nw] = [A | B] [d x (d+r)]  .  [Zin ; U_t] [(d+r) x nw]
 // with both MFMA operands K-major so every wave-load is 4 rows x 128 contiguous bytes:
 //     A operand  ABt[j][i] = [A|B][i][j]         (transposed once per call)
 //     B operand  Zin[j][w] for j < d,  Ucur[(j-d)][w] for the input rows.
-// A wave owns 4 feature tiles x 6 window tiles (same 192-VGPR accumulator block as the Gram).
+// A wave owns 3 feature tiles x 8 window tiles (the 192-VGPR accumulator block of the Gram, turned: d = 524 or 525
+// pads to 528 = 11 x 48 features instead of 576, and 45 723 windows give 358 x 11 = 3 938 waves = two nearly full
+// rounds of the chip's 2 048 wave slots; the 4 x 6 shape needed 4 296 = two rounds and a 5 % third).
 #include "brov2_kernels.h"
 
 namespace brov {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
-constexpr int PTA = 4, PTB = 6;
+typedef double v2d_a8 __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte access that is only 8-byte aligned (shifted input windows)
+constexpr int PTA = 3, PTB = 8;
 constexpr int PNMAX = 16;
 
 // Zt[i][w] for window w = lane: x rows then rbf rows.  grid.x over 256-window groups, grid.y over 64-centre groups (+1 for x rows)
@@ -51,40 +54,70 @@ __global__ void __launch_bounds__(256) transpose_kernel(int64_t rows, int64_t co
     if (c0 + ty < cols && r0 + tx < rows) dst[(c0 + ty) * ldd + r0 + tx] = tile[tx][ty];
 }
 
-// One propagation step.  grid.x = window blocks (96 windows), grid.y = feature blocks (64 features); 1 wave per block.
+// One propagation step.  One wave per block; operands of the next K-step are loaded while the MFMAs of the current
+// one run.
+//  * Window tiles are "virtual": tile b of a block holds the windows w0 + 8 c + b, c = 0..15, so the eight B-operand
+//    values of a lane (k = lane >> 4, c = lane & 15) are 64 contiguous bytes (4 x 16-byte loads instead of 8 x 8), and
+//    so are the eight results it stores per feature row.  Which windows share a tile is immaterial to the product.
+//  * Blocks are numbered so that the 11 feature blocks of one window block run on the same XCD (blockIdx % 8 selects
+//    the XCD, observed round-robin): a window block's columns of Zin are pulled into one L2 only.  With the natural
+//    2-D grid every XCD read all of Zin.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 propagate_kernel(int d, int ksteps, int64_t ldab, const double* __restrict__ ABt, int64_t nwp, const double* __restrict__ Zin,
-                 const double* __restrict__ Ucur, int64_t ldu, double* __restrict__ Zout) {
+                 const double* __restrict__ Ucur, int64_t ldu, double* __restrict__ Zout, int nfb, int64_t nitems, int64_t items_per_xcd) {
+    const int64_t bid = blockIdx.x;
+    const int64_t item = (bid & 7) * items_per_xcd + (bid >> 3);
+    if ((bid >> 3) >= items_per_xcd || item >= nitems) return;
+    const int64_t wb = item / nfb;
+    const int fb = (int)(item - wb * nfb);
     const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
-    const int64_t w0 = (int64_t)blockIdx.x * (PTB * 16);
-    const int i0 = blockIdx.y * (PTA * 16);
+    const int64_t w0 = wb * (PTB * 16);
+    const int i0 = fb * (PTA * 16);
     v4d acc[PTA][PTB];
 #pragma unroll
     for (int a = 0; a < PTA; ++a)
 #pragma unroll
         for (int b = 0; b < PTB; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    // per-lane row pointers of K index j = 4 ks + kq: [A|B]^T row j; Zin row j for j < d, else input row j - d
+    const double* ap = ABt + (int64_t)kq * ldab + i0 + col;
+    const double* zp = Zin + (int64_t)kq * nwp + w0 + 8 * col;
+    const double* up = Ucur + ((int64_t)kq - d) * ldu + w0 + 8 * col;     // dereferenced only once j >= d
+    const int64_t astep = 4 * ldab, zstep = 4 * nwp, ustep = 4 * ldu;
+    int j = kq;
+    double an[PTA], bn[PTB];
+    auto load = [&]() {
+        const double* bp = (j < d) ? zp : up;
+#pragma unroll
+        for (int a = 0; a < PTA; ++a) an[a] = ap[a * 16];
+#pragma unroll
+        for (int b = 0; b < PTB; b += 2) {
+            const v2d_a8 v = *reinterpret_cast<const v2d_a8*>(bp + b);
+            bn[b] = v[0]; bn[b + 1] = v[1];
+        }
+    };
+    load();
     for (int ks = 0; ks < ksteps; ++ks) {
-        const int j = ks * 4 + kq;                               // K index of this lane
-        const double* arow = ABt + (int64_t)j * ldab + i0 + col;
-        const double* brow = (j < d) ? Zin + (int64_t)j * nwp + w0 + col : Ucur + (int64_t)(j - d) * ldu + w0 + col;
         double av[PTA], bv[PTB];
 #pragma unroll
-        for (int a = 0; a < PTA; ++a) av[a] = arow[a * 16];
+        for (int a = 0; a < PTA; ++a) av[a] = an[a];
 #pragma unroll
-        for (int b = 0; b < PTB; ++b) bv[b] = brow[b * 16];
+        for (int b = 0; b < PTB; ++b) bv[b] = bn[b];
+        if (ks + 1 < ksteps) { ap += astep; zp += zstep; up += ustep; j += 4; }     // the last step re-reads its own rows (never consumed)
+        load();
 #pragma unroll
         for (int a = 0; a < PTA; ++a)
 #pragma unroll
             for (int b = 0; b < PTB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
     }
-    // C/D layout: row (feature) = (lane>>4) + 4 reg, col (window) = lane & 15
+    // C/D layout: row (feature) = (lane >> 4) + 4 reg, column c = lane & 15 -> windows w0 + 8 c + b
 #pragma unroll
     for (int a = 0; a < PTA; ++a)
 #pragma unroll
-        for (int b = 0; b < PTB; ++b)
+        for (int r = 0; r < 4; ++r) {
+            double* o = Zout + (int64_t)(i0 + a * 16 + kq + 4 * r) * nwp + w0 + 8 * col;
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                Zout[(int64_t)(i0 + a * 16 + kq + 4 * r) * nwp + w0 + b * 16 + col] = acc[a][b][r];
+            for (int b = 0; b < PTB; b += 2) *reinterpret_cast<double2*>(o + b) = make_double2(acc[a][b][r], acc[a][b + 1][r]);
+        }
 }
 
 // se[w] = sum_i (Xref[w][i] - Zt[i][w])^2 ; optional xhat [nw][n]
@@ -143,8 +176,11 @@ hipError_t launch_transpose(hipStream_t st, int64_t rows, int64_t cols, const do
     return hipGetLastError();
 }
 hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Ucur, int64_t ldu, double* Zout) {
-    hipLaunchKernelGGL(propagate_kernel, dim3((unsigned)(s.nwp / (PTB * 16)), (unsigned)(s.dpad / (PTA * 16))), dim3(64), 0, st,
-                       s.d, s.ksteps, (int64_t)s.dpad, ABt, s.nwp, Zin, Ucur, ldu, Zout);
+    const int nfb = s.dpad / (PTA * 16);
+    const int64_t nitems = (s.nwp / (PTB * 16)) * nfb;
+    const int64_t per_xcd = (nitems + 7) / 8;
+    hipLaunchKernelGGL(propagate_kernel, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.d, s.ksteps, (int64_t)s.dpad, ABt, s.nwp, Zin, Ucur,
+                       ldu, Zout, nfb, nitems, per_xcd);
     return hipGetLastError();
 }
 hipError_t launch_endpoint_se(hipStream_t st, const PropShape& s, int64_t xstride, const double* Xref, const double* Zt, double* se, double* xhat) {
