@@ -110,10 +110,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    # Rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): BROV2_BENCH_SHARE_GPU=1 maps every
+    # rank to cuda:0 and BROV2_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
+    backend = os.environ.get("BROV2_BENCH_BACKEND", "nccl")
+    if os.environ.get("BROV2_BENCH_SHARE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from bluerov2_dynamics_amd import _lib, engine
     ctx = _lib.default_context(local)
@@ -127,7 +135,7 @@ def main():
     def max_over_ranks(x):
         if world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -224,7 +232,12 @@ def main():
                            "lloyd_ms_total": lloyd_ms, "lloyd_ms_per_iteration": lloyd_ms / max(n_iter, 1),
                            "wall_s_incl_host_kmeanspp": time.perf_counter() - tk, "inertia": inertia}
         if world > 1:
-            dist.broadcast(Cc, 0)
+            if backend == "nccl":
+                dist.broadcast(Cc, 0)
+            else:
+                Ch = Cc.cpu()
+                dist.broadcast(Ch, 0)
+                Cc.copy_(Ch)
         p, d = n + k + r, n + k
         GG = torch.zeros((p * p + p * d,), dtype=torch.float64, device=dev)   # one buffer -> one all-reduce
         GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
@@ -232,7 +245,12 @@ def main():
         def estep():
             engine.gram_dev(Xe.view(-1, n), Ue.view(-1, r), Cc, gamma, nb, L, L + 1, L, GtG, GtY, ctx=ctx)
             if world > 1:
-                dist.all_reduce(GG, op=dist.ReduceOp.SUM)
+                if backend == "nccl":
+                    dist.all_reduce(GG, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 4.5 MB, the only collective of the fit
+                else:
+                    Gh = GG.cpu()
+                    dist.all_reduce(Gh, op=dist.ReduceOp.SUM)
+                    GG.copy_(Gh)
 
         estep()
         barrier()
