@@ -91,6 +91,8 @@ SIGNATURES = {
                                           ctypes.c_double, c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
     "edmdc_kmeans_lloyd_dev": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, c_void_p, i64, c_void_p, c_void_p, ctypes.c_int,
                                               ctypes.c_double, c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),
+    "edmdc_kmeanspp_dev": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, c_void_p, i64, c_void_p, i64, ctypes.c_int, c_void_p,
+                                          c_void_p, c_void_p]),
     "edmdc_multistep_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                           c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_simulate": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,

@@ -1023,6 +1023,43 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     return BROV_OK;
 }
 
+// ---- k-means++ seeding (scikit-learn's algorithm, scikit-learn's random numbers) ----------------------------
+int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host,
+                       int64_t first_index, int n_trials, const double* uniforms_host, double* d_C, int64_t* indices_host) {
+    if (!c || N < 1 || n < 1 || n > 16 || k < 1 || k > N || !d_X || !d_C || xstride < n || first_index < 0 || first_index >= N ||
+        n_trials < 1 || n_trials > 16 || (k > 1 && !uniforms_host) || N > 30000000)
+        return fail(c, BROV_ERR_ARG, "edmdc_kmeanspp_dev: bad argument (need 1<=n<=16, 1<=n_trials<=16, k<=N<=3e7)");
+    DeviceGuard g(c);
+    const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
+    const size_t nu = (size_t)(k > 1 ? k - 1 : 1) * n_trials;
+    Arena a(c);
+    int rc = a.reserve(2 * Arena::al((size_t)N * 8) + Arena::al((size_t)nchunks * 8) + Arena::al((size_t)nblk * 16 * 8) + Arena::al(nu * 8) +
+                       Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + 8192);
+    if (rc) return rc;
+    double* xsq = a.take<double>(N);
+    double* closest = a.take<double>(N);
+    double* chunk_sum = a.take<double>(nchunks);
+    double* partial = a.take<double>((size_t)nblk * 16);
+    double* du = a.take<double>(nu);
+    long long* dind = a.take<long long>(k);
+    char* state = a.take<char>(kmeanspp_state_bytes());
+    double* dmean = a.take<double>(16);
+    if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
+    if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, nu * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, xsq,
+                                 closest, chunk_sum, partial, state, d_C, dind));
+    }
+    if (indices_host) {
+        static_assert(sizeof(long long) == sizeof(int64_t), "index width");
+        HIPCK(c, hipMemcpyAsync(indices_host, dind, (size_t)k * 8, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
 int edmdc_kmeans_lloyd(brov_ctx* c, int64_t N, int n, int k, const double* X, const double* mean, double* C_io, int max_iter,
                        double tol_abs, int32_t* labels, double* inertia, int* n_iter) {
     if (!c || N < 1 || n < 1 || k < 1 || !X || !C_io) return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: bad argument");

@@ -140,6 +140,258 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
     c2[c] = s;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// k-means++ seeding on device: scikit-learn 1.7.2 `_kmeans_plusplus` (sklearn/cluster/_kmeans.py) with unit sample
+// weights, which is what KMeans(n_init="auto", random_state=0).fit runs before Lloyd (Koopman/koopmanEDMDc.py:85,126).
+// The random numbers stay scikit-learn's: the host draws them from numpy's RandomState in the order
+// `_kmeans_plusplus` consumes them (one `choice` for the first centre, then `uniform(size=L)` per centre,
+// L = 2 + int(log k)) and hands them over; everything that touches the N samples runs here:
+//   closest_i = min_j d(x_i, c_j),  d(x, c) = max(0, (-2 x.c + |c|^2) + |x|^2)          (sklearn's _euclidean_distances)
+//   candidates = searchsorted(cumsum(closest), u * pot)  (first index whose running sum reaches the value)
+//   candidate with the smallest new potential sum_i min(closest_i, d(x_i, cand)) wins.
+// The running sum is formed per 4096-sample chunk (tree) + a sequential pass over the chunk sums + a sequential pass
+// inside the chunk that contains the value, not as one sequential np.cumsum: a candidate could differ from
+// scikit-learn's only if a drawn value fell within ~1e-13 (relative) of a running-sum boundary.
+// Per centre: pp_update_chunksum (1 pass over X), pp_pick (1 block), pp_candidates (1 pass over X), pp_select (1 block);
+// nothing returns to the host until all k centres are chosen.
+constexpr int PP_CHUNK = 4096;
+constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
+constexpr int PP_THREADS = 256;
+
+struct PPState {                      // device-resident scalars of the seeding loop
+    double pot;                       // current potential
+    long long cand[PP_LMAX];          // candidate sample indices of this round
+    long long last;                   // sample index of the centre chosen last
+    int pad[2];
+};
+
+template <int NS>
+__device__ __forceinline__ void pp_load_row(const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean, int n, int64_t i, double x[KM_NMAX]) {
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) {
+        const bool on = NS > 0 ? (j < NS) : (j < n);
+        x[j] = on ? X[i * xstride + j] - (mean ? mean[j] : 0.0) : 0.0;
+    }
+}
+
+// squared norms of the centred rows (sklearn: row_norms(X, squared=True))
+template <int NS>
+__global__ void __launch_bounds__(PP_THREADS) pp_norms_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
+                                                             const double* __restrict__ mean, double* __restrict__ xsq) {
+    const int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
+    if (i >= N) return;
+    double x[KM_NMAX], s = 0.0;
+    pp_load_row<NS>(X, xstride, mean, n, i, x);
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) s += x[j] * x[j];
+    xsq[i] = s;
+}
+
+// closest_i = min(closest_i, d(x_i, x_last))  (first = 1: closest_i = d) and the sum of every 4096-sample chunk.
+// One block per chunk, 256 threads x 16 samples, fixed reduction tree.
+template <int NS>
+__global__ void __launch_bounds__(PP_THREADS) pp_update_chunksum_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
+                                                                       const double* __restrict__ mean, const double* __restrict__ xsq,
+                                                                       const PPState* __restrict__ st, int first,
+                                                                       double* __restrict__ closest, double* __restrict__ chunk_sum) {
+    __shared__ double sh[PP_THREADS];
+    const int64_t last = st->last;
+    double c[KM_NMAX];
+    pp_load_row<NS>(X, xstride, mean, n, last, c);
+    const double cc = xsq[last];
+    double acc = 0.0;
+    const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
+#pragma unroll 1
+    for (int q = 0; q < PP_CHUNK / PP_THREADS; ++q) {
+        const int64_t i = base + q * PP_THREADS + threadIdx.x;
+        if (i < N) {
+            double x[KM_NMAX], dot = 0.0;
+            pp_load_row<NS>(X, xstride, mean, n, i, x);
+#pragma unroll
+            for (int j = 0; j < KM_NMAX; ++j) dot = fma(x[j], c[j], dot);
+            double d = (-2.0 * dot + cc) + xsq[i];
+            d = d > 0.0 ? d : 0.0;
+            if (!first) { const double o = closest[i]; d = o < d ? o : d; }
+            closest[i] = d;
+            acc += d;
+        }
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = PP_THREADS / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sh[0];
+}
+
+// One block, one wave per trial: pot = sum of the chunk sums (round 0 only, else the winner's potential stands);
+// value = u * pot; chunk = first chunk whose running sum reaches it; inside the chunk lane l owns 64 consecutive
+// samples.  cand = first index with running sum >= value, clipped to N - 1 (np.searchsorted + np.clip).
+__global__ void __launch_bounds__(64 * PP_LMAX) pp_pick_kernel(int64_t N, int nchunks, int L, const double* __restrict__ u,
+                                                              const double* __restrict__ closest, const double* __restrict__ chunk_sum,
+                                                              PPState* __restrict__ st, int set_pot) {
+    extern __shared__ double prefix[];            // [nchunks + 1] exclusive running sums of the chunks
+    if (threadIdx.x == 0) {
+        double run = 0.0;
+        for (int b = 0; b < nchunks; ++b) { prefix[b] = run; run += chunk_sum[b]; }
+        prefix[nchunks] = run;
+        if (set_pot) st->pot = run;
+    }
+    __syncthreads();
+    const int trial = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (trial >= L) return;
+    const double pot = set_pot ? prefix[nchunks] : st->pot;
+    const double v = u[trial] * pot;
+    // first chunk b with prefix[b + 1] >= v (binary search, wave-uniform)
+    int lo = 0, hi = nchunks;                     // answer in [lo, hi]; hi = nchunks means "beyond the end"
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid + 1] >= v) hi = mid; else lo = mid + 1;
+    }
+    long long found = N - 1;
+    if (lo < nchunks) {
+        const int64_t base = (int64_t)lo * PP_CHUNK + lane * 64;
+        double seg = 0.0;
+        for (int q = 0; q < 64; ++q) { const int64_t i = base + q; if (i < N) seg += closest[i]; }
+        // exclusive prefix of the 64 segment sums, in lane order
+        double incl = seg;
+        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        const double start = prefix[lo] + (incl - seg);
+        // the crossing segment: first lane whose inclusive running sum reaches v
+        const unsigned long long reach = __ballot(prefix[lo] + incl >= v);
+        if (reach) {
+            const int owner = __ffsll((long long)reach) - 1;
+            long long idx = -1;
+            if (lane == owner) {
+                double run = start;
+                idx = base + 63 < N ? base + 63 : N - 1;
+                for (int q = 0; q < 64; ++q) {
+                    const int64_t i = base + q;
+                    if (i >= N) break;
+                    run += closest[i];
+                    if (run >= v) { idx = i; break; }
+                }
+            }
+            found = __shfl(idx, owner);
+        } else {
+            // rounding between the chunk's tree sum and its sequential sum: the value lies just past this chunk
+            const long long nxt = (long long)(lo + 1) * PP_CHUNK;
+            found = nxt < N ? nxt : N - 1;
+        }
+    }
+    if (lane == 0) st->cand[trial] = found;
+}
+
+// partial[block][trial] = sum over the block's samples of min(closest_i, d(x_i, x_cand[trial]))
+template <int NS>
+__global__ void __launch_bounds__(PP_THREADS) pp_candidates_kernel(int64_t N, int n, int L, const double* __restrict__ X, int64_t xstride,
+                                                                  const double* __restrict__ mean, const double* __restrict__ xsq,
+                                                                  const double* __restrict__ closest, const PPState* __restrict__ st,
+                                                                  double* __restrict__ partial) {
+    __shared__ double cs[PP_LMAX][KM_NMAX + 1];
+    __shared__ double red[PP_THREADS / 64][PP_LMAX];
+    for (int e = threadIdx.x; e < L * (KM_NMAX + 1); e += PP_THREADS) {
+        const int t = e / (KM_NMAX + 1), j = e % (KM_NMAX + 1);
+        const int64_t ci = st->cand[t];
+        cs[t][j] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? X[ci * xstride + j] - (mean ? mean[j] : 0.0) : 0.0) : xsq[ci];
+    }
+    __syncthreads();
+    double acc[PP_LMAX];
+#pragma unroll
+    for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * PP_THREADS) {
+        double x[KM_NMAX];
+        pp_load_row<NS>(X, xstride, mean, n, i, x);
+        const double xx = xsq[i], old = closest[i];
+#pragma unroll
+        for (int t = 0; t < PP_LMAX; ++t) {
+            if (t < L) {
+                double dot = 0.0;
+#pragma unroll
+                for (int j = 0; j < KM_NMAX; ++j) dot = fma(x[j], cs[t][j], dot);
+                double d = (-2.0 * dot + cs[t][KM_NMAX]) + xx;
+                d = d > 0.0 ? d : 0.0;
+                acc[t] += old < d ? old : d;
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < PP_LMAX; ++t) {
+        double a = acc[t];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x < L) {
+        double a = 0.0;
+        for (int w = 0; w < PP_THREADS / 64; ++w) a += red[w][threadIdx.x];
+        partial[(int64_t)blockIdx.x * PP_LMAX + threadIdx.x] = a;
+    }
+}
+
+// winner = first trial with the smallest potential (np.argmin); records it as centre c
+__global__ void __launch_bounds__(64) pp_select_kernel(int nblocks, int n, int L, int c, const double* __restrict__ X, int64_t xstride,
+                                                      const double* __restrict__ mean, const double* __restrict__ partial,
+                                                      PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+    __shared__ double pots[PP_LMAX];
+    const int t = threadIdx.x;
+    if (t < L) {
+        double a = 0.0;
+        for (int b = 0; b < nblocks; ++b) a += partial[(int64_t)b * PP_LMAX + t];
+        pots[t] = a;
+    }
+    __syncthreads();
+    __shared__ long long win;
+    if (t == 0) {
+        int best = 0;
+        for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
+        st->pot = pots[best];
+        st->last = st->cand[best];
+        indices[c] = st->cand[best];
+        win = st->cand[best];
+    }
+    __syncthreads();
+    if (t < n) C[(int64_t)c * n + t] = X[win * xstride + t] - (mean ? mean[t] : 0.0);
+}
+
+__global__ void pp_first_kernel(int n, long long first, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                                PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+    const int t = threadIdx.x;
+    if (t == 0) { st->last = first; st->pot = 0.0; indices[0] = first; }
+    if (t < n) C[t] = X[first * xstride + t] - (mean ? mean[t] : 0.0);
+}
+
+int kmeanspp_chunks(int64_t N) { return (int)((N + PP_CHUNK - 1) / PP_CHUNK); }
+int kmeanspp_blocks(int64_t N) {
+    const int64_t need = (N + PP_THREADS - 1) / PP_THREADS;
+    return (int)(need < 2048 ? (need > 0 ? need : 1) : 2048);
+}
+size_t kmeanspp_state_bytes() { return sizeof(PPState); }
+
+// the whole seeding loop, stream ordered; u: device [(k-1) * L] uniforms; C: device [k][n]; indices: device [k] (int64)
+hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
+                           long long first, const double* u, double* xsq, double* closest, double* chunk_sum, double* partial,
+                           void* state, double* C, long long* indices) {
+    if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
+    const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
+    if ((size_t)(nchunks + 1) * 8 > 60 * 1024) return hipErrorInvalidValue;        // prefix table of pp_pick in LDS: N <= 3.1e7
+    PPState* ps = reinterpret_cast<PPState*>(state);
+    const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
+#define PP_DISPATCH(NS_) do { \
+        hipLaunchKernelGGL(pp_norms_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, xsq); \
+        hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
+        for (int c = 1; c < k; ++c) { \
+            hipLaunchKernelGGL(pp_update_chunksum_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, xsq, ps, c == 1 ? 1 : 0, closest, chunk_sum); \
+            hipLaunchKernelGGL(pp_pick_kernel, dim3(1), dim3(64 * L), (size_t)(nchunks + 1) * 8, st, N, nchunks, L, u + (size_t)(c - 1) * L, closest, chunk_sum, ps, c == 1 ? 1 : 0); \
+            hipLaunchKernelGGL(pp_candidates_kernel<NS_>, dim3(nblk), dim3(PP_THREADS), 0, st, N, n, L, X, xstride, mean, xsq, closest, ps, partial); \
+            hipLaunchKernelGGL(pp_select_kernel, dim3(1), dim3(64), 0, st, nblk, n, L, c, X, xstride, mean, partial, ps, C, indices); \
+        } } while (0)
+    if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
+#undef PP_DISPATCH
+    return hipGetLastError();
+}
+
 int kmeans_blocks(int64_t N);
 size_t kmeans_workspace_doubles(int n, int k) { return (size_t)KM_BLOCKS * k * (n + 1) + KM_BLOCKS + k + 8; }
 

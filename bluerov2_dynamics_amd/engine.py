@@ -231,44 +231,86 @@ def kmeans_lloyd(X, C_init, max_iter=300, tol_abs=0.0, mean=None, ctx=None):
     return C, labels, inertia.value, n_iter.value
 
 
-def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init_rows=200_000, ctx=None):
-    """RBF centres the way KoopmanEDMDc.fit gets them (sklearn KMeans(k, n_init="auto", random_state=0),
-    Koopman/koopmanEDMDc.py:85): scikit-learn's seeded k-means++ initialisation on the host (on a seeded
-    subsample beyond `init_rows` rows), then Lloyd's E/M loop on the GPU with scikit-learn's stopping rules.
-    With the full data used for the initialisation the result equals sklearn's cluster_centers_ to rounding."""
-    from sklearn.cluster import kmeans_plusplus
-    X = as_f64(X)
-    mean = X.mean(axis=0)
-    Xi = X
-    if len(X) > init_rows:
-        Xi = X[np.random.RandomState(random_state).choice(len(X), init_rows, replace=False)]
-    C0, _ = kmeans_plusplus(Xi - mean, k, random_state=np.random.RandomState(random_state))
-    tol_abs = float(np.mean(np.var(X, axis=0)) * tol)
-    C, _, _, _ = kmeans_lloyd(X, C0, max_iter=max_iter, tol_abs=tol_abs, mean=mean, ctx=ctx)
-    return C + mean
+def kmeanspp_draws(N, k, random_state=0):
+    """The random numbers scikit-learn's `_kmeans_plusplus` consumes, in its order, from numpy's legacy RandomState:
+    (first_index, uniforms [(k-1), n_trials], n_trials).  `choice(N, p=uniform)` is evaluated the way numpy does
+    (cumsum of p, normalise, searchsorted side='right' of one random_sample)."""
+    rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+    L = 2 + int(np.log(k))
+    w = np.ones(N)
+    first = int(rs.choice(N, p=w / w.sum()))
+    U = np.empty((max(k - 1, 0), L))
+    for c in range(k - 1):
+        U[c] = rs.uniform(size=L)
+    return first, U, L
 
 
-def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init_rows=100_000, ctx=None):
-    """kmeans_centers for a device-resident X (torch CUDA tensor [N,n]): k-means++ on a seeded host subsample,
-    Lloyd on the full set in HBM.  Returns (centres CUDA tensor [k,n], inertia, n_iter)."""
+def kmeanspp_dev(X, k, mean=None, random_state=0, ctx=None):
+    """k-means++ seeding of a device-resident X (torch CUDA [N,n]) with scikit-learn's algorithm and random stream
+    (edmdc_kmeanspp_dev).  Returns (C0 CUDA [k,n] in the frame of X - mean, indices [k] int64 numpy)."""
     import torch
-    from sklearn.cluster import kmeans_plusplus
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    N, n = X.shape
+    assert X.stride(1) == 1
+    first, U, L = kmeanspp_draws(N, k, random_state)
+    C = torch.empty((k, n), dtype=torch.float64, device=X.device)
+    ind = np.empty(k, dtype=np.int64)
+    m = None if mean is None else as_f64(mean).reshape(n)
+    Uc = np.ascontiguousarray(U)
+    torch.cuda.current_stream(X.device).synchronize()
+    ctx.check(ctx.lib.edmdc_kmeanspp_dev(ctx.h, N, n, k, _dptr(X), X.stride(0), _hptr(m), first, L, _hptr(Uc) if k > 1 else None,
+                                         _dptr(C), ind.ctypes.data), "edmdc_kmeanspp_dev")
+    return C, ind
+
+
+def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", ctx=None):
+    """RBF centres the way KoopmanEDMDc.fit gets them (sklearn KMeans(k, n_init="auto", random_state=0),
+    Koopman/koopmanEDMDc.py:85): k-means++ seeding with scikit-learn's random stream, then Lloyd's E/M loop with
+    scikit-learn's stopping rules, both on the GPU over the full data.  init="sklearn" seeds with
+    sklearn.cluster.kmeans_plusplus on the host instead (same centres; kept for cross-checks).  X: host array [N,n]."""
+    import torch
+    X = as_f64(X)
+    ctx = ctx or default_context()
+    Xd = torch.from_numpy(X).to(torch.device("cuda", ctx.device))
+    C, _, _ = kmeans_centers_dev(Xd, k, random_state=random_state, max_iter=max_iter, tol=tol, init=init, ctx=ctx)
+    return C.cpu().numpy()
+
+
+def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", init_rows=None, ctx=None, timings=None):
+    """kmeans_centers for a device-resident X (torch CUDA tensor [N,n]).  Returns (centres CUDA tensor [k,n], inertia,
+    n_iter).  init_rows: seed on a seeded subsample of that many rows instead of all N (not what scikit-learn does;
+    only useful with init="sklearn", whose host seeding takes minutes at N = 1e7).  timings: dict that receives
+    kmeanspp_ms / lloyd_ms (kernel time, needs ctx.set_timing(True)) and host_draws_s."""
+    import torch
     ctx = ctx or default_context(X.device.index)
     ctx.use_torch_stream()
     N, n = X.shape
     mean = X.mean(dim=0)
-    tol_abs = float(X.var(dim=0, unbiased=False).mean().item() * tol)
-    idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, min(N, init_rows), replace=False)).to(X.device)
-    Xi = (X[idx] - mean).cpu().numpy()
-    C0, _ = kmeans_plusplus(Xi, k, random_state=np.random.RandomState(random_state))
-    C = torch.from_numpy(np.ascontiguousarray(C0)).to(X.device)
-    labels = torch.empty(N, dtype=torch.int32, device=X.device)
     mean_h = as_f64(mean.cpu().numpy())
+    tol_abs = float(X.var(dim=0, unbiased=False).mean().item() * tol)
+    Xi = X
+    if init_rows is not None and N > init_rows:
+        idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, init_rows, replace=False)).to(X.device)
+        Xi = X[idx].contiguous()
+    if init == "hip":
+        C, _ = kmeanspp_dev(Xi, k, mean=mean_h, random_state=random_state, ctx=ctx)
+        if timings is not None:
+            timings["kmeanspp_ms"] = ctx.last_kernel_ms()
+    elif init == "sklearn":
+        from sklearn.cluster import kmeans_plusplus
+        C0, _ = kmeans_plusplus((Xi - mean).cpu().numpy(), k, random_state=np.random.RandomState(random_state))
+        C = torch.from_numpy(np.ascontiguousarray(C0)).to(X.device)
+    else:
+        raise ValueError("init must be 'hip' or 'sklearn'")
+    labels = torch.empty(N, dtype=torch.int32, device=X.device)
     inertia = ctypes.c_double(0.0)
     n_iter = ctypes.c_int(0)
     torch.cuda.current_stream(X.device).synchronize()
-    ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _dptr(X), n, _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
+    ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _dptr(X), X.stride(0), _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
                                              labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
+    if timings is not None:
+        timings["lloyd_ms"] = ctx.last_kernel_ms()
     return C + mean, inertia.value, n_iter.value
 
 

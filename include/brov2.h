@@ -218,6 +218,18 @@ BROV_API int edmdc_kmeans_lloyd_dev(brov_ctx* ctx, int64_t N, int n, int k, cons
                                     const double* mean_host, double* d_C_io, int max_iter, double tol_abs,
                                     int32_t* d_labels, double* inertia, int* n_iter);
 
+/* k-means++ seeding on device: scikit-learn 1.7.2 `_kmeans_plusplus` with unit sample weights, i.e. the initialisation
+ * of the KMeans(n_clusters, n_init="auto", random_state=0) that KoopmanEDMDc.fit constructs
+ * (Koopman/koopmanEDMDc.py:85,126).  The random numbers are the caller's, in the order scikit-learn draws them from
+ * its RandomState: first_index = random_state.choice(N, p=uniform), then uniforms[(c-1)*n_trials + j] =
+ * random_state.uniform(size=n_trials)[j] for centre c = 1..k-1, n_trials = 2 + int(log(k)).  d_X [N][n] (row stride
+ * x_stride), mean_host [n] subtracted from every row (NULL = none).  Outputs: d_C [k][n] (centred frame, device),
+ * indices_host [k] = rows of X chosen (optional).  Same candidates as scikit-learn unless a drawn value falls within
+ * rounding (~1e-13 relative) of a running-sum boundary. */
+BROV_API int edmdc_kmeanspp_dev(brov_ctx* ctx, int64_t N, int n, int k, const double* d_X, int64_t x_stride,
+                                const double* mean_host, int64_t first_index, int n_trials, const double* uniforms_host,
+                                double* d_C, int64_t* indices_host);
+
 #ifdef __cplusplus
 }
 #endif

@@ -471,6 +471,29 @@ def test_gpu_lloyd_kmeans_matches_sklearn(eng):
     assert np.sum((C2 + mean - ref.cluster_centers_) ** 2) <= tol_abs
 
 
+def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
+    """edmdc_kmeanspp_dev == sklearn.cluster.kmeans_plusplus (1.7.2) given the same RandomState: same sample indices,
+    for sizes around the 4096-sample chunking of the running sum, 12/13/5 features, with and without centring."""
+    import torch
+    from sklearn.cluster import kmeans_plusplus
+    rng = np.random.default_rng(12)
+    for N, n, k, centre in ((1000, 12, 16, True), (4096, 13, 64, True), (30011, 12, 512, True), (70000, 5, 100, False),
+                            (8193, 12, 3, True), (60, 12, 20, False)):
+        X = np.concatenate([rng.normal(m, 0.4, (N // 5 + 1, n)) for m in rng.uniform(-2, 2, (5, n))])[:N]
+        mean = X.mean(0) if centre else None
+        Xc = X - mean if centre else X
+        for seed in (0, 3):
+            C_ref, idx_ref = kmeans_plusplus(Xc, k, random_state=np.random.RandomState(seed))
+            C, idx = eng.kmeanspp_dev(torch.from_numpy(X).cuda(), k, mean=mean, random_state=seed)
+            assert np.array_equal(idx, idx_ref), (N, n, k, seed, int(np.sum(idx != idx_ref)))
+            assert np.array_equal(C.cpu().numpy(), C_ref)
+    # the random numbers are consumed exactly as scikit-learn consumes them
+    first, U, L = eng.kmeanspp_draws(1000, 16, 5)
+    rs = np.random.RandomState(5)
+    assert first == rs.choice(1000, p=np.full(1000, 1e-3)) and L == 2 + int(np.log(16))
+    assert np.array_equal(U[0], rs.uniform(size=L))
+
+
 def test_gram_full_width_vs_oracle_chunked_and_bags(eng):
     """k = 512 (p = 532, the benchmark shape), several chunks, bag boundaries inside chunks."""
     import torch
