@@ -1033,9 +1033,10 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
     const size_t nu = (size_t)(k > 1 ? k - 1 : 1) * n_trials;
     Arena a(c);
-    int rc = a.reserve(2 * Arena::al((size_t)N * 8) + Arena::al((size_t)nchunks * 8) + Arena::al((size_t)nblk * 16 * 8) + Arena::al(nu * 8) +
+    int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al((size_t)nchunks * 8) + Arena::al((size_t)nblk * 16 * 8) + Arena::al(nu * 8) +
                        Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + 8192);
     if (rc) return rc;
+    double* Xt = a.take<double>((size_t)N * n);
     double* xsq = a.take<double>(N);
     double* closest = a.take<double>(N);
     double* chunk_sum = a.take<double>(nchunks);
@@ -1049,7 +1050,7 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
-        HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, xsq,
+        HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
                                  closest, chunk_sum, partial, state, d_C, dind));
     }
     if (indices_host) {

@@ -14,6 +14,7 @@
 // accumulate member sums and counts with LDS fp64 atomics and write one partial per block; a second
 // kernel reduces the partials in block order and forms the new centres.
 #include "brov2_kernels.h"
+#include <cstdint>
 
 namespace brov {
 
@@ -165,39 +166,42 @@ struct PPState {                      // device-resident scalars of the seeding 
     int pad[2];
 };
 
+// The seeding makes 2 (k - 1) passes over the data, so the rows are first copied, centred, into a coordinate-major
+// array Xt[j][i] (one strided read of X; every later access is a coalesced 512-byte wave load), with |x_i|^2 alongside
+// (sklearn: row_norms(X, squared=True)).
 template <int NS>
-__device__ __forceinline__ void pp_load_row(const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean, int n, int64_t i, double x[KM_NMAX]) {
-#pragma unroll
-    for (int j = 0; j < KM_NMAX; ++j) {
-        const bool on = NS > 0 ? (j < NS) : (j < n);
-        x[j] = on ? X[i * xstride + j] - (mean ? mean[j] : 0.0) : 0.0;
-    }
-}
-
-// squared norms of the centred rows (sklearn: row_norms(X, squared=True))
-template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_norms_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
-                                                             const double* __restrict__ mean, double* __restrict__ xsq) {
+__global__ void __launch_bounds__(PP_THREADS) pp_transpose_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
+                                                                 const double* __restrict__ mean, double* __restrict__ Xt, double* __restrict__ xsq) {
     const int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
     if (i >= N) return;
-    double x[KM_NMAX], s = 0.0;
-    pp_load_row<NS>(X, xstride, mean, n, i, x);
+    double s = 0.0;
 #pragma unroll
-    for (int j = 0; j < KM_NMAX; ++j) s += x[j] * x[j];
+    for (int j = 0; j < KM_NMAX; ++j) {
+        if (NS > 0 ? (j < NS) : (j < n)) {
+            const double v = X[i * xstride + j] - (mean ? mean[j] : 0.0);
+            Xt[(int64_t)j * N + i] = v;
+            s += v * v;
+        }
+    }
     xsq[i] = s;
+}
+
+template <int NS>
+__device__ __forceinline__ void pp_load_col(const double* __restrict__ Xt, int64_t N, int n, int64_t i, double x[KM_NMAX]) {
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) x[j] = (NS > 0 ? (j < NS) : (j < n)) ? Xt[(int64_t)j * N + i] : 0.0;
 }
 
 // closest_i = min(closest_i, d(x_i, x_last))  (first = 1: closest_i = d) and the sum of every 4096-sample chunk.
 // One block per chunk, 256 threads x 16 samples, fixed reduction tree.
 template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_update_chunksum_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
-                                                                       const double* __restrict__ mean, const double* __restrict__ xsq,
-                                                                       const PPState* __restrict__ st, int first,
+__global__ void __launch_bounds__(PP_THREADS) pp_update_chunksum_kernel(int64_t N, int n, const double* __restrict__ Xt,
+                                                                       const double* __restrict__ xsq, const PPState* __restrict__ st, int first,
                                                                        double* __restrict__ closest, double* __restrict__ chunk_sum) {
     __shared__ double sh[PP_THREADS];
     const int64_t last = st->last;
     double c[KM_NMAX];
-    pp_load_row<NS>(X, xstride, mean, n, last, c);
+    pp_load_col<NS>(Xt, N, n, last, c);
     const double cc = xsq[last];
     double acc = 0.0;
     const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
@@ -206,7 +210,7 @@ __global__ void __launch_bounds__(PP_THREADS) pp_update_chunksum_kernel(int64_t 
         const int64_t i = base + q * PP_THREADS + threadIdx.x;
         if (i < N) {
             double x[KM_NMAX], dot = 0.0;
-            pp_load_row<NS>(X, xstride, mean, n, i, x);
+            pp_load_col<NS>(Xt, N, n, i, x);
 #pragma unroll
             for (int j = 0; j < KM_NMAX; ++j) dot = fma(x[j], c[j], dot);
             double d = (-2.0 * dot + cc) + xsq[i];
@@ -285,32 +289,43 @@ __global__ void __launch_bounds__(64 * PP_LMAX) pp_pick_kernel(int64_t N, int nc
 
 // partial[block][trial] = sum over the block's samples of min(closest_i, d(x_i, x_cand[trial]))
 template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_candidates_kernel(int64_t N, int n, int L, const double* __restrict__ X, int64_t xstride,
-                                                                  const double* __restrict__ mean, const double* __restrict__ xsq,
-                                                                  const double* __restrict__ closest, const PPState* __restrict__ st,
-                                                                  double* __restrict__ partial) {
-    __shared__ double cs[PP_LMAX][KM_NMAX + 1];
+__global__ void __launch_bounds__(PP_THREADS) pp_candidates_kernel(int64_t N, int n, int L, const double* __restrict__ Xt,
+                                                                  const double* __restrict__ xsq, const double* __restrict__ closest,
+                                                                  const PPState* __restrict__ st, double* __restrict__ partial) {
+    // candidate rows in LDS: [trial][16 coordinates | norm | pad].  A compiler-level memory barrier in front of every
+    // trial keeps their reads where they are used: as plain loop invariants the compiler hoisted all 16 x 17 of them
+    // into registers (256 VGPRs + scratch, one wave per SIMD, 1.2 ms per pass over 1e7 rows).
+    constexpr int CSW = KM_NMAX + 2;
+    __shared__ double cs[PP_LMAX * CSW];
     __shared__ double red[PP_THREADS / 64][PP_LMAX];
-    for (int e = threadIdx.x; e < L * (KM_NMAX + 1); e += PP_THREADS) {
-        const int t = e / (KM_NMAX + 1), j = e % (KM_NMAX + 1);
+    for (int e = threadIdx.x; e < L * CSW; e += PP_THREADS) {
+        const int t = e / CSW, j = e % CSW;
         const int64_t ci = st->cand[t];
-        cs[t][j] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? X[ci * xstride + j] - (mean ? mean[j] : 0.0) : 0.0) : xsq[ci];
+        cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
     }
     __syncthreads();
+    const double2* csv = reinterpret_cast<const double2*>(cs);
     double acc[PP_LMAX];
 #pragma unroll
     for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * PP_THREADS) {
         double x[KM_NMAX];
-        pp_load_row<NS>(X, xstride, mean, n, i, x);
+        pp_load_col<NS>(Xt, N, n, i, x);
         const double xx = xsq[i], old = closest[i];
 #pragma unroll
         for (int t = 0; t < PP_LMAX; ++t) {
             if (t < L) {
-                double dot = 0.0;
+                asm volatile("" ::: "memory");
+                double dot = 0.0, dot1 = 0.0;
+                constexpr int NJ = NS > 0 ? (NS + 1) / 2 * 2 : KM_NMAX;     // coordinates beyond n are zero on both sides
 #pragma unroll
-                for (int j = 0; j < KM_NMAX; ++j) dot = fma(x[j], cs[t][j], dot);
-                double d = (-2.0 * dot + cs[t][KM_NMAX]) + xx;
+                for (int j = 0; j < NJ; j += 2) {
+                    const double cx = csv[(t * CSW + j) / 2].x, cy = csv[(t * CSW + j) / 2].y;
+                    dot = fma(x[j], cx, dot);
+                    dot1 = fma(x[j + 1], cy, dot1);
+                }
+                const double cn = csv[(t * CSW + KM_NMAX) / 2].x;
+                double d = (-2.0 * (dot + dot1) + cn) + xx;
                 d = d > 0.0 ? d : 0.0;
                 acc[t] += old < d ? old : d;
             }
@@ -330,20 +345,28 @@ __global__ void __launch_bounds__(PP_THREADS) pp_candidates_kernel(int64_t N, in
     }
 }
 
-// winner = first trial with the smallest potential (np.argmin); records it as centre c
-__global__ void __launch_bounds__(64) pp_select_kernel(int nblocks, int n, int L, int c, const double* __restrict__ X, int64_t xstride,
-                                                      const double* __restrict__ mean, const double* __restrict__ partial,
-                                                      PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+// winner = first trial with the smallest potential (np.argmin); records it as centre c.  The per-block partial
+// potentials are summed in a fixed order: 16 threads per trial take every 16th block, then a fixed tree.
+__global__ void __launch_bounds__(16 * PP_LMAX) pp_select_kernel(int nblocks, int n, int L, int c, const double* __restrict__ X, int64_t xstride,
+                                                                const double* __restrict__ mean, const double* __restrict__ partial,
+                                                                PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+    __shared__ double part[PP_LMAX][16];
     __shared__ double pots[PP_LMAX];
-    const int t = threadIdx.x;
+    __shared__ long long win;
+    const int t = threadIdx.x >> 4, l = threadIdx.x & 15;
     if (t < L) {
         double a = 0.0;
-        for (int b = 0; b < nblocks; ++b) a += partial[(int64_t)b * PP_LMAX + t];
-        pots[t] = a;
+        for (int b = l; b < nblocks; b += 16) a += partial[(int64_t)b * PP_LMAX + t];
+        part[t][l] = a;
     }
     __syncthreads();
-    __shared__ long long win;
-    if (t == 0) {
+    if (threadIdx.x < L) {
+        const double* q = part[threadIdx.x];
+        pots[threadIdx.x] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
+                            (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
         int best = 0;
         for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
         st->pot = pots[best];
@@ -352,7 +375,7 @@ __global__ void __launch_bounds__(64) pp_select_kernel(int nblocks, int n, int L
         win = st->cand[best];
     }
     __syncthreads();
-    if (t < n) C[(int64_t)c * n + t] = X[win * xstride + t] - (mean ? mean[t] : 0.0);
+    if (threadIdx.x < n) C[(int64_t)c * n + threadIdx.x] = X[win * xstride + threadIdx.x] - (mean ? mean[threadIdx.x] : 0.0);
 }
 
 __global__ void pp_first_kernel(int n, long long first, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
@@ -369,9 +392,10 @@ int kmeanspp_blocks(int64_t N) {
 }
 size_t kmeanspp_state_bytes() { return sizeof(PPState); }
 
-// the whole seeding loop, stream ordered; u: device [(k-1) * L] uniforms; C: device [k][n]; indices: device [k] (int64)
+// the whole seeding loop, stream ordered; u: device [(k-1) * L] uniforms; Xt: device scratch [n][N]; C: device [k][n];
+// indices: device [k] (int64)
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
-                           long long first, const double* u, double* xsq, double* closest, double* chunk_sum, double* partial,
+                           long long first, const double* u, double* Xt, double* xsq, double* closest, double* chunk_sum, double* partial,
                            void* state, double* C, long long* indices) {
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
     const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
@@ -379,13 +403,13 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     PPState* ps = reinterpret_cast<PPState*>(state);
     const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
 #define PP_DISPATCH(NS_) do { \
-        hipLaunchKernelGGL(pp_norms_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, xsq); \
+        hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq); \
         hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
         for (int c = 1; c < k; ++c) { \
-            hipLaunchKernelGGL(pp_update_chunksum_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, xsq, ps, c == 1 ? 1 : 0, closest, chunk_sum); \
+            hipLaunchKernelGGL(pp_update_chunksum_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, Xt, xsq, ps, c == 1 ? 1 : 0, closest, chunk_sum); \
             hipLaunchKernelGGL(pp_pick_kernel, dim3(1), dim3(64 * L), (size_t)(nchunks + 1) * 8, st, N, nchunks, L, u + (size_t)(c - 1) * L, closest, chunk_sum, ps, c == 1 ? 1 : 0); \
-            hipLaunchKernelGGL(pp_candidates_kernel<NS_>, dim3(nblk), dim3(PP_THREADS), 0, st, N, n, L, X, xstride, mean, xsq, closest, ps, partial); \
-            hipLaunchKernelGGL(pp_select_kernel, dim3(1), dim3(64), 0, st, nblk, n, L, c, X, xstride, mean, partial, ps, C, indices); \
+            hipLaunchKernelGGL(pp_candidates_kernel<NS_>, dim3(nblk), dim3(PP_THREADS), 0, st, N, n, L, Xt, xsq, closest, ps, partial); \
+            hipLaunchKernelGGL(pp_select_kernel, dim3(1), dim3(16 * PP_LMAX), 0, st, nblk, n, L, c, X, xstride, mean, partial, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
 #undef PP_DISPATCH

@@ -13,7 +13,10 @@ import json
 import sys
 
 root = sys.argv[1]
-pats = sys.argv[2:] or ["rollout_kernel", "gram_kernel", "lift_rows_kernel", "kmeans_assign_kernel", "propagate_kernel"]
+NAMES = {"rollout_kernel<0, 1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
+          "gram_kernel": "gram", "lift_rows_kernel": "lift", "kmeans_assign_kernel": "kmeans_assign",
+         "propagate_kernel": "propagate", "pp_candidates_kernel": "kmeanspp_candidates", "pp_update_chunksum_kernel": "kmeanspp_update"}
+pats = sys.argv[2:] or list(NAMES)
 out = {p: {} for p in pats}
 for f in glob.glob(root + "/*/**/*counter_collection.csv", recursive=True):
     acc = {}
@@ -31,4 +34,14 @@ for p, d in out.items():
         d["hbm_write_GB_per_launch"] = d["WRITE_SIZE"] * 1024 / 1e9
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         d["hbm_total_GB_per_launch"] = d["hbm_read_GB_per_launch_corrected_x2"] + d["hbm_write_GB_per_launch"]
+for p, d in out.items():
+    if d.get("SQ_INSTS_MFMA"):
+        # SQ_VALU_MFMA_BUSY_CYCLES counts per SIMD; GRBM_GUI_ACTIVE is summed over the 8 XCDs by rocprofv3
+        d["cycles_per_mfma"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / d["SQ_INSTS_MFMA"]
+        if d.get("GRBM_GUI_ACTIVE"):
+            d["mfma_busy_fraction"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (d["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+out = {NAMES.get(p, p): d for p, d in out.items()}
+out["_method"] = ("rocprofv3 --pmc <group> --kernel-trace, one pass per counter group (tools/profile_round.sh), python3 bench.py --steps 1 "
+                  "--warmup 1 --edmdc-steps 1 --no-cpu; per-kernel means over the dispatches of each pass; FETCH_SIZE doubled per "
+                  "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); sizes in KiB; SQ_*_CYCLES in units of 4 clocks")
 json.dump(out, sys.stdout, indent=1)

@@ -1,0 +1,23 @@
+#!/bin/bash
+# Run on the GPU box from the repo root:  tools/profile_round.sh TAG
+# Produces under gpurun_out/prof_TAG/: bench.json (default bench.py run), kernel_stats.csv (rocprofv3 --kernel-trace
+# --stats of the same command), pmc/<pass>/ (one rocprofv3 --pmc pass per counter group, kernel trace only) and
+# pmc_summary.json.  Copy what should be judged into profiles/.
+set -e -o pipefail
+tag=${1:-r01}
+out=gpurun_out/prof_$tag
+mkdir -p $out
+root=$(pwd)
+python3 bench.py > $out/bench.json 2> $out/bench.err
+echo "bench done"
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu > $root/$out/trace.log 2>&1 )
+cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+echo "trace done"
+short="--steps 1 --warmup 1 --edmdc-steps 1 --no-cpu"
+tools/pmc_pass.sh $out/pmc/fetch "FETCH_SIZE" -- python3 $root/bench.py $short
+tools/pmc_pass.sh $out/pmc/write "WRITE_SIZE" -- python3 $root/bench.py $short
+tools/pmc_pass.sh $out/pmc/sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" -- python3 $root/bench.py $short
+tools/pmc_pass.sh $out/pmc/sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_VALU_FMA_F64" -- python3 $root/bench.py $short
+tools/pmc_pass.sh $out/pmc/grbm "GRBM_GUI_ACTIVE" -- python3 $root/bench.py $short
+python3 tools/pmc_summary.py $out/pmc > $out/pmc_summary.json
+echo "pmc done"

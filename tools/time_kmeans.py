@@ -27,3 +27,11 @@ for rep in range(2):
     wall = time.perf_counter() - t0
     print("rep %d: %d iterations, wall %.1f ms, %.2f ms/iteration (+1 final assignment), inertia %.6e" % (
         rep, n_iter.value, wall * 1e3, wall * 1e3 / (n_iter.value + 1), inertia.value))
+
+# k-means++ seeding over the same rows (scikit-learn's algorithm and random stream)
+for rep in range(2):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    C0, idx = engine.kmeanspp_dev(X, k, mean=None, random_state=0, ctx=ctx)
+    torch.cuda.synchronize()
+    print("k-means++ rep %d: wall %.1f ms, device %.1f ms" % (rep, (time.perf_counter() - t0) * 1e3, ctx.last_kernel_ms()))
