@@ -115,6 +115,12 @@ def load_library():
             raise BrovError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is
+        # loaded first serves both; with /opt/rocm's first, torch later finds no GPU.  So torch, when installed, goes first.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError = ABI mismatch, fail loudly

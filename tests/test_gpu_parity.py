@@ -599,3 +599,64 @@ def test_full_comparison_script_matches_reference_table(tmp_path):
     from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
     m = KoopmanEDMDc.load(p)
     assert abs(m.multistep_rmse(g["X"][int(g["split"]):], g["U"][int(g["split"]):], 10) - r2["table"][0, 1]) < 1e-15
+
+
+def _load_example(name):
+    import importlib.util
+    import os
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REPO, "examples", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_sim_script_single_matches_reference_fixture(eng):
+    """examples/sim_koopman.py `single` == training/train_sim_brov2_koopmanEDMDc.py's loop replayed with the reference's
+    classes (tests/golden/simscript.npz): same data set sample for sample, same centres from the device k-means, same
+    one-/10-/100-step RMSE and open-loop prediction."""
+    sk = _load_example("sim_koopman")
+    g = load_golden("simscript.npz")
+    N, k = int(g["N"]), int(g["k"])
+    X, U, X_true = sk.reference_dataset(N, float(g["dt"]))
+    assert np.array_equal(U, g["U"])
+    assert rel_err(X_true, g["X_true"]) < 1e-11 and np.max(np.abs(X - g["X"])) < 1e-12
+    out = sk.run_single(N, float(g["dt"]), n_rbfs=k, verbose=False)
+    got = np.array([out["rmse_1"], out["rmse_10"], out["rmse_100"]])
+    if rel_err(out["model"].centers_, g["centers"]) < 1e-9:          # scikit-learn is third party: same version -> same centres
+        assert np.max(np.abs(got - g["rmse"])) < 1e-6, (got, g["rmse"])
+        assert rel_err(out["pred_traj"], g["pred200"]) < 1e-6
+    else:                                                             # other sklearn version: score with the fixture's centres
+        from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+        split = out["split"]
+        m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=1.0, ridge=1e-3)
+        m.fit(X[:split], U[:split], centers=g["centers"])
+        got = np.array([m.evaluate(X[split - 1:], U[split - 1:]), m.multistep_rmse(X[split - 1:], U[split - 1:], H=10),
+                        m.multistep_rmse(X[split - 1:], U[split - 1:], H=100)])
+        assert np.max(np.abs(got - g["rmse"])) < 1e-6
+
+
+def test_sim_script_ensemble_against_oracle(eng, fc):
+    """examples/sim_koopman.py `ensemble` (BASELINE config 3 at test size): device command stream -> rollouts -> noise ->
+    device k-means -> lift + Gram -> solve, checked piecewise against the oracle on the same data."""
+    import torch
+    from oracle import controls, edmdc_numpy as ek
+    sk = _load_example("sim_koopman")
+    nb, L, k = 60, 80, 32
+    out = sk.run_ensemble(rollouts=nb, L=L, n_rbfs=k, verbose=False)
+    assert np.isfinite(out["A"]).all() and out["pairs_local"] == (nb - 6) * L
+    # rebuild the data the way the example does and redo the fit on the host with the example's centres
+    Uo = controls.controls_ar1(0xED3D, 0, nb, L)
+    Xo = fc.rollout(0, fc.INTEG_EULER, np.zeros((nb, 12)), Uo, 0.02)["traj"]
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1234)
+    Xn = Xo + (torch.randn((nb, L + 1, 12), generator=g, dtype=torch.float64, device="cuda").cpu().numpy() * sk.NOISE_STD)
+    ntr = nb - 6
+    A, B = ek.fit([Xn[i] for i in range(ntr)], [np.vstack([Uo[i], np.zeros((1, 8))]) for i in range(ntr)], out["centers"], 1.0, 1e-3)
+    assert rel_err(out["A"], A) < 1e-6 and rel_err(out["B"], B) < 1e-6
+    se, cnt = 0.0, 0
+    for q in range(ntr, nb):
+        r = ek.multistep_rmse(Xn[q], np.vstack([Uo[q], np.zeros((1, 8))]), out["centers"], 1.0, A, B, 10)
+        se += r * r * (L + 1 - 10) * 12
+        cnt += (L + 1 - 10) * 12
+    assert abs(out["rmse_10"] - np.sqrt(se / cnt)) < 1e-6

@@ -185,3 +185,28 @@ def test_controls_stream_properties():
     assert full.min() >= -1.0 and full.max() < 1.0 and abs(full.mean()) < 5e-3
     a = controls.controls_ar1(1, 0, 2, 300)
     assert np.all(np.abs(a) <= 1.0) and np.abs(np.diff(a, axis=1)).max() < 0.15
+
+
+def test_simscript_dataset_and_scores():
+    """training/train_sim_brov2_koopmanEDMDc.py's data loop (numpy global RNG, seed 42) and its scores: the oracle
+    rollout fed with the same draws reproduces the reference's states; the NumPy EDMDc restatement its scores."""
+    g = load_golden("simscript.npz")
+    N, dt, k = int(g["N"]), float(g["dt"]), int(g["k"])
+    z = np.random.RandomState(42).randn(N, 20)
+    U = np.empty((N, 8))
+    u = np.zeros(8)
+    for i in range(N):
+        u = np.clip(0.98 * u + 0.02 * z[i, :8], -1.0, 1.0)
+        U[i] = u
+    assert np.array_equal(U, g["U"])
+    r = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_EULER, np.zeros((1, 12)), U[None], dt)
+    Xt = r["traj"][0, 1:]
+    assert rel_err(Xt, g["X_true"]) < 1e-11
+    X = Xt + z[:, 8:] * np.array([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3)
+    assert np.max(np.abs(X - g["X"])) < 1e-12
+    split = int(0.8 * N)
+    A, B = ek.fit([g["X"][:split]], [g["U"][:split]], g["centers"], 1.0, 1e-3)
+    assert rel_err(A, g["A"]) < 1e-7 and rel_err(B, g["B"]) < 1e-7
+    Xte, Ute = g["X"][split - 1:], g["U"][split - 1:]
+    got = [ek.evaluate(Xte, Ute, g["centers"], 1.0, A, B)] + [ek.multistep_rmse(Xte, Ute, g["centers"], 1.0, A, B, H) for H in (10, 100)]
+    assert np.max(np.abs(np.array(got) - g["rmse"])) < 1e-8

@@ -14,6 +14,7 @@ Fixtures (all float64):
   windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
+  simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
   cfg5_dataset.csv.gz + cfg5.npz   script-level run (loader, split, Koopman / Fossen / DI RMSE table)
 """
 import argparse
@@ -378,7 +379,41 @@ def gen_cfg5():
     print(table)
 
 
-GENS = dict(cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+def gen_simscript():
+    """The data loop and scores of training/train_sim_brov2_koopmanEDMDc.py:150-226, replayed with the reference's
+    classes and numpy's GLOBAL generator exactly as the script uses it (np.random.seed(42); per step randn(8) for the
+    input, then randn(3) four times for the sensor noise), shortened to N steps (the script: 240 000) and k = 60 RBFs
+    (the script: 200) so that the Python loop finishes in seconds.  The script itself cannot be imported: it has no
+    main guard and ends in a matplotlib animation."""
+    N, dt, k = 3000, 0.05, 60
+    np.random.seed(42)
+    rov = RefThruster(dt=dt)
+    states_true, states, inputs = np.zeros((N, 12)), np.zeros((N, 12)), np.zeros((N, 8))
+    x, u_prev = np.zeros(12), np.zeros(8)
+    for i in range(N):
+        u = np.clip(0.98 * u_prev + 0.02 * np.random.randn(rov.n_thrusters), -1.0, 1.0)
+        x = x + dt * rov.dynamics(x, u, dt)
+        states_true[i] = x
+        ns = x.copy()
+        ns[0:3] += 0.0005 * np.random.randn(3)
+        ns[3:6] += 0.001 * np.random.randn(3)
+        ns[6:9] += 0.0005 * np.random.randn(3)
+        ns[9:12] += 0.001 * np.random.randn(3)
+        states[i] = ns
+        inputs[i] = u
+        u_prev = u
+    split = int(0.8 * N)
+    Xtr, Utr = states[:split], inputs[:split]
+    Xte, Ute = states[split - 1:], inputs[split - 1:]
+    m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=1.0, ridge=1e-3)
+    m.fit(Xtr, Utr)
+    np.savez(os.path.join(OUT, "simscript.npz"), N=np.int64(N), dt=np.float64(dt), k=np.int64(k), X=states, U=inputs, X_true=states_true,
+             centers=m.centers_, A=m.A_, B=m.B_, rmse=np.array([m.evaluate(Xte, Ute), m.multistep_rmse(Xte, Ute, H=10),
+                                                                 m.multistep_rmse(Xte, Ute, H=100)]),
+             pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
+
+
+GENS = dict(simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
