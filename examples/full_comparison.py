@@ -4,6 +4,8 @@ engine, for the rows this engine covers: Koopman EDMDc, Fossen (BlueROV2) and th
 (The PINc row is a PyTorch network of the reference that runs unchanged on PyTorch-ROCm; it is not part of this repo.)
 
     python examples/full_comparison.py path/to/koopman_dataset_50Hz.csv [--rbfs 500 --gamma 3 --ridge 0.1 --rk4]
+    python examples/full_comparison.py path/to/koopman_dataset_50Hz_with_wrench.csv --variant wrench   # train_tank_brov2_wrench_comp.py
+    python examples/full_comparison.py path/to/koopman_dataset_50Hz_with_wrench.csv --variant quat     # train_tank_brov2_wrench_quat.py
 
 Same data handling (load_dataset, 80/20 split), same metrics (endpoint RMSE at H = 1/10/100 over all sliding
 windows, one vehicle object for all windows => thruster lag carried across windows), same table layout.
@@ -20,29 +22,35 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bluerov2_dynamics_amd.baselines import DoubleIntegrator          # noqa: E402
 from bluerov2_dynamics_amd.data import load_dataset                   # noqa: E402
 from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2             # noqa: E402
+from bluerov2_dynamics_amd.fossen.BlueROV2_thrust import BlueROV2 as BlueROV2Wrench          # noqa: E402
+from bluerov2_dynamics_amd.fossen.BlueROV2_wrench import BlueROV2 as BlueROV2Quat            # noqa: E402
 from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc    # noqa: E402
 
 TRAIN_SPLIT = 0.80
 
 
-def compare(csv_path, n_rbfs=500, gamma=3.0, ridge=1e-1, integrator="euler", centers=None, verbose=True):
-    """Returns dict(table [3,3] rows Koopman / Fossen / DI x H = 1, 10, 100, timings, dt, split)."""
-    X, U, dt = load_dataset(csv_path, verbose=verbose)
+def compare(csv_path, n_rbfs=500, gamma=3.0, ridge=1e-1, integrator="euler", centers=None, verbose=True, variant="thruster"):
+    """Returns dict(table [3,3] rows Koopman / Fossen / DI x H = 1, 10, 100, timings, dt, split).
+    variant: "thruster" (8 PWM inputs, Euler angles), "wrench" (6-D body wrench, Euler angles), "quat" (wrench, quaternion
+    state; RK4 exists only for the thruster script in the reference)."""
+    X, U, dt = load_dataset(csv_path, verbose=verbose, variant=variant)
+    nx, nu = X.shape[1], U.shape[1]
+    make_rov = {"thruster": lambda: BlueROV2(dt=dt), "wrench": BlueROV2Wrench, "quat": BlueROV2Quat}[variant]
     if len(X) < 3:
         raise RuntimeError("Not enough samples to train/evaluate.")
     split = int(TRAIN_SPLIT * len(X))
     Xtr, Utr, Xte, Ute = X[:split], U[:split], X[split:], U[split:]
     t = {}
     t0 = perf_counter()
-    koop = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=n_rbfs, gamma=gamma, ridge=ridge)
+    koop = KoopmanEDMDc(state_dim=nx, input_dim=nu, n_rbfs=n_rbfs, gamma=gamma, ridge=ridge)
     koop.fit(Xtr, Utr, centers=centers)
     t["fit_koopman"] = perf_counter() - t0
     t0 = perf_counter()
-    di = DoubleIntegrator.fit(Xtr, Utr, dt, ridge=1e-3)
+    di = DoubleIntegrator.fit(Xtr, Utr, dt, ridge=1e-3, quaternion=(variant == "quat"))
     t["fit_di"] = perf_counter() - t0
     rows = []
     for name, fn in (("Koopman", lambda H: koop.multistep_rmse(Xte, Ute, H=H)),
-                     ("Fossen (BlueROV2)", lambda H: BlueROV2(dt=dt).multistep_rmse_endpoint(Xte, Ute, H, dt, integrator)),
+                     ("Fossen (BlueROV2)", lambda H: make_rov().multistep_rmse_endpoint(Xte, Ute, H, dt, integrator)),
                      ("Double Integrator", lambda H: di.multistep_rmse_endpoint(Xte, Ute, H, dt, integrator))):
         vals = []
         for H in (1, 10, 100):
@@ -52,7 +60,7 @@ def compare(csv_path, n_rbfs=500, gamma=3.0, ridge=1e-1, integrator="euler", cen
         rows.append(vals)
     table = np.array(rows)
     if verbose:
-        print("\n[metrics] Endpoint RMSE (full 12D state) with identical evaluator:")
+        print(f"\n[metrics] Endpoint RMSE (full {nx}D state) with identical evaluator:")
         print("  Model                 | 1-step RMSE | 10-step RMSE | 100-step RMSE")
         print("  ----------------------|------------:|-------------:|--------------:")
         for name, r in zip(("Koopman", "Fossen (BlueROV2)", "Double Integrator"), table):
@@ -68,5 +76,6 @@ if __name__ == "__main__":
     ap.add_argument("--gamma", type=float, default=3.0)
     ap.add_argument("--ridge", type=float, default=1e-1)
     ap.add_argument("--rk4", action="store_true")
+    ap.add_argument("--variant", default="thruster", choices=["thruster", "wrench", "quat"])
     a = ap.parse_args()
-    compare(a.csv, a.rbfs, a.gamma, a.ridge, "rk4" if a.rk4 else "euler")
+    compare(a.csv, a.rbfs, a.gamma, a.ridge, "rk4" if a.rk4 else "euler", variant=a.variant)

@@ -601,6 +601,28 @@ def test_full_comparison_script_matches_reference_table(tmp_path):
     assert abs(m.multistep_rmse(g["X"][int(g["split"]):], g["U"][int(g["split"]):], 10) - r2["table"][0, 1]) < 1e-15
 
 
+def test_full_comparison_wrench_and_quaternion_variants():
+    """examples/full_comparison.py --variant wrench / quat == the tables the reference's wrench_comp / wrench_quat
+    functions produced for the same CSV (tests/golden/cfg5w.npz): Koopman given the reference's centres <= 1e-6, the
+    stateless Fossen wrench models and the double integrators to rounding; with device k-means the Koopman row too."""
+    import os
+    from conftest import GOLDEN
+    fcmp = _load_example("full_comparison")
+    g = load_golden("cfg5w.npz")
+    csv = os.path.join(GOLDEN, "cfg5w_dataset.csv.gz")
+    for tag, variant in (("we", "wrench"), ("wq", "quat")):
+        r = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g[f"{tag}_gamma"]), ridge=float(g[f"{tag}_ridge"]),
+                         centers=g[f"{tag}_centers"], verbose=False, variant=variant)
+        ref = g[f"{tag}_table"]
+        assert r["split"] == int(g[f"{tag}_split"]) and r["dt"] == float(g[f"{tag}_dt"])
+        assert np.max(np.abs(r["table"][0] - ref[0])) < 1e-6, (tag, r["table"][0], ref[0])
+        assert np.max(np.abs(r["table"][1:] - ref[1:]) / np.maximum(1e-3, np.abs(ref[1:]))) < 1e-8, (tag, r["table"], ref)
+        assert np.array_equal(np.argsort(r["table"], axis=0), np.argsort(ref, axis=0))          # same ranking per horizon
+        r2 = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g[f"{tag}_gamma"]), ridge=float(g[f"{tag}_ridge"]), verbose=False, variant=variant)
+        if rel_err(r2["model"].centers_, g[f"{tag}_centers"]) < 1e-9:
+            assert np.max(np.abs(r2["table"][0] - ref[0])) < 1e-6
+
+
 def _load_example(name):
     import importlib.util
     import os

@@ -93,3 +93,20 @@ def test_load_dataset_matches_reference_loader(tmp_path):
     df.drop(columns=["t"]).to_csv(p, index=False)
     with pytest.raises(ValueError, match="'t' time column"):
         load_dataset(p, verbose=False)
+
+
+def test_load_dataset_wrench_and_quaternion_variants():
+    """Wrench-input and quaternion-state loaders == the reference's (train_tank_brov2_wrench_comp.py:172-200,
+    train_tank_brov2_wrench_quat.py:180-245) on the same file, incl. the Euler -> quaternion conversion path."""
+    import os
+    from bluerov2_dynamics_amd.data import load_dataset
+    from conftest import GOLDEN
+    g = load_golden("cfg5w.npz")
+    path = os.path.join(GOLDEN, "cfg5w_dataset.csv.gz")
+    X, U, dt = load_dataset(path, verbose=False, variant="wrench")
+    assert np.array_equal(X, g["we_X"]) and np.array_equal(U, g["we_U"]) and dt == float(g["we_dt"])
+    Xq, Uq, dtq = load_dataset(path, verbose=False, variant="quat")
+    assert Xq.shape[1] == 13 and np.max(np.abs(Xq - g["wq_X"])) < 1e-15 and np.array_equal(Uq, g["wq_U"]) and dtq == float(g["wq_dt"])
+    assert np.max(np.abs(np.linalg.norm(Xq[:, 3:7], axis=1) - 1.0)) < 1e-15
+    with pytest.raises(ValueError):
+        load_dataset(path, verbose=False, variant="nope")

@@ -15,6 +15,7 @@ Fixtures (all float64):
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
   simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
+  cfg5w_dataset.csv.gz + cfg5w.npz  the same recording with wrench inputs through the wrench_comp / wrench_quat scripts' functions
   cfg5_dataset.csv.gz + cfg5.npz   script-level run (loader, split, Koopman / Fossen / DI RMSE table)
 """
 import argparse
@@ -379,6 +380,43 @@ def gen_cfg5():
     print(table)
 
 
+def gen_cfg5w():
+    """Config 5, wrench variants: the cfg5 recording re-expressed with body-wrench inputs (columns Fx..Mz, the schema of
+    rosbags/create_thrust_torque_csv.py) and run through the reference's own wrench scripts' functions:
+    train_tank_brov2_wrench_comp.py (Euler-angle state) and train_tank_brov2_wrench_quat.py (quaternion state; its loader
+    converts the Euler-angle file).  Wrench = allocation . thrust-curve(u), no lag -- any consistent wrench column serves
+    the purpose of exercising loader + models + evaluators."""
+    import pandas as pd
+    import train_tank_brov2_wrench_comp as ref_we
+    import train_tank_brov2_wrench_quat as ref_wq
+    src = pd.read_csv(os.path.join(OUT, "cfg5_dataset.csv.gz"))
+    V = src[[f"u{i}" for i in range(1, 9)]].to_numpy(float)
+    F = -140.3 * V ** 9 + 389.9 * V ** 7 - 404.1 * V ** 5 + 176.0 * V ** 3 + 8.9 * V
+    W = F @ np.load(os.path.join(OUT, "fossen_constants.npz"))["alloc"].T
+    df = src.drop(columns=[f"u{i}" for i in range(1, 9)])
+    for j, name in enumerate(["Fx", "Fy", "Fz", "Mx", "My", "Mz"]):
+        df[name] = W[:, j]
+    path = os.path.join(OUT, "cfg5w_dataset.csv.gz")
+    df.to_csv(path, index=False, float_format="%.12g", compression="gzip")
+    out = {}
+    k = 40
+    for tag, ref in (("we", ref_we), ("wq", ref_wq)):
+        Xl, Ul, dtl = ref.load_dataset(path)
+        split = int(ref.TRAIN_SPLIT * len(Xl))
+        Xtr, Utr, Xte, Ute = Xl[:split], Ul[:split], Xl[split:], Ul[split:]
+        m = RefKoopman(state_dim=Xl.shape[1], input_dim=6, n_rbfs=k, gamma=ref.GAMMA, ridge=ref.RIDGE)
+        m.fit(Xtr, Utr)
+        Kl, Ka = ref.estimate_di_gains(Xtr, Utr, dtl)
+        table = np.array([[m.multistep_rmse(Xte, Ute, H=H) for H in (1, 10, 100)],
+                          [ref.multistep_rmse_endpoint_physics(Xte, Ute, H=H, dt=dtl) for H in (1, 10, 100)],
+                          [ref.multistep_rmse_endpoint_di(Xte, Ute, H=H, dt=dtl, K_lin=Kl, K_ang=Ka) for H in (1, 10, 100)]])
+        out.update({f"{tag}_X": Xl, f"{tag}_U": Ul, f"{tag}_dt": np.float64(dtl), f"{tag}_split": np.int64(split),
+                    f"{tag}_centers": m.centers_, f"{tag}_table": table, f"{tag}_gamma": np.float64(ref.GAMMA),
+                    f"{tag}_ridge": np.float64(ref.RIDGE)})
+        print(tag, table)
+    np.savez(os.path.join(OUT, "cfg5w.npz"), k=np.int64(k), versions=versions(), **out)
+
+
 def gen_simscript():
     """The data loop and scores of training/train_sim_brov2_koopmanEDMDc.py:150-226, replayed with the reference's
     classes and numpy's GLOBAL generator exactly as the script uses it (np.random.seed(42); per step randn(8) for the
@@ -413,7 +451,7 @@ def gen_simscript():
              pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
 
 
-GENS = dict(simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+GENS = dict(cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
