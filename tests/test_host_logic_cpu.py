@@ -110,3 +110,16 @@ def test_load_dataset_wrench_and_quaternion_variants():
     assert np.max(np.abs(np.linalg.norm(Xq[:, 3:7], axis=1) - 1.0)) < 1e-15
     with pytest.raises(ValueError):
         load_dataset(path, verbose=False, variant="nope")
+
+
+def test_bluerov_torch_rhs_matches_reference_fixture():
+    """The PINc physics-loss model stays on PyTorch (last row): same numbers as fossen/bluerov_torch.py."""
+    import torch
+    from bluerov2_dynamics_amd.fossen.bluerov_torch import bluerov_compute, ssa
+    g = load_golden("torch_rhs.npz")
+    x, u = torch.from_numpy(g["x"]), torch.from_numpy(g["u"])
+    assert rel_err(bluerov_compute(0.0, x, u).numpy(), g["xdot64"]) < 1e-14
+    assert rel_err(bluerov_compute(0.0, x.float(), u.float()).numpy(), g["xdot32"]) < 1e-5
+    one = bluerov_compute(0.0, x[3], u[3])
+    assert one.shape == (1, 9) and rel_err(one.numpy(), g["xdot_1d"]) < 1e-14
+    assert np.max(np.abs(ssa(torch.from_numpy(g["ang"])).numpy() - g["ssa"])) < 1e-14

@@ -14,6 +14,7 @@ Fixtures (all float64):
   windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
+  torch_rhs.npz         fossen/bluerov_torch.py bluerov_compute / ssa on random batches
   simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
   cfg5w_dataset.csv.gz + cfg5w.npz  the same recording with wrench inputs through the wrench_comp / wrench_quat scripts' functions
   cfg5_dataset.csv.gz + cfg5.npz   script-level run (loader, split, Koopman / Fossen / DI RMSE table)
@@ -380,6 +381,21 @@ def gen_cfg5():
     print(table)
 
 
+def gen_torchrhs():
+    """fossen/bluerov_torch.py: bluerov_compute and ssa on random batches (float64 and float32)."""
+    import torch
+    from fossen.bluerov_torch import bluerov_compute as ref_compute, ssa as ref_ssa
+    rng = np.random.default_rng(9)
+    x = rng.normal(size=(64, 9))
+    u = rng.normal(size=(64, 4)) * 20.0
+    out = dict(x=x, u=u, xdot64=ref_compute(0.0, torch.from_numpy(x), torch.from_numpy(u)).numpy(),
+               xdot32=ref_compute(0.0, torch.from_numpy(x).float(), torch.from_numpy(u).float()).numpy(),
+               xdot_1d=ref_compute(0.0, torch.from_numpy(x[3]), torch.from_numpy(u[3])).numpy())
+    a = rng.uniform(-20, 20, 200)
+    out.update(ang=a, ssa=ref_ssa(torch.from_numpy(a)).numpy(), versions=versions())
+    np.savez(os.path.join(OUT, "torch_rhs.npz"), **out)
+
+
 def gen_cfg5w():
     """Config 5, wrench variants: the cfg5 recording re-expressed with body-wrench inputs (columns Fx..Mz, the schema of
     rosbags/create_thrust_torque_csv.py) and run through the reference's own wrench scripts' functions:
@@ -451,7 +467,7 @@ def gen_simscript():
              pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
 
 
-GENS = dict(cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+GENS = dict(torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
