@@ -572,6 +572,89 @@ def test_full_size_rollout_properties(eng):
     assert np.array_equal(Uh[-1], controls.controls_iid(0x5EED, 65535, 1, 5000, nt=T)[0])
 
 
+def test_full_size_window_evaluator_properties(eng, fc):
+    """The reference's recorded size (45 823 samples, H = 100; best_results.txt:3) through the windowed evaluator.
+    Quirk Q2 (one vehicle object for all windows) makes window k start from the lag state that k earlier windows of
+    commands left behind; the evaluator gets that state from a parallel response + sequential affine scan.  Here it is
+    recomputed the long way for a few windows: ONE rollout over the concatenated command streams of windows 0..k-1
+    (k H steps on a single lane), then window k from that lag state."""
+    from bluerov2_dynamics_amd import _lib
+    N, H, dt = 45823, 100, 0.02
+    # a smooth recording: an Euler rollout under AR(1) commands plus sensor noise (the examples' recipe)
+    from oracle import controls
+    U = controls.controls_ar1(0x7A, 0, 1, N)[0]
+    X = eng.rollout(0, "euler", np.zeros((1, 12)), U[None], dt, return_lag=False)["traj"][0][1:]
+    X = X + np.random.default_rng(2).normal(size=X.shape) * 1e-3
+    for integ in ("euler", "rk4"):
+        se, per = eng.window_endpoint_se(0, integ, X, U, H, dt, carry_lag=True)
+        assert per.shape == (N - H,) and np.isfinite(per).all() and abs(per.sum() - se) <= 1e-12 * se
+        se0, per0 = eng.window_endpoint_se(0, integ, X, U, H, dt, carry_lag=False)
+        assert per0[0] == per[0] and not np.allclose(per0[1:200], per[1:200], rtol=1e-3, atol=0)   # the carried lag matters
+        for k in (1, 57, 300):
+            Ucat = np.concatenate([U[j:j + H] for j in range(k)])[None]                 # what the shared object has seen
+            lag_k = eng.rollout(0, integ, np.zeros((1, 12)), Ucat, dt)["lag"]
+            end = eng.rollout(0, integ, X[k][None], U[k:k + H][None], dt, lag=lag_k)["xT"][0]
+            want = float(np.sum((end - X[k + H]) ** 2))
+            assert abs(per[k] - want) <= 1e-9 * max(want, 1e-12), (integ, k, per[k], want)
+            # without carrying, a window is just a fresh rollout
+            end0 = eng.rollout(0, integ, X[k][None], U[k:k + H][None], dt)["xT"][0]
+            assert abs(per0[k] - float(np.sum((end0 - X[k + H]) ** 2))) <= 1e-9 * max(per0[k], 1e-12)
+    # the wrench models have no lag: windows are independent by construction
+    TAU = U[:, :6] * 20.0
+    sw, pw = eng.window_endpoint_se(1, "euler", X, TAU, H, dt)
+    endw = eng.rollout(1, "euler", X[4000][None], TAU[4000:4100][None], dt)["xT"][0]
+    assert abs(pw[4000] - float(np.sum((endw - X[4100]) ** 2))) <= 1e-9 * pw[4000]
+
+
+def test_full_size_gram_properties(eng):
+    """BASELINE config-3 sized fit (1e7 pairs, k = 512): size-independent properties instead of an oracle run --
+    linearity over bags (two accumulated halves == one pass), exact symmetry of G^T G, the linear blocks of the Gram
+    ([x|u]^T [x|u] and [x|u]^T x+, pair-wise without crossing bag ends) against fp64 torch on the same data, the
+    RBF block bounded by the pair count, and the lifted-feature sums against a direct lift of the same rows."""
+    import torch
+    n, r, k, gamma = 12, 8, 512, 1.0
+    nb, L = 20000, 500
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn((nb, L + 1, n), dtype=torch.float64, device="cuda", generator=g) * 0.4
+    X = torch.cumsum(X, dim=1) * 0.05                                  # smooth-ish bags
+    U = torch.rand((nb, L, r), dtype=torch.float64, device="cuda", generator=g) * 2 - 1
+    C = X[:, ::50].reshape(-1, n)[torch.randperm(nb * 11, device="cuda", generator=g)[:k]].contiguous()
+    p, d = n + k + r, n + k
+    def run(b0, b1, GtG, GtY, acc):
+        eng.gram_dev(X[b0:b1].reshape(-1, n), U[b0:b1].reshape(-1, r), C, gamma, b1 - b0, L, L + 1, L, GtG, GtY, accumulate=acc)
+    A1, Y1 = torch.zeros((p, p), dtype=torch.float64, device="cuda"), torch.zeros((p, d), dtype=torch.float64, device="cuda")
+    run(0, nb, A1, Y1, False)
+    A2, Y2 = torch.zeros_like(A1), torch.zeros_like(Y1)
+    run(0, 7001, A2, Y2, False)
+    run(7001, nb, A2, Y2, True)
+    torch.cuda.synchronize()
+    scale = A1.abs().max()
+    assert torch.isfinite(A1).all() and torch.isfinite(Y1).all()
+    assert (A1 - A2).abs().max() / scale < 1e-12 and (Y1 - Y2).abs().max() / Y1.abs().max() < 1e-12
+    assert torch.equal(A1, A1.T)
+    # linear blocks: G = [x | rbf | u], Y = [x+ | rbf+]
+    Xc, Xn = X[:, :-1].reshape(-1, n), X[:, 1:].reshape(-1, n)
+    Uc = U.reshape(-1, r)
+    lin = torch.cat([Xc, Uc], dim=1)
+    ref = lin.T @ lin
+    idx = list(range(n)) + list(range(d, p))
+    got = A1[idx][:, idx]
+    assert (got - ref).abs().max() / ref.abs().max() < 1e-11
+    refy = lin.T @ Xn
+    assert (Y1[idx][:, :n] - refy).abs().max() / refy.abs().max() < 1e-11
+    # RBF block: entries are sums over nb*L pairs of products of values in (0, 1]
+    R = A1[n:d, n:d]
+    assert R.min() >= 0.0 and R.max() <= nb * L * (1 + 1e-12) and torch.all(torch.diagonal(R) > 0)
+    # row sums of the lifted features: (1^T G) recovered from the u-constant trick is not available, so lift a slice directly
+    sl = slice(0, 64)
+    Zs = torch.from_numpy(eng.lift(X[sl, :-1].reshape(-1, n).cpu().numpy(), C.cpu().numpy(), gamma)).cuda()
+    As = torch.zeros_like(A1)
+    Ys = torch.zeros_like(Y1)
+    run(0, 64, As, Ys, False)
+    Gs = torch.cat([Zs, U[sl].reshape(-1, r)], dim=1)
+    assert (As - Gs.T @ Gs).abs().max() / As.abs().max() < 1e-11
+
+
 # ------------------------------------------------------------------------------------------ config 5: script level
 def test_full_comparison_script_matches_reference_table(tmp_path):
     """examples/full_comparison.py on the CSV fixture == the table the reference's own functions produced for it
