@@ -301,6 +301,16 @@ def main():
                 "windows": nw, "H": Hm, "wall_ms_host_to_host": wall_ms, "kernel_ms": kms,
                 "tflops": 2.0 * nw * d * p * Hm / (kms * 1e-3) / 1e12, "finite": bool(np.isfinite(se)),
                 "note": "lift + 100 fp64 MFMA GEMM steps + endpoint error; reference CPU log: 41.19 s"}
+            # K3: multistep_rmse_endpoint_physics (Fossen thruster model, carried lag) at the same size; the reference's own
+            # log has 1247 s for H = 100 with the Euler integrator
+            wt = {}
+            for integ in ("euler", "rk4"):
+                ctx.set_timing(True)
+                t1 = time.perf_counter()
+                rm = engine.window_rmse(_lib.THRUSTER_EULER, integ, Xm, Um, Hm, dt, ctx=ctx)
+                wt[integ] = {"wall_ms_host_to_host": (time.perf_counter() - t1) * 1e3, "kernel_ms": ctx.last_kernel_ms(), "rmse_finite": bool(np.isfinite(rm))}
+                ctx.set_timing(False)
+            out["fossen_window_rmse_H100"] = {"windows": nw, "H": Hm, **wt, "note": "reference CPU log: 1247 s (Euler)"}
         if rank == 0 and not a.no_cpu:
             out["edmdc"]["cpu_baseline"] = cpu_baseline_gram(Cc.cpu().numpy(), gamma)
 

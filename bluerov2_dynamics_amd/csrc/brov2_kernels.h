@@ -77,6 +77,7 @@ hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* AB
 hipError_t launch_endpoint_se(hipStream_t st, const PropShape& s, int64_t xstride, const double* Xref, const double* Zt, double* se, double* xhat);
 hipError_t launch_extract_state(hipStream_t st, const PropShape& s, int64_t T1, int64_t t, const double* Zt, double* Xp);
 hipError_t launch_useq_t(hipStream_t st, const PropShape& s, int64_t T, const double* Us, double* Ust);
+int window_scan_chunk();
 hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 
 // ---- k-means (kmeans.hip) ------------------------------------------------------------------

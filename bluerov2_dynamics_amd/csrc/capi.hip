@@ -662,10 +662,12 @@ static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t
     double *d_resp = nullptr, *d_start = nullptr, *d_phi = nullptr;
     if (model == BROV_THRUSTER_EULER && carry) {
         d_resp = a.take<double>(nwin * 18);
-        d_start = a.take<double>(nwin * 18);
-        d_phi = a.take<double>(16);
-        double Phi[9];
-        lag_window_phi(*dp, H * (integ == BROV_RK4 ? 4 : 1), Phi);
+        d_start = a.take<double>((nwin + (nwin + window_scan_chunk() - 1) / window_scan_chunk()) * 18);   // start states + chunk states
+        d_phi = a.take<double>(32);
+        double Phi[18];                             // Phi, Phi^chunk (blocked scan of rollout.hip)
+        const int64_t spw = H * (integ == BROV_RK4 ? 4 : 1);
+        lag_window_phi(*dp, spw, Phi);
+        lag_window_phi(*dp, spw * window_scan_chunk(), Phi + 9);
         HIPCK(c, hipMemcpyAsync(d_phi, Phi, sizeof Phi, hipMemcpyHostToDevice, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));   // Phi is a stack temporary
     }
@@ -685,7 +687,7 @@ int brov_window_endpoint_se_dev(brov_ctx* c, int model, int integ, int64_t N, in
     if (nwin <= 0) { HIPCK(c, hipMemsetAsync(d_se_total, 0, 8, c->stream)); return BROV_OK; }
     if (!d_X || !d_U || !d_per_window) return fail(c, BROV_ERR_ARG, "brov_window_endpoint_se_dev: NULL array");
     Arena a(c);
-    int rc = a.reserve(Arena::al(nwin * 24 * 8) * 2 + 1024);
+    int rc = a.reserve(Arena::al(nwin * 24 * 8) * 2 + Arena::al((nwin / window_scan_chunk() + 2) * 18 * 8) + 4096);
     if (rc) return rc;
     return window_dev_impl(c, model, integ, N, H, dt, d_X, d_U, carry_lag, d_se_total, d_per_window, a);
 }
@@ -700,7 +702,8 @@ int brov_window_endpoint_se(brov_ctx* c, int model, int integ, int64_t N, int64_
     DeviceGuard g(c);
     const int nx = NX(model), nu = NU(model);
     Arena a(c);
-    int rc = a.reserve(Arena::al(N * nx * 8) + Arena::al(N * nu * 8) + Arena::al(nwin * 8) + Arena::al(nwin * 24 * 8) * 2 + 2048);
+    int rc = a.reserve(Arena::al(N * nx * 8) + Arena::al(N * nu * 8) + Arena::al(nwin * 8) + Arena::al(nwin * 24 * 8) * 2 +
+                       Arena::al((nwin / window_scan_chunk() + 2) * 18 * 8) + 4096);
     if (rc) return rc;
     double* dX = a.take<double>(N * nx);
     double* dU = a.take<double>(N * nu);

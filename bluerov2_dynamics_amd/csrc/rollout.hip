@@ -391,28 +391,62 @@ __global__ void __launch_bounds__(256) window_lag_response_kernel(const FastPara
     store_row<18>(resp + k * 18, &lz.z[0][0]);
 }
 
-// start[k] = acceleration-space lag state at the beginning of window k; start[0] = 0 (fresh vehicle object).
-// One lane per wrench component; 9 FMA per window on the critical path.
-__global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nwin, const double* __restrict__ Phi9,
-                                                             const double* __restrict__ resp, double* __restrict__ start) {
-    const int i = threadIdx.x;  // wrench component
-    if (i >= 6) return;
+// start[k] = acceleration-space lag state at the beginning of window k; start[0] = 0 (fresh vehicle object):
+//     x_{k+1} = Phi x_k + b_k,  Phi = Ad^(samples per window), the same matrix for every window.
+// Blocked scan over chunks of WSCAN_CHUNK windows, one lane per (chunk, wrench component):
+//   (1) chunk_end[c]   = the recurrence over chunk c from a zero state               (parallel over chunks)
+//   (2) chunk_start[c] : S_{c+1} = Phi^CHUNK S_c + chunk_end[c]                      (sequential over nwin/CHUNK chunks)
+//   (3) start[k]       = the recurrence over chunk c from chunk_start[c]             (parallel over chunks)
+// A single sequential pass over all windows (the first version) paid one exposed global-memory latency per window:
+// 11 ms for the reference's 45 723 windows, more than everything else in the evaluator together.
+constexpr int WSCAN_CHUNK = 64;
+
+__device__ __forceinline__ void wscan_step(const double P[9], double& x0, double& x1, double& x2, double b0, double b1, double b2) {
+    const double n0 = fma(P[2], x2, fma(P[1], x1, fma(P[0], x0, b0)));
+    const double n1 = fma(P[5], x2, fma(P[4], x1, fma(P[3], x0, b1)));
+    const double n2 = fma(P[8], x2, fma(P[7], x1, fma(P[6], x0, b2)));
+    x0 = n0; x1 = n1; x2 = n2;
+}
+
+// phase 1 (store_start = 0): chunk_io[c] <- end state of chunk c from zero;  phase 3 (store_start = 1): start[k] for the
+// chunk's windows, beginning from chunk_io[c]
+__global__ void __launch_bounds__(256) window_lag_chunk_kernel(int64_t nwin, const double* __restrict__ Phi9, const double* __restrict__ resp,
+                                                              double* __restrict__ chunk_io, double* __restrict__ start, int store_start) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t c = g / 6;
+    const int i = (int)(g - c * 6);
+    const int64_t k0 = c * WSCAN_CHUNK;
+    if (k0 >= nwin) return;
     double P[9];
 #pragma unroll
     for (int j = 0; j < 9; ++j) P[j] = Phi9[j];
     double x0 = 0.0, x1 = 0.0, x2 = 0.0;
-    const double* r = resp + i * 3;
-    double* s = start + i * 3;
+    if (store_start) { x0 = chunk_io[c * 18 + i * 3]; x1 = chunk_io[c * 18 + i * 3 + 1]; x2 = chunk_io[c * 18 + i * 3 + 2]; }
+    const int64_t k1 = k0 + WSCAN_CHUNK < nwin ? k0 + WSCAN_CHUNK : nwin;
+    for (int64_t k = k0; k < k1; ++k) {
+        const double* r = resp + k * 18 + i * 3;
+        if (store_start) { double* s = start + k * 18 + i * 3; s[0] = x0; s[1] = x1; s[2] = x2; }
+        wscan_step(P, x0, x1, x2, r[0], r[1], r[2]);
+    }
+    if (!store_start) { chunk_io[c * 18 + i * 3] = x0; chunk_io[c * 18 + i * 3 + 1] = x1; chunk_io[c * 18 + i * 3 + 2] = x2; }
+}
+
+// phase 2: in place, chunk_io[c] (end-from-zero) -> state at the beginning of chunk c.  PhiC9 = Phi^WSCAN_CHUNK.
+__global__ void __launch_bounds__(64) window_lag_scan_kernel(int64_t nchunks, const double* __restrict__ PhiC9, double* __restrict__ chunk_io) {
+    const int i = threadIdx.x;  // wrench component
+    if (i >= 6) return;
+    double P[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) P[j] = PhiC9[j];
+    double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+    double* e = chunk_io + i * 3;
     double b0 = 0, b1 = 0, b2 = 0;
-    if (nwin > 0) { b0 = r[0]; b1 = r[1]; b2 = r[2]; }
-    for (int64_t k = 0; k < nwin; ++k) {
-        s[k * 18 + 0] = x0; s[k * 18 + 1] = x1; s[k * 18 + 2] = x2;
-        double c0 = b0, c1 = b1, c2 = b2;
-        if (k + 1 < nwin) { b0 = r[(k + 1) * 18 + 0]; b1 = r[(k + 1) * 18 + 1]; b2 = r[(k + 1) * 18 + 2]; }
-        const double n0 = fma(P[2], x2, fma(P[1], x1, fma(P[0], x0, c0)));
-        const double n1 = fma(P[5], x2, fma(P[4], x1, fma(P[3], x0, c1)));
-        const double n2 = fma(P[8], x2, fma(P[7], x1, fma(P[6], x0, c2)));
-        x0 = n0; x1 = n1; x2 = n2;
+    if (nchunks > 0) { b0 = e[0]; b1 = e[1]; b2 = e[2]; }
+    for (int64_t c = 0; c < nchunks; ++c) {
+        const double c0 = b0, c1 = b1, c2 = b2;
+        if (c + 1 < nchunks) { b0 = e[(c + 1) * 18 + 0]; b1 = e[(c + 1) * 18 + 1]; b2 = e[(c + 1) * 18 + 2]; }
+        e[c * 18 + 0] = x0; e[c * 18 + 1] = x1; e[c * 18 + 2] = x2;
+        wscan_step(P, x0, x1, x2, c0, c1, c2);
     }
 }
 
@@ -563,6 +597,8 @@ static hipError_t launch_window_t(hipStream_t st, const FastParams* p, int64_t n
     return hipGetLastError();
 }
 // scratch: resp [nwin][18], start [nwin][18], phi [9] (device) -- only used for the thruster model with carry_lag
+int window_scan_chunk() { return WSCAN_CHUNK; }
+
 hipError_t launch_window_endpoint(hipStream_t st, const FastParams* p, int model, int integ, int64_t N, int64_t H, double dt,
                                   const double* X, const double* U, int carry_lag, const double* d_phi9,
                                   double* d_resp, double* d_start, double* d_se, double* d_total) {
@@ -575,7 +611,14 @@ hipError_t launch_window_endpoint(hipStream_t st, const FastParams* p, int model
         else
             hipLaunchKernelGGL(window_lag_response_kernel<1>, dim3(nblk(nwin, 256)), dim3(256), 0, st, p, nwin, H, U, d_resp);
         BROV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(window_lag_scan_kernel, dim3(1), dim3(64), 0, st, nwin, d_phi9, d_resp, d_start);
+        // d_phi9: [Phi (9) | Phi^WSCAN_CHUNK (9)]; the chunk states live behind the nwin start states in d_start
+        const int64_t nchunks = (nwin + WSCAN_CHUNK - 1) / WSCAN_CHUNK;
+        double* d_chunk = d_start + nwin * 18;
+        hipLaunchKernelGGL(window_lag_chunk_kernel, dim3(nblk(nchunks * 6, 256)), dim3(256), 0, st, nwin, d_phi9, d_resp, d_chunk, d_start, 0);
+        BROV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(window_lag_scan_kernel, dim3(1), dim3(64), 0, st, nchunks, d_phi9 + 9, d_chunk);
+        BROV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(window_lag_chunk_kernel, dim3(nblk(nchunks * 6, 256)), dim3(256), 0, st, nwin, d_phi9, d_resp, d_chunk, d_start, 1);
         BROV_LAUNCH_CHECK();
         lag_start = d_start;
     }
