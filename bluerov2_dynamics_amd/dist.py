@@ -26,9 +26,12 @@ def world_info():
     return 0, 1
 
 
-def allreduce_gram_(GtG, GtY, group=None):
+def allreduce_gram_(GtG, GtY, group=None, deterministic=False):
     """In-place sum over ranks of both blocks with a single collective.  GtG/GtY: torch tensors
-    (CUDA for nccl, CPU for gloo).  Returns (GtG, GtY)."""
+    (CUDA for nccl, CPU for gloo).  Returns (GtG, GtY).
+    deterministic=True: all-gather the per-rank blocks and add them in rank order on every rank (world x 4.5 MB at
+    k = 512) -- the same bits for a given sharding whatever algorithm the collective library picks; the all-reduce
+    leaves the order of the additions to RCCL (ring / tree, chunked)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -37,7 +40,15 @@ def allreduce_gram_(GtG, GtY, group=None):
     buf = torch.empty(p2 + pd, dtype=GtG.dtype, device=GtG.device)
     buf[:p2].copy_(GtG.reshape(-1))
     buf[p2:].copy_(GtY.reshape(-1))
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    if deterministic:
+        world = dist.get_world_size(group)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)          # supported by both nccl (RCCL) and gloo
+        buf = parts[0].clone()
+        for w in range(1, world):
+            buf += parts[w]
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     GtG.copy_(buf[:p2].view_as(GtG))
     GtY.copy_(buf[p2:].view_as(GtY))
     return GtG, GtY
@@ -62,7 +73,7 @@ def _device_gram(X, U, C, gamma, nbags, L, xs, us):
     return GtG, GtY
 
 
-def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None):
+def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, deterministic=False):
     """EDMDc fit over trajectories sharded across ranks.
 
     X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);
@@ -76,7 +87,7 @@ def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None):
     assert U_local.shape[0] == nb and U_local.shape[1] == L
     gram_fn = gram_fn or _device_gram
     GtG, GtY = gram_fn(X_local, U_local, C, gamma, nb, L, L + 1, L)
-    allreduce_gram_(GtG, GtY, group)
+    allreduce_gram_(GtG, GtY, group, deterministic=deterministic)
     d = n + C.shape[0]
     return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d)
 

@@ -28,6 +28,15 @@ def _oracle_gram(X, U, C, gamma, nbags, L, xs, us):
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception as e:          # surface the failure instead of letting the parent wait for its timeout
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from bluerov2_dynamics_amd import dist as bd
@@ -40,6 +49,14 @@ def _worker(rank, world, port, q):
     C = torch.from_numpy(g["centers"].copy()) if rank == 0 else torch.zeros(g["centers"].shape, dtype=torch.float64)
     bd.broadcast_centers_(C)
     A, B = bd.fit_sharded(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, 1e-3, gram_fn=_oracle_gram)
+    # fixed-order variant (all-gather + rank-order sum): same reduced system up to the order of two additions
+    Ad, Bd = bd.fit_sharded(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, 1e-3, gram_fn=_oracle_gram, deterministic=True)
+    assert np.max(np.abs(Ad - A)) < 1e-9 and np.max(np.abs(Bd - B)) < 1e-9
+    G1, Y1 = _oracle_gram(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, b1 - b0, L, L + 1, L)
+    G2, Y2 = G1.clone(), Y1.clone()
+    bd.allreduce_gram_(G1, Y1, deterministic=True)
+    bd.allreduce_gram_(G2, Y2, deterministic=True)
+    assert torch.equal(G1, G2) and torch.equal(Y1, Y2)
     q.put((rank, A, B))
     dist.barrier()
     dist.destroy_process_group()
@@ -54,6 +71,8 @@ def test_two_rank_fit_equals_single_process():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), r[2]
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
