@@ -38,6 +38,40 @@ def test_extension_is_loaded_and_device_is_gfx950():
 
 
 # ------------------------------------------------------------------------------------------ RHS
+def test_c_abi_rejects_bad_arguments_with_a_message():
+    """Every entry point validates before it launches: negative sizes, unknown enums, NULL arrays and non-positive dt
+    return BROV_ERR_ARG (-1) and leave a message in brov_last_error; the context stays usable afterwards."""
+    import ctypes
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.Context(0)
+    lib, h = ctx.lib, ctx.h
+    x = np.zeros((4, 12)); u = np.zeros((4, 5, 8)); xT = np.zeros((4, 12))
+    P = lambda a: a.ctypes.data
+    bad = [
+        lib.brov_rollout(h, 99, 1, 0, 0, 4, 5, 0.02, P(x), P(u), None, None, 1, P(xT)),          # unknown model
+        lib.brov_rollout(h, 0, 7, 0, 0, 4, 5, 0.02, P(x), P(u), None, None, 1, P(xT)),           # unknown integrator
+        lib.brov_rollout(h, 0, 1, 0, 9, 4, 5, 0.02, P(x), P(u), None, None, 1, P(xT)),           # unknown layout
+        lib.brov_rollout(h, 0, 1, 0, 0, -1, 5, 0.02, P(x), P(u), None, None, 1, P(xT)),          # negative batch
+        lib.brov_rollout(h, 0, 1, 0, 0, 4, 5, 0.0, P(x), P(u), None, None, 1, P(xT)),            # dt = 0
+        lib.brov_rollout(h, 0, 1, 0, 0, 4, 5, float("nan"), P(x), P(u), None, None, 1, P(xT)),   # dt = NaN
+        lib.brov_rollout(h, 0, 1, 0, 0, 4, 5, 0.02, None, P(u), None, None, 1, P(xT)),           # NULL x0
+        lib.brov_rollout(h, 0, 1, 0, 0, 4, 5, 0.02, P(x), P(u), None, P(x), 0, P(xT)),           # stride 0 with a trajectory buffer
+        lib.brov_rhs(h, 0, -3, P(x), P(u), 0.02, None, P(xT)),
+        lib.edmdc_lift(h, 4, 12, 0, 1.0, P(x), P(x), P(x)),                                       # k = 0
+        lib.edmdc_lift(h, 4, 40, 8, 1.0, P(x), P(x), P(x)),                                       # n beyond the supported 16
+    ]
+    assert all(rc == -1 for rc in bad), bad
+    assert b"" != lib.brov_last_error(h) and len(lib.brov_last_error(h)) > 10
+    with pytest.raises(_lib.BrovError, match="BROV_ERR_ARG"):
+        ctx.check(bad[0], "brov_rollout")
+    # double-integrator models need gains first
+    rc = lib.brov_rollout(h, 3, 0, 0, 0, 4, 5, 0.02, P(x), P(u), None, None, 1, P(xT))
+    assert rc == -1 and b"brov_set_di_gains" in lib.brov_last_error(h)
+    # still usable
+    assert lib.brov_rollout(h, 0, 1, 0, 0, 4, 5, 0.02, P(x), P(u), None, None, 1, P(xT)) == 0
+    ctx.close()
+
+
 @pytest.mark.parametrize("tag", ["thr", "thr_cur"])
 def test_thruster_rhs_matches_reference_fixture(eng, tag):
     from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
