@@ -236,11 +236,25 @@ __global__ void __launch_bounds__(64 * PP_LMAX) pp_pick_kernel(int64_t N, int nc
                                                               const double* __restrict__ closest, const double* __restrict__ chunk_sum,
                                                               PPState* __restrict__ st, int set_pot) {
     extern __shared__ double prefix[];            // [nchunks + 1] exclusive running sums of the chunks
-    if (threadIdx.x == 0) {
-        double run = 0.0;
-        for (int b = 0; b < nchunks; ++b) { prefix[b] = run; run += chunk_sum[b]; }
-        prefix[nchunks] = run;
-        if (set_pot) st->pot = run;
+    __shared__ double seg[64 * PP_LMAX];
+    {
+        // running sums of the chunk sums, in chunk order: every thread adds up a contiguous segment, thread 0 chains the
+        // segment totals, every thread then writes its segment's prefixes (fixed grouping -> same result every run)
+        const int nt = blockDim.x, per = (nchunks + nt - 1) / nt;
+        const int b0 = threadIdx.x * per, b1 = b0 + per < nchunks ? b0 + per : nchunks;
+        double a = 0.0;
+        for (int b = b0; b < b1; ++b) a += chunk_sum[b];
+        seg[threadIdx.x] = a;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double run = 0.0;
+            for (int t = 0; t < nt; ++t) { const double v = seg[t]; seg[t] = run; run += v; }
+            prefix[nchunks] = run;
+            if (set_pot) st->pot = run;
+        }
+        __syncthreads();
+        double run = seg[threadIdx.x];
+        for (int b = b0; b < b1; ++b) { prefix[b] = run; run += chunk_sum[b]; }
     }
     __syncthreads();
     const int trial = threadIdx.x >> 6, lane = threadIdx.x & 63;
