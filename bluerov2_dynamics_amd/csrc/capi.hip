@@ -980,17 +980,17 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 // ---- k-means (Lloyd) --------------------------------------------------------------------------------------
 int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host,
                            double* d_C, int max_iter, double tol_abs, int32_t* d_labels, double* inertia, int* n_iter) {
-    if (!c || N < 1 || n < 1 || n > 16 || k < 1 || !d_X || !d_C || !d_labels || max_iter < 1 || xstride < n || (size_t)k * (n + 1) * 8 > 150 * 1024)
-        return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd_dev: bad argument (need 1<=n<=16, k*(n+1)*8 <= 150 KiB of LDS)");
+    if (!c || N < 1 || n < 1 || n > 15 || k < 1 || !d_X || !d_C || !d_labels || max_iter < 1 || xstride < n || (size_t)k * (n + 1) * 8 > 150 * 1024)
+        return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd_dev: bad argument (need 1<=n<=15, k*(n+1)*8 <= 150 KiB of LDS)");
     DeviceGuard g(c);
     const int nb = kmeans_blocks(N);
     Arena a(c);
-    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al(k * 8) + 4096);
+    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) + 4096);
     if (rc) return rc;
     double* partial = a.take<double>((size_t)nb * k * (n + 1));
     double* binert = a.take<double>(nb);
     int* bchg = a.take<int>(nb);
-    double* c2 = a.take<double>(k);
+    double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* stats = a.take<double>(8);
     double* dmean = a.take<double>(16);
     if (mean_host) {

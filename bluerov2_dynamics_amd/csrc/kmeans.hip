@@ -3,7 +3,8 @@
 //
 // scikit-learn stays the owner of the initialisation (k-means++, seeded) -- the host layer calls it --
 // and this file restates what scikit-learn 1.7.2's `_kmeans_single_lloyd` iterates:
-//   E-step: label_i = argmin_c (|c|^2 - 2 x_i.c)          (first minimum; |x_i|^2 is common to all c)
+//   E-step: label_i = argmin_c (|c|^2 - 2 x_i.c)          (first minimum; |x_i|^2 is common to all c;
+//           evaluated as argmax_c (x_i.c - |c|^2 / 2))
 //   M-step: c <- mean of its members (an empty cluster keeps its centre: sklearn relocates it instead)
 //   stop  : labels unchanged ("strict convergence") or sum |c_new - c_old|^2 <= tol, or max_iter
 // on the mean-centred data (the host passes the column means), so that centres agree with
@@ -24,11 +25,15 @@ constexpr int KM_THREADS = 1024;      // 16 waves per block -> 8 waves per SIMD:
                                       // per centre, and only other waves can fill that time (256-thread blocks: 4x slower)
 
 typedef const double __attribute__((address_space(4)))* cdp;
+// packed centre table: one 128-byte record per centre = n coordinates, |c|^2 / 2 in slot n, zeros (n <= 15)
+constexpr int KM_CMAX = 15;
+struct __attribute__((aligned(128))) Cen { double v[16]; };
+typedef const Cen __attribute__((address_space(4)))* ccp;
 
 template <int NS>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) kmeans_assign_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride,
-                                                            const double* __restrict__ mean, const double* __restrict__ C,
-                                                            const double* __restrict__ c2, int* __restrict__ labels,
+                                                            const double* __restrict__ mean,
+                                                            const double* __restrict__ Ct /* [k][16]: coordinates, |c|^2/2 at [n] */, int* __restrict__ labels,
                                                             double* __restrict__ partial /* [blocks][k][n+1] */,
                                                             double* __restrict__ block_inertia, int* __restrict__ block_changed) {
     extern __shared__ double sums[];                  // [k][n+1]: member sums and count
@@ -37,8 +42,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
     __shared__ double sh_inertia[KM_THREADS / 64];
     __shared__ int sh_changed[KM_THREADS / 64];
     __syncthreads();
-    const cdp Cc = (cdp)(unsigned long long)C;
-    const cdp c2c = (cdp)(unsigned long long)c2;
+    const ccp T = (ccp)(unsigned long long)Ct;
     double inertia = 0.0;
     int changed = 0;
     for (int64_t base = (int64_t)blockIdx.x * KM_THREADS; base < N; base += (int64_t)gridDim.x * KM_THREADS) {
@@ -52,27 +56,41 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
             x[j] = on ? X[ii * xstride + j] - (mean ? mean[j] : 0.0) : 0.0;
             x2 = fma(x[j], x[j], x2);
         }
-        double best = 1.0e300;
+        // argmin_c (|c|^2 - 2 x.c) as argmax_c (x.c - |c|^2 / 2): the half norm seeds the FMA chain, the running best is
+        // one v_max, the index one compare + select -- 16 VALU instructions per centre instead of 19
+        double best = -1.0e300;
         int bi = 0;
-        for (int c = 0; c < k; ++c) {
-            const cdp cc = Cc + (int64_t)c * n;
+        auto eval = [&](const Cen& t, int c) {
             double dot = 0.0, dot1 = 0.0;                 // two chains: dependent fp64 FMAs do not issue back to back
-            if constexpr (NS > 0) {
+            constexpr int NJ = NS > 0 ? NS : KM_CMAX;     // generic n: slots beyond n hold zeros (and the half norm, read below)
 #pragma unroll
-                for (int j = 0; j + 1 < NS; j += 2) { dot = fma(x[j], cc[j], dot); dot1 = fma(x[j + 1], cc[j + 1], dot1); }
-                if constexpr (NS & 1) dot = fma(x[NS - 1], cc[NS - 1], dot);
-            } else {
+            for (int j = 0; j + 1 < NJ; j += 2) { dot = fma(x[j], t.v[j], dot); dot1 = fma(x[j + 1], t.v[j + 1], dot1); }
+            if constexpr (NJ & 1) dot = fma(x[NJ - 1], t.v[NJ - 1], dot);
+            const double hn = NS > 0 ? t.v[NS] : t.v[n];
+            const double sc = fma(hn, -1.0, dot + dot1);
+            bi = (sc <= best) ? bi : c;               // strict '>' to replace: the first extremum wins, like np.argmin
+            asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));      // plain max: fmax() adds a canonicalising self-max
+        };
+        // two centres per trip: their four 64-byte scalar loads go out together and are waited for once
+        int c = 0;
+#pragma unroll 1
+        for (; c + 1 < k; c += 2) {
+            Cen a, b;
 #pragma unroll
-                for (int j = 0; j < KM_NMAX; ++j) if (j < n) dot = fma(x[j], cc[j], dot);
-            }
-            dot += dot1;
-            const double d = fma(-2.0, dot, c2c[c]);
-            if (d < best) { best = d; bi = c; }       // strict '<': first minimum wins, like argmin
+            for (int j = 0; j < 16; ++j) { a.v[j] = T[c].v[j]; b.v[j] = T[c + 1].v[j]; }
+            eval(a, c);
+            eval(b, c + 1);
+        }
+        if (c < k) {
+            Cen a;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) a.v[j] = T[c].v[j];
+            eval(a, c);
         }
         if (live) {
             if (labels[i] != bi) ++changed;
             labels[i] = bi;
-            inertia += best + x2;
+            inertia += fma(-2.0, best, x2);
             double* s = sums + bi * np1;
             for (int j = 0; j < n; ++j) atomicAdd(&s[j], x[j]);
             atomicAdd(&s[n], 1.0);
@@ -100,7 +118,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 // stats[0] = sum of squared centre shifts, stats[1] = inertia, stats[2] = changed labels
 __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, int k, const double* __restrict__ partial,
                                                             const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
-                                                            double* __restrict__ C, double* __restrict__ c2, double* __restrict__ stats) {
+                                                            double* __restrict__ C, double* __restrict__ Ct, double* __restrict__ stats) {
     const int np1 = n + 1;
     const int c = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per centre
     const int j = threadIdx.x & 63;
@@ -122,7 +140,9 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
         }
         double q = nv * nv;
         for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); shift2 += __shfl_down(shift2, off); }
-        if (j == 0) { c2[c] = q; atomicAdd(&stats[0], shift2); }
+        q = __shfl(q, 0);
+        if (j < 16) Ct[c * 16 + j] = j < n ? nv : (j == n ? 0.5 * q : 0.0);
+        if (j == 0) atomicAdd(&stats[0], shift2);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         double in = 0.0;
@@ -133,12 +153,13 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
     }
 }
 
-__global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const double* __restrict__ C, double* __restrict__ c2) {
+// packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros]
+__global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const double* __restrict__ C, double* __restrict__ Ct) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= k) return;
     double s = 0.0;
     for (int j = 0; j < n; ++j) s = fma(C[c * n + j], C[c * n + j], s);
-    c2[c] = s;
+    for (int j = 0; j < 16; ++j) Ct[c * 16 + j] = j < n ? C[c * n + j] : (j == n ? 0.5 * s : 0.0);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -431,24 +452,25 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
 }
 
 int kmeans_blocks(int64_t N);
-size_t kmeans_workspace_doubles(int n, int k) { return (size_t)KM_BLOCKS * k * (n + 1) + KM_BLOCKS + k + 8; }
+size_t kmeans_workspace_doubles(int n, int k) { return (size_t)KM_BLOCKS * k * (n + 1) + KM_BLOCKS + (size_t)k * 16 + 8; }
 
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2) {
     hipLaunchKernelGGL(kmeans_c2_kernel, dim3((k + 255) / 256), dim3(256), 0, st, n, k, C, c2);
     return hipGetLastError();
 }
 
-// one E-step (+ accumulation); pass C/c2 as they stand
+// one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_update maintain
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed) {
-    if (n > KM_NMAX) return hipErrorInvalidValue;
+    (void)C;
+    if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
     const size_t lds = (size_t)k * (n + 1) * sizeof(double) ;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N);
 #define KM_LAUNCH(NS_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL(kmeans_assign_kernel<NS_>, dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, C, c2, labels, partial, \
+        hipLaunchKernelGGL(kmeans_assign_kernel<NS_>, dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, \
                            block_inertia, block_changed); } while (0)
     if (n == 12) KM_LAUNCH(12); else if (n == 13) KM_LAUNCH(13); else KM_LAUNCH(0);
 #undef KM_LAUNCH
