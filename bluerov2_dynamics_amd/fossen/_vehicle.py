@@ -82,6 +82,11 @@ class VehicleBase:
             self._lag[...] = r["lag"][0]
         return r["traj"][0]
 
+    def one_step_rmse(self, X, U, dt):
+        """one_step_rmse_physics (training/train_tank_brov2_koopmanEDMDc.py:237-247): Euler one-step predictions over a
+        recording with ONE vehicle object (the lag runs through the whole sequence) == the H = 1 window evaluator."""
+        return self.multistep_rmse_endpoint(X, U, 1, dt, "euler", carry_lag=True)
+
     def multistep_rmse_endpoint(self, X, U, H, dt, integrator="euler", carry_lag=True):
         """multistep_rmse_endpoint_physics (training/train_tank_brov2_full_comparison.py:469-487)."""
         self._sync_params()

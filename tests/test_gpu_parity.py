@@ -385,6 +385,16 @@ def test_window_rmse_matches_reference_fixture(eng):
     assert abs(BlueROV2(dt=dt).multistep_rmse_endpoint(X, U, 10, dt) - g["thr_euler_rmse"][1]) < 1e-10
 
 
+def test_one_step_rmse_method_matches_reference_fixture():
+    """BlueROV2.one_step_rmse == the reference's one_step_rmse_physics (fixture: quaternion wrench script) and == H = 1."""
+    from bluerov2_dynamics_amd.fossen.BlueROV2_wrench import BlueROV2 as Quat
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
+    g = load_golden("windows.npz")
+    dt = float(g["dt"])
+    assert abs(Quat().one_step_rmse(g["Xq"], g["TAU"], dt) - float(g["wq_onestep_rmse"])) < 1e-10
+    assert abs(BlueROV2(dt=dt).one_step_rmse(g["X"], g["U"], dt) - float(g["thr_euler_rmse"][0])) < 1e-10
+
+
 def test_window_se_vs_oracle_larger(eng, fc):
     rng = np.random.default_rng(2)
     N = 3000
