@@ -51,7 +51,10 @@ template <int N>
 __device__ __forceinline__ void load_pairs(const double* __restrict__ p, int64_t ld2, double* r) {
 #pragma unroll
     for (int i = 0; i < (N + 1) / 2; ++i) {
-        const double2 v = *reinterpret_cast<const double2*>(p + i * ld2);
+        // streamed once: nontemporal (slc) accesses keep the rows out of each other's way in L2 (-1 % kernel time)
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d w = __builtin_nontemporal_load(reinterpret_cast<const v2d*>(p + i * ld2));
+        const double2 v = make_double2(w[0], w[1]);
         r[2 * i] = v.x;
         if (2 * i + 1 < N) r[2 * i + 1] = v.y;
     }
@@ -59,8 +62,11 @@ __device__ __forceinline__ void load_pairs(const double* __restrict__ p, int64_t
 template <int N>
 __device__ __forceinline__ void store_pairs(double* __restrict__ p, int64_t ld2, const double* r) {
 #pragma unroll
-    for (int i = 0; i < (N + 1) / 2; ++i)
-        *reinterpret_cast<double2*>(p + i * ld2) = make_double2(r[2 * i], (2 * i + 1 < N) ? r[2 * i + 1] : 0.0);
+    for (int i = 0; i < (N + 1) / 2; ++i) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d w; w[0] = r[2 * i]; w[1] = (2 * i + 1 < N) ? r[2 * i + 1] : 0.0;
+        __builtin_nontemporal_store(w, reinterpret_cast<v2d*>(p + i * ld2));
+    }
 }
 
 // ---------------------------------------------------------------------------------------

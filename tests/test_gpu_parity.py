@@ -318,6 +318,40 @@ def test_custom_vehicle_fast_path_equals_literal_rhs_loop(eng):
         ctx.close()
 
 
+def test_tpb_layout_equals_btu_layout_all_models(eng):
+    """Paired time-major layout (the benchmark's) against the caller layout on the same data: all models, both
+    integrators, both lag modes, with and without trajectory storage / lag bookkeeping, block-aligned batches and
+    horizons from 1 step up -- bit-identical results."""
+    rng = np.random.default_rng(21)
+    dt = 0.02
+    for model in (0, 1, 2):
+        nx, nu = (13, 6) if model == 2 else (12, 8 if model == 0 else 6)
+        for B, T in ((256, 1), (512, 3), (256, 4), (768, 5), (512, 37)):
+            X0 = rng.uniform(-0.4, 0.4, (B, nx))
+            if model == 2:
+                X0[:, 3:7] /= np.linalg.norm(X0[:, 3:7], axis=1, keepdims=True)
+            U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 12.0)
+            Up = np.ascontiguousarray(U.reshape(B, T, nu // 2, 2).transpose(1, 2, 0, 3))
+            lag0 = rng.uniform(-1, 1, (B, 8, 3)) if model == 0 else None
+            for integ in ("euler", "rk4"):
+                for lag_mode in ((0, 1) if (model == 0 and integ == "rk4") else (0,)):
+                    a = eng.rollout(model, integ, X0, U, dt, lag=lag0, lag_mode=lag_mode)
+                    b = eng.rollout(model, integ, X0, Up, dt, lag=lag0, lag_mode=lag_mode, layout="tpb")
+                    nxp = (nx + 1) // 2
+                    tb = b["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 2 * nxp)[:, :, :nx]
+                    assert np.array_equal(tb, a["traj"]), (model, B, T, integ, lag_mode)
+                    assert np.array_equal(b["xT"], a["xT"])
+                    if model == 0:
+                        assert np.array_equal(b["lag"], a["lag"])
+                    c = eng.rollout(model, integ, X0, Up, dt, lag=lag0, lag_mode=lag_mode, layout="tpb", store=False)
+                    assert c["traj"] is None and np.array_equal(c["xT"], a["xT"])
+                    if model == 0:
+                        d = eng.rollout(model, integ, X0, Up, dt, layout="tpb", return_lag=False)      # untracked kernel, zero lag
+                        e = eng.rollout(model, integ, X0, U, dt, return_lag=False)
+                        assert np.array_equal(d["xT"], e["xT"]) and np.array_equal(
+                            d["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 2 * nxp)[:, :, :nx], e["traj"])
+
+
 def test_btu_lds_staged_and_direct_paths_agree(eng, fc):
     """BROV_LAYOUT_BTU has two data paths (LDS-staged tiles vs lane-per-row): both must equal the oracle
     and each other bit for bit, for odd horizons (partial last tile) and ragged batches."""
