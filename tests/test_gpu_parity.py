@@ -352,6 +352,33 @@ def test_tpb_layout_equals_btu_layout_all_models(eng):
                             d["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 2 * nxp)[:, :, :nx], e["traj"])
 
 
+def test_rollout_checkpoint_resume_is_exact(eng):
+    """A rollout is resumable from (xT, lag): T steps in one launch == T1 + T2 steps in two launches, for every model /
+    integrator / lag mode (the thruster lag state [B,8,3] and the body state are the whole checkpoint).  Bit for bit for
+    the wrench models; to rounding for the thruster model, whose kernel carries the lag bank in acceleration-space
+    observer coordinates and re-derives them from the per-thruster state at every launch."""
+    rng = np.random.default_rng(33)
+    B, T, T1, dt = 300, 60, 23, 0.02
+    for model in (0, 1, 2):
+        nx, nu = (13, 6) if model == 2 else (12, 8 if model == 0 else 6)
+        X0 = rng.uniform(-0.4, 0.4, (B, nx))
+        if model == 2:
+            X0[:, 3:7] /= np.linalg.norm(X0[:, 3:7], axis=1, keepdims=True)
+        U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 12.0)
+        lag0 = rng.uniform(-1, 1, (B, 8, 3)) if model == 0 else None
+        for integ in ("euler", "rk4"):
+            for lag_mode in ((0, 1) if (model == 0 and integ == "rk4") else (0,)):
+                full = eng.rollout(model, integ, X0, U, dt, lag=lag0, lag_mode=lag_mode)
+                a = eng.rollout(model, integ, X0, U[:, :T1], dt, lag=lag0, lag_mode=lag_mode)
+                b = eng.rollout(model, integ, a["xT"], U[:, T1:], dt, lag=a["lag"], lag_mode=lag_mode)
+                joined = np.concatenate([a["traj"], b["traj"][:, 1:]], axis=1)
+                if model == 0:
+                    assert rel_err(b["xT"], full["xT"]) < 1e-13 and rel_err(joined, full["traj"]) < 1e-13, (integ, lag_mode)
+                    assert rel_err(b["lag"], full["lag"]) < 1e-13
+                else:
+                    assert np.array_equal(b["xT"], full["xT"]) and np.array_equal(joined, full["traj"]), (model, integ)
+
+
 def test_btu_lds_staged_and_direct_paths_agree(eng, fc):
     """BROV_LAYOUT_BTU has two data paths (LDS-staged tiles vs lane-per-row): both must equal the oracle
     and each other bit for bit, for odd horizons (partial last tile) and ragged batches."""
