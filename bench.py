@@ -198,6 +198,11 @@ def main():
                      "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay != "btu" and B == 65536 and T == 5000) else None},
     }
 
+    # the same kernel against the HBM roofline (second, not binding: intensity 19 flop/B > ridge 9.8), in the plain schema
+    out["roofline_hbm"] = {"kernel": "rollout_kernel<THRUSTER_EULER,RK4>", "bound": "hbm", "achieved": byte_rate, "peak": PEAK_HBM_GBS,
+                           "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS, "kernel_ms": kern_s * 1e3,
+                           "bytes_per_step": bytes_per_step, "traffic": out["roofline"]["traffic"]}
+
     # ------------------------------------------------------------------ EDMDc leg
     del traj
     if not a.no_edmdc:
