@@ -24,6 +24,19 @@ import numpy as np
 from .. import engine
 
 
+def _rbf_mat(X, C, gamma):
+    """RBF feature matrix exp(-gamma |x - c|^2) in the reference's expanded form (Koopman/koopmanEDMDc.py:41-48):
+    X [N,n], C [k,n] -> [N,k], evaluated by the lift kernel."""
+    X = np.atleast_2d(np.asarray(X, dtype=float))
+    C = np.atleast_2d(np.asarray(C, dtype=float))
+    return engine.lift(X, C, float(gamma))[:, X.shape[1]:]
+
+
+def _rbf(x, c, gamma):
+    """One RBF value (Koopman/koopmanEDMDc.py:37-39)."""
+    return float(_rbf_mat(np.asarray(x, dtype=float)[None, :], np.asarray(c, dtype=float)[None, :], gamma)[0, 0])
+
+
 def _kmeans_centers(X, n_rbfs, backend="hip"):
     if backend == "sklearn":
         from sklearn.cluster import KMeans

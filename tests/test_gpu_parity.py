@@ -554,6 +554,17 @@ def test_koopman_dropin_scores_match_reference_fixture():
         m2.fit(X[:10], U[:9])
 
 
+def test_module_level_rbf_helpers_match_reference_kat():
+    """Koopman.koopmanEDMDc._rbf_mat / _rbf (module-level helpers of the reference) on the SURVEY KAT."""
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import _rbf, _rbf_mat
+    g = load_golden("edmdc.npz")
+    x = np.array([[0.3, -0.2, 1.0, 0.1, -0.2, 0.7, 0.4, -0.3, 0.2, 0.05, -0.1, 0.2]])
+    C = np.array([[0.0] * 12, [0.1] * 12])
+    got = _rbf_mat(x, C, 3.0)
+    assert got.shape == (1, 2) and np.max(np.abs(got - g["rbf_kat"])) < 1e-15
+    assert abs(_rbf(x[0], C[1], 3.0) - g["rbf_kat"][0, 1]) < 1e-15
+
+
 def test_gpu_lloyd_kmeans_matches_sklearn(eng):
     """Centres from the GPU Lloyd loop == sklearn KMeans(n_init="auto", random_state=0) (the reference's call),
     on the fixture data (reference centres stored) and on a larger random set; labels / inertia consistent."""
