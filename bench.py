@@ -292,7 +292,7 @@ def main():
         # f1: KoopmanEDMDc.multistep_rmse on the recorded-data size of the reference (45 823 samples, H = 100;
         # training/best_results.txt:801 logs 41.19 s for it on the authors' CPU) -- rank 0 only, host arrays in/out
         if rank == 0:
-            Nm, Hm = 45823, 100
+            Nm, Hm = min(45823, nb * L), 100              # the recorded size; smaller only when --edmdc-samples is
             Xm = Xe.view(-1, n)[: Nm].cpu().numpy()
             Um = Ue.view(-1, r)[: Nm].cpu().numpy()      # timing only: alignment across bag ends is irrelevant
             ctx.set_timing(True)

@@ -881,3 +881,35 @@ def test_sim_script_ensemble_against_oracle(eng, fc):
         se += r * r * (L + 1 - 10) * 12
         cnt += (L + 1 - 10) * 12
     assert abs(out["rmse_10"] - np.sqrt(se / cnt)) < 1e-6
+
+
+def test_bench_prints_one_json_line_with_the_contract_fields():
+    """bench.py at toy sizes: ONE JSON line on stdout with every field of the driver's contract, the roofline object
+    of the dominant kernel and the CPU baseline (kind "port" = the C oracle on the host cores)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1024", "--horizon", "40",
+           "--edmdc-samples", "40000", "--edmdc-steps", "1", "--kmeans-iters", "2", "--cpu-seconds", "0.3"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "rk4_rollout_steps_per_s" and d["unit"] == "steps/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 1024 * 40 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"] and k in d["roofline_hbm"] and k in d["edmdc"]["roofline"], k
+    assert d["roofline_hbm"]["bound"] == "hbm" and d["edmdc"]["roofline"]["bound"] == "mfma"
+    assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-12
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"] and k in d["edmdc"]["cpu_baseline"], k
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    assert d["edmdc"]["A_finite"] and d["edmdc"]["multistep_rmse_H100"]["finite"]
