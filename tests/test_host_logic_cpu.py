@@ -123,3 +123,20 @@ def test_bluerov_torch_rhs_matches_reference_fixture():
     one = bluerov_compute(0.0, x[3], u[3])
     assert one.shape == (1, 9) and rel_err(one.numpy(), g["xdot_1d"]) < 1e-14
     assert np.max(np.abs(ssa(torch.from_numpy(g["ang"])).numpy() - g["ssa"])) < 1e-14
+
+
+def test_driver_entry_points_exist_and_bench_parses_its_flags():
+    """__graft_entry__ exposes build() and smoke(); bench.py accepts the driver's flags (checked without a GPU via --help)."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    spec = importlib.util.spec_from_file_location("graft_entry", os.path.join(REPO, "__graft_entry__.py"))
+    ge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ge)
+    assert callable(ge.build) and callable(ge.smoke)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert flag in out.stdout
