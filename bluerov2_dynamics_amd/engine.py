@@ -231,6 +231,9 @@ def kmeans_lloyd(X, C_init, max_iter=300, tol_abs=0.0, mean=None, ctx=None):
     return C, labels, inertia.value, n_iter.value
 
 
+KMEANSPP_MAX_ROWS = 30_000_000      # edmdc_kmeanspp_dev's limit (include/brov2.h)
+
+
 def kmeanspp_draws(N, k, random_state=0):
     """The random numbers scikit-learn's `_kmeans_plusplus` consumes, in its order, from numpy's legacy RandomState:
     (first_index, uniforms [(k-1), n_trials], n_trials).  `choice(N, p=uniform)` is evaluated the way numpy does
@@ -280,7 +283,8 @@ def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", ctx
 def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", init_rows=None, ctx=None, timings=None):
     """kmeans_centers for a device-resident X (torch CUDA tensor [N,n]).  Returns (centres CUDA tensor [k,n], inertia,
     n_iter).  init_rows: seed on a seeded subsample of that many rows instead of all N (not what scikit-learn does;
-    only useful with init="sklearn", whose host seeding takes minutes at N = 1e7).  timings: dict that receives
+    useful with init="sklearn", whose host seeding takes minutes at N = 1e7, and applied automatically -- 1.5e7 rows --
+    beyond the 3e7 rows the device seeding accepts); the Lloyd iterations always run over all N rows.  timings: dict that receives
     kmeanspp_ms / lloyd_ms (kernel time, needs ctx.set_timing(True)) and host_draws_s."""
     import torch
     ctx = ctx or default_context(X.device.index)
@@ -290,6 +294,8 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
     mean_h = as_f64(mean.cpu().numpy())
     tol_abs = float(X.var(dim=0, unbiased=False).mean().item() * tol)
     Xi = X
+    if init_rows is None and N > KMEANSPP_MAX_ROWS:
+        init_rows = KMEANSPP_MAX_ROWS // 2          # the device seeding holds its running-sum table in LDS: N <= 3e7 rows
     if init_rows is not None and N > init_rows:
         idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, init_rows, replace=False)).to(X.device)
         Xi = X[idx].contiguous()
