@@ -1,20 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): RK4 rollout steps/s (batch x horizon) on MI355X, fp64,
-plus the EDMDc Gram build samples/s, each against its roofline, with the CPU oracle timed beside it.
+"""Headline benchmark (BASELINE.json): RK4 rollout steps/s (batch x horizon) on MI355X, fp64, plus the EDMDc Gram build
+samples/s and the sharded 2^20-rollout ensemble (config 4), each against its roofline, with the CPU baselines timed beside.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one batch = ONE launch of the rollout kernel over
-65 536 trajectories x 5 000 RK4 steps (BASELINE config 2: thruster model, dt = 0.02, iid U(-1,1)
-commands from the counter-based stream, every state stored).  Inputs are resident in HBM before the
-timed region.  With N GPUs every rank runs its own 65 536-trajectory shard (weak scaling, no
-collective on the rollout path); the EDMDc leg all-reduces the per-rank Gram blocks over RCCL.
-Prints ONE JSON line on rank 0.
+`python bench.py --gpus N` with N > 1 and no torch.distributed environment starts its N ranks itself (a child
+`torch.distributed.run`, before this process touches the GPU) or exits non-zero -- it never measures fewer GPUs than asked.
+
+One "step" = one pass of the hot path over one batch = ONE launch of the rollout kernel over 65 536 trajectories x
+5 000 RK4 steps (BASELINE config 2: thruster model, dt = 0.02, iid U(-1,1) commands from the counter-based stream, every
+state stored).  Inputs are resident in HBM before the timed region.  With N GPUs every rank runs its own 65 536-trajectory
+shard (weak scaling, no collective on the rollout path).  Legs after the timed headline loop (all reported in the same JSON
+line, rank 0):
+  verified     the trajectories the TIMED launches wrote, lanes 0..7, every 50th state, against the reference's own
+               states (tests/golden/fossen_rollouts.npz: cfg2_rk4), plus random lanes against single-lane re-runs
+  rollout_ar1  the same launch on the AR(1) command stream ("dist B", training/train_sim_brov2_koopmanEDMDc.py:161-164)
+  edmdc        BASELINE config 3: 10^7 pairs per GPU, lift + G^T[G|Y] on device, RCCL all-reduce of the blocks
+  config4      BASELINE config 4: 2^20 rollouts x 500 RK4 steps in total, sharded over the ranks (STRONG scaling), local
+               Gram per rank, ONE RCCL all-reduce, fingerprint of the summed Gram (independent of the sharding)
+  cpu_baseline the C/OpenMP port of the oracle on the host cores the box grants, and the reference-shaped scalar NumPy loop
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,25 +36,31 @@ sys.path.insert(0, REPO)
 
 # algorithmic work per unit
 ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (reference algebra)
-ROLLOUT_EXEC_FP64_INSTR = {"rk4": 779, "euler": 284}   # fp64 VALU instructions the shipped kernel issues per step (ISA count)
+# fp64 VALU instructions the shipped kernel issues per trajectory-wave and step (ISA count of the time loop,
+# tools/isa_count.py; tests/test_cabi_cpu.py re-derives them from the compiler's listing)
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 786, "euler": 284}
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0
-# /opt/skills/guides/MI355X_MICROARCH.md (HBM) and gfx950 datasheet (fp64): SURVEY.md 8(d)
+# /opt/skills/guides/MI355X_MICROARCH.md (HBM, clock) and gfx950 datasheet (fp64): SURVEY.md 8(d)
 PEAK_HBM_GBS = 8000.0
 PEAK_FP64_VALU_TFLOPS = 78.6
 PEAK_FP64_MFMA_TFLOPS = 78.6
+CLOCK_HZ = 2.4e9                     # nominal; the chip holds 1.9-2.1 GHz under this load, so issue-slot fractions are conservative
+SIMDS = 1024
 
 
 def pmc_traffic(kernel, launches=1):
-    """HBM bytes per launch from the committed PMC run (profiles/r01_pmc_summary.json: rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this same command, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  PMC counters
-    cannot be read from inside the timed process, so this is the recorded figure, not a live one."""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r01_pmc_summary.json")))[kernel]
-        return {"bytes": d["hbm_total_GB_per_launch"] * 1e9 * launches, "source": "profiles/r01_pmc_summary.json (rocprofv3 --pmc, recorded run)"}
-    except Exception:
-        return None
+    """HBM bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed
+    process, so this is the recorded figure, not a live one."""
+    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))[kernel]
+            return {"bytes": d["hbm_total_GB_per_launch"] * 1e9 * launches, "source": f"profiles/{name} (rocprofv3 --pmc, recorded run)"}
+        except Exception:
+            continue
+    return None
 
 
 def parse():
@@ -56,13 +73,39 @@ def parse():
     ap.add_argument("--layout", default="tpb", choices=["tpb", "tub", "btu"])
     ap.add_argument("--no-store", action="store_true", help="endpoint only (64 B/step algorithmic)")
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "euler"])
+    ap.add_argument("--controls", default="iid", choices=["iid", "ar1"], help="command stream of the timed rollout leg")
+    ap.add_argument("--no-ar1", action="store_true", help="skip the AR(1) (dist B) rollout variant")
     ap.add_argument("--edmdc-samples", type=int, default=10_000_000, help="(x,u,x+) pairs per GPU for the Gram leg")
     ap.add_argument("--edmdc-steps", type=int, default=2)
     ap.add_argument("--kmeans-iters", type=int, default=30, help="cap on Lloyd iterations for the centres of the EDMDc leg")
     ap.add_argument("--no-edmdc", action="store_true")
+    ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 ensemble leg")
+    ap.add_argument("--cfg4-rollouts", type=int, default=1 << 20, help="TOTAL rollouts of the config-4 ensemble (all ranks together)")
+    ap.add_argument("--cfg4-horizon", type=int, default=500)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=3.0, help="budget of EACH host baseline leg")
     return ap.parse_args()
+
+
+# ---------------------------------------------------------------------------------------------- self launch
+def self_launch(a):
+    """`python bench.py --gpus N` outside torch.distributed.run: become the launcher.  Runs before anything initialises
+    the GPU in this process (device_count() does not on this image); the ranks are children, their exit code is ours."""
+    import torch
+    have = torch.cuda.device_count()
+    share = os.environ.get("BROV2_BENCH_SHARE_GPU") == "1"
+    if have < a.gpus and not share:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} requested but {have} GPU(s) visible: refusing to measure fewer GPUs than asked\n")
+        sys.exit(2)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.exit(subprocess.call(cmd, env=env))
 
 
 def usable_cores():
@@ -89,6 +132,7 @@ def usable_cores():
     return max(1, n)
 
 
+# ---------------------------------------------------------------------------------------------- CPU baselines
 def cpu_baseline_rollout(budget_s, integrator):
     """C oracle (oracle/brov2_oracle.c), one thread per usable host core, same stream / model / integrator."""
     from oracle import controls, fossen_c as fc
@@ -98,32 +142,50 @@ def cpu_baseline_rollout(budget_s, integrator):
     x0 = np.zeros((cores, 12))
     x0[:, 2] = 5.0
     U = controls.controls_iid(0x5EED, 0, cores, T)
-    t0 = time.perf_counter()
-    fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)
-    probe = time.perf_counter() - t0
-    # a batch of up to 64 trajectories per thread (0.3 GB of controls at 16 threads), rolled out as often as the budget allows
-    per_thread = max(1, min(64, int(budget_s / max(probe, 1e-3))))
-    nb = cores * per_thread
-    x0 = np.zeros((nb, 12))
-    x0[:, 2] = 5.0
-    U = controls.controls_iid(0x5EED, 0, nb, T)
     fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)      # warm (page faults, thread pool)
     t0 = time.perf_counter()
     fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)
     one = time.perf_counter() - t0
-    reps = max(1, min(200, int(round(budget_s / max(one, 1e-3)))))
+    reps = max(1, min(400, int(round(budget_s / max(one, 1e-3)))))
     t0 = time.perf_counter()
     for _ in range(reps):
         fc.rollout(fc.MODEL_THRUSTER_EULER, integ, x0, U, 0.02, store=False, nthreads=cores)
     el = time.perf_counter() - t0
-    return {"value": reps * nb * T / el, "unit": "steps/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} x {nb} trajectories x {T} {integrator} steps of the config-2 stream, C oracle with {cores} OpenMP threads "
+    return {"value": reps * cores * T / el, "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} x {cores} trajectories x {T} {integrator} steps of the config-2 stream, C oracle with {cores} OpenMP threads "
                       f"(usable cores of the box), {el:.1f} s"}
 
 
-def cpu_baseline_gram(C, gamma, n_pairs=200_000):
+def cpu_baseline_reference_shape(budget_s, integrator):
+    """The reference's way of computing, restated (oracle/fossen_scalar.py): one Python call per right-hand side, small
+    ndarray temporaries, one lag update and one cross product per thruster -- sequential, one core.  The reference itself
+    measured 775 RK4 steps/s in the build container; this restatement 755 there."""
+    import warnings
+    from oracle import controls, fossen_scalar as fs
+    T = 4000
+    U = controls.controls_iid(0x5EED, 0, 1, 5000)[0]
+    x0 = np.zeros(12)
+    x0[2] = 5.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fs.simulate(x0, U[:20], 0.02, integrator)
+        rov = fs.ScalarBlueROV2()
+        x = x0.copy()
+        n = 0
+        t0 = time.perf_counter()
+        while n < T and time.perf_counter() - t0 < budget_s:
+            x = fs.simulate(x, U[n:n + 50], 0.02, integrator, rov=rov)[-1]
+            n += 50
+        el = time.perf_counter() - t0
+    return {"value": n / el, "unit": "steps/s", "cores": 1, "kind": "port",
+            "sample": f"{n} sequential {integrator} steps of trajectory 0 of the config-2 stream, scalar per-call NumPy loop in the reference's "
+                      f"shape (oracle/fossen_scalar.py), {el:.1f} s; the reference itself: 775 RK4 steps/s on one core of the build container"}
+
+
+def cpu_baseline_gram(C, gamma, budget_s):
     """NumPy restatement of the reference's lift + G^T G + G^T Y (BLAS threads as configured on the box)."""
     from oracle import edmdc_numpy as ek
+    n_pairs = int(max(20_000, min(200_000, 1.3e5 * budget_s)))
     rng = np.random.default_rng(0)
     X = rng.normal(0, 0.5, (n_pairs + 1, 12))
     U = rng.uniform(-1, 1, (n_pairs + 1, 8))
@@ -142,14 +204,38 @@ def cpu_baseline_gram(C, gamma, n_pairs=200_000):
             "sample": f"{n_pairs} pairs, k={C.shape[0]}, NumPy/BLAS lift + Gram on {cores} threads, {el:.1f} s"}
 
 
+# ---------------------------------------------------------------------------------------------- verification helpers
+def lanes_from_traj(traj, lay, lanes, rows):
+    """[len(lanes), len(rows), nx] host array out of a device trajectory buffer of any layout."""
+    import torch
+    li = torch.as_tensor(lanes, device=traj.device)
+    ri = torch.as_tensor(rows, device=traj.device)
+    if lay == "btu":
+        out = traj.index_select(0, li).index_select(1, ri)
+    elif lay == "tub":
+        out = traj.index_select(0, ri).index_select(2, li).permute(2, 0, 1)
+    else:
+        t = traj.index_select(0, ri).index_select(2, li)               # [rows, nx/2, lanes, 2]
+        out = t.permute(2, 0, 1, 3).reshape(len(lanes), len(rows), -1)
+    return out.cpu().numpy()
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        self_launch(a)                     # does not return
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == a.gpus or world == 1, f"--gpus {a.gpus} but WORLD_SIZE={world}"
+    if world != a.gpus:
+        sys.stderr.write(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}\n")
+        sys.exit(2)
     # Rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): BROV2_BENCH_SHARE_GPU=1 maps every
     # rank to cuda:0 and BROV2_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one device).
     backend = os.environ.get("BROV2_BENCH_BACKEND", "nccl")
@@ -164,6 +250,7 @@ def main():
             dist.init_process_group(backend)
 
     from bluerov2_dynamics_amd import _lib, engine
+    from bluerov2_dynamics_amd import dist as bdist
     ctx = _lib.default_context(local)
 
     def barrier():
@@ -179,13 +266,33 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    # ------------------------------------------------------------------ rollout leg
+    def gather_ranks(x):
+        if world == 1:
+            return [x]
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        out = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(out, t)
+        return [float(o.item()) for o in out]
+
+    def allreduce_sum_(t):
+        """the Gram exchange: RCCL over xGMI (gloo only in the shared-GPU rehearsal)"""
+        if world == 1:
+            return t
+        if backend == "nccl":
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM)
+            t.copy_(h)
+        return t
+
+    # ------------------------------------------------------------------ rollout leg (config 2)
     B, T, dt = a.batch, a.horizon, 0.02
     nu, nx = 8, 12
     lay = a.layout
     shape = {"tub": lambda r_, c_: (r_, c_, B), "btu": lambda r_, c_: (B, r_, c_), "tpb": lambda r_, c_: (r_, c_ // 2, B, 2)}[lay]
     U = torch.empty(shape(T, nu), dtype=torch.float64, device=dev)
-    engine.fill_controls_dev(U, lay, "iid", seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)
+    engine.fill_controls_dev(U, lay, a.controls, seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)
     x0 = torch.zeros((B, nx), dtype=torch.float64, device=dev)
     x0[:, 2] = 5.0
     traj = None
@@ -196,28 +303,37 @@ def main():
     def step():
         engine.rollout_dev(_lib.THRUSTER_EULER, a.integrator, x0, U, dt, traj=traj, xT=xT, layout=lay, stride=1, ctx=ctx)
 
+    def timed_launches(nsteps):
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        for i in range(nsteps):
+            step()
+            ev[i + 1].record()       # same stream as the kernel (ctx launches on torch's current stream)
+        barrier()
+        wall_ = max_over_ranks(time.perf_counter() - t0)
+        return wall_, [ev[i].elapsed_time(ev[i + 1]) for i in range(nsteps)]
+
     for _ in range(a.warmup):
         step()
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(a.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(a.steps):
-        step()
-        ev[i + 1].record()       # same stream as the kernel (ctx uses torch's current stream)
-    barrier()
-    wall = max_over_ranks(time.perf_counter() - t0)
-    kern_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(a.steps)]
+    wall, kern_ms = timed_launches(a.steps)
     kern_s = float(np.mean(kern_ms)) * 1e-3
     steps_total = world * B * T * a.steps
     value = steps_total / wall
     bytes_per_step = ROLLOUT_BYTES_PER_STEP if not a.no_store else 64.0
     flop_per_step = ROLLOUT_FLOP_PER_STEP if a.integrator == "rk4" else ROLLOUT_FLOP_PER_STEP * 0.76 / 3.1
     flop_rate = B * T * flop_per_step / kern_s / 1e12
-    # fraction of the SIMD fp64 issue slots the kernel actually fills: (fp64 instr/step x 4 cycles) / cycles per step
-    cyc_per_step = kern_s * 2.4e9 / T / max(1, -(-B // 65536))
-    valu_busy = ROLLOUT_EXEC_FP64_INSTR[a.integrator] * 4.0 / cyc_per_step
     byte_rate = B * T * bytes_per_step / kern_s / 1e9
+    # The bound of this kernel is the fp64 VALU issue rate: every fp64 vector instruction (FMA, mul or add alike) holds its
+    # SIMD for 4 clocks, so the peak is SIMDS * clock / 4 wave-instructions per second, i.e. 78.6 TFLOP/s only if every slot
+    # held an FMA.  achieved = the fp64 instructions the kernel really issues, priced as FMAs (2 flop x 64 lanes): the
+    # fraction is the share of issue slots doing fp64 arithmetic and cannot exceed 1 whatever the algebra saves.
+    instr = ROLLOUT_EXEC_FP64_INSTR[a.integrator]
+    waves = -(-B // 64)
+    issue_rate = waves * T * instr / kern_s                        # wave-instructions per second, whole chip
+    issue_tflops = issue_rate * 64 * 2 / 1e12
+    issue_frac = issue_tflops / PEAK_FP64_VALU_TFLOPS             # == issue_rate / (SIMDS * CLOCK_HZ / 4) up to the datasheet's rounding
     assert torch.isfinite(xT).all()
 
     out = {
@@ -226,28 +342,74 @@ def main():
         "ms_per_step": wall / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"BASELINE config 2: {B} trajectories/GPU x {T} {a.integrator.upper()} steps, thruster model, dt=0.02, "
-                               f"iid U(-1,1) commands (splitmix64 stream 0x5EED), layout {lay}, "
+                               + ("iid U(-1,1) commands" if a.controls == "iid" else "AR(1) commands (dist B)")
+                               + f" (splitmix64 stream 0x5EED), layout {lay}, "
                                + ("all states stored" if traj is not None else "endpoint only"),
                    "trajectories_per_gpu": B, "horizon": T, "parallelism": f"{world} x independent shards, no collective"},
-        "roofline": {"kernel": "rollout_kernel<THRUSTER_EULER,RK4>", "bound": "valu_fp64", "achieved": flop_rate,
-                     "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": flop_rate / PEAK_FP64_VALU_TFLOPS,
-                     "kernel_ms": kern_s * 1e3, "flop_per_step": flop_per_step,
-                     "executed_fp64_instr_per_step": ROLLOUT_EXEC_FP64_INSTR[a.integrator], "fp64_issue_slot_utilisation": valu_busy,
+        "roofline": {"kernel": f"rollout_kernel<THRUSTER_EULER,{a.integrator.upper()}>", "bound": "valu_fp64_issue",
+                     "achieved": issue_tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": issue_frac,
+                     "kernel_ms": kern_s * 1e3, "kernel_ms_each": kern_ms,
+                     "executed_fp64_instr_per_step": instr,
+                     "note": "achieved = fp64 VALU instructions issued x 64 lanes x 2 flop (every slot priced as an FMA) / kernel time; "
+                             "frac = share of the chip's fp64 issue slots (1024 SIMDs x 2.4 GHz / 4) the kernel fills",
+                     "algorithmic": {"achieved": flop_rate, "frac": flop_rate / PEAK_FP64_VALU_TFLOPS, "flop_per_step": flop_per_step,
+                                     "note": "SURVEY 8(d) figure: the reference's dense 6x6 algebra per step / kernel time -- credit for "
+                                             "algebra, can exceed what the pipe executes"},
                      "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
                              "bytes_per_step": bytes_per_step},
                      "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay != "btu" and B == 65536 and T == 5000) else None},
     }
-
     # the same kernel against the HBM roofline (second, not binding: intensity 19 flop/B > ridge 9.8), in the plain schema
-    out["roofline_hbm"] = {"kernel": "rollout_kernel<THRUSTER_EULER,RK4>", "bound": "hbm", "achieved": byte_rate, "peak": PEAK_HBM_GBS,
+    out["roofline_hbm"] = {"kernel": out["roofline"]["kernel"], "bound": "hbm", "achieved": byte_rate, "peak": PEAK_HBM_GBS,
                            "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS, "kernel_ms": kern_s * 1e3,
                            "bytes_per_step": bytes_per_step, "traffic": out["roofline"]["traffic"]}
 
-    # ------------------------------------------------------------------ EDMDc leg
-    del traj
+    # ------------------------------------------------------------------ what did the timed launches write?
+    if traj is not None and rank == 0:
+        ver = {}
+        gpath = os.path.join(REPO, "tests", "golden", "fossen_rollouts.npz")
+        defaults = (a.integrator in ("rk4", "euler") and a.controls == "iid" and B >= 8 and os.path.exists(gpath))
+        if defaults:
+            g = np.load(gpath)
+            sub, Tg = int(g["cfg2_sub"]), int(g["cfg2_T"])
+            if T == Tg and float(g["cfg2_dt"]) == dt:
+                got = lanes_from_traj(traj, lay, list(range(8)), list(range(0, T + 1, sub)))
+                ref = g["cfg2_rk4" if a.integrator == "rk4" else "cfg2_euler"]
+                ver["vs_reference_fixture"] = {"max_rel_err": rel_err(got, ref), "lanes": 8, "states_per_lane": int(ref.shape[1]),
+                                               "fixture": "tests/golden/fossen_rollouts.npz (generated by importing the reference)"}
+        # random lanes of the big launch against re-runs of those lanes alone (another grid, the BTU layout)
+        rng = np.random.default_rng(7)
+        lanes = sorted(set(int(v) for v in rng.integers(0, B, 6)) | {B - 1})
+        rows = list(range(0, T + 1, max(1, T // 20)))
+        got = lanes_from_traj(traj, lay, lanes, rows)
+        Ul = torch.empty((len(lanes), T, nu), dtype=torch.float64, device=dev)
+        for i, b in enumerate(lanes):
+            engine.fill_controls_dev(Ul[i:i + 1], "btu", a.controls, seed=0x5EED, b0=rank * B + b, T_total=T, ctx=ctx)
+        tl = torch.empty((len(lanes), T + 1, nx), dtype=torch.float64, device=dev)
+        engine.rollout_dev(_lib.THRUSTER_EULER, a.integrator, x0[: len(lanes)].contiguous(), Ul, dt, traj=tl, layout="btu", stride=1, ctx=ctx)
+        ver["random_lanes_vs_single_lane_runs"] = {"max_rel_err": rel_err(got, tl[:, rows].cpu().numpy()), "lanes": lanes}
+        ver["max_rel_err"] = max(v["max_rel_err"] for v in ver.values())
+        ver["tolerance"] = 1e-9
+        ver["ok"] = bool(ver["max_rel_err"] <= 1e-9)
+        out["verified"] = ver
+        del Ul, tl
+
+    # ------------------------------------------------------------------ AR(1) commands (dist B), same launch
+    if not a.no_ar1 and a.controls == "iid":
+        engine.fill_controls_dev(U, lay, "ar1", seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)
+        step()
+        w2, k2 = timed_launches(max(1, min(2, a.steps)))
+        out["rollout_ar1"] = {"value": world * B * T * len(k2) / w2, "unit": "steps/s", "kernel_ms": float(np.mean(k2)),
+                              "finite": bool(torch.isfinite(xT).all().item()),
+                              "note": "same kernel and sizes on the AR(1) command stream u_t = clip(0.98 u_{t-1} + 0.02 xi_t) (dist B)"}
+
+    # ------------------------------------------------------------------ EDMDc leg (config 3)
+    del traj, U
+    torch.cuda.empty_cache()
+    n, r, k, gamma, ridge = 12, 8, 512, 1.0, 1e-3
+    p, d = n + k + r, n + k
+    Cc = None
     if not a.no_edmdc:
-        torch.cuda.empty_cache()
-        n, r, k, gamma, ridge = 12, 8, 512, 1.0, 1e-3
         L = 500
         nb = max(1, a.edmdc_samples // L)
         Ue = torch.empty((nb, L, r), dtype=torch.float64, device=dev)
@@ -286,19 +448,12 @@ def main():
                 Ch = Cc.cpu()
                 dist.broadcast(Ch, 0)
                 Cc.copy_(Ch)
-        p, d = n + k + r, n + k
         GG = torch.zeros((p * p + p * d,), dtype=torch.float64, device=dev)   # one buffer -> one all-reduce
         GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
 
         def estep():
             engine.gram_dev(Xe.view(-1, n), Ue.view(-1, r), Cc, gamma, nb, L, L + 1, L, GtG, GtY, ctx=ctx)
-            if world > 1:
-                if backend == "nccl":
-                    dist.all_reduce(GG, op=dist.ReduceOp.SUM)      # RCCL over xGMI: 4.5 MB, the only collective of the fit
-                else:
-                    Gh = GG.cpu()
-                    dist.all_reduce(Gh, op=dist.ReduceOp.SUM)
-                    GG.copy_(Gh)
+            allreduce_sum_(GG)                 # RCCL over xGMI: 4.5 MB, the only collective of the fit
 
         estep()
         barrier()
@@ -356,11 +511,96 @@ def main():
                 wt[integ] = {"wall_ms_host_to_host": (time.perf_counter() - t1) * 1e3, "kernel_ms": ctx.last_kernel_ms(), "rmse_finite": bool(np.isfinite(rm))}
                 ctx.set_timing(False)
             out["fossen_window_rmse_H100"] = {"windows": nw, "H": Hm, **wt, "note": "reference CPU log: 1247 s (Euler)"}
-        if rank == 0 and not a.no_cpu:
-            out["edmdc"]["cpu_baseline"] = cpu_baseline_gram(Cc.cpu().numpy(), gamma)
+        if rank == 0 and not a.no_cpu and world == 1:
+            out["edmdc"]["cpu_baseline"] = cpu_baseline_gram(Cc.cpu().numpy(), gamma, a.cpu_seconds / 2)
+        del Xe, Ue, GG, GtG, GtY
+        torch.cuda.empty_cache()
 
-    if rank == 0 and not a.no_cpu:
+    # ------------------------------------------------------------------ config 4: the sharded ensemble (strong scaling)
+    if not a.no_cfg4:
+        Bt, T4 = a.cfg4_rollouts, a.cfg4_horizon
+        b0, b1 = bdist.shard_range(Bt, rank, world)
+        Bl = b1 - b0
+        k4 = 512
+        p4, d4 = n + k4 + r, n + k4
+        U4 = torch.empty((Bl, T4, r), dtype=torch.float64, device=dev)
+        X4 = torch.empty((Bl, T4 + 1, n), dtype=torch.float64, device=dev)
+        x40 = torch.zeros((Bl, n), dtype=torch.float64, device=dev)
+        x40[:, 2] = 5.0
+        GG4 = torch.zeros((p4 * p4 + p4 * d4,), dtype=torch.float64, device=dev)
+        G4, Y4 = GG4[: p4 * p4].view(p4, p4), GG4[p4 * p4:].view(p4, d4)
+        engine.fill_controls_dev(U4, "btu", "ar1", seed=0xC0F4, b0=b0, T_total=T4, ctx=ctx)     # value depends on the GLOBAL trajectory index only
+
+        def roll4():
+            engine.rollout_dev(_lib.THRUSTER_EULER, "rk4", x40, U4, dt, traj=X4, layout="btu", stride=1, ctx=ctx)
+
+        roll4()
+        # centres: from the first 2048 trajectories of the ensemble, which rank 0 owns at every world size <= 512, so the
+        # centres -- and with them the summed Gram -- do not depend on the sharding
+        C4 = torch.empty((k4, n), dtype=torch.float64, device=dev)
+        if rank == 0:
+            nbc = min(2048, Bl)
+            Ck, _, _ = engine.kmeans_centers_dev(X4[:nbc].reshape(-1, n), k4, random_state=0, max_iter=5, ctx=ctx)
+            C4.copy_(Ck)
+        if world > 1:
+            if backend == "nccl":
+                dist.broadcast(C4, 0)
+            else:
+                Ch = C4.cpu()
+                dist.broadcast(Ch, 0)
+                C4.copy_(Ch)
+        barrier()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        t0 = time.perf_counter()
+        ev[0].record()
+        roll4()
+        ev[1].record()
+        engine.gram_dev(X4.view(-1, n), U4.view(-1, r), C4, gamma, Bl, T4, T4 + 1, T4, G4, Y4, ctx=ctx)
+        ev[2].record()
+        allreduce_sum_(GG4)
+        ev[3].record()
+        torch.cuda.synchronize()
+        local_s = time.perf_counter() - t0
+        barrier()
+        wall4 = max_over_ranks(time.perf_counter() - t0)
+        per_rank = gather_ranks(local_s * 1e3)
+        roll_ms, gram_ms, ar_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
+        # independent check of the summed blocks: their x-x corners are plain sums over all pairs of the ensemble,
+        # recomputed here with torch matmuls on every rank's shard and summed over the ranks
+        Xa, Xb = X4[:, :-1, :].reshape(-1, n), X4[:, 1:, :].reshape(-1, n)
+        chk = torch.cat([(Xa.T @ Xa).reshape(-1), (Xa.T @ Xb).reshape(-1)])
+        allreduce_sum_(chk)
+        cgg, cgy = chk[: n * n].view(n, n), chk[n * n:].view(n, n)
+        e_gg = float(((G4[:n, :n] - cgg).norm() / cgg.norm()).item())
+        e_gy = float(((Y4[:n, :n] - cgy).norm() / cgy.norm()).item())
+        pairs4 = Bt * T4
+        roll_max = max(gather_ranks(roll_ms))          # collectives: every rank, same order
+        gram_max = max(gather_ranks(gram_ms))
+        if rank == 0:
+            Gh = G4.cpu().numpy()
+            out["config4"] = {
+                "metric": "ensemble_rollout_plus_gram", "scaling": "strong", "total_rollouts": Bt, "horizon": T4, "rollouts_this_rank": Bl,
+                "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": ("rccl (torch.distributed nccl)" if backend == "nccl" else backend) if world > 1 else "none (single rank)",
+                "wall_ms": wall4 * 1e3, "per_rank_ms": per_rank,
+                "rank0_ms": {"rollout_rk4_btu": roll_ms, "lift_plus_gram": gram_ms, "allreduce_4.5MB": ar_ms},
+                "rollout_steps_per_s": Bt * T4 / (roll_max * 1e-3),
+                "gram_samples_per_s": pairs4 / (gram_max * 1e-3),
+                "pairs_total": pairs4,
+                "verified": {"GtG_xx_vs_torch_rel": e_gg, "GtY_xx_vs_torch_rel": e_gy, "ok": bool(e_gg < 1e-11 and e_gy < 1e-11),
+                             "note": "x-x corners of the all-reduced blocks against X^T X / X^T X+ from torch matmuls summed over the ranks"},
+                "gram_fingerprint": {"trace_GtG": float(np.trace(Gh)), "sum_GtY": float(Y4.sum().item()), "GtG_00": float(Gh[0, 0]),
+                                     "GtG_rbf0_rbf0": float(Gh[n, n]), "frobenius_GtG": float(np.linalg.norm(Gh)),
+                                     "note": "the ensemble, its command stream and the centres do not depend on the sharding: these numbers "
+                                             "agree to ~1e-12 relative between runs at 1/2/4/8 GPUs (summed Gram == 1-GPU Gram)"},
+                "config": {"workload": f"BASELINE config 4: {Bt} rollouts x {T4} RK4 steps in total (AR(1) commands, stream 0xC0F4), contiguous shards over the "
+                                       f"ranks, trajectories stored [B][T+1][12], local lift + G^T[G|Y] (k=512) per rank, one all-reduce of {p4 * p4 + p4 * d4} doubles"},
+            }
+        del U4, X4, GG4, G4, Y4, Xa, Xb
+        torch.cuda.empty_cache()
+
+    if rank == 0 and not a.no_cpu and world == 1:
         out["cpu_baseline"] = cpu_baseline_rollout(a.cpu_seconds, a.integrator)
+        out["cpu_baseline_reference_shape"] = cpu_baseline_reference_shape(a.cpu_seconds, a.integrator)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

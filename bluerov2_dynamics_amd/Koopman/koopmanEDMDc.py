@@ -10,9 +10,10 @@ What runs where:
     calls scikit-learn for the whole thing instead;
   * lift phi(x) = [x, exp(-gamma(|x|^2+|c|^2-2x.c))] and the G^T[G|Y] normal-equation blocks:
     HIP kernels (csrc/edmdc.hip, fp64 MFMA);
-  * the p x p ridge solve: NumPy pinv on the host, in fit_multi's association
-    M = pinv(G^T G + ridge I) (G^T Y) (:147).  The reference's fit() evaluates the same product as
-    (pinv G^T) Y (:97); the two agree to the conditioning of the Gram (tests quantify it);
+  * the p x p ridge solve: NumPy pinv on the host.  fit_multi associates M = pinv(G^T G + ridge I) (G^T Y) (:147) and so
+    does fit_multi here; fit() evaluates (pinv G^T) Y left to right (:97) and so does fit() here (two more MFMA passes:
+    rows of W = G P^T, then W^T Y).  The two differ by the conditioning of the Gram -- 1e-6 in the H = 100 RMSE at the
+    class defaults (k = 200, ridge = 1e-8) -- which is why each method keeps its own order;
   * evaluate / multistep_rmse / simulate: H-step propagation Z <- Z A^T + U B^T as fp64 MFMA GEMMs
     (csrc/propagate.hip).
 Unlike the reference, importing this module does not set OMP_NUM_THREADS / LOKY_MAX_CPU_COUNT.
@@ -67,7 +68,7 @@ class KoopmanEDMDc:
         N, n = X.shape
         assert U.shape[0] == N and U.shape[1] == self.input_dim
         self.centers_ = _kmeans_centers(X, self.n_rbfs, self.kmeans) if centers is None else np.asarray(centers, dtype=float)
-        self._solve([X], [U])
+        self._solve([X], [U], fit_order=True)
 
     def fit_multi(self, X_list, U_list, centers=None) -> None:
         """Fit from several independent trajectories without cross-bag transitions (reference :113-152)."""
@@ -80,10 +81,13 @@ class KoopmanEDMDc:
         self.centers_ = np.asarray(centers, dtype=float)
         self._solve(list(X_list), list(U_list))
 
-    def _solve(self, X_list, U_list):
+    def _solve(self, X_list, U_list, fit_order=False):
         GtG, GtY, _ = engine.gram(X_list, U_list, self.centers_, self.gamma)
         d = self.state_dim + self.centers_.shape[0]
-        self.A_, self.B_ = engine.solve_AB(GtG, GtY, self.ridge, d)
+        if fit_order:       # (pinv G^T) Y, Koopman/koopmanEDMDc.py:97
+            self.A_, self.B_ = engine.solve_AB_fit_order(X_list, U_list, self.centers_, self.gamma, GtG, self.ridge, d)
+        else:               # pinv (G^T Y), :147
+            self.A_, self.B_ = engine.solve_AB(GtG, GtY, self.ridge, d)
         self.lift_dim_ = d
 
     # ------------------------------------------------------------------ scoring

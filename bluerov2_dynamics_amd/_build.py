@@ -6,7 +6,7 @@ import subprocess
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("BROV2_LIBRARY") or os.path.join(PKG, "libbrov2.so")     # override: A/B runs of experimental builds
-SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "kmeans.hip", "controls.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "kmeans.hip", "controls.hip", "comm.hip"]
 HEADERS = ["brov2_device.h", "brov2_fast.h", "brov2_kernels.h", os.path.join("..", "..", "include", "brov2.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden",
          "-DBROV2_BUILDING=1"]
@@ -33,7 +33,7 @@ def build_library(force=False, verbose=False):
         return LIB
     srcs = [os.path.join(CSRC, s) for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
     extra = os.environ.get("BROV2_HIPCC_EXTRA", "").split()      # experiments only (e.g. -DBROV_STAGE_RELOAD=0)
-    cmd = [hipcc()] + FLAGS + extra + ["-o", LIB + ".tmp"] + srcs
+    cmd = [hipcc()] + FLAGS + extra + ["-o", LIB + ".tmp"] + srcs + ["-ldl"]      # dl: librccl is bound at run time (comm.hip)
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd, cwd=CSRC)

@@ -21,7 +21,8 @@ LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB = 0, 1, 2
 DIST_IID_UNIFORM, DIST_AR1 = 0, 1
 NX = {THRUSTER_EULER: 12, WRENCH_EULER: 12, WRENCH_QUAT: 13, DI_THRUSTER_EULER: 12, DI_WRENCH_EULER: 12, DI_WRENCH_QUAT: 13}
 NU = {THRUSTER_EULER: 8, WRENCH_EULER: 6, WRENCH_QUAT: 6, DI_THRUSTER_EULER: 8, DI_WRENCH_EULER: 6, DI_WRENCH_QUAT: 6}
-STATUS = {0: "BROV_OK", -1: "BROV_ERR_ARG", -2: "BROV_ERR_HIP", -3: "BROV_ERR_NOMEM", -4: "BROV_ERR_NODEVICE"}
+STATUS = {0: "BROV_OK", -1: "BROV_ERR_ARG", -2: "BROV_ERR_HIP", -3: "BROV_ERR_NOMEM", -4: "BROV_ERR_NODEVICE", -5: "BROV_ERR_COMM"}
+COMM_ID_BYTES = 128
 
 
 class BrovParams(ctypes.Structure):
@@ -51,6 +52,9 @@ SIGNATURES = {
     "brov_create": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(c_void_p)]),
     "brov_destroy": (None, [c_void_p]),
     "brov_last_error": (ctypes.c_char_p, [c_void_p]),
+    "brov_arch_is_supported": (ctypes.c_int, [ctypes.c_char_p]),
+    "brov_device_arch": (ctypes.c_int, [c_void_p, ctypes.c_char_p, ctypes.c_size_t]),
+    "brov_xcd_round_robin": (ctypes.c_int, [c_void_p]),
     "brov_set_stream": (ctypes.c_int, [c_void_p, c_void_p]),
     "brov_sync": (ctypes.c_int, [c_void_p]),
     "brov_set_timing": (ctypes.c_int, [c_void_p, ctypes.c_int]),
@@ -97,6 +101,18 @@ SIGNATURES = {
                                           c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_simulate": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                       c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p]),
+    "edmdc_pinv_apply": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                        i64, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edmdc_pinv_apply_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                            i64, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "brov_comm_available": (ctypes.c_int, []),
+    "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
+    "brov_comm_init_rank": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void_p)]),
+    "brov_comm_destroy": (None, [c_void_p]),
+    "brov_comm_nranks": (ctypes.c_int, [c_void_p]),
+    "brov_comm_rank": (ctypes.c_int, [c_void_p]),
+    "brov_comm_last_error": (ctypes.c_char_p, [c_void_p]),
+    "edmdc_gram_allreduce_dev": (ctypes.c_int, [c_void_p, c_void_p, i64, c_void_p, i64, c_void_p]),
 }
 
 
@@ -187,6 +203,18 @@ class Context:
                             "there is no CPU fallback")
         self.h = h
         self.device = int(device)
+        self._stream = 0          # handle the ctx currently launches on (0 = the null stream)
+
+    @property
+    def arch(self) -> str:
+        buf = ctypes.create_string_buffer(64)
+        self.check(self.lib.brov_device_arch(self.h, buf, 64), "brov_device_arch")
+        return buf.value.decode()
+
+    @property
+    def xcd_round_robin(self) -> int:
+        """1 if blocks b and b+8 shared an XCD when the ctx was created (the kernels' L2-sharing assumption), 0 / -1 otherwise."""
+        return int(self.lib.brov_xcd_round_robin(self.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -215,11 +243,22 @@ class Context:
 
     # -- stream / timing
     def set_stream(self, stream_handle):
-        self.check(self.lib.brov_set_stream(self.h, c_void_p(stream_handle or 0)), "brov_set_stream")
+        """Launch on another HIP stream.  The library orders the new stream behind whatever this ctx still has queued on
+        the old one (its scratch buffers are shared), so switching is safe at any point."""
+        stream_handle = int(stream_handle or 0)
+        if stream_handle != self._stream:
+            self.check(self.lib.brov_set_stream(self.h, c_void_p(stream_handle)), "brov_set_stream")
+            self._stream = stream_handle
 
     def use_torch_stream(self):
+        """Device path: launch on torch's current stream for this device."""
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def use_null_stream(self):
+        """Host path (arrays in, arrays out, synchronous): back to the null stream, so that a torch stream handle bound by
+        an earlier device-path call -- possibly destroyed since -- is never used again."""
+        self.set_stream(0)
 
     def set_di_gains(self, K_lin, K_ang):
         """Gains [nu,3] of the double-integrator models (include/brov2.h: brov_set_di_gains)."""
@@ -253,3 +292,55 @@ def default_context(device: int = None) -> Context:
     if device not in _default:
         _default[device] = Context(device)
     return _default[device]
+
+
+class Comm:
+    """One RCCL communicator (brov_comm): the direct, torch-free form of the path's only collective.  Rank 0 creates the
+    id with Comm.unique_id() and hands the 128 bytes to the other ranks; every rank then constructs Comm(device, id,
+    nranks, rank) (collective)."""
+
+    def __init__(self, device: int, unique_id: bytes, nranks: int, rank: int):
+        self.lib = load_library()
+        assert len(unique_id) == COMM_ID_BYTES
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        h = c_void_p()
+        rc = self.lib.brov_comm_init_rank(int(device), ctypes.addressof(buf), int(nranks), int(rank), ctypes.byref(h))
+        if rc != 0:
+            raise BrovError(f"brov_comm_init_rank: {STATUS.get(rc, rc)}: {self.lib.brov_comm_last_error(None).decode()}")
+        self.h = h
+        self.nranks, self.rank, self.device = int(nranks), int(rank), int(device)
+
+    @staticmethod
+    def available() -> bool:
+        return bool(load_library().brov_comm_available())
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = load_library()
+        buf = (ctypes.c_ubyte * COMM_ID_BYTES)()
+        rc = lib.brov_comm_unique_id(ctypes.addressof(buf))
+        if rc != 0:
+            raise BrovError(f"brov_comm_unique_id: {STATUS.get(rc, rc)}: {lib.brov_comm_last_error(None).decode()}")
+        return bytes(buf)
+
+    def allreduce_gram_(self, GtG, GtY, stream_handle=None):
+        """In-place sum over ranks of two fp64 CUDA tensors, one grouped RCCL call on torch's current stream."""
+        import torch
+        assert GtG.is_cuda and GtY.is_cuda and GtG.dtype == torch.float64 and GtY.dtype == torch.float64
+        assert GtG.is_contiguous() and GtY.is_contiguous()
+        st = torch.cuda.current_stream(GtG.device).cuda_stream if stream_handle is None else stream_handle
+        rc = self.lib.edmdc_gram_allreduce_dev(self.h, GtG.data_ptr(), GtG.numel(), GtY.data_ptr(), GtY.numel(), c_void_p(st or 0))
+        if rc != 0:
+            raise BrovError(f"edmdc_gram_allreduce_dev: {STATUS.get(rc, rc)}: {self.lib.brov_comm_last_error(self.h).decode()}")
+        return GtG, GtY
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.brov_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -21,6 +21,8 @@ hipError_t launch_window_endpoint(hipStream_t st, const FastParams* d_fp, int mo
 hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed,
                                 int64_t b0, int64_t T_total, const double* scale8, double* U);
 
+int probe_xcd_round_robin(hipStream_t st);
+
 // ---- EDMDc -----------------------------------------------------------------------------
 // Lifted row layout (device native, "Z rows"): [rbf_0 .. rbf_{kp-1} | x_0..x_{n-1} u_0..u_{r-1} 0..]
 // with kp = k rounded up to 16 and the tail block (n + r) rounded up to 16; width = kp + tailp.
@@ -50,13 +52,18 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
                                   const double* X, const double* U, double* Zrows, double* wrow);
 // Gram task table (device copy owned by the ctx) and sizes.
 // partial: [ntasks][nslab][24 tiles][64 lanes][4] doubles.
-size_t gram_partial_doubles(const EdmdcShape& s, int* ntasks_out, int* nslab_out);
-size_t gram_task_bytes();
-hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, void* d_tasks, size_t cap_bytes, int* ntasks);
+// mode 0: tasks of G^T[G|Y]; mode 1: tasks of W^T Y (edmdc_pinv_apply)
+size_t gram_partial_doubles(const EdmdcShape& s, int mode, int* ntasks_out, int* nslab_out);
+size_t gram_task_bytes(const EdmdcShape& s, int mode);
+hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, int mode, void* d_tasks, size_t cap_bytes, int* ntasks);
 // Gram of one chunk: pairs (row, row+1) for row in [0, npairs) of Zrows (4*ceil(npairs/4)+1 rows lifted),
 // weight wrow[row]; accumulated into `partial` in place when `accumulate`.
+// Arows: rows the A operand is cut from (== Zrows for the Gram; the rows of W = G P^T for edmdc_pinv_apply)
 hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
-                                   const double* Zrows, const double* wrow, double* partial, int accumulate);
+                                   const double* Arows, const double* Zrows, const double* wrow, double* partial, int accumulate);
+// Wrows[rows][width] = Zrows . PdT  (PdT [width][width] = P^T in device feature order)
+hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows);
+int edmdc_dev_to_ref_feature(const EdmdcShape& s, int f);
 // Sum partials over slabs (fixed order) and scatter into reference-order GtG [p][p], GtY [p][d].
 hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, const double* partial,
                                     int accumulate_out, double* GtG, double* GtY);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -40,12 +41,16 @@ struct brov_ctx {
     // EDMDc
     int btu_staging = 0;
     int64_t chunk_rows = (int64_t)1 << 20;
-    void* d_tasks = nullptr;
-    EdmdcShape task_shape{};
-    int ntasks = 0;
+    void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
+    EdmdcShape task_shape[2] = {};
+    int ntasks[2] = {0, 0};
     // persistent EDMDc workspaces (separate from the per-call arena so that accumulate works across calls)
     double* d_partial = nullptr;
     size_t partial_cap = 0;
+    size_t tasks_cap[2] = {0, 0};     // bytes behind d_tasks[]
+    hipEvent_t ev_handover = nullptr; // orders the work queued on the previous stream before the next one (brov_set_stream)
+    int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
+    char arch[64] = {0};
 };
 
 namespace {
@@ -59,8 +64,18 @@ int hip_fail(brov_ctx* c, hipError_t e, const char* what) {
 }
 #define HIPCK(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return hip_fail((ctx), e__, #call); } while (0)
 
+// Makes the ctx's device current for the duration of one API call and puts the caller's device back afterwards:
+// the process-wide "current device" belongs to the caller (PyTorch reads it for its own allocations and launches).
 struct DeviceGuard {
-    explicit DeviceGuard(const brov_ctx* c) { (void)hipSetDevice(c->device); }
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(const brov_ctx* c) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) { (void)hipSetDevice(c->device); switched = true; }
+    }
+    ~DeviceGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
 // RAII: records the HIP events that bracket the kernels of one API call
@@ -373,20 +388,39 @@ void brov_default_params(brov_params* p) {
     for (int i = 0; i < 3; ++i) { p->lag_Bc[i] = Bc[i]; p->lag_Cc[i] = Cc[i]; }
 }
 
+int brov_arch_is_supported(const char* gcn_arch_name) {
+    // the library carries gfx950 code objects only ("gfx950:sramecc+:xnack-" is what hipDeviceProp_t.gcnArchName reads on MI355X)
+    return gcn_arch_name && std::strncmp(gcn_arch_name, "gfx950", 6) == 0 && (gcn_arch_name[6] == '\0' || gcn_arch_name[6] == ':');
+}
+
 int brov_create(int device_id, brov_ctx** out) {
     if (!out) return BROV_ERR_ARG;
     *out = nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return BROV_ERR_NODEVICE;
     if (device_id < 0 || device_id >= ndev) return BROV_ERR_ARG;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return BROV_ERR_HIP;
+    if (!brov_arch_is_supported(prop.gcnArchName)) return BROV_ERR_NODEVICE;     // a GPU, but not one this library has code for
     brov_ctx* c = new (std::nothrow) brov_ctx();
     if (!c) return BROV_ERR_NOMEM;
     c->device = device_id;
+    std::snprintf(c->arch, sizeof c->arch, "%s", prop.gcnArchName);
     brov_default_params(&c->params);
-    if (hipSetDevice(device_id) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) {
+    DeviceGuard g(c);               // the caller's current device is restored on return
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_handover, hipEventDisableTiming) != hipSuccess) {
+        if (c->ev0) (void)hipEventDestroy(c->ev0);
+        if (c->ev1) (void)hipEventDestroy(c->ev1);
         delete c;
         return BROV_ERR_HIP;
     }
+    // gram_kernel / propagate_kernel group work items by blockIdx % 8 so that blocks sharing an XCD share rows through its
+    // L2.  That placement is observed behaviour, not a HIP guarantee: probe it once and remember (speed only, never correctness).
+    c->xcd_round_robin = probe_xcd_round_robin(nullptr);
+    if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
+        std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
+                             "the XCD-aware block mappings lose their L2 sharing (results unaffected)\n", device_id, c->xcd_round_robin);
     *out = c;
     return BROV_OK;
 }
@@ -396,20 +430,38 @@ void brov_destroy(brov_ctx* c) {
     DeviceGuard g(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
-    if (c->d_tasks) (void)hipFree(c->d_tasks);
+    for (int m = 0; m < 2; ++m) if (c->d_tasks[m]) (void)hipFree(c->d_tasks[m]);
     if (c->d_fp) (void)hipFree(c->d_fp);
     if (c->d_fp_di) (void)hipFree(c->d_fp_di);
     if (c->d_partial) (void)hipFree(c->d_partial);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
     delete c;
 }
+
+int brov_device_arch(const brov_ctx* c, char* buf, size_t cap) {
+    if (!c || !buf || cap == 0) return BROV_ERR_ARG;
+    std::snprintf(buf, cap, "%s", c->arch);
+    return BROV_OK;
+}
+int brov_xcd_round_robin(const brov_ctx* c) { return c ? c->xcd_round_robin : BROV_ERR_ARG; }
 
 const char* brov_last_error(const brov_ctx* c) { return c ? c->err.c_str() : "null ctx"; }
 
 int brov_set_stream(brov_ctx* c, void* s) {
     if (!c) return BROV_ERR_ARG;
-    c->stream = reinterpret_cast<hipStream_t>(s);
+    hipStream_t ns = reinterpret_cast<hipStream_t>(s);
+    if (ns == c->stream) return BROV_OK;
+    // The scratch arena, the Gram partials and the constant buffers are per ctx: work still queued on the old stream may be
+    // using them, so the new stream waits for it (event hand-over).  If the old handle is no longer valid (a destroyed torch
+    // stream), fall back to a device-wide sync.
+    DeviceGuard g(c);
+    if (hipEventRecord(c->ev_handover, c->stream) != hipSuccess || hipStreamWaitEvent(ns, c->ev_handover, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();
+    }
+    c->stream = ns;
     return BROV_OK;
 }
 int brov_sync(brov_ctx* c) {
@@ -770,15 +822,34 @@ int edmdc_lift(brov_ctx* c, int64_t N, int n, int k, double gamma, const double*
     return BROV_OK;
 }
 
-static int ensure_tasks(brov_ctx* c, const EdmdcShape& s) {
-    if (!c->d_tasks) HIPCK(c, hipMalloc(&c->d_tasks, gram_task_bytes()));
-    if (c->ntasks == 0 || c->task_shape.n != s.n || c->task_shape.r != s.r || c->task_shape.k != s.k) {
+static int ensure_tasks(brov_ctx* c, const EdmdcShape& s, int mode) {
+    if (c->ntasks[mode] == 0 || c->task_shape[mode].n != s.n || c->task_shape[mode].r != s.r || c->task_shape[mode].k != s.k) {
+        // the table grows with the shape (k = 512: 81 tasks, k = 1024: 295): sized from the task list, not a fixed cap
+        const size_t need = gram_task_bytes(s, mode);
+        if (need > c->tasks_cap[mode]) {
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (c->d_tasks[mode]) (void)hipFree(c->d_tasks[mode]);
+            c->d_tasks[mode] = nullptr; c->tasks_cap[mode] = 0; c->ntasks[mode] = 0;
+            HIPCK(c, hipMalloc(&c->d_tasks[mode], need));
+            c->tasks_cap[mode] = need;
+        }
         int nt = 0;
-        hipError_t e = upload_gram_tasks(c->stream, s, c->d_tasks, gram_task_bytes(), &nt);
-        if (e != hipSuccess) return hip_fail(c, e, "upload_gram_tasks (too many tasks for this shape?)");
+        hipError_t e = upload_gram_tasks(c->stream, s, mode, c->d_tasks[mode], c->tasks_cap[mode], &nt);
+        if (e != hipSuccess) return hip_fail(c, e, "upload_gram_tasks");
         HIPCK(c, hipStreamSynchronize(c->stream));   // source vector is a temporary
-        c->ntasks = nt;
-        c->task_shape = s;
+        c->ntasks[mode] = nt;
+        c->task_shape[mode] = s;
+    }
+    return BROV_OK;
+}
+
+static int ensure_partial(brov_ctx* c, size_t pdoubles) {
+    if (pdoubles * 8 > c->partial_cap) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        if (c->d_partial) (void)hipFree(c->d_partial);
+        c->d_partial = nullptr; c->partial_cap = 0;
+        HIPCK(c, hipMalloc((void**)&c->d_partial, pdoubles * 8));
+        c->partial_cap = pdoubles * 8;
     }
     return BROV_OK;
 }
@@ -791,20 +862,15 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
         return fail(c, BROV_ERR_ARG, "edmdc_gram_dev: bad argument");
     DeviceGuard g(c);
     const EdmdcShape s = edmdc_shape(n, r, k);
-    rc = ensure_tasks(c, s);
+    rc = ensure_tasks(c, s, 0);
     if (rc) return rc;
     if (nbags <= 1) { xs = L + 1; us = L; }
     const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
     const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;   // rows that can start a pair
     int nslab = 0, ntasks = 0;
-    const size_t pdoubles = gram_partial_doubles(s, &ntasks, &nslab);
-    if (pdoubles * 8 > c->partial_cap) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        if (c->d_partial) (void)hipFree(c->d_partial);
-        c->d_partial = nullptr; c->partial_cap = 0;
-        HIPCK(c, hipMalloc((void**)&c->d_partial, pdoubles * 8));
-        c->partial_cap = pdoubles * 8;
-    }
+    const size_t pdoubles = gram_partial_doubles(s, 0, &ntasks, &nslab);
+    rc = ensure_partial(c, pdoubles);
+    if (rc) return rc;
     int64_t chunk = c->chunk_rows;
     if (chunk > (total_pairs_rows + 3) / 4 * 4) chunk = (total_pairs_rows + 3) / 4 * 4;
     if (chunk < 4) chunk = 4;
@@ -822,10 +888,98 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
         const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
         HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
-        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks, c->d_tasks, npairs, dZ, dw, c->d_partial, first ? 0 : 1));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], npairs, dZ, dZ, dw, c->d_partial, first ? 0 : 1));
         first = 0;
     }
-    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks, c->d_tasks, c->d_partial, accumulate, d_GtG, d_GtY));
+    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], c->d_partial, accumulate, d_GtG, d_GtY));
+    return BROV_OK;
+}
+
+// ---- fit()'s own association: M = (P G^T) Y  (Koopman/koopmanEDMDc.py:97) ------------------------------------------
+int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
+                         int64_t xs, int64_t us, const double* d_X, const double* d_U, const double* P_host, double* d_M) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !d_C || !P_host || !d_M || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_dev: bad argument");
+    DeviceGuard g(c);
+    const EdmdcShape s = edmdc_shape(n, r, k);
+    rc = ensure_tasks(c, s, 1);
+    if (rc) return rc;
+    if (nbags <= 1) { xs = L + 1; us = L; }
+    const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;
+    int nslab = 0, ntasks = 0;
+    const size_t pdoubles = gram_partial_doubles(s, 1, &ntasks, &nslab);
+    rc = ensure_partial(c, pdoubles);
+    if (rc) return rc;
+    int64_t chunk = c->chunk_rows;
+    if (chunk > (total_pairs_rows + 3) / 4 * 4) chunk = (total_pairs_rows + 3) / 4 * 4;
+    if (chunk < 4) chunk = 4;
+    const int W = s.width;
+    Arena a(c);
+    rc = a.reserve(2 * Arena::al((size_t)(chunk + 8) * W * 8) + Arena::al((chunk + 8) * 8) + Arena::al((size_t)W * W * 8));
+    if (rc) return rc;
+    double* dZ = a.take<double>((size_t)(chunk + 8) * W);
+    double* dWr = a.take<double>((size_t)(chunk + 8) * W);
+    double* dw = a.take<double>(chunk + 8);
+    double* dPt = a.take<double>((size_t)W * W);
+    {   // PdT[f][j] = P[ref(j)][ref(f)]: P^T permuted to the device feature order, zero for padding features
+        std::vector<double> h((size_t)W * W, 0.0);
+        const int p = s.p;
+        for (int f = 0; f < W; ++f) {
+            const int rf = edmdc_dev_to_ref_feature(s, f);
+            if (rf < 0) continue;
+            for (int j = 0; j < W; ++j) {
+                const int rj = edmdc_dev_to_ref_feature(s, j);
+                if (rj >= 0) h[(size_t)f * W + j] = P_host[(size_t)rj * p + rf];
+            }
+        }
+        HIPCK(c, hipMemcpyAsync(dPt, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+    }
+    HIPCK(c, hipMemsetAsync(dWr, 0, (size_t)(chunk + 8) * W * 8, c->stream));   // the Gram kernel prefetches up to 8 rows past the chunk
+    CallTimer t(c);
+    if (total_pairs_rows == 0) HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
+    int first = 1;
+    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk) {
+        const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
+        const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
+        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
+        HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, dZ, dPt, dWr));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], npairs, dWr, dZ, dw, c->d_partial, first ? 0 : 1));
+        first = 0;
+    }
+    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], c->d_partial, 0, nullptr, d_M));
+    return BROV_OK;
+}
+
+int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
+                     const double* X, const double* U, const double* P, double* M) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !C || !P || !M || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply: bad argument");
+    DeviceGuard g(c);
+    if (nbags <= 1) { xs = L + 1; us = L; }
+    const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
+    const int d = n + k, p = d + r;
+    double *dX = nullptr, *dU = nullptr, *dC = nullptr, *dM = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dC); (void)hipFree(dM); };
+#define HIPCK_CLEAN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(c, e__, #call); } } while (0)
+    HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)(xrows > 0 ? xrows : 1) * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dU, (size_t)(urows > 0 ? urows : 1) * (r > 0 ? r : 1) * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
+    HIPCK_CLEAN(hipMalloc((void**)&dM, (size_t)p * d * 8));
+    if (xrows) HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)xrows * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (urows && r) HIPCK_CLEAN(hipMemcpyAsync(dU, U, (size_t)urows * r * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK_CLEAN(hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK_CLEAN(hipMemsetAsync(dM, 0, (size_t)p * d * 8, c->stream));
+    rc = edmdc_pinv_apply_dev(c, n, r, k, gamma, dC, nbags, L, xs, us, dX, dU, P, dM);
+    if (rc) { cleanup(); return rc; }
+    HIPCK_CLEAN(hipMemcpyAsync(M, dM, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(hipStreamSynchronize(c->stream));
+    cleanup();
     return BROV_OK;
 }
 
@@ -842,7 +996,6 @@ int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, 
     // inputs live in plain device allocations (the arena is used by edmdc_gram_dev itself)
     double *dX = nullptr, *dU = nullptr, *dC = nullptr, *dG = nullptr, *dY = nullptr;
     auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dC); (void)hipFree(dG); (void)hipFree(dY); };
-#define HIPCK_CLEAN(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(c, e__, #call); } } while (0)
     HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)(xrows > 0 ? xrows : 1) * n * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dU, (size_t)(urows > 0 ? urows : 1) * (r > 0 ? r : 1) * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
@@ -906,7 +1059,13 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     double* dxh = a.take<double>(nw * n);
     double* dtot = a.take<double>(8);
     HIPCK(c, hipMemcpyAsync(dX, X, N * n * 8, hipMemcpyHostToDevice, c->stream));
-    if (r) HIPCK(c, hipMemcpyAsync(dU, U, N * r * 8, hipMemcpyHostToDevice, c->stream));
+    // the windows read input rows 0 .. N-2 only (window k, step t uses U[k+t], k+t <= N-2): like the reference's
+    // multistep_rmse / evaluate, accept a U with N-1 rows and never touch row N-1 of the caller's buffer
+    const int64_t urows = N - 1;
+    if (r) {
+        HIPCK(c, hipMemsetAsync(dU + urows * r, 0, (size_t)r * 8, c->stream));
+        if (urows > 0) HIPCK(c, hipMemcpyAsync(dU, U, urows * r * 8, hipMemcpyHostToDevice, c->stream));
+    }
     HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
     rc = upload_ABt(c, s, A, B, dABt);
     if (rc) return rc;

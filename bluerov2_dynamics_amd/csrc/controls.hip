@@ -87,4 +87,25 @@ hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B,
     return hipGetLastError();
 }
 
+// ---- XCD placement probe ------------------------------------------------------------------------------
+// gram_kernel / propagate_kernel assume that blocks b and b + 8 land on the same XCD (round-robin dealing, observed on
+// gfx950, not promised by HIP).  Every block records the XCC id it runs on (HW_REG_XCC_ID = hwreg 20, bits 3:0).
+__global__ void __launch_bounds__(64) xcc_probe_kernel(int* __restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF);
+}
+// 1: blockIdx % 8 groups blocks by XCD; 0: it does not; -1: the probe itself failed.  Synchronous (context creation only).
+int probe_xcd_round_robin(hipStream_t st) {
+    constexpr int NB = 256;
+    int* d = nullptr;
+    if (hipMalloc((void**)&d, NB * sizeof(int)) != hipSuccess) return -1;
+    int h[NB];
+    hipLaunchKernelGGL(xcc_probe_kernel, dim3(NB), dim3(64), 0, st, d);
+    const bool ok = hipGetLastError() == hipSuccess && hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost) == hipSuccess;
+    (void)hipFree(d);
+    if (!ok) return -1;
+    for (int b = 8; b < NB; ++b) if (h[b] != h[b - 8]) return 0;
+    for (int a = 0; a < 8; ++a) for (int b = a + 1; b < 8; ++b) if (h[a] == h[b]) return 0;
+    return 1;
+}
+
 }  // namespace brov

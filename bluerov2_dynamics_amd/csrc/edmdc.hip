@@ -219,14 +219,15 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
 // (G^T Y part).  -1 = empty slot.
 struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; };
 
-static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks) {
+// mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T)
+static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, int mode) {
     const int nt = s.width / 16;                     // G tiles
     const int nty = s.kp / 16 + (s.n + 15) / 16;     // Y tiles: rbf block + the x part of the tail
     tasks.clear();
     for (int a0 = 0; a0 < nt; a0 += GRAM_TA) {
         std::vector<int> bl;
-        for (int tb = a0; tb < nt; ++tb) bl.push_back(tb);              // upper triangle of G^T G (block granularity)
-        for (int tb = 0; tb < nty; ++tb) bl.push_back(tb | 0x10000);    // all of G^T Y
+        if (mode == 0) for (int tb = a0; tb < nt; ++tb) bl.push_back(tb);   // upper triangle of G^T G (block granularity)
+        for (int tb = 0; tb < nty; ++tb) bl.push_back(tb | 0x10000);        // all of G^T Y
         for (size_t o = 0; o < bl.size(); o += GRAM_TB) {
             GramTask t;
             for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < nt) ? a0 + i : -1;
@@ -246,29 +247,36 @@ static int gram_nslab(int ntasks) {
     return ns;
 }
 
-size_t gram_partial_doubles(const EdmdcShape& s, int* ntasks_out, int* nslab_out) {
+size_t gram_partial_doubles(const EdmdcShape& s, int mode, int* ntasks_out, int* nslab_out) {
     std::vector<GramTask> tasks;
-    build_gram_tasks(s, tasks);
+    build_gram_tasks(s, tasks, mode);
     if (ntasks_out) *ntasks_out = (int)tasks.size();
     const int ns = gram_nslab((int)tasks.size());
     if (nslab_out) *nslab_out = ns;
     return tasks.size() * (size_t)ns * GRAM_TA * GRAM_TB * 256;
 }
 
-size_t gram_task_bytes() { return 256 * sizeof(GramTask); }
+size_t gram_task_bytes(const EdmdcShape& s, int mode) {
+    std::vector<GramTask> tasks;
+    build_gram_tasks(s, tasks, mode);
+    return tasks.size() * sizeof(GramTask);
+}
 
 // d_tasks: device copy of the task table (owned by the ctx, rebuilt when the shape changes)
-hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, void* d_tasks, size_t cap_bytes, int* ntasks) {
+hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, int mode, void* d_tasks, size_t cap_bytes, int* ntasks) {
     std::vector<GramTask> tasks;
-    build_gram_tasks(s, tasks);
+    build_gram_tasks(s, tasks, mode);
     *ntasks = (int)tasks.size();
     if (tasks.size() * sizeof(GramTask) > cap_bytes) return hipErrorInvalidValue;
     return hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(GramTask), hipMemcpyHostToDevice, st);
 }
 
+template <bool SEPARATE_A>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_total, const GramTask* __restrict__ tasks,
-            const double* __restrict__ Z, const double* __restrict__ wrow, double* __restrict__ partial, int accumulate) {
+            const double* __restrict__ ZA, const double* __restrict__ Z, const double* __restrict__ wrow, double* __restrict__ partial,
+            int accumulate) {
+    // ZA: rows the A tiles are cut from (== Z for the Gram; the rows of W = G P^T for edmdc_pinv_apply), same width W
     // XCD-aware item mapping: blocks b and b+8 share an XCD (observed round-robin, speed only); items are
     // ordered slab-major and each XCD takes a contiguous run, so the ~81 task-waves of a slab share one L2.
     const int bid = blockIdx.x;
@@ -302,11 +310,12 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
 
     if (ks0 < ks1) {
         const double* zp = Z + ks0 * 4 * W;       // wave-uniform base of the current 4 rows
+        const double* za = SEPARATE_A ? ZA + ks0 * 4 * W : zp;      // the Gram proper keeps a single row pointer
         const double* wp = wrow + ks0 * 4;
         double an[GRAM_TA], bn[GRAM_TB], wn;
         wn = wp[kq];
 #pragma unroll
-        for (int a = 0; a < GRAM_TA; ++a) an[a] = zp[aoff[a]];
+        for (int a = 0; a < GRAM_TA; ++a) an[a] = za[aoff[a]];
 #pragma unroll
         for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
         for (int64_t ks = ks0; ks < ks1; ++ks) {
@@ -318,10 +327,11 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
             // prefetch the next 4 rows while the 32 MFMAs below run (unconditional: the row buffer is
             // padded by 8 rows, and what the last step prefetches is never consumed)
             zp += 4 * W;
+            if constexpr (SEPARATE_A) za += 4 * W; else za = zp;
             wp += 4;
             wn = wp[kq];
 #pragma unroll
-            for (int a = 0; a < GRAM_TA; ++a) an[a] = zp[aoff[a]];
+            for (int a = 0; a < GRAM_TA; ++a) an[a] = za[aoff[a]];
 #pragma unroll
             for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
 #pragma unroll
@@ -350,13 +360,70 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
 }
 
 hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
-                                   const double* Zrows, const double* wrow, double* partial, int accumulate) {
+                                   const double* Arows, const double* Zrows, const double* wrow, double* partial, int accumulate) {
     const int64_t ksteps = (npairs + 3) / 4;
     const int nslab = gram_nslab(ntasks);
     const int per_xcd = (ntasks * nslab + 7) / 8;
-    hipLaunchKernelGGL(gram_kernel, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.width, ntasks, nslab, per_xcd, ksteps,
-                       reinterpret_cast<const GramTask*>(d_tasks), Zrows, wrow, partial, accumulate);
+    if (Arows == Zrows)
+        hipLaunchKernelGGL(gram_kernel<false>, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.width, ntasks, nslab, per_xcd, ksteps,
+                           reinterpret_cast<const GramTask*>(d_tasks), Arows, Zrows, wrow, partial, accumulate);
+    else
+        hipLaunchKernelGGL(gram_kernel<true>, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.width, ntasks, nslab, per_xcd, ksteps,
+                           reinterpret_cast<const GramTask*>(d_tasks), Arows, Zrows, wrow, partial, accumulate);
     return hipGetLastError();
+}
+
+// W rows for edmdc_pinv_apply: Wrows[row][j] = sum_f Zrows[row][f] PdT[f][j]  (PdT = P^T in device feature order, [W][W],
+// zero rows / columns for padding features), i.e. row t of W is (P g_t)^T, the t-th column of P G^T
+// (Koopman/koopmanEDMDc.py:97 evaluated left to right).  One wave = 16 rows x RXP_TB column tiles;
+// v_mfma_f64_16x16x4_f64 with A[i][k] = Z[row0+i][f0+k], B[k][j] = PdT[f0+k][j0+j].
+constexpr int RXP_TB = 17;
+__global__ void __launch_bounds__(64) rows_times_pt_kernel(int W, int64_t rows, const double* __restrict__ Zrows,
+                                                           const double* __restrict__ PdT, double* __restrict__ Wrows) {
+    const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
+    const int64_t row0 = (int64_t)blockIdx.x * 16;
+    const int j0 = blockIdx.y * (RXP_TB * 16);
+    v4d acc[RXP_TB];
+#pragma unroll
+    for (int b = 0; b < RXP_TB; ++b) acc[b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    int64_t ar = row0 + col;
+    if (ar >= rows) ar = rows - 1;                        // clamp: the clamped rows are never stored
+    const double* ap = Zrows + ar * W + kq;
+    const double* bp = PdT + (int64_t)kq * W + j0 + col;
+    for (int f0 = 0; f0 < W; f0 += 4) {
+        const double av = ap[f0];
+#pragma unroll
+        for (int b = 0; b < RXP_TB; ++b) {
+            const double bv = (j0 + b * 16 < W) ? bp[(int64_t)f0 * W + b * 16] : 0.0;      // wave-uniform predicate
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < RXP_TB; ++b) {
+        if (j0 + b * 16 >= W) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = row0 + kq + 4 * r;
+            if (row < rows) Wrows[row * W + j0 + b * 16 + col] = acc[b][r];
+        }
+    }
+}
+hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows) {
+    if (rows <= 0) return hipSuccess;
+    const int ntile = s.width / 16;
+    hipLaunchKernelGGL(rows_times_pt_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)((ntile + RXP_TB - 1) / RXP_TB)), dim3(64), 0, st,
+                       s.width, rows, Zrows, PdT, Wrows);
+    return hipGetLastError();
+}
+
+// device feature f (column of Zrows) -> reference feature index of G = [x | rbf | u] (or -1 for padding)
+int edmdc_dev_to_ref_feature(const EdmdcShape& s, int f) {
+    if (f < s.k) return s.n + f;
+    if (f < s.kp) return -1;
+    const int j = f - s.kp;
+    if (j < s.n) return j;
+    if (j < s.n + s.r) return s.d + (j - s.n);
+    return -1;
 }
 
 // Finish: one thread per (task, tile, lane, reg); sums the slabs in index order and scatters to the

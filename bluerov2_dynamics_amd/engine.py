@@ -13,7 +13,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
@@ -53,6 +53,7 @@ def _dptr(t):
 def rhs(model, x, u, dt=0.02, lag=None, ctx=None):
     """Batched dynamics().  Returns (xdot [B,nx], lag_after [B,8,3] or None)."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     x = as_f64(x).reshape(-1, NX[model])
     u = as_f64(u).reshape(-1, NU[model])
     B = x.shape[0]
@@ -68,6 +69,7 @@ def rhs(model, x, u, dt=0.02, lag=None, ctx=None):
 def thruster_forces(u, dt=0.02, lag=None, ctx=None):
     """Batched compute_thruster_forces().  Returns (tau [B,6], lag_after [B,8,3])."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     u = as_f64(u).reshape(-1, 8)
     B = u.shape[0]
     lag_io = np.zeros((B, 8, 3)) if lag is None else as_f64(lag).reshape(B, 8, 3).copy()
@@ -84,6 +86,7 @@ def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layou
     Returns dict(traj, xT [B,nx], lag [B,8,3] | None); traj is [B,T//stride+1,nx] or [T//stride+1,nx,B].
     return_lag=False with lag=None starts from a zero lag state and skips the per-thruster bookkeeping."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     integ, lay = INTEGRATORS[integrator], LAYOUTS[layout]
     nx, nu = NX[model], NU[model]
     U = as_f64(U)
@@ -106,6 +109,7 @@ def rollout(model, integrator, x0, U, dt, lag=None, lag_mode=LAG_PER_CALL, layou
 def window_endpoint_se(model, integrator, X, U, H, dt, carry_lag=True, ctx=None):
     """Sum of squared endpoint errors over all sliding windows; returns (se_total, per_window[N-H])."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     X = as_f64(X).reshape(-1, NX[model])
     U = as_f64(U).reshape(-1, NU[model])
     N = X.shape[0]
@@ -172,6 +176,7 @@ def window_endpoint_se_dev(model, integrator, X, U, H, dt, se_total, per_window,
 def lift(X, C, gamma, ctx=None):
     """phi(X) = [X, rbf(X)]  (KoopmanEDMDc._lift); X [N,n] -> [N,n+k]."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     X = as_f64(X)
     C = as_f64(C)
     N, n = X.shape
@@ -184,6 +189,7 @@ def lift(X, C, gamma, ctx=None):
 def gram(X_list, U_list, C, gamma, ctx=None):
     """G^T G [p,p] and G^T Y [p,d] over bags (no cross-bag pairs) -- fit / fit_multi normal equations."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     C = as_f64(C)
     k, n = C.shape
     r = np.asarray(U_list[0]).shape[1]
@@ -218,6 +224,7 @@ def kmeans_lloyd(X, C_init, max_iter=300, tol_abs=0.0, mean=None, ctx=None):
     """Lloyd iterations on the GPU (edmdc_kmeans_lloyd): returns (centres [k,n] in the frame of X - mean,
     labels [N] int32, inertia, n_iter)."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     X = as_f64(X)
     C = as_f64(C_init).copy()
     N, n = X.shape
@@ -320,6 +327,41 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
     return C + mean, inertia.value, n_iter.value
 
 
+def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
+    """M [p,d] = (P G^T) Y evaluated in that order over bags (KoopmanEDMDc.fit's association,
+    Koopman/koopmanEDMDc.py:97), P [p,p] = pinv(G^T G + ridge I) from the host."""
+    ctx = ctx or default_context()
+    ctx.use_null_stream()
+    C = as_f64(C)
+    P = as_f64(P)
+    k, n = C.shape
+    r = np.asarray(U_list[0]).shape[1]
+    d, p = n + k, n + k + r
+    assert P.shape == (p, p)
+    M = np.zeros((p, d))
+    for X, U in zip(X_list, U_list):
+        if len(X) < 2:
+            continue
+        X = as_f64(X)
+        L = len(X) - 1
+        Uc = as_f64(as_f64(U)[:L])
+        Mi = np.empty((p, d))
+        ctx.check(ctx.lib.edmdc_pinv_apply(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(Uc),
+                                           _hptr(P), _hptr(Mi)), "edmdc_pinv_apply")
+        M += Mi
+    return M
+
+
+def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None):
+    """(A, B) exactly as KoopmanEDMDc.fit associates the product (Koopman/koopmanEDMDc.py:97-101):
+    M = (pinv(G^T G + ridge I) @ G.T) @ Y, the pinv on the host (numpy, like the reference), the two large products on
+    the GPU.  Better conditioned than fit_multi's pinv(.) @ (G^T Y): at the class defaults (k = 200, ridge = 1e-8) the two
+    differ by 1e-6 in the H = 100 RMSE."""
+    P = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0]))
+    M = pinv_apply(X_list, U_list, C, gamma, P, ctx=ctx).T
+    return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
+
+
 def solve_AB(GtG, GtY, ridge, d):
     """Host solve of the ridge normal equations exactly as the reference does it
     (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
@@ -331,6 +373,7 @@ def solve_AB(GtG, GtY, ridge, d):
 def multistep_se(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
     """H-step lifted propagation + endpoint squared error (KoopmanEDMDc.multistep_rmse / evaluate)."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     X = as_f64(X)
     U = as_f64(U)
     C = as_f64(C)
@@ -339,6 +382,8 @@ def multistep_se(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
     N, n = X.shape
     k, r = C.shape[0], U.shape[1]
     ns = N - H
+    # like the reference (Koopman/koopmanEDMDc.py:172-200) accept len(U) == len(X) - 1: only rows 0..N-2 are ever read
+    assert U.shape[0] >= N - 1, f"U has {U.shape[0]} rows, need at least len(X) - 1 = {N - 1}"
     xhat = np.empty((max(ns, 0), n)) if want_xhat else None
     se = ctypes.c_double(0.0)
     ctx.check(ctx.lib.edmdc_multistep_se(ctx.h, n, r, k, float(gamma), _hptr(C), _hptr(A), _hptr(B), N, int(H), _hptr(X), _hptr(U),
@@ -349,6 +394,7 @@ def multistep_se(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
 def simulate_lifted(x0, U_seq, C, gamma, A, B, ctx=None):
     """KoopmanEDMDc.simulate, batched: x0 [nb,n], U_seq [nb,T,r] -> [nb,T+1,n]."""
     ctx = ctx or default_context()
+    ctx.use_null_stream()
     x0 = as_f64(x0)
     U_seq = as_f64(U_seq)
     nb, n = x0.shape

@@ -99,6 +99,10 @@ class BlueROV2(VehicleBase):
                 p.thr_r[i][k] = float(th["r"][k])
                 p.thr_dir[i][k] = float(th["dir"][k])
 
+    def _extra_key(self):
+        # thruster geometry is part of the change key: editing rov.thrusters_r[i]["r" | "dir"] takes effect on the next call
+        return tuple(float(v) for th in self.thrusters_r for name in ("r", "dir") for v in np.asarray(th[name], dtype=float).reshape(3))
+
     def _thruster_rotational_matrix(self, alpha):
         s, c = np.sin(alpha), np.cos(alpha)
         return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=float)

@@ -22,8 +22,6 @@ class VehicleBase:
         p = self._ctx.get_params()
         self.rho = rho
         self.g, self.m, self.volume = p.g, p.m, p.volume
-        self.W = self.m * self.g
-        self.B = self.rho * self.g * self.volume
         self.xg = self.yg = self.zg = 0.0
         self.xb, self.yb, self.zb = p.xb, p.yb, p.zb
         self.Ix, self.Iy, self.Iz = p.Ix, p.Iy, p.Iz
@@ -31,13 +29,54 @@ class VehicleBase:
             setattr(self, a, p.added_mass[i])
             setattr(self, l, p.lin_damp[i])
             setattr(self, l + "_abs", p.quad_damp[i])
-        self.MRB = np.diag([self.m, self.m, self.m, self.Ix, self.Iy, self.Iz]).astype(float)
-        self.MA = np.diag([-getattr(self, a) for a in _ATTR6]).astype(float)
-        self.M = self.MRB + self.MA
-        self.Minv = np.linalg.inv(self.M)
         self.current_speed = current_speed
         self._pushed = None
         self._params = p
+
+    # Derived quantities.  The reference stores W, B, MRB, MA, M, Minv as plain attributes computed once in __init__ and reads
+    # them on every dynamics() call (fossen/BlueROV2.py:96-126,340-355,391).  Here the device holds the primary constants
+    # (m, g, rho, volume, inertias, added mass), so the derived ones are views of those: reading always reflects the
+    # current primaries; B can be assigned (it maps onto `volume`); the others refuse assignment instead of silently
+    # ignoring it.
+    @property
+    def W(self):
+        return self.m * self.g
+
+    @W.setter
+    def W(self, v):
+        raise AttributeError("W is derived (m * g): set m or g")
+
+    @property
+    def B(self):
+        return self.rho * self.g * self.volume
+
+    @B.setter
+    def B(self, v):
+        self.volume = float(v) / (self.rho * self.g)
+
+    @property
+    def MRB(self):
+        return np.diag([self.m, self.m, self.m, self.Ix, self.Iy, self.Iz]).astype(float)
+
+    @property
+    def MA(self):
+        return np.diag([-getattr(self, a) for a in _ATTR6]).astype(float)
+
+    @property
+    def M(self):
+        return self.MRB + self.MA
+
+    @property
+    def Minv(self):
+        return np.linalg.inv(self.M)
+
+    def _derived_readonly(self, name):
+        raise AttributeError(f"{name} is derived from m, Ix..Iz and the added-mass attributes: set those")
+
+    MRB = MRB.setter(lambda self, v: self._derived_readonly("MRB"))
+    MA = MA.setter(lambda self, v: self._derived_readonly("MA"))
+    M = M.setter(lambda self, v: self._derived_readonly("M"))
+    Minv = Minv.setter(lambda self, v: self._derived_readonly("Minv"))
 
     def _sync_params(self):
         """Push attribute values that differ from what the device context holds."""
@@ -45,7 +84,7 @@ class VehicleBase:
         key = (float(self.rho), float(self.m), float(self.g), float(self.volume), float(self.zb), tuple(cur),
                tuple(float(getattr(self, a)) for a in _ATTR6),
                tuple(float(getattr(self, l)) for l in _LIN6), tuple(float(getattr(self, l + "_abs")) for l in _LIN6),
-               float(self.Ix), float(self.Iy), float(self.Iz), float(self.xb), float(self.yb))
+               float(self.Ix), float(self.Iy), float(self.Iz), float(self.xb), float(self.yb), self._extra_key())
         if key == self._pushed:
             return
         p = self._params
@@ -64,6 +103,10 @@ class VehicleBase:
 
     def _push_extra(self, p):
         pass
+
+    def _extra_key(self):
+        """Model-specific part of the change key (the thruster model adds its geometry)."""
+        return ()
 
     # ---- batched API (new; the reference only has the scalar dynamics()) --------------------
     def rollout(self, x0, U, dt, integrator="euler", lag=None, stride=1, lag_mode=_lib.LAG_PER_CALL):

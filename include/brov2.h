@@ -51,7 +51,8 @@ typedef enum brov_status {
     BROV_ERR_ARG = -1,     /* bad argument (NULL, negative size, unknown enum) */
     BROV_ERR_HIP = -2,     /* a HIP runtime call failed (message has hipGetErrorString) */
     BROV_ERR_NOMEM = -3,   /* device or host allocation failed */
-    BROV_ERR_NODEVICE = -4 /* no gfx950 device visible */
+    BROV_ERR_NODEVICE = -4,/* no gfx950 device visible (no GPU at all, or a GPU of another architecture) */
+    BROV_ERR_COMM = -5     /* RCCL missing or an RCCL call failed (brov_comm_last_error) */
 } brov_status;
 
 typedef enum brov_model {
@@ -93,6 +94,13 @@ BROV_API int brov_abi_version(void);
 BROV_API int brov_create(int device_id, brov_ctx** out);
 BROV_API void brov_destroy(brov_ctx* ctx);
 BROV_API const char* brov_last_error(const brov_ctx* ctx);
+/* 1 if a device whose hipDeviceProp_t.gcnArchName is `gcn_arch_name` can run this library ("gfx950[:features]"), else 0.
+ * brov_create applies it to the selected device and returns BROV_ERR_NODEVICE otherwise.  Host only. */
+BROV_API int brov_arch_is_supported(const char* gcn_arch_name);
+BROV_API int brov_device_arch(const brov_ctx* ctx, char* buf, size_t cap);   /* gcnArchName of the ctx's device */
+/* 1 if workgroups b and b+8 were seen to share an XCD when the ctx was created (the assumption behind the XCD-aware block
+ * numbering of the Gram / propagation kernels; speed only), 0 if not, -1 if the probe could not run. */
+BROV_API int brov_xcd_round_robin(const brov_ctx* ctx);
 BROV_API int brov_set_stream(brov_ctx* ctx, void* hip_stream);     /* hipStream_t; NULL = null stream */
 BROV_API int brov_sync(brov_ctx* ctx);                             /* hipStreamSynchronize(ctx stream) */
 /* HIP-event timing of the kernels launched by the most recent call on this ctx
@@ -193,7 +201,8 @@ BROV_API int edmdc_gram_dev(brov_ctx* ctx, int n, int r, int k, double gamma, co
 BROV_API int edmdc_set_chunk_rows(brov_ctx* ctx, int64_t rows);
 
 /* H-step propagation in lifted space + endpoint squared error: KoopmanEDMDc.multistep_rmse /
- * evaluate (Koopman/koopmanEDMDc.py:157-200).  X [N][n], U [N][r], A [d][d], B [d][r];
+ * evaluate (Koopman/koopmanEDMDc.py:157-200).  X [N][n], U [N-1][r] or longer (only rows 0..N-2 are read, as in the
+ * reference, which accepts len(U) == len(X) - 1), A [d][d], B [d][r];
  * se_total = sum over k < N-H and the n state coordinates of (X[k+H] - x_hat)^2;
  * rmse = sqrt(se_total / ((N-H) * n)).  xhat_end [N-H][n] optional (NULL). */
 BROV_API int edmdc_multistep_se(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
@@ -229,6 +238,38 @@ BROV_API int edmdc_kmeans_lloyd_dev(brov_ctx* ctx, int64_t N, int n, int k, cons
 BROV_API int edmdc_kmeanspp_dev(brov_ctx* ctx, int64_t N, int n, int k, const double* d_X, int64_t x_stride,
                                 const double* mean_host, int64_t first_index, int n_trials, const double* uniforms_host,
                                 double* d_C, int64_t* indices_host);
+
+/* KoopmanEDMDc.fit evaluates M = pinv(G^T G + ridge I) @ G.T @ Y left to right, i.e. (P G^T) Y
+ * (Koopman/koopmanEDMDc.py:97), whereas fit_multi forms P (G^T Y) (:147).  The two differ by the conditioning of the Gram
+ * (1e-6 in the H = 100 RMSE at the class defaults k = 200, ridge = 1e-8).  This entry point reproduces fit()'s order on
+ * the device: P [p][p] is the host's pinv of the regularised Gram (from edmdc_gram), rows W = G P^T are formed chunk by
+ * chunk (fp64 MFMA) and M [p][d] = W^T Y is accumulated over the same pairs as edmdc_gram.  Data layout as edmdc_gram. */
+BROV_API int edmdc_pinv_apply(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+                              int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
+                              const double* X, const double* U, const double* P, double* M);
+BROV_API int edmdc_pinv_apply_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
+                                  int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
+                                  const double* d_X, const double* d_U, const double* P_host, double* d_M);
+
+/* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
+ * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over
+ * ranks of the local [GtG | GtY] blocks (4.5 MB at k = 512), after which every rank solves the same p x p system.
+ * librccl is bound with dlopen at first use (BROV2_RCCL_LIBRARY overrides the search; a copy already mapped by the process,
+ * e.g. PyTorch's, is reused).  Rank 0 calls brov_comm_unique_id and hands the 128 bytes to the other ranks out of band
+ * (file, socket, MPI, torch.distributed store ...); every rank then calls brov_comm_init_rank (collective, blocks until
+ * all nranks have joined).  A communicator is bound to one device and is independent of any brov_ctx. */
+#define BROV_COMM_ID_BYTES 128
+typedef struct brov_comm brov_comm;
+BROV_API int brov_comm_available(void);                               /* 1 if librccl could be bound */
+BROV_API int brov_comm_unique_id(unsigned char id[BROV_COMM_ID_BYTES]);
+BROV_API int brov_comm_init_rank(int device_id, const unsigned char id[BROV_COMM_ID_BYTES], int nranks, int rank, brov_comm** out);
+BROV_API void brov_comm_destroy(brov_comm* comm);
+BROV_API int brov_comm_nranks(const brov_comm* comm);
+BROV_API int brov_comm_rank(const brov_comm* comm);
+BROV_API const char* brov_comm_last_error(const brov_comm* comm);
+/* In-place sum over all ranks of d_GtG (n_gtg doubles) and d_GtY (n_gty doubles), issued as ONE grouped RCCL all-reduce on
+ * `hip_stream` (hipStream_t, NULL = null stream; asynchronous: order later work on the same stream or synchronise it). */
+BROV_API int edmdc_gram_allreduce_dev(brov_comm* comm, double* d_GtG, int64_t n_gtg, double* d_GtY, int64_t n_gty, void* hip_stream);
 
 #ifdef __cplusplus
 }

@@ -52,6 +52,18 @@ def solve_AB(GtG, GtY, ridge, d):
     return M[:, :d], M[:, d:]
 
 
+def fit_single(X, U, C, gamma, ridge):
+    """KoopmanEDMDc.fit's own association (Koopman/koopmanEDMDc.py:94-101): M = pinv(G^T G + ridge I) @ G.T @ Y evaluated
+    left to right, i.e. (P G^T) Y -- better conditioned than fit_multi's P (G^T Y) (:147)."""
+    Z = lift(X[:-1], C, gamma)
+    Zp = lift(X[1:], C, gamma)
+    G = np.hstack([Z, U[:-1]])
+    M = np.linalg.pinv(G.T @ G + ridge * np.eye(G.shape[1])) @ G.T @ Zp
+    M = M.T
+    d = Z.shape[1]
+    return M[:, :d], M[:, d:]
+
+
 def fit(X_list, U_list, C, gamma, ridge):
     GtG, GtY, _ = gram(X_list, U_list, C, gamma)
     d = X_list[0].shape[1] + C.shape[0]

@@ -132,3 +132,58 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
     out = subprocess.check_output([str(exe)], text=True).split()
     g = load_golden("fossen_constants.npz")
     assert abs(float(out[0]) - g["Ad_0.02"][0, 0]) < 1e-15 and abs(float(out[1]) - g["Bd_0.02"][0]) < 1e-15 and float(out[2]) == 13.5
+
+
+def test_arch_gate_and_comm_entry_points(lib):
+    """brov_create refuses any device that is not gfx950 (BROV_ERR_NODEVICE): the predicate it applies is exported, so the
+    negative case is testable without such a device.  The RCCL entry points bind (dlopen) without a GPU."""
+    assert lib.brov_arch_is_supported(b"gfx950:sramecc+:xnack-") == 1
+    assert lib.brov_arch_is_supported(b"gfx950") == 1
+    for other in (b"gfx942:sramecc+:xnack-", b"gfx90a", b"gfx9500", b"", b"sm_90"):
+        assert lib.brov_arch_is_supported(other) == 0, other
+    assert lib.brov_arch_is_supported(None) == 0
+    assert lib.brov_comm_available() in (0, 1)
+    h = ctypes.c_void_p()
+    ident = (ctypes.c_ubyte * 128)()
+    assert lib.brov_comm_init_rank(0, ctypes.addressof(ident), 0, 0, ctypes.byref(h)) == -1      # nranks < 1: BROV_ERR_ARG
+    assert lib.brov_comm_init_rank(0, None, 1, 0, ctypes.byref(h)) == -1
+    assert lib.brov_comm_nranks(None) == -1 and lib.edmdc_gram_allreduce_dev(None, None, 0, None, 0, None) == -1
+
+
+def test_bench_refuses_to_measure_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` outside torch.distributed.run launches its own ranks or fails loudly; with fewer than N GPUs
+    visible (none here) it must exit non-zero before touching anything."""
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the self-launch would really run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "BROV2_BENCH_SHARE_GPU")}
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                         timeout=300, env=env)
+    assert out.returncode == 2 and "refusing" in out.stderr, (out.returncode, out.stderr[-300:])
+    # a world size that contradicts --gpus is refused as well
+    env2 = dict(env, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    if not torch.cuda.is_available():
+        return       # (the rank path needs a GPU to get as far as the check on a CPU-only host only via set_device: skip)
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env2)
+    assert out.returncode == 2
+
+
+def test_bench_instruction_counts_match_the_compiler_listing(tmp_path):
+    """bench.py prices the rollout kernel's issue-slot utilisation with the number of fp64 VALU instructions in its time
+    loop; re-derive that number from the compiler's own listing of the shipped source (tools/isa_count.py)."""
+    import importlib.util
+    import sys
+    from bluerov2_dynamics_amd import _build
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    asm = tmp_path / "rollout.s"
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBROV2_BUILDING=1", "--offload-device-only", "-S",
+                           "-o", str(asm), os.path.join(_build.CSRC, "rollout.hip")], stderr=subprocess.DEVNULL)
+    for integ, pat in (("rk4", "rollout_kernelILi0ELi1ELi2ELi0ELb0ELb0E"), ("euler", "rollout_kernelILi0ELi0ELi2ELi0ELb0ELb0E")):
+        out = subprocess.check_output([sys.executable, os.path.join(REPO, "tools", "isa_count.py"), str(asm), pat], text=True)
+        m = re.search(r"'f64': (\d+)", out)
+        assert m, out
+        # the listing's loop also holds the rarely taken range-extension blocks of trig_delta (a few dozen instructions)
+        assert abs(int(m.group(1)) - bench.ROLLOUT_EXEC_FP64_INSTR[integ]) <= 0.06 * bench.ROLLOUT_EXEC_FP64_INSTR[integ], (integ, out)

@@ -883,6 +883,301 @@ def test_sim_script_ensemble_against_oracle(eng, fc):
     assert abs(out["rmse_10"] - np.sqrt(se / cnt)) < 1e-6
 
 
+# ------------------------------------------------------------------------------------------ round 2: boundary / contract
+def test_bluerov_torch_rhs_on_the_rocm_device():
+    """SURVEY 8(a) last row: fossen/bluerov_torch.py stays PyTorch -- here on the ROCm device, called the way the reference's
+    physics_loss does (training/train_tank_brov2_full_comparison.py:747-757: under no_grad, batched and 1-D input)."""
+    import torch
+    from bluerov2_dynamics_amd.fossen.bluerov_torch import bluerov_compute, ssa
+    g = load_golden("torch_rhs.npz")
+    dev = torch.device("cuda")
+    x, u = torch.from_numpy(g["x"]).to(dev), torch.from_numpy(g["u"]).to(dev)
+    with torch.no_grad():
+        xd64 = bluerov_compute(0.0, x, u)
+        xd32 = bluerov_compute(0.0, x.float(), u.float())
+        one = bluerov_compute(0.0, x[3], u[3])
+        sa = ssa(torch.from_numpy(g["ang"]).to(dev))
+    assert xd64.is_cuda and xd64.dtype == torch.float64 and xd32.dtype == torch.float32
+    assert rel_err(xd64.cpu().numpy(), g["xdot64"]) < 1e-14
+    assert rel_err(xd32.cpu().numpy(), g["xdot32"]) < 1e-5
+    assert one.shape == (1, 9) and rel_err(one.cpu().numpy(), g["xdot_1d"]) < 1e-14
+    assert np.max(np.abs(sa.cpu().numpy() - g["ssa"])) < 1e-14
+
+
+def test_context_arch_xcd_probe_and_current_device_is_left_alone():
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    before = torch.cuda.current_device()
+    ctx = _lib.Context(0)
+    assert ctx.arch.startswith("gfx950")
+    assert ctx.xcd_round_robin in (0, 1)          # 1 on every box seen so far; 0 only costs speed
+    assert torch.cuda.current_device() == before
+    x = np.zeros((3, 12)); u = np.zeros((3, 8))
+    from bluerov2_dynamics_amd import engine
+    engine.rhs(_lib.THRUSTER_EULER, x, u, ctx=ctx)
+    assert torch.cuda.current_device() == before
+    if torch.cuda.device_count() > 1:             # a ctx on another device must not move torch's current device
+        c1 = _lib.Context(1)
+        engine.rhs(_lib.THRUSTER_EULER, x, u, ctx=c1)
+        assert torch.cuda.current_device() == before
+        c1.close()
+    ctx.close()
+
+
+def test_switching_streams_between_calls_is_ordered(eng):
+    """The scratch arena and the Gram partials belong to the ctx: a call on a new torch stream must wait for what the
+    previous call queued on the old one (brov_set_stream hands over with an event)."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.Context(0)
+    rng = np.random.default_rng(3)
+    n, r, k, nb, L = 12, 8, 64, 40, 300
+    X = torch.from_numpy(rng.normal(0, 0.4, (nb, L + 1, n))).cuda()
+    U = torch.from_numpy(rng.uniform(-1, 1, (nb, L, r))).cuda()
+    C = torch.from_numpy(rng.normal(0, 0.4, (k, n))).cuda()
+    p, d = n + k + r, n + k
+    ref = [torch.zeros((p, p), dtype=torch.float64, device="cuda"), torch.zeros((p, d), dtype=torch.float64, device="cuda")]
+    eng.gram_dev(X.view(-1, n), U.view(-1, r), C, 1.0, nb, L, L + 1, L, ref[0], ref[1], ctx=ctx)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for i in range(6):
+        G = torch.zeros((p, p), dtype=torch.float64, device="cuda")
+        Y = torch.zeros((p, d), dtype=torch.float64, device="cuda")
+        with torch.cuda.stream(s1 if i % 2 == 0 else s2):
+            eng.gram_dev(X.view(-1, n), U.view(-1, r), C, 1.0, nb, L, L + 1, L, G, Y, ctx=ctx)
+        outs.append((G, Y))
+    torch.cuda.synchronize()
+    for G, Y in outs:
+        assert torch.equal(G, ref[0]) and torch.equal(Y, ref[1])
+    # a host-path call afterwards goes back to the null stream (never a stale torch stream handle)
+    del s1, s2
+    Z = eng.lift(X[0, :5].cpu().numpy(), C.cpu().numpy(), 1.0, ctx=ctx)
+    assert Z.shape == (5, n + k) and ctx._stream == 0
+    ctx.close()
+
+
+def test_vehicle_attribute_edits_reach_the_device(fc):
+    """Editing thrusters_r / B on the drop-in object takes effect on the next call (the reference reads its attributes on
+    every dynamics() call); derived attributes that the device cannot honour refuse assignment instead of ignoring it."""
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import BlueROV2
+    rov = BlueROV2()
+    x = np.array([0.3, -0.2, 1.0, 0.1, -0.2, 0.7, 0.4, -0.3, 0.2, 0.05, -0.1, 0.2])
+    u = np.array([0.1, -0.2, 0.3, -0.4, 0.5, -0.6, 0.7, -0.8])
+    a = rov.dynamics(x, u, 0.02)
+    rov2 = BlueROV2()
+    rov2.thrusters_r[0]["r"] = rov2.thrusters_r[0]["r"] + np.array([0.05, 0.0, 0.0])     # nothing else changes
+    b = rov2.dynamics(x, u, 0.02)
+    assert np.max(np.abs(a - b)) > 1e-6
+    p = rov2._ctx.get_params()
+    assert abs(p.thr_r[0][0] - rov2.thrusters_r[0]["r"][0]) == 0.0
+    rov3 = BlueROV2()
+    W, B = rov3.W, rov3.B
+    assert abs(W - 13.5 * 9.82) < 1e-12 and abs(B - 1000.0 * 9.82 * 0.0134) < 1e-12 and rov3.Minv.shape == (6, 6)
+    rov3.B = B * 1.01                                                                     # more buoyancy: heave acceleration changes
+    c = rov3.dynamics(x, u, 0.02)
+    assert abs(rov3.volume - 0.0134 * 1.01) < 1e-15 and abs(c[8] - a[8]) > 1e-4
+    for name in ("W", "Minv", "M", "MRB", "MA"):
+        with pytest.raises(AttributeError):
+            setattr(rov3, name, 1.0)
+
+
+def test_multistep_accepts_inputs_one_row_shorter_than_states(eng):
+    """The reference's multistep_rmse / evaluate only read U[:N-1] (Koopman/koopmanEDMDc.py:172-200): len(U) == len(X) - 1
+    must work and give the same number as a padded U."""
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(11)
+    N, n, r, k = 700, 12, 8, 40
+    X = np.cumsum(rng.normal(0, 0.02, (N, n)), 0)
+    U = rng.uniform(-1, 1, (N, r))
+    C = X[rng.choice(N, k, replace=False)]
+    A, B = ek.fit([X], [U], C, 1.0, 1e-3)
+    A, B = np.ascontiguousarray(A), np.ascontiguousarray(B)
+    for H in (1, 10, 100):
+        se_full, _ = eng.multistep_se(X, U, C, 1.0, A, B, H)
+        # a U that ends exactly where the reads end, placed at the end of its buffer: an over-read would leave the array
+        Ushort = np.ascontiguousarray(U[:N - 1])
+        se_short, _ = eng.multistep_se(X, Ushort, C, 1.0, A, B, H)
+        assert se_short == se_full
+        want = ek.multistep_rmse(X, U, C, 1.0, A, B, H)
+        assert abs(np.sqrt(se_short / ((N - H) * n)) - want) < 1e-10
+    with pytest.raises(AssertionError):
+        eng.multistep_se(X, U[:N - 2], C, 1.0, A, B, 1)
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=1.0, ridge=1e-3)
+    m.centers_, m.A_, m.B_, m.lift_dim_ = C, A, B, n + k
+    assert abs(m.evaluate(X, U[:N - 1]) - ek.evaluate(X, U, C, 1.0, A, B)) < 1e-10
+
+
+def test_gram_with_more_than_256_tasks(eng):
+    """k = 1024 needs 295 Gram tasks: the task table is sized from the shape (it used to be a fixed 256-entry buffer)."""
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(2)
+    n, r, k, N = 12, 8, 1024, 1500
+    X = rng.normal(0, 0.5, (N, n))
+    U = rng.uniform(-1, 1, (N, r))
+    C = rng.normal(0, 0.5, (k, n))
+    GtG, GtY, npairs = eng.gram([X], [U], C, 0.5)
+    Go, Yo, _ = ek.gram([X], [U], C, 0.5)
+    assert npairs == N - 1
+    assert np.linalg.norm(GtG - Go) / np.linalg.norm(Go) < 1e-12 and np.linalg.norm(GtY - Yo) / np.linalg.norm(Yo) < 1e-12
+
+
+def test_fit_keeps_the_references_own_product_order(eng):
+    """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
+    (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
+    defaults (k = 200, ridge = 1e-8) and at the tank script's settings (k = 500, gamma = 3, ridge = 0.1) on 8 000 samples;
+    (3) the ill-conditioned 1 600-sample case where the two orders are 1e-6 apart at H = 100: fit() must land on the
+    reference's fit() figure, within north_star's 1e-6."""
+    from oracle import edmdc_numpy as ek
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    g = load_golden("edmdc_fit.npz")
+    X, U, ntr = g["X"], g["U"], int(g["n_train"])
+    # (1) the kernel pair (rows of W = G P^T, then W^T Y) on a small case, several bags of unequal length
+    rng = np.random.default_rng(0)
+    C = X[rng.choice(ntr, 40, replace=False)]
+    bags = [(0, 700), (700, 1500), (1500, 1903)]
+    Xl, Ul = [X[a:b] for a, b in bags], [U[a:b] for a, b in bags]
+    Go, Yo, _ = ek.gram(Xl, Ul, C, 1.0)
+    P = np.linalg.pinv(Go + 1e-6 * np.eye(Go.shape[0]))
+    M = eng.pinv_apply(Xl, Ul, C, 1.0, P)
+    Mo = np.zeros_like(M)
+    for Xb, Ub in zip(Xl, Ul):
+        G = np.hstack([ek.lift(Xb[:-1], C, 1.0), Ub[:-1]])
+        Mo += (P @ G.T) @ ek.lift(Xb[1:], C, 1.0)
+    assert np.linalg.norm(M - Mo) / np.linalg.norm(Mo) < 1e-12
+    # (2) fit() at the two settings
+    Xt, Ut = X[ntr:], U[ntr:]
+    for tag in ("def", "tank"):
+        m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=int(g[f"{tag}_k"]), gamma=float(g[f"{tag}_gamma"]), ridge=float(g[f"{tag}_ridge"]))
+        m.fit(X[:ntr], U[:ntr], centers=g[f"{tag}_centers"])
+        assert rel_err(m.A_[:32, :32], g[f"{tag}_A_block"]) < 1e-6 and rel_err(m.B_[:32], g[f"{tag}_B_block"]) < 1e-6, tag
+        assert rel_err(m.A_.sum(1), g[f"{tag}_A_rowsum"]) < 1e-6 and rel_err(m.A_.sum(0), g[f"{tag}_A_colsum"]) < 1e-6
+        assert abs(np.linalg.norm(m.A_) / float(g[f"{tag}_A_fro"]) - 1) < 1e-8
+        ours = np.array([m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)])
+        assert np.max(np.abs(ours - g[f"{tag}_ms_rmse"])) < 1e-7, (tag, ours - g[f"{tag}_ms_rmse"])       # north_star: 1e-6
+        assert abs(m.evaluate(Xt, Ut) - float(g[f"{tag}_eval_rmse"])) < 1e-8
+        assert rel_err(m.simulate(Xt[0], Ut[:100]), g[f"{tag}_sim100"]) < 1e-6
+    # (3) ill-conditioned: 1 599 pairs, 220 features, ridge 1e-8
+    e = load_golden("edmdc.npz")
+    Xs, Us, ns = e["X"], e["U"], int(e["n_train"])
+    m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=200, gamma=1.0, ridge=1e-8)
+    m.fit(Xs[:ns], Us[:ns], centers=g["small_centers"])
+    ours = np.array([m.multistep_rmse(Xs[ns:], Us[ns:], H) for H in (1, 10, 100)])
+    err = np.abs(ours - g["small_ms_rmse"])
+    print("fit() order, ill-conditioned case: |dRMSE| H=1/10/100 =", err, " (fit_multi's order would be",
+          np.abs(g["small_multi_order_ms_rmse"] - g["small_ms_rmse"]), ")")
+    assert np.max(err) < 1e-6, err
+
+
+def test_rccl_entry_points_single_rank():
+    """brov_comm_* / edmdc_gram_allreduce_dev on a one-rank communicator (all this box has): init, in-place all-reduce = identity,
+    destroy.  N > 1 runs at the driver's scaling bench; the two-rank logic is covered with gloo on CPU (test_dist_gloo_cpu.py)."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    if not _lib.Comm.available():
+        pytest.skip("librccl not loadable")
+    ident = _lib.Comm.unique_id()
+    assert len(ident) == 128 and any(ident)
+    comm = _lib.Comm(0, ident, 1, 0)
+    assert comm.lib.brov_comm_nranks(comm.h) == 1 and comm.lib.brov_comm_rank(comm.h) == 0
+    G = torch.randn(300, 300, dtype=torch.float64, device="cuda")
+    Y = torch.randn(300, 292, dtype=torch.float64, device="cuda")
+    G0, Y0 = G.clone(), Y.clone()
+    comm.allreduce_gram_(G, Y)
+    torch.cuda.synchronize()
+    assert torch.equal(G, G0) and torch.equal(Y, Y0)
+    comm.close()
+
+
+def test_timed_config2_launch_is_the_references_trajectories(eng, fc):
+    """THE launch bench.py times -- rollout_kernel<THRUSTER, RK4, TPB, per-call lag, untracked, reference vehicle>,
+    B = 65 536, T = 5 000, every state stored (52 GB) -- checked directly: lanes 0..7, every 50th state, against the states
+    the reference produced (fixture); random lanes against the C oracle; and lanes against themselves run alone."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from oracle import controls
+    g = load_golden("fossen_rollouts.npz")
+    B, T, dt, sub, seed = 65536, int(g["cfg2_T"]), float(g["cfg2_dt"]), int(g["cfg2_sub"]), int(g["cfg2_seed"])
+    assert T == 5000
+    U = torch.empty((T, 4, B, 2), dtype=torch.float64, device="cuda")
+    eng.fill_controls_dev(U, "tpb", "iid", seed=seed, b0=0, T_total=T)
+    x0 = torch.zeros((B, 12), dtype=torch.float64, device="cuda")
+    x0[:, 2] = 5.0
+    traj = torch.empty((T + 1, 6, B, 2), dtype=torch.float64, device="cuda")
+    xT = torch.empty((B, 12), dtype=torch.float64, device="cuda")
+    eng.rollout_dev(_lib.THRUSTER_EULER, "rk4", x0, U, dt, traj=traj, xT=xT, layout="tpb", stride=1)
+    torch.cuda.synchronize()
+
+    def lanes(idx, rows):
+        t = traj[rows][:, :, idx, :]                       # [rows, 6, lanes, 2]
+        return t.permute(2, 0, 1, 3).reshape(len(idx), len(rows), 12).cpu().numpy()
+
+    rows = list(range(0, T + 1, sub))
+    got = lanes(list(range(8)), rows)
+    assert rel_err(got, g["cfg2_rk4"]) < TOL_TRAJ
+    assert torch.equal(traj[-1].permute(1, 0, 2).reshape(B, 12), xT)
+    rng = np.random.default_rng(42)
+    pick = sorted(set(int(v) for v in rng.integers(0, B, 10)) | {63, 64, 255, 256, B - 1})
+    Uo = np.concatenate([controls.controls_iid(seed, b, 1, T) for b in pick])
+    o = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_RK4, np.tile(g["cfg2_x0"], (len(pick), 1)), Uo, dt, sub=sub, nthreads=8)
+    assert rel_err(lanes(pick, rows), o["traj"]) < TOL_TRAJ
+    r = eng.rollout(_lib.THRUSTER_EULER, "rk4", np.tile(g["cfg2_x0"], (len(pick), 1)), Uo, dt, stride=sub, return_lag=False)
+    assert rel_err(lanes(pick, rows), r["traj"]) < 1e-12       # another grid, another layout, same step function
+    assert torch.isfinite(xT).all()
+
+
+def test_config4_shard_rollouts_and_gram(eng, fc):
+    """BASELINE config 4 at the per-GPU shard of the 8-GPU run: 131 072 rollouts x 500 RK4 steps (AR(1) commands, global
+    trajectory indices of rank 3), trajectories stored [B][T+1][12], local lift + G^T[G|Y].
+      * lanes of the big launch against the C oracle on the same commands;
+      * the shard's Gram equals the sum of the Grams of its two halves (what the all-reduce adds up) to 1e-12, and its x-x
+        corners equal plain torch matmuls over all 6.5e7 pairs;
+      * a 96-trajectory slice of the shard against the NumPy oracle's Gram."""
+    import torch
+    from bluerov2_dynamics_amd import _lib, dist as bdist
+    from oracle import edmdc_numpy as ek
+    Bt, T, dt, n, r, k = 1 << 20, 500, 0.02, 12, 8, 512
+    b0, b1 = bdist.shard_range(Bt, 3, 8)
+    B = b1 - b0
+    assert B == 131072
+    U = torch.empty((B, T, r), dtype=torch.float64, device="cuda")
+    eng.fill_controls_dev(U, "btu", "ar1", seed=0xC0F4, b0=b0, T_total=T)
+    x0 = torch.zeros((B, n), dtype=torch.float64, device="cuda")
+    x0[:, 2] = 5.0
+    X = torch.empty((B, T + 1, n), dtype=torch.float64, device="cuda")
+    eng.rollout_dev(_lib.THRUSTER_EULER, "rk4", x0, U, dt, traj=X, layout="btu", stride=1)
+    torch.cuda.synchronize()
+    pick = [0, 1, 63, 64, 4095, 65536, B - 1]
+    Uh = U[pick].cpu().numpy()
+    o = fc.rollout(fc.MODEL_THRUSTER_EULER, fc.INTEG_RK4, x0[pick].cpu().numpy(), Uh, dt, sub=1, nthreads=8)
+    assert rel_err(X[pick].cpu().numpy(), o["traj"]) < TOL_TRAJ
+    C = X[:64].reshape(-1, n)[torch.randperm(64 * (T + 1), generator=torch.Generator().manual_seed(0))[:k]].contiguous()
+    p, d = n + k + r, n + k
+
+    def gram(lo, hi):
+        G = torch.zeros((p, p), dtype=torch.float64, device="cuda")
+        Y = torch.zeros((p, d), dtype=torch.float64, device="cuda")
+        eng.gram_dev(X[lo:hi].reshape(-1, n), U[lo:hi].reshape(-1, r), C, 1.0, hi - lo, T, T + 1, T, G, Y)
+        return G, Y
+
+    G, Y = gram(0, B)
+    Ga, Ya = gram(0, B // 2)
+    Gb, Yb = gram(B // 2, B)
+    torch.cuda.synchronize()
+    assert float(((Ga + Gb) - G).norm() / G.norm()) < 1e-12 and float(((Ya + Yb) - Y).norm() / Y.norm()) < 1e-12
+    Xa, Xb = X[:, :-1].reshape(-1, n), X[:, 1:].reshape(-1, n)
+    cgg, cgy = Xa.T @ Xa, Xa.T @ Xb
+    assert float((G[:n, :n] - cgg).norm() / cgg.norm()) < 1e-12 and float((Y[:n, :n] - cgy).norm() / cgy.norm()) < 1e-12
+    cuu = U.reshape(-1, r).T @ U.reshape(-1, r)
+    assert float((G[d:, d:] - cuu).norm() / cuu.norm()) < 1e-12
+    Gs, Ys = gram(1000, 1096)
+    Ub = [np.vstack([u, np.zeros((1, r))]) for u in U[1000:1096].cpu().numpy()]        # the oracle wants U aligned with X (N rows)
+    Go, Yo, _ = ek.gram(list(X[1000:1096].cpu().numpy()), Ub, C.cpu().numpy(), 1.0)
+    assert np.linalg.norm(Gs.cpu().numpy() - Go) / np.linalg.norm(Go) < 1e-12
+    assert np.linalg.norm(Ys.cpu().numpy() - Yo) / np.linalg.norm(Yo) < 1e-12
+
+
 def test_bench_prints_one_json_line_with_the_contract_fields():
     """bench.py at toy sizes: ONE JSON line on stdout with every field of the driver's contract, the roofline object
     of the dominant kernel and the CPU baseline (kind "port" = the C oracle on the host cores)."""
@@ -892,7 +1187,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     import sys
     from conftest import REPO
     cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1024", "--horizon", "40",
-           "--edmdc-samples", "40000", "--edmdc-steps", "1", "--kmeans-iters", "2", "--cpu-seconds", "0.3"]
+           "--edmdc-samples", "40000", "--edmdc-steps", "1", "--kmeans-iters", "2", "--cpu-seconds", "0.3",
+           "--cfg4-rollouts", "4096", "--cfg4-horizon", "50"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -913,3 +1209,11 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
         assert k in d["cpu_baseline"] and k in d["edmdc"]["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
     assert d["edmdc"]["A_finite"] and d["edmdc"]["multistep_rmse_H100"]["finite"]
+    # round 2: the timed launches are verified, the AR(1) variant and config 4 are there, the reference-shaped CPU loop is timed
+    assert d["verified"]["ok"] and d["verified"]["max_rel_err"] <= 1e-9
+    assert d["rollout_ar1"]["finite"] and d["rollout_ar1"]["value"] > 0
+    c4 = d["config4"]
+    assert c4["scaling"] == "strong" and c4["total_rollouts"] == 4096 and c4["rccl_ranks"] == 1 and c4["verified"]["ok"]
+    assert len(c4["per_rank_ms"]) == 1 and c4["rollout_steps_per_s"] > 0 and c4["gram_samples_per_s"] > 0
+    assert d["cpu_baseline_reference_shape"]["cores"] == 1 and d["cpu_baseline_reference_shape"]["value"] > 0
+    assert d["roofline"]["bound"] == "valu_fp64_issue" and 0 < d["roofline"]["frac"] <= 1.0

@@ -210,3 +210,47 @@ def test_simscript_dataset_and_scores():
     Xte, Ute = g["X"][split - 1:], g["U"][split - 1:]
     got = [ek.evaluate(Xte, Ute, g["centers"], 1.0, A, B)] + [ek.multistep_rmse(Xte, Ute, g["centers"], 1.0, A, B, H) for H in (10, 100)]
     assert np.max(np.abs(np.array(got) - g["rmse"])) < 1e-8
+
+
+def test_scalar_reference_shaped_restatement_matches_reference_rollouts():
+    """oracle/fossen_scalar.py (the per-call NumPy loop bench.py times as `cpu_baseline_reference_shape`) against the
+    reference's own states: config-2 stream, trajectory 0, first 400 RK4 and Euler steps, every 50th state."""
+    import warnings
+    from oracle import fossen_scalar as fs
+    g = load_golden("fossen_rollouts.npz")
+    T, dt, sub = 400, float(g["cfg2_dt"]), int(g["cfg2_sub"])
+    U = controls.controls_iid(int(g["cfg2_seed"]), 0, 1, int(g["cfg2_T"]))[0][:T]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for integ, key in (("rk4", "cfg2_rk4"), ("euler", "cfg2_euler")):
+            tr = fs.simulate(g["cfg2_x0"], U, dt, integ)
+            assert rel_err(tr[::sub], g[key][0][: T // sub + 1]) < 1e-13, integ
+        # and against the C oracle on a random state / command (one dynamics() call, fresh lag)
+        rng = np.random.default_rng(5)
+        x, u = rng.uniform(-0.5, 0.5, 12), rng.uniform(-1, 1, 8)
+        xd = fs.ScalarBlueROV2().dynamics(x, u, 0.02)
+    xo, _ = fc.rhs(0, x[None], u[None], 0.02, lag=np.zeros((1, 8, 3)))
+    assert rel_err(xd, xo[0]) < 1e-12
+
+
+def test_edmdc_fit_order_fixture_defaults_and_tank_settings():
+    """KoopmanEDMDc.fit's own association (pinv G^T) Y (Koopman/koopmanEDMDc.py:97) at the class defaults and at the tank
+    script's settings: the NumPy oracle in that order reproduces the reference's A, B and H = 1/10/100 RMSE; and the fixture
+    itself records what fit_multi's order would have cost (1e-6 at H = 100 in the ill-conditioned 1 600-sample case)."""
+    g = load_golden("edmdc_fit.npz")
+    X, U, ntr = g["X"], g["U"], int(g["n_train"])
+    for tag in ("def", "tank"):
+        C, gamma, ridge = g[f"{tag}_centers"], float(g[f"{tag}_gamma"]), float(g[f"{tag}_ridge"])
+        A, B = ek.fit_single(X[:ntr], U[:ntr], C, gamma, ridge)
+        assert rel_err(A[:32, :32], g[f"{tag}_A_block"]) < 1e-7 and rel_err(B[:32], g[f"{tag}_B_block"]) < 1e-7
+        assert abs(np.linalg.norm(A) / float(g[f"{tag}_A_fro"]) - 1) < 1e-9
+        ms = np.array([ek.multistep_rmse(X[ntr:], U[ntr:], C, gamma, A, B, H) for H in (1, 10, 100)])
+        assert np.max(np.abs(ms - g[f"{tag}_ms_rmse"])) < 1e-8, (tag, ms - g[f"{tag}_ms_rmse"])
+        assert np.max(np.abs(g[f"{tag}_multi_order_ms_rmse"] - g[f"{tag}_ms_rmse"])) < 1e-8      # well conditioned: orders agree
+    e = load_golden("edmdc.npz")
+    Xs, Us, ns = e["X"], e["U"], int(e["n_train"])
+    A, B = ek.fit_single(Xs[:ns], Us[:ns], g["small_centers"], 1.0, 1e-8)
+    ms = np.array([ek.multistep_rmse(Xs[ns:], Us[ns:], g["small_centers"], 1.0, A, B, H) for H in (1, 10, 100)])
+    assert np.max(np.abs(ms - g["small_ms_rmse"])) < 1e-7, ms - g["small_ms_rmse"]
+    # the reference's own two orders, as recorded: 1.06e-6 apart at H = 100 -- above north_star's 1e-6
+    assert abs(g["small_multi_order_ms_rmse"][2] - g["small_ms_rmse"][2]) > 5e-7

@@ -13,6 +13,8 @@ Fixtures (all float64):
                         (every 50th state) + wrench / quaternion rollouts
   windows.npz           multistep_rmse_endpoint_physics (lag carried across windows)
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
+  edmdc_fit.npz         KoopmanEDMDc.fit at the class defaults (k=200, ridge=1e-8) and the tank script's settings (k=500, gamma=3,
+                        ridge=0.1) on 10 000 samples: the cases where fit()'s own product order matters
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
   torch_rhs.npz         fossen/bluerov_torch.py bluerov_compute / ssa on random batches
   simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
@@ -313,6 +315,56 @@ def gen_edmdc():
     np.savez(os.path.join(OUT, "edmdc.npz"), **out)
 
 
+def gen_edmdc_fit():
+    """KoopmanEDMDc.fit at the settings where the association of M = pinv(G^T G + ridge I) @ G.T @ Y matters
+    (Koopman/koopmanEDMDc.py:97 evaluates it left to right): the dataclass defaults (n_rbfs=200, gamma=1, ridge=1e-8, :56-61)
+    and the tank script's settings (N_RBFS=500, GAMMA=3.0, RIDGE=1e-1, training/train_tank_brov2_full_comparison.py:40-44),
+    on a 10 000-sample recording-like data set (8 000 train / 2 000 test).  A and B are too large to store whole (k = 500:
+    2 MB): the fixture keeps the scores, a corner block, row / column sums and norms."""
+    N, ntr, dt = 10000, 8000, 0.05
+    X, U = _sim_dataset(N, dt, seed=2024)
+    out = dict(X=X, U=U, n_train=np.int64(ntr), dt=np.float64(dt))
+    Xt, Ut = X[ntr:], U[ntr:]
+    for tag, k, gamma, ridge in (("def", 200, 1.0, 1e-8), ("tank", 500, 3.0, 1e-1)):
+        m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge)
+        m.fit(X[:ntr], U[:ntr])
+        out.update({f"{tag}_k": np.int64(k), f"{tag}_gamma": np.float64(gamma), f"{tag}_ridge": np.float64(ridge),
+                    f"{tag}_centers": m.centers_,
+                    f"{tag}_A_block": m.A_[:32, :32].copy(), f"{tag}_B_block": m.B_[:32].copy(),
+                    f"{tag}_A_rowsum": m.A_.sum(1), f"{tag}_A_colsum": m.A_.sum(0), f"{tag}_B_colsum": m.B_.sum(0),
+                    f"{tag}_A_fro": np.float64(np.linalg.norm(m.A_)), f"{tag}_B_fro": np.float64(np.linalg.norm(m.B_)),
+                    f"{tag}_eval_rmse": np.float64(m.evaluate(Xt, Ut)),
+                    f"{tag}_ms_rmse": np.array([m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)]),
+                    f"{tag}_train_ms_rmse": np.array([m.multistep_rmse(X[:ntr], U[:ntr], H) for H in (1, 10, 100)]),
+                    f"{tag}_sim100": m.simulate(Xt[0], Ut[:100])})
+        # the same data through fit_multi's association (one bag): quantifies what the order of the products is worth
+        m2 = RefKoopman(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge)
+        m2.centers_ = m.centers_
+        Z, Zp = m._lift(X[:ntr - 1]), m._lift(X[1:ntr])
+        G = np.hstack([Z, U[:ntr - 1]])
+        M2 = (np.linalg.pinv(G.T @ G + ridge * np.eye(G.shape[1])) @ (G.T @ Zp)).T
+        m2.A_, m2.B_, m2.lift_dim_ = M2[:, :Z.shape[1]], M2[:, Z.shape[1]:], Z.shape[1]
+        out[f"{tag}_multi_order_ms_rmse"] = np.array([m2.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)])
+        out[f"{tag}_multi_order_relA"] = np.float64(np.linalg.norm(m2.A_ - m.A_) / np.linalg.norm(m.A_))
+    # the ill-conditioned case: the class defaults on the 1 600-sample training set of edmdc.npz (1 599 pairs for 220
+    # features, ridge 1e-8) -- here the two orders differ by 1e-6 in the H = 100 RMSE
+    e = np.load(os.path.join(OUT, "edmdc.npz"))
+    Xs, Us, ns = e["X"], e["U"], int(e["n_train"])
+    m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=200, gamma=1.0, ridge=1e-8)
+    m.fit(Xs[:ns], Us[:ns])
+    Z, Zp = m._lift(Xs[:ns - 1]), m._lift(Xs[1:ns])
+    G = np.hstack([Z, Us[:ns - 1]])
+    M2 = (np.linalg.pinv(G.T @ G + 1e-8 * np.eye(G.shape[1])) @ (G.T @ Zp)).T
+    m2 = RefKoopman(state_dim=12, input_dim=8, n_rbfs=200, gamma=1.0, ridge=1e-8)
+    m2.centers_, m2.A_, m2.B_, m2.lift_dim_ = m.centers_, M2[:, :Z.shape[1]], M2[:, Z.shape[1]:], Z.shape[1]
+    out.update(small_centers=m.centers_, small_A=m.A_, small_B=m.B_,
+               small_ms_rmse=np.array([m.multistep_rmse(Xs[ns:], Us[ns:], H) for H in (1, 10, 100)]),
+               small_multi_order_ms_rmse=np.array([m2.multistep_rmse(Xs[ns:], Us[ns:], H) for H in (1, 10, 100)]),
+               small_multi_order_relA=np.float64(np.linalg.norm(m2.A_ - m.A_) / np.linalg.norm(m.A_)))
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "edmdc_fit.npz"), **out)
+
+
 # --------------------------------------------------------------------------- double integrator
 def gen_di():
     """Learned double-integrator baseline of the comparison scripts: estimate_di_gains,
@@ -467,7 +519,7 @@ def gen_simscript():
              pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
 
 
-GENS = dict(torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc)
+GENS = dict(torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
