@@ -60,21 +60,40 @@ struct FastParams {
 typedef const FastParams __attribute__((address_space(4)))* CFP;
 __device__ __forceinline__ CFP as_constant(const FastParams* g) { return (CFP)(unsigned long long)g; }
 
-struct HotConsts {
+// RESIDENT: the stage constants (da, G, ld, al4) are held in SGPRs for the whole launch (kernels whose time loop leaves the
+// scalar register file room for them: the body wave of rollout_pair_kernel); otherwise they are re-read through the
+// per-step laundered pointer, so that no loop-invariant SGPRs have to be spilled around the sin/cos literals and the
+// per-step scalar loads.  E and db are pinned in VGPRs either way (fma(db, |nu|, da) needs a non-scalar second constant).
+template <bool RES>
+struct HotConstsT {
+    static constexpr bool RESIDENT = RES;
     double E[12], db[6];
+    double da[6], G[5], ld[4], al4[3];     // RESIDENT only
 };
+typedef HotConstsT<false> HotConsts;
+typedef HotConstsT<true> HotConstsResident;
 
 #define BROV_PIN_V(x) asm volatile("" : "+v"(x))
+#define BROV_PIN_S(x) asm volatile("" : "+s"(x))
+#define BROV_SC(h, p, f) (HC::RESIDENT ? (h).f : (p)->f)
 
-// E and db are pinned in VGPRs for the whole launch (fma(db, |nu|, da) needs a non-scalar second constant
-// anyway); G and da are re-read through the per-step laundered pointer as scalar operands, so that no
-// loop-invariant SGPRs have to be spilled around the sin/cos literals and the per-step scalar loads.
-__device__ __forceinline__ void load_hot(CFP pp, HotConsts& h) {
+template <bool RES>
+__device__ __forceinline__ void load_hot(CFP pp, HotConstsT<RES>& h) {
     const auto& p = *pp;
 #pragma unroll
     for (int i = 0; i < 12; ++i) { h.E[i] = p.E[i]; BROV_PIN_V(h.E[i]); }
 #pragma unroll
     for (int i = 0; i < 6; ++i) { h.db[i] = p.db[i]; BROV_PIN_V(h.db[i]); }
+    if constexpr (RES) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { h.da[i] = p.da[i]; BROV_PIN_S(h.da[i]); }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { h.G[i] = p.G[i]; BROV_PIN_S(h.G[i]); }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h.ld[i] = p.ld[i]; BROV_PIN_S(h.ld[i]); }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { h.al4[i] = p.al4[i]; BROV_PIN_S(h.al4[i]); }
+    }
 }
 
 // pointer laundering: makes the compiler re-issue the (scalar) loads behind `p` at this point
@@ -198,8 +217,8 @@ __device__ __forceinline__ double recip_fast(double x) {
 // GENERIC = false is the reference's vehicle (no current, xb = yb = 0): one straight-line block per stage.  The
 // uniform branches of the generic form cost a scalar load + wait + branch each and stop the scheduler from
 // overlapping a stage's scalar constant loads with its sin/cos work.
-template <bool GENERIC>
-__device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const double R[9], const double nu[6],
+template <bool GENERIC, class HC>
+__device__ __forceinline__ void nu_dot_fast(const HC& h, CFP p, const double R[9], const double nu[6],
                                             const double a[6], double sth, double ctsp, double ctcp, double out[6]) {
     const double u = nu[0], v = nu[1], w = nu[2], pp = nu[3], q = nu[4], r = nu[5];
     double nr0 = u, nr1 = v, nr2 = w;
@@ -214,17 +233,17 @@ __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const dou
     double o3 = fma(-h.E[6], v * w, a[3]);  o3 = fma(-h.E[7], q * r, o3);
     double o4 = fma(-h.E[8], u * w, a[4]);  o4 = fma(-h.E[9], pp * r, o4);
     double o5 = fma(-h.E[10], u * v, a[5]); o5 = fma(-h.E[11], pp * q, o5);
-    o0 = fma(-fma(h.db[0], fabs(nr0), p->da[0]), nr0, o0);
-    o1 = fma(-fma(h.db[1], fabs(nr1), p->da[1]), nr1, o1);
-    o2 = fma(-fma(h.db[2], fabs(nr2), p->da[2]), nr2, o2);
-    o3 = fma(-fma(h.db[3], fabs(pp), p->da[3]), pp, o3);
-    o4 = fma(-fma(h.db[4], fabs(q), p->da[4]), q, o4);
-    o5 = fma(-fma(h.db[5], fabs(r), p->da[5]), r, o5);
-    o0 = fma(-p->G[0], sth, o0);
-    o1 = fma(p->G[1], ctsp, o1);
-    o2 = fma(p->G[2], ctcp, o2);
-    o3 = fma(p->G[3], ctsp, o3);
-    o4 = fma(p->G[4], sth, o4);
+    o0 = fma(-fma(h.db[0], fabs(nr0), BROV_SC(h, p, da[0])), nr0, o0);
+    o1 = fma(-fma(h.db[1], fabs(nr1), BROV_SC(h, p, da[1])), nr1, o1);
+    o2 = fma(-fma(h.db[2], fabs(nr2), BROV_SC(h, p, da[2])), nr2, o2);
+    o3 = fma(-fma(h.db[3], fabs(pp), BROV_SC(h, p, da[3])), pp, o3);
+    o4 = fma(-fma(h.db[4], fabs(q), BROV_SC(h, p, da[4])), q, o4);
+    o5 = fma(-fma(h.db[5], fabs(r), BROV_SC(h, p, da[5])), r, o5);
+    o0 = fma(-BROV_SC(h, p, G[0]), sth, o0);
+    o1 = fma(BROV_SC(h, p, G[1]), ctsp, o1);
+    o2 = fma(BROV_SC(h, p, G[2]), ctcp, o2);
+    o3 = fma(BROV_SC(h, p, G[3]), ctsp, o3);
+    o4 = fma(BROV_SC(h, p, G[4]), sth, o4);
     if (GENERIC && p->has_xy) {        // xb, yb != 0: never for the reference's vehicle
         o3 = fma(-p->XY[0], ctcp, o3);
         o4 = fma(p->XY[1], ctcp, o4);
@@ -235,8 +254,8 @@ __device__ __forceinline__ void nu_dot_fast(const HotConsts& h, CFP p, const dou
 }
 
 // xdot for the Euler-angle state; a = Minv tau
-template <bool GENERIC>
-__device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const double x[12], const double a[6], double xd[12], const Trig& tg) {
+template <bool GENERIC, class HC>
+__device__ __forceinline__ void rhs_fast_euler(const HC& h, CFP p, const double x[12], const double a[6], double xd[12], const Trig& tg) {
     const double sphi = tg.sphi, cphi = tg.cphi, sth = tg.sth, cth = tg.cth, spsi = tg.spsi, cpsi = tg.cpsi;   // x[3..5] enter only through these
     const double* nu = x + 6;
     const double ctsp = cth * sphi, ctcp = cth * cphi;         // R[7], R[8]
@@ -268,8 +287,8 @@ __device__ __forceinline__ void rhs_fast_euler(const HotConsts& h, CFP p, const 
     xd[5] = ic * m;
 }
 
-template <bool GENERIC>
-__device__ __forceinline__ void rhs_fast_quat(const HotConsts& h, CFP p, const double x[13], const double a[6], double xd[13]) {
+template <bool GENERIC, class HC>
+__device__ __forceinline__ void rhs_fast_quat(const HC& h, CFP p, const double x[13], const double a[6], double xd[13]) {
     double q[4] = {x[3], x[4], x[5], x[6]};
     quat_normalize(q);
     const double qw = q[0], qx = q[1], qy = q[2], qz = q[3];
@@ -323,8 +342,8 @@ __device__ __forceinline__ void rhs_di_quat(const double x[13], const double a[6
 }
 
 // tg: sin/cos of x[3..5] for the Euler-angle models (ignored by the quaternion ones)
-template <int MODEL, bool GENERIC>
-__device__ __forceinline__ void rhs_fast(const HotConsts& h, CFP p, const double* x, const double a[6], double* xd, const Trig& tg) {
+template <int MODEL, bool GENERIC, class HC>
+__device__ __forceinline__ void rhs_fast(const HC& h, CFP p, const double* x, const double a[6], double* xd, const Trig& tg) {
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) rhs_di_quat(x, a, xd);
     else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd, tg);
     else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat<GENERIC>(h, p, x, a, xd);
@@ -370,13 +389,14 @@ struct LagZ {
             z[k][2] = fma(p->Ob[8], a2, fma(p->Ob[7], a1, p->Ob[6] * a0));
         }
     }
-    __device__ __forceinline__ void obs_accel_after(CFP p, int s, const double acmd[6], double a[6]) const {
+    template <class HC>
+    __device__ __forceinline__ void obs_accel_after(const HC& h, CFP p, int s, const double acmd[6], double a[6]) const {
         if (s <= 3) {
-            const double d = p->ld[s - 1];
+            const double d = BROV_SC(h, p, ld[s - 1]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) a[k] = fma(d, acmd[k], z[k][s - 1]);
         } else {
-            const double c0 = p->al4[0], c1 = p->al4[1], c2 = p->al4[2], d = p->ld[3];
+            const double c0 = BROV_SC(h, p, al4[0]), c1 = BROV_SC(h, p, al4[1]), c2 = BROV_SC(h, p, al4[2]), d = BROV_SC(h, p, ld[3]);
 #pragma unroll
             for (int k = 0; k < 6; ++k) a[k] = fma(c2, z[k][2], fma(c1, z[k][1], fma(c0, z[k][0], d * acmd[k])));
         }
@@ -461,35 +481,46 @@ __device__ __forceinline__ void command_accel(CFP p, const double* u, double fcm
     }
 }
 
-// One integrator step.  TRACK: also advance the per-thruster lag state X (for lag_io).
+// ---- one integrator step, in two halves ------------------------------------------------------------
+// The thruster model's step separates cleanly: the THRUST half (polynomial, allocation, lag bank) never looks at the
+// vehicle state, the BODY half (rigid-body right-hand sides + the integrator) sees the thrust only as the acceleration
+// a_s = Minv tau of its s-th dynamics() call.  step_fast runs both in one lane; rollout_pair_kernel (rollout.hip) gives
+// each half its own wave.
+//
+// BODY: integrate_fast.  accel(s, a) delivers the commanded acceleration seen by the s-th dynamics() call of the step
+// (s = 1..4 for RK4; quirk Q1: the reference's lag filters advance on every call, so the four stages see different thrust).
 // RK4 is accumulated as xn = x + dt/6 k1 + dt/3 k2 + dt/3 k3 + dt/6 k4 (four FMAs per state instead of forming
 // k1 + 2 k2 + 2 k3 + k4 first; same value up to rounding, 24 instructions fewer per step).
-template <int MODEL, int INTEG, int LAGMODE, bool TRACK, bool GENERIC>
-__device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt, double* x, const double* u,
-                                          LagZ& lz, double X[8][3], const double2* qt) {
+// carry != nullptr: the sin/cos of the angles at the start of the step are carried over from the end of the previous step,
+// where they were advanced by the addition theorem on the step's angle increment (trig_delta: 15 instructions per angle
+// instead of 27 + a table look-up); `refresh` (wave-uniform) forces the full evaluation, which callers request every 64
+// steps so that the accumulated rounding (a few ulp per update) stays ~1e-14.
+template <int MODEL, int INTEG, bool GENERIC, class HC, class AccelFn>
+__device__ __forceinline__ void integrate_fast(const HC& h, CFP p, double dt, double* x, AccelFn&& accel,
+                                               const double2* qt, Trig* carry, bool refresh) {
     constexpr int NX = Dims<MODEL>::NX;
-    constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
-    constexpr bool OBS = !GENERIC;                       // lag state held in the observer basis (kernels call to_observer once)
     constexpr bool ANG = !model_is_quat(MODEL);          // x[3..5] are Euler angles
-    CFP p = relaunder(p0);
-    double fcmd[8], acmd[6], a[6];
-    if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) quat_normalize(x + 3);   // the reference normalises q before its update (wrench_quat.py:339)
-    command_accel<MODEL, !GENERIC>(p, u, fcmd, acmd);
-    auto accel = [&](CFP pp, int s) {
-        if constexpr (THR) { if constexpr (OBS) lz.obs_accel_after(pp, s, acmd, a); else lz.accel_after(pp, s, acmd, a); }
-    };
+    double a[6];
     Trig tb, ts;
-    if constexpr (ANG) trig_full(x + 3, tb, qt);
+    const bool CARRY = ANG && carry != nullptr;
+    if constexpr (ANG) {
+        if (!CARRY || refresh) trig_full(x + 3, tb, qt);
+        else tb = *carry;
+    }
+    double dang[3];          // angle increment of the whole step (carry only)
     if constexpr (INTEG == INTEG_EULER) {
         double k[NX];
-        accel(p, 1);
-        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, tb);
+        accel(1, a);
+        rhs_fast<MODEL, GENERIC>(h, p, x, a, k, tb);
+        if (CARRY) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
-        if constexpr (THR) {
-            CFP pl = relaunder(p0);
-            if constexpr (OBS) lz.obs_advance1(pl, acmd); else lz.advance(pl->A1, pl->b1, acmd);
-            if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
+            for (int i = 0; i < NX; ++i) {
+                if (i >= 3 && i < 6) { dang[i - 3] = dt * k[i]; x[i] += dang[i - 3]; }
+                else x[i] = fma(dt, k[i], x[i]);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = fma(dt, k[i], x[i]);
         }
     } else {
         double k[NX], xn[NX], xs[NX], dl[3];
@@ -504,37 +535,77 @@ __device__ __forceinline__ void step_fast(const HotConsts& h, CFP p0, double dt,
             }
             if constexpr (ANG) trig_delta(tb, dl, ts);
         };
-        accel(p, 1);
-        rhs_fast<MODEL, GENERIC>(h, p, x, THR ? a : acmd, k, tb);
+        accel(1, a);
+        rhs_fast<MODEL, GENERIC>(h, p, x, a, k, tb);
+        // with a carry the three angles accumulate their INCREMENT in xn (x is added at the end), so that the increment is
+        // available for the addition theorem
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xn[i] = fma(h6, k[i], x[i]);
+        for (int i = 0; i < NX; ++i) xn[i] = (CARRY && i >= 3 && i < 6) ? h6 * k[i] : fma(h6, k[i], x[i]);
         stage_state(h2);
-        if constexpr (LAGMODE == 0) accel(p, 2);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
+        accel(2, a);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
         stage_state(h2);
-        if constexpr (LAGMODE == 0) accel(p, 3);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
+        accel(3, a);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
         stage_state(dt);
-        if constexpr (LAGMODE == 0) accel(p, 4);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, THR ? a : acmd, k, ts);
+        accel(4, a);
+        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
+        if (CARRY) {
 #pragma unroll
-        for (int i = 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
-        if constexpr (THR) {
-            CFP pl = relaunder(p0);
-            if constexpr (LAGMODE == 0) {
-                if constexpr (OBS) lz.advance(pl->Aw4, pl->bw4, acmd); else lz.advance(pl->A4, pl->b4, acmd);
-                if constexpr (TRACK) advance_thrusters(pl->A4, pl->b4, fcmd, X);
-            } else {
-                if constexpr (OBS) lz.obs_advance1(pl, acmd); else lz.advance(pl->A1, pl->b1, acmd);
-                if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
+            for (int i = 0; i < NX; ++i) {
+                if (i >= 3 && i < 6) { dang[i - 3] = fma(h6, k[i], xn[i]); x[i] += dang[i - 3]; }
+                else x[i] = fma(h6, k[i], xn[i]);
             }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
         }
     }
+    if constexpr (ANG) { if (CARRY) trig_delta(tb, dang, *carry); }
     if constexpr (model_is_quat(MODEL)) quat_normalize(x + 3);
+}
+
+// THRUST: the lag bank after one step's worth of dynamics() calls (RK4 per-call mode: four samples; otherwise one).
+// TRACK: also advance the per-thruster lag state X (for lag_io).
+template <int INTEG, int LAGMODE, bool TRACK, bool GENERIC>
+__device__ __forceinline__ void lag_step_advance(CFP pl, LagZ& lz, const double fcmd[8], const double acmd[6], double X[8][3]) {
+    constexpr bool OBS = !GENERIC;                       // lag state held in the observer basis (kernels call to_observer once)
+    if constexpr (INTEG == INTEG_RK4 && LAGMODE == 0) {
+        if constexpr (OBS) lz.advance(pl->Aw4, pl->bw4, acmd); else lz.advance(pl->A4, pl->b4, acmd);
+        if constexpr (TRACK) advance_thrusters(pl->A4, pl->b4, fcmd, X);
+    } else {
+        if constexpr (OBS) lz.obs_advance1(pl, acmd); else lz.advance(pl->A1, pl->b1, acmd);
+        if constexpr (TRACK) advance_thrusters(pl->A1, pl->b1, fcmd, X);
+    }
+}
+// acceleration seen by the s-th dynamics() call since the last lag_step_advance (s = 1 in per-step mode: thrust frozen)
+template <int LAGMODE, bool GENERIC, class HC>
+__device__ __forceinline__ void lag_stage_accel(const HC& h, CFP p, const LagZ& lz, int s, const double acmd[6], double a[6]) {
+    const int se = LAGMODE == 0 ? s : 1;
+    if constexpr (!GENERIC) lz.obs_accel_after(h, p, se, acmd, a); else lz.accel_after(p, se, acmd, a);
+}
+
+// Both halves in one lane (every model; the thruster model's production rollouts use rollout_pair_kernel instead).
+template <int MODEL, int INTEG, int LAGMODE, bool TRACK, bool GENERIC, class HC>
+__device__ __forceinline__ void step_fast(const HC& h, CFP p0, double dt, double* x, const double* u,
+                                          LagZ& lz, double X[8][3], const double2* qt, Trig* carry = nullptr, bool refresh = true) {
+    constexpr bool THR = (MODEL == MODEL_THRUSTER_EULER);
+    CFP p = relaunder(p0);
+    double fcmd[8], acmd[6];
+    if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) quat_normalize(x + 3);   // the reference normalises q before its update (wrench_quat.py:339)
+    command_accel<MODEL, !GENERIC>(p, u, fcmd, acmd);
+    integrate_fast<MODEL, INTEG, GENERIC>(h, p, dt, x, [&](int s, double* a) {
+        if constexpr (THR) lag_stage_accel<LAGMODE, GENERIC>(h, p, lz, s, acmd, a);
+        else {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) a[k] = acmd[k];
+        }
+    }, qt, carry, refresh);
+    if constexpr (THR) lag_step_advance<INTEG, LAGMODE, TRACK, GENERIC>(relaunder(p0), lz, fcmd, acmd, X);
 }
 
 }  // namespace brov

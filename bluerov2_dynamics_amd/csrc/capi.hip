@@ -40,6 +40,7 @@ struct brov_ctx {
     bool di_set = false;
     // EDMDc
     int btu_staging = 0;
+    int single_lane = 0;          // 1: never use the two-wave rollout kernel (A/B measurements: BROV2_ROLLOUT_SINGLE_LANE=1)
     int64_t chunk_rows = (int64_t)1 << 20;
     void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
     EdmdcShape task_shape[2] = {};
@@ -418,6 +419,7 @@ int brov_create(int device_id, brov_ctx** out) {
     // gram_kernel / propagate_kernel group work items by blockIdx % 8 so that blocks sharing an XCD share rows through its
     // L2.  That placement is observed behaviour, not a HIP guarantee: probe it once and remember (speed only, never correctness).
     c->xcd_round_robin = probe_xcd_round_robin(nullptr);
+    if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
                              "the XCD-aware block mappings lose their L2 sharing (results unaffected)\n", device_id, c->xcd_round_robin);
@@ -657,7 +659,8 @@ int brov_rollout_dev(brov_ctx* c, int model, int integ, int lag_mode, int layout
     CallTimer t(c);
     HIPCK(c, launch_rollout(c->stream, model_is_di_h(model) ? c->d_fp_di : c->d_fp, model, integ, lag_mode, layout, B, T, dt, d_x0, d_U,
                             d_lag_io, d_traj, d_traj ? stride : 1, d_xT,
-                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy || c->fp.tm_dense || c->fp.obs_bad) ? 4 : 0)));
+                            c->btu_staging | ((c->fp.has_current || c->fp.has_xy || c->fp.tm_dense || c->fp.obs_bad) ? 4 : 0) |
+                                (c->single_lane ? 8 : 0)));
     return BROV_OK;
 }
 

@@ -11,6 +11,8 @@
 
 namespace brov {
 
+constexpr int TRIG_REFRESH = 64;   // steps between full sin/cos evaluations of the carried attitude trig (power of two)
+
 // ---------------------------------------------------------------------------------------
 // global <-> register movement for one row of NX/NU doubles
 // ---------------------------------------------------------------------------------------
@@ -230,17 +232,20 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
     // (storing the previous state at the top of the iteration, before the prefetch, measured 2 % slower)
     if (traj) store_state();
     int64_t countdown = stride;
+    Trig tcarry;           // sin/cos of the attitude angles, carried from step to step (integrate_fast)
     for (int64_t t = 0; t < T; ++t) {
         double u[NU];
 #pragma unroll
         for (int i = 0; i < NU; ++i) u[i] = un[i];
-        up += ustep;
-        if (t + 1 < T) {  // prefetch the next control row while this step computes
+        // prefetch the next control row while this step computes -- unconditionally: the last step re-reads its own row
+        // (never consumed), so `un` is defined by one load on every path and costs no copy between register files
+        up += (t + 1 < T) ? ustep : 0;
+        {
             if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un);
             else if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un);
             else load_pairs<NU>(up, 2 * B, un);
         }
-        step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
+        step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt, &tcarry, (t & (TRIG_REFRESH - 1)) == 0);
         if (traj && --countdown == 0) {
             countdown = stride;
             store_state();
@@ -248,6 +253,124 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
     }
     if (XT) store_row<NX>(XT + b * NX, x);
     if constexpr (MODEL == MODEL_THRUSTER_EULER && TRACK) store_row<24>(lag_io + b * 24, &Xl[0][0]);
+}
+
+// ---------------------------------------------------------------------------------------
+// K1p: thruster-model rollouts with every step split over TWO waves of one SIMD (time-major layouts).
+//
+// A lone wave issues one instruction of any kind every ~4.3 clocks (tools/gen_ubench_valu.py: fp64 FMA, mul, add, s_mov,
+// v_mov, s_nop all cost the same slot, dependent or not), and BASELINE config 2 has exactly one wave of trajectories per
+// SIMD, so in rollout_kernel every scalar instruction, every register-file shuffle and every wait comes straight out of the
+// fp64 issue stream.  With two waves on a SIMD the fp64 pipe is still one instruction per ~4.15 clocks in total, but scalar
+// instructions, waits and half of the move traffic of one wave disappear behind the fp64 work of the other.  The thruster
+// model's step splits cleanly into two such streams (brov2_fast.h):
+//   THRUST wave (waves 4-7 of a 512-thread workgroup): control row -> thrust polynomial -> allocation -> lag bank ->
+//       the four accelerations a_s = Minv tau_s the step's four dynamics() calls will see (quirk Q1); never sees the state.
+//       ~200 fp64 instructions per step, holds the control prefetch and all allocation / lag constants.
+//   BODY wave (waves 0-3): rigid-body right-hand sides + RK4 + trajectory stores; reads a_s, never sees a control.
+//       ~590 fp64 instructions per step, no lag state, no controls: ~70 VGPRs fewer than the one-lane form, nothing spills.
+// Wave w and wave w + 4 serve the same 64 trajectories and (workgroup waves are dealt round-robin over the four SIMDs) share
+// a SIMD.  The thrust wave runs one step ahead through a two-slot LDS exchange (24 doubles per lane and step, 16-byte
+// accesses, conflict-free), one workgroup barrier per step:
+//       thrust: produce a(0);  for t: barrier; produce a(t+1) -> slot (t+1)&1
+//       body  :                for t: barrier; consume a(t)   <- slot t&1, integrate, store
+// Slot (t+1)&1 was last read during step t-1, i.e. before the barrier the body wave has just passed.  The barrier waits for
+// LDS traffic only (s_waitcnt lgkmcnt(0)): trajectory stores and control loads stay in flight across it.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
+__global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __restrict__ pg, int64_t B, int64_t T, double dt,
+                                                           const double* __restrict__ X0, const double* __restrict__ U,
+                                                           double* __restrict__ lag_io, double* __restrict__ traj,
+                                                           int64_t stride, double* __restrict__ XT) {
+    static_assert(LAYOUT != LAYOUT_BTU, "time-major layouts only");
+    constexpr int MODEL = MODEL_THRUSTER_EULER;
+    constexpr int NX = 12, NU = 8, NXP = 6, NUP = 4;
+    constexpr int NS = (INTEG == INTEG_RK4) ? 4 : 1;          // dynamics() calls per step
+    __shared__ double2 qt[4];
+    __shared__ __attribute__((aligned(16))) double2 xch[2][4][NS * 3][64];     // [slot][pair][stage, channel pair][lane]
+    init_quadrant_table(qt);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, pair = wave & 3, lane = threadIdx.x & 63;
+    const bool thrust = wave >= 4;                            // wave-uniform
+    const int64_t b_raw = (int64_t)blockIdx.x * 256 + pair * 64 + lane;
+    const bool live = b_raw < B;
+    const int64_t b = live ? b_raw : B - 1;                   // dead lanes shadow the last trajectory, never store
+    const CFP p = as_constant(pg);
+    HotConstsResident h;
+    load_hot(p, h);
+
+    if (thrust) {
+        LagZ lz;
+        double Xl[8][3];
+        if constexpr (TRACK) { load_row<24>(lag_io + b * 24, &Xl[0][0]); lz.from_thrusters(p, Xl); }
+        else lz.zero();
+        if constexpr (!GENERIC) lz.to_observer(p);
+        const double* up;
+        int64_t ustep;
+        if constexpr (LAYOUT == LAYOUT_TUB) { up = U + b; ustep = (int64_t)NU * B; }
+        else { up = U + 2 * b; ustep = (int64_t)NUP * 2 * B; }
+        double un[NU];
+        int64_t tl = 0;                                       // step whose controls sit in `un`
+        if (T > 0) {
+            if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un); else load_pairs<NU>(up, 2 * B, un);
+        }
+        auto produce = [&](int slot) {
+            double u[NU], fcmd[8], acmd[6], a[6];
+#pragma unroll
+            for (int i = 0; i < NU; ++i) u[i] = un[i];
+            up += (tl + 1 < T) ? ustep : 0;                   // prefetch the next row (the last step re-reads its own, unused)
+            ++tl;
+            if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un); else load_pairs<NU>(up, 2 * B, un);
+            const CFP pp = relaunder(p);
+            command_accel<MODEL, !GENERIC>(pp, u, fcmd, acmd);
+#pragma unroll
+            for (int s = 1; s <= NS; ++s) {
+                lag_stage_accel<LAGMODE, GENERIC>(h, pp, lz, s, acmd, a);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) xch[slot][pair][(s - 1) * 3 + j][lane] = make_double2(a[2 * j], a[2 * j + 1]);
+            }
+            lag_step_advance<INTEG, LAGMODE, TRACK, GENERIC>(relaunder(p), lz, fcmd, acmd, Xl);
+        };
+        if (T > 0) produce(0);
+        for (int64_t t = 0; t < T; ++t) {
+            pair_barrier();
+            if (t + 1 < T) produce((int)((t + 1) & 1));
+        }
+        if constexpr (TRACK) { if (live) store_row<24>(lag_io + b * 24, &Xl[0][0]); }
+    } else {
+        double x[NX];
+        load_row<NX>(X0 + b * NX, x);
+        double* tp = nullptr;
+        int64_t tstep = 0;
+        if (traj) {
+            if constexpr (LAYOUT == LAYOUT_TUB) { tp = traj + b; tstep = (int64_t)NX * B; }
+            else { tp = traj + 2 * b; tstep = (int64_t)NXP * 2 * B; }
+        }
+        auto store_state = [&]() {
+            if (live) {
+                if constexpr (LAYOUT == LAYOUT_TUB) store_soa<NX>(tp, B, x); else store_pairs<NX>(tp, 2 * B, x);
+            }
+            tp += tstep;
+        };
+        if (traj) store_state();
+        int64_t countdown = stride;
+        Trig tcarry;
+        for (int64_t t = 0; t < T; ++t) {
+            pair_barrier();
+            const double2* src = &xch[t & 1][pair][0][lane];
+            integrate_fast<MODEL, INTEG, GENERIC>(h, p, dt, x, [&](int s, double* a) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const double2 v = src[((s - 1) * 3 + j) * 64]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
+            }, qt, &tcarry, (t & (TRIG_REFRESH - 1)) == 0);
+            if (traj && --countdown == 0) {
+                countdown = stride;
+                store_state();
+            }
+        }
+        if (XT && live) store_row<NX>(XT + b * NX, x);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -328,6 +451,7 @@ __global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* 
     };
 
     const int64_t ntiles = (T + BTU_TILE - 1) / BTU_TILE;
+    Trig tcarry;
     if (ntiles > 0) issue_tile(0);
     for (int64_t k = 0; k < ntiles; ++k) {
         __syncthreads();                     // tile k has landed (vmcnt(0)); last tile's LDS reads are finished
@@ -345,7 +469,7 @@ __global__ void __launch_bounds__(256) rollout_btu_lds_kernel(const FastParams* 
                     const double2 v = *reinterpret_cast<const double2*>(ib + (lane * CH + in_swizzle<NU>(d, lane)) * 2);
                     u[2 * cc] = v.x; u[2 * cc + 1] = v.y;
                 }
-                step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
+                step_fast<MODEL, INTEG, LAGMODE, TRACK, GENERIC>(h, p, dt, x, u, lz, Xl, qt, &tcarry, ((t0 + s) & (TRIG_REFRESH - 1)) == 0);
                 if (traj) store_row<NX>(ob + s * NX, x);
             }
         }
@@ -481,6 +605,8 @@ __global__ void __launch_bounds__(256) window_endpoint_kernel(const FastParams* 
     for (int64_t t = 0; t < H; ++t) {
         double u[NU];
         load_row<NU>(U + (k + t) * NU, u);   // lane k reads row k+t: coalesced across the wave
+        // full sin/cos at every step (no carry): the evaluator's windows are short, and recorded wrench sequences drive the
+        // open-loop models far off the data (RMSE ~ 20), where every ulp is amplified
         step_fast<MODEL, INTEG, 0, false, GENERIC>(h, p, dt, x, u, lz, Xl, qt);
     }
     double ref[NX], e = 0.0;
@@ -536,7 +662,14 @@ hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B,
 
 template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
 static hipError_t launch_rollout_g(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
-                                   const double* U, double* lag, double* traj, int64_t stride, double* xT, bool want_lds) {
+                                   const double* U, double* lag, double* traj, int64_t stride, double* xT, bool want_lds, bool want_pair) {
+    if constexpr (MODEL == MODEL_THRUSTER_EULER && LAYOUT != LAYOUT_BTU) {
+        if (want_pair) {
+            hipLaunchKernelGGL((rollout_pair_kernel<INTEG, LAYOUT, LAGMODE, TRACK, GENERIC>), dim3(nblk(B, 256)), dim3(512), 0, st,
+                               p, B, T, dt, x0, U, lag, traj, stride, xT);
+            return hipGetLastError();
+        }
+    }
     if (LAYOUT == LAYOUT_BTU && (!traj || stride == 1) && T > 0 && want_lds)
         hipLaunchKernelGGL((rollout_btu_lds_kernel<MODEL, INTEG, LAGMODE, TRACK, GENERIC>), dim3(nblk(B, 256)), dim3(256), 0, st,
                            p, B, T, dt, x0, U, lag, traj, xT);
@@ -552,15 +685,16 @@ static hipError_t launch_rollout_t(hipStream_t st, const FastParams* p, int64_t 
     // instruction-issue bound at one wave per SIMD and loses 14 % to the staging instructions
     const bool want_lds = (btu_staging & 3) == 1 || ((btu_staging & 3) == 0 && (INTEG == INTEG_EULER || MODEL != MODEL_THRUSTER_EULER));
     const bool generic = (btu_staging & 4) != 0;      // bit 2: vehicle has a current or xb/yb != 0 (set by the C ABI layer)
+    const bool want_pair = (btu_staging & 8) == 0;    // bit 3: keep every step in one lane (A/B runs; set by the C ABI layer)
     constexpr bool DI = model_is_di(MODEL);
     if (MODEL == MODEL_THRUSTER_EULER && lag) {
         if constexpr (MODEL == MODEL_THRUSTER_EULER) {
-            return generic ? launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds)
-                           : launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
+            return generic ? launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds, want_pair)
+                           : launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, true, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds, want_pair);
         }
     }
-    if (generic && !DI) return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
-    return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds);
+    if (generic && !DI) return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, true>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds, want_pair);
+    return launch_rollout_g<MODEL, INTEG, LAYOUT, LAGMODE, false, false>(st, p, B, T, dt, x0, U, lag, traj, stride, xT, want_lds, want_pair);
 }
 template <int MODEL, int INTEG, int LAYOUT>
 static hipError_t launch_rollout_l(hipStream_t st, const FastParams* p, int lag_mode, int64_t B, int64_t T, double dt,

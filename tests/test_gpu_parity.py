@@ -339,24 +339,29 @@ def test_tpb_layout_equals_btu_layout_all_models(eng):
                     b = eng.rollout(model, integ, X0, Up, dt, lag=lag0, lag_mode=lag_mode, layout="tpb")
                     nxp = (nx + 1) // 2
                     tb = b["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 2 * nxp)[:, :, :nx]
-                    assert np.array_equal(tb, a["traj"]), (model, B, T, integ, lag_mode)
-                    assert np.array_equal(b["xT"], a["xT"])
+                    # the wrench models run the same one-lane kernel in both layouts: identical bits.  The thruster model's
+                    # time-major layouts run the two-wave kernel (rollout_pair_kernel): same step functions, another
+                    # compilation unit of them, so equal to rounding (a few ulp per step), not bit for bit
+                    same = (lambda p_, q_: np.array_equal(p_, q_)) if model != 0 else (lambda p_, q_: rel_err(p_, q_) < 1e-13)
+                    assert same(tb, a["traj"]), (model, B, T, integ, lag_mode)
+                    assert same(b["xT"], a["xT"])
                     if model == 0:
-                        assert np.array_equal(b["lag"], a["lag"])
+                        assert same(b["lag"], a["lag"])
                     c = eng.rollout(model, integ, X0, Up, dt, lag=lag0, lag_mode=lag_mode, layout="tpb", store=False)
-                    assert c["traj"] is None and np.array_equal(c["xT"], a["xT"])
+                    assert c["traj"] is None and np.array_equal(c["xT"], b["xT"])        # stored and endpoint-only runs: same kernel
                     if model == 0:
                         d = eng.rollout(model, integ, X0, Up, dt, layout="tpb", return_lag=False)      # untracked kernel, zero lag
                         e = eng.rollout(model, integ, X0, U, dt, return_lag=False)
-                        assert np.array_equal(d["xT"], e["xT"]) and np.array_equal(
+                        assert same(d["xT"], e["xT"]) and same(
                             d["traj"].transpose(2, 0, 1, 3).reshape(B, T + 1, 2 * nxp)[:, :, :nx], e["traj"])
 
 
 def test_rollout_checkpoint_resume_is_exact(eng):
     """A rollout is resumable from (xT, lag): T steps in one launch == T1 + T2 steps in two launches, for every model /
     integrator / lag mode (the thruster lag state [B,8,3] and the body state are the whole checkpoint).  Bit for bit for
-    the wrench models; to rounding for the thruster model, whose kernel carries the lag bank in acceleration-space
-    observer coordinates and re-derives them from the per-thruster state at every launch."""
+    the quaternion model; to rounding for the Euler-angle models, whose kernels carry sin/cos of the attitude from step to
+    step (re-evaluated in full at every launch and every 64 steps), and for the thruster model, which also carries the lag
+    bank in acceleration-space observer coordinates and re-derives them from the per-thruster state at every launch."""
     rng = np.random.default_rng(33)
     B, T, T1, dt = 300, 60, 23, 0.02
     for model in (0, 1, 2):
@@ -372,9 +377,10 @@ def test_rollout_checkpoint_resume_is_exact(eng):
                 a = eng.rollout(model, integ, X0, U[:, :T1], dt, lag=lag0, lag_mode=lag_mode)
                 b = eng.rollout(model, integ, a["xT"], U[:, T1:], dt, lag=a["lag"], lag_mode=lag_mode)
                 joined = np.concatenate([a["traj"], b["traj"][:, 1:]], axis=1)
-                if model == 0:
-                    assert rel_err(b["xT"], full["xT"]) < 1e-13 and rel_err(joined, full["traj"]) < 1e-13, (integ, lag_mode)
-                    assert rel_err(b["lag"], full["lag"]) < 1e-13
+                if model != 2:
+                    assert rel_err(b["xT"], full["xT"]) < 1e-12 and rel_err(joined, full["traj"]) < 1e-12, (model, integ, lag_mode)
+                    if model == 0:
+                        assert rel_err(b["lag"], full["lag"]) < 1e-13
                 else:
                     assert np.array_equal(b["xT"], full["xT"]) and np.array_equal(joined, full["traj"]), (model, integ)
 
@@ -1039,13 +1045,15 @@ def test_fit_keeps_the_references_own_product_order(eng):
     bags = [(0, 700), (700, 1500), (1500, 1903)]
     Xl, Ul = [X[a:b] for a, b in bags], [U[a:b] for a, b in bags]
     Go, Yo, _ = ek.gram(Xl, Ul, C, 1.0)
-    P = np.linalg.pinv(Go + 1e-6 * np.eye(Go.shape[0]))
+    P = np.linalg.pinv(Go + 1e-2 * np.eye(Go.shape[0]))        # moderately conditioned: this part checks the kernels, not the algebra
     M = eng.pinv_apply(Xl, Ul, C, 1.0, P)
     Mo = np.zeros_like(M)
     for Xb, Ub in zip(Xl, Ul):
         G = np.hstack([ek.lift(Xb[:-1], C, 1.0), Ub[:-1]])
         Mo += (P @ G.T) @ ek.lift(Xb[1:], C, 1.0)
-    assert np.linalg.norm(M - Mo) / np.linalg.norm(Mo) < 1e-12
+    Gn = sum(np.linalg.norm(np.hstack([ek.lift(Xb[:-1], C, 1.0), Ub[:-1]])) * np.linalg.norm(ek.lift(Xb[1:], C, 1.0)) for Xb, Ub in zip(Xl, Ul))
+    assert np.linalg.norm(M - Mo) < 1e-14 * np.linalg.norm(P) * Gn          # rounding of two products of that size
+    assert np.linalg.norm(M - Mo) / np.linalg.norm(Mo) < 1e-10
     # (2) fit() at the two settings
     Xt, Ut = X[ntr:], U[ntr:]
     for tag in ("def", "tank"):
