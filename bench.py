@@ -36,9 +36,10 @@ sys.path.insert(0, REPO)
 
 # algorithmic work per unit
 ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (reference algebra)
-# fp64 VALU instructions the shipped kernel issues per trajectory-wave and step (ISA count of the time loop,
-# tools/isa_count.py; tests/test_cabi_cpu.py re-derives them from the compiler's listing)
-ROLLOUT_EXEC_FP64_INSTR = {"rk4": 786, "euler": 284}
+# fp64 VALU instructions the shipped kernel (rollout_pair_kernel: body wave + thrust wave) executes per 64 trajectories and
+# step: static count of the two time loops (tools/isa_loops.py) minus the rarely executed blocks;
+# tests/test_cabi_cpu.py re-derives them from the compiler's listing, profiles/r02_rollout_pmc.txt has the counter view
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 757, "euler": 253}
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0
@@ -346,7 +347,7 @@ def main():
                                + f" (splitmix64 stream 0x5EED), layout {lay}, "
                                + ("all states stored" if traj is not None else "endpoint only"),
                    "trajectories_per_gpu": B, "horizon": T, "parallelism": f"{world} x independent shards, no collective"},
-        "roofline": {"kernel": f"rollout_kernel<THRUSTER_EULER,{a.integrator.upper()}>", "bound": "valu_fp64_issue",
+        "roofline": {"kernel": f"rollout_pair_kernel<{a.integrator.upper()},{lay.upper()}> (thruster model, two waves per SIMD)", "bound": "valu_fp64_issue",
                      "achieved": issue_tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": issue_frac,
                      "kernel_ms": kern_s * 1e3, "kernel_ms_each": kern_ms,
                      "executed_fp64_instr_per_step": instr,

@@ -1049,14 +1049,14 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     const int64_t NUt = s.nwp + H + 16;
     Arena a(c);
     rc = a.reserve(Arena::al(N * n * 8) + Arena::al(N * (r ? r : 1) * 8) + Arena::al((size_t)k * n * 8) + Arena::al((size_t)s.ppad * s.dpad * 8) +
-                   2 * Arena::al((size_t)s.dpad * s.nwp * 8) + Arena::al((size_t)rpad * NUt * 8) + Arena::al(nw * 8) + Arena::al(nw * n * 8) + 4096);
+                   2 * Arena::al((size_t)s.zrows * s.nwp * 8) + Arena::al((size_t)rpad * NUt * 8) + Arena::al(nw * 8) + Arena::al(nw * n * 8) + 4096);
     if (rc) return rc;
     double* dX = a.take<double>(N * n);
     double* dU = a.take<double>(N * (r ? r : 1));
     double* dC = a.take<double>((size_t)k * n);
     double* dABt = a.take<double>((size_t)s.ppad * s.dpad);
-    double* dZ0 = a.take<double>((size_t)s.dpad * s.nwp);
-    double* dZ1 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dZ0 = a.take<double>((size_t)s.zrows * s.nwp);
+    double* dZ1 = a.take<double>((size_t)s.zrows * s.nwp);
     double* dUt = a.take<double>((size_t)rpad * NUt);
     double* dse = a.take<double>(nw);
     double* dxh = a.take<double>(nw * n);
@@ -1073,14 +1073,17 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     rc = upload_ABt(c, s, A, B, dABt);
     if (rc) return rc;
     HIPCK(c, hipMemsetAsync(dUt, 0, (size_t)rpad * NUt * 8, c->stream));
-    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.dpad * s.nwp * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.zrows * s.nwp * 8, c->stream));   // padding rows are K rows of the step: must be finite
+    HIPCK(c, hipMemsetAsync(dZ1, 0, (size_t)s.zrows * s.nwp * 8, c->stream));
     {
         CallTimer t(c);
         HIPCK(c, launch_transpose(c->stream, N, r, dU, r, dUt, NUt));
         HIPCK(c, launch_lift_t(c->stream, s, gamma, n, dX, dC, dZ0));
+        HIPCK(c, launch_set_input_rows(c->stream, s, dUt, NUt, dZ0));                 // u_0 of every window: U[w]
         double *zin = dZ0, *zout = dZ1;
         for (int64_t t = 0; t < H; ++t) {
-            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, dUt + t, NUt, zout));
+            // window w at step t+1 reads U[w + t + 1]: the transposed input array shifted by t + 1
+            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, t + 1 < H ? dUt + t + 1 : nullptr, NUt, zout));
             std::swap(zin, zout);
         }
         HIPCK(c, launch_endpoint_se(c->stream, s, n, dX + H * n, zin, dse, xhat_end ? dxh : nullptr));
@@ -1104,15 +1107,15 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
     const int64_t ust_rows = (T > 0 ? T : 1) * (int64_t)rpad;   // [t][rpad][nbp]: step t uses rows t*r .. (reads up to rpad rows)
     Arena a(c);
     rc = a.reserve(Arena::al(nb * n * 8) + Arena::al((size_t)nb * T * (r ? r : 1) * 8 + 8) + Arena::al((size_t)k * n * 8) +
-                   Arena::al((size_t)s.ppad * s.dpad * 8) + 2 * Arena::al((size_t)s.dpad * s.nwp * 8) +
+                   Arena::al((size_t)s.ppad * s.dpad * 8) + 2 * Arena::al((size_t)s.zrows * s.nwp * 8) +
                    Arena::al((size_t)(ust_rows + rpad) * s.nwp * 8) + Arena::al((size_t)nb * (T + 1) * n * 8) + 4096);
     if (rc) return rc;
     double* dx0 = a.take<double>(nb * n);
     double* dUs = a.take<double>((size_t)nb * T * (r ? r : 1) + 1);
     double* dC = a.take<double>((size_t)k * n);
     double* dABt = a.take<double>((size_t)s.ppad * s.dpad);
-    double* dZ0 = a.take<double>((size_t)s.dpad * s.nwp);
-    double* dZ1 = a.take<double>((size_t)s.dpad * s.nwp);
+    double* dZ0 = a.take<double>((size_t)s.zrows * s.nwp);
+    double* dZ1 = a.take<double>((size_t)s.zrows * s.nwp);
     double* dUst = a.take<double>((size_t)(ust_rows + rpad) * s.nwp);
     double* dXp = a.take<double>((size_t)nb * (T + 1) * n);
     HIPCK(c, hipMemcpyAsync(dx0, x0, nb * n * 8, hipMemcpyHostToDevice, c->stream));
@@ -1121,15 +1124,17 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
     rc = upload_ABt(c, s, A, B, dABt);
     if (rc) return rc;
     HIPCK(c, hipMemsetAsync(dUst, 0, (size_t)(ust_rows + rpad) * s.nwp * 8, c->stream));
-    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.dpad * s.nwp * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.zrows * s.nwp * 8, c->stream));
+    HIPCK(c, hipMemsetAsync(dZ1, 0, (size_t)s.zrows * s.nwp * 8, c->stream));
     {
         CallTimer t(c);
         HIPCK(c, launch_useq_t(c->stream, s, T, dUs, dUst));
         HIPCK(c, launch_lift_t(c->stream, s, gamma, n, dx0, dC, dZ0));
+        HIPCK(c, launch_set_input_rows(c->stream, s, dUst, s.nwp, dZ0));                 // u_0
         double *zin = dZ0, *zout = dZ1;
         HIPCK(c, launch_extract_state(c->stream, s, T + 1, 0, zin, dXp));
         for (int64_t t = 0; t < T; ++t) {
-            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, dUst + (size_t)t * r * s.nwp, s.nwp, zout));
+            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, t + 1 < T ? dUst + (size_t)(t + 1) * r * s.nwp : nullptr, s.nwp, zout));
             std::swap(zin, zout);
             HIPCK(c, launch_extract_state(c->stream, s, T + 1, t + 1, zin, dXp));
         }

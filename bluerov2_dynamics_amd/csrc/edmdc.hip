@@ -135,35 +135,42 @@ hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma
     return hipGetLastError();
 }
 
-// Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (+1 block row for the tail).
+// Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (+1 block row for the tail);
+// 128-thread blocks.  A lane owns FOUR adjacent centres (their 4 x 12 coordinates in VGPRs): |x|^2 and the row's scalar
+// loads are paid once per four RBF values (40 instructions per value instead of 65 with two centres per lane), and a lane's
+// results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  The kernel is bound by its stores, not
+// by the exp: with the stores removed a 10^7-row lift takes 5.5 ms, with the arithmetic removed 14.4 ms (43.6 GB at
+// 3.0 TB/s, against 6.6 TB/s for a plain fill on the same box; nontemporal stores and other row-tile heights change nothing).
+constexpr int LIFT_NC = 4;          // centres per lane
+constexpr int LIFT_BLOCK = 128;     // threads per block: 128 x 4 = 512 centres per block row
 template <int NS>
-__global__ void __launch_bounds__(256) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
+__global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
                                                         int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
                                                         const double* __restrict__ X, const double* __restrict__ U,
                                                         double* __restrict__ Zrows, double* __restrict__ wrow) {
     const int n = s.n, k = s.k, W = s.width;
     constexpr int RT = 64;                             // rows per block
-    constexpr int NC = 2;                              // centres per lane: block covers 512 centres
+    constexpr int NC = LIFT_NC;
     const int64_t l0 = (int64_t)blockIdx.x * RT;       // local row index within the chunk buffer
-    const int ngroups = (s.kp + 256 * NC - 1) / (256 * NC);
+    const int ngroups = (s.kp + LIFT_BLOCK * NC - 1) / (LIFT_BLOCK * NC);
     // (bag, step) of the first row: one 64-bit division per block, then incremental (a division per row
     // costs ~130 scalar instructions, three times the useful work of a row)
     const int64_t g0 = row0 + l0;
     int64_t bag = g0 / xs, t = g0 - bag * xs;
     const int64_t lend = (l0 + RT < rows) ? l0 + RT : rows;
     if ((int)blockIdx.y < ngroups) {
-        // lane holds centres c0 and c0 + 256 (both store streams stay 512 contiguous bytes per wave)
-        const int c0 = blockIdx.y * 256 * NC + threadIdx.x;
+        const int c0 = (blockIdx.y * LIFT_BLOCK + threadIdx.x) * NC;       // first of this lane's four centres
         double cc[NC][LIFT_NMAX], c2[NC];
 #pragma unroll
         for (int q = 0; q < NC; ++q) {
-            const int c = c0 + 256 * q;
+            const int c = c0 + q;
             c2[q] = 0.0;
 #pragma unroll
             for (int j = 0; j < LIFT_NMAX; ++j) { cc[q][j] = (j < n && c < k) ? C[(int64_t)c * n + j] : 0.0; c2[q] = fma(cc[q][j], cc[q][j], c2[q]); }
         }
         const double* xp = X + (g0 < total_rows ? g0 : total_rows - 1) * n;
         double* zp = Zrows + l0 * W + c0;
+        const bool store = c0 < s.kp;                  // kp is a multiple of 16: a lane's four columns are inside or outside together
 #pragma unroll 1
         for (int64_t l = l0; l < lend; ++l) {
             const int64_t g = row0 + l;
@@ -171,9 +178,10 @@ __global__ void __launch_bounds__(256) lift_rows_kernel(EdmdcShape s, double gam
             rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
             const bool valid = g < total_rows && t <= L;                     // wave-uniform
 #pragma unroll
-            for (int q = 0; q < NC; ++q) {
-                const int c = c0 + 256 * q;
-                if (c < s.kp) zp[256 * q] = (valid && c < k) ? z[q] : 0.0;
+            for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
+            if (store) {
+                *reinterpret_cast<double2*>(zp) = make_double2(z[0], z[1]);
+                *reinterpret_cast<double2*>(zp + 2) = make_double2(z[2], z[3]);
             }
             zp += W;
             if (g + 1 < total_rows) xp += n;                                 // clamp: rows past the end are masked
@@ -181,19 +189,17 @@ __global__ void __launch_bounds__(256) lift_rows_kernel(EdmdcShape s, double gam
         }
     } else {
         // tail block: [x | u | 0], and the pair weight
-        const int j = threadIdx.x;
         for (int64_t l = l0; l < lend; ++l) {
             const int64_t g = row0 + l;
-            double v = 0.0, w = 0.0;
-            if (g < total_rows) {
-                if (t <= L) {
+            for (int j = threadIdx.x; j < s.tailp; j += LIFT_BLOCK) {
+                double v = 0.0;
+                if (g < total_rows && t <= L) {
                     if (j < n) v = X[g * n + j];
                     else if (j < n + s.r && t < L) v = U[(bag * us + t) * s.r + (j - n)];
                 }
-                if (t < L) w = 1.0;
+                Zrows[l * W + s.kp + j] = v;
             }
-            if (j < s.tailp) Zrows[l * W + s.kp + j] = v;
-            if (j == 0) wrow[l] = w;
+            if (threadIdx.x == 0) wrow[l] = (g < total_rows && t < L) ? 1.0 : 0.0;
             if (++t == xs) { t = 0; ++bag; }
         }
     }
@@ -203,11 +209,11 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
                                   const double* X, const double* U, double* Zrows, double* wrow) {
     if (rows <= 0) return hipSuccess;
     if (s.n > LIFT_NMAX || s.tailp > 256 || xs < 2 || total_rows < 1) return hipErrorInvalidValue;
-    const int ngroups = (s.kp + 511) / 512;
+    const int ngroups = (s.kp + LIFT_BLOCK * LIFT_NC - 1) / (LIFT_BLOCK * LIFT_NC);
     const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(ngroups + 1));
-    if (s.n == 12) hipLaunchKernelGGL(lift_rows_kernel<12>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
-    else if (s.n == 13) hipLaunchKernelGGL(lift_rows_kernel<13>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
-    else hipLaunchKernelGGL(lift_rows_kernel<0>, grid, dim3(256), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    if (s.n == 12) hipLaunchKernelGGL(lift_rows_kernel<12>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    else if (s.n == 13) hipLaunchKernelGGL(lift_rows_kernel<13>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    else hipLaunchKernelGGL(lift_rows_kernel<0>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     return hipGetLastError();
 }
 
@@ -292,16 +298,18 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
     int64_t ks1 = ks0 + per;
     if (ks1 > ksteps_total) ks1 = ksteps_total;
 
-    // per-lane element offsets (doubles, 32-bit) relative to the first row of the current k-step
-    int aoff[GRAM_TA], boff[GRAM_TB];
+    // per-lane BYTE offsets (unsigned 32-bit) relative to the first row of the current k-step: with a wave-uniform base
+    // pointer the loads take the "SGPR base + 32-bit VGPR offset" form, one address register per operand instead of two
+    unsigned aoff[GRAM_TA], boff[GRAM_TB];
 #pragma unroll
-    for (int a = 0; a < GRAM_TA; ++a) { const int ta = tasks[task].a[a]; aoff[a] = kq * W + (ta < 0 ? 0 : ta * 16) + col; }
+    for (int a = 0; a < GRAM_TA; ++a) { const int ta = tasks[task].a[a]; aoff[a] = 8u * (unsigned)(kq * W + (ta < 0 ? 0 : ta * 16) + col); }
 #pragma unroll
     for (int b = 0; b < GRAM_TB; ++b) {
         const int tbe = tasks[task].b[b];
         const int tb = tbe < 0 ? 0 : tbe;
-        boff[b] = (kq + ((tb >> 16) & 1)) * W + (tb & 0xFFFF) * 16 + col;
+        boff[b] = 8u * (unsigned)((kq + ((tb >> 16) & 1)) * W + (tb & 0xFFFF) * 16 + col);
     }
+    const unsigned woff = 8u * (unsigned)kq;
     v4d acc[GRAM_TA][GRAM_TB];
 #pragma unroll
     for (int a = 0; a < GRAM_TA; ++a)
@@ -312,34 +320,57 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
         const double* zp = Z + ks0 * 4 * W;       // wave-uniform base of the current 4 rows
         const double* za = SEPARATE_A ? ZA + ks0 * 4 * W : zp;      // the Gram proper keeps a single row pointer
         const double* wp = wrow + ks0 * 4;
-        double an[GRAM_TA], bn[GRAM_TB], wn;
-        wn = wp[kq];
+        // Operands are double-buffered by hand: two register sets, loop unrolled by two, the 11 loads of K-step k+1 issued
+        // BEFORE the 24 MFMAs of K-step k, so that they have that whole K-step to arrive.  Left to the compiler the loop is
+        // rotated so that a step's rows are waited for right after they are asked for, and with two register sets it keeps
+        // a 64-bit VGPR pointer per operand and set (loop strength reduction) and spills.  So the loads are written out in
+        // their "SGPR base + 32-bit VGPR offset" form (one address register per operand, shared by both sets), which takes
+        // them out of the compiler's s_waitcnt bookkeeping: the waits are explicit -- vmcnt(11) = "everything but the 11
+        // loads just issued has landed" -- and sched_barriers pin the order of the four phases (guide section 5.7, form iii).
+        // Loads run up to two K-steps past the slab (the row buffers are padded by 8 rows) and are drained before the epilogue.
+        static_assert(GRAM_TA + GRAM_TB + 1 == 11, "the vmcnt immediates below count 11 loads per register set");
+        double a0[GRAM_TA], b0[GRAM_TB], w0, a1[GRAM_TA], b1[GRAM_TB], w1;
+        auto gload = [](const double* base, unsigned byte_off) {
+            double v;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+            return v;
+        };
+        auto load = [&](double* an, double* bn, double& wn) {
+            wn = gload(wp, woff);
 #pragma unroll
-        for (int a = 0; a < GRAM_TA; ++a) an[a] = za[aoff[a]];
+            for (int a = 0; a < GRAM_TA; ++a) an[a] = gload(za, aoff[a]);
 #pragma unroll
-        for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
-        for (int64_t ks = ks0; ks < ks1; ++ks) {
-            double av[GRAM_TA], bv[GRAM_TB];
+            for (int b = 0; b < GRAM_TB; ++b) bn[b] = gload(zp, boff[b]);
+        };
+        auto advance = [&]() { zp += 4 * W; if constexpr (SEPARATE_A) za += 4 * W; else za = zp; wp += 4; };
+        auto mfma = [&](double* an, const double* bn, double wn) {
 #pragma unroll
-            for (int a = 0; a < GRAM_TA; ++a) av[a] = an[a] * wn;
-#pragma unroll
-            for (int b = 0; b < GRAM_TB; ++b) bv[b] = bn[b];
-            // prefetch the next 4 rows while the 32 MFMAs below run (unconditional: the row buffer is
-            // padded by 8 rows, and what the last step prefetches is never consumed)
-            zp += 4 * W;
-            if constexpr (SEPARATE_A) za += 4 * W; else za = zp;
-            wp += 4;
-            wn = wp[kq];
-#pragma unroll
-            for (int a = 0; a < GRAM_TA; ++a) an[a] = za[aoff[a]];
-#pragma unroll
-            for (int b = 0; b < GRAM_TB; ++b) bn[b] = zp[boff[b]];
-#pragma unroll
-            for (int a = 0; a < GRAM_TA; ++a)
+            for (int a = 0; a < GRAM_TA; ++a) {
+                an[a] *= wn;                        // pair weight (0 at bag ends / padding), in place: no third register set
 #pragma unroll
                 for (int b = 0; b < GRAM_TB; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[a], bn[b], acc[a][b], 0, 0, 0);
+            }
+        };
+        load(a0, b0, w0);
+        int64_t ks = ks0;
+        for (; ks + 2 <= ks1; ks += 2) {
+            advance();
+            load(a1, b1, w1);                       // K-step ks + 1
+            asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // set 0 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(a0, b0, w0);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            load(a0, b0, w0);                       // K-step ks + 2 (past the slab on the last trip: padded, never consumed)
+            asm volatile("s_waitcnt vmcnt(11)" ::: "memory");      // set 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(a1, b1, w1);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain: nothing may land in a register the epilogue reuses
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < ks1) mfma(a0, b0, w0);             // odd tail: set 0 holds the last K-step
     }
     // partial[(task * NSLAB + slab)][tile = a * TB + b][lane][4]
     double* out = partial + ((int64_t)task * nslab + slab) * (GRAM_TA * GRAM_TB * 256) + lane * 4;

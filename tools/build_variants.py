@@ -15,12 +15,15 @@ _build.build_library()
 specs = []
 for a in sys.argv[1:]:
     name, _, flags = a.partition("=")
-    specs.append((name, [f for f in flags.split(",") if f]))
+    src = "rollout.hip"
+    if ":" in name:                      # file:name=flags
+        src, name = name.split(":", 1)
+    specs.append((name, src, [f for f in flags.split(",") if f]))
 
 
 def one(spec):
-    name, flags = spec
-    lib = _build.variant(name, {"rollout.hip": flags})
+    name, src, flags = spec
+    lib = _build.variant(name, {src: flags})
     return name, lib
 
 
