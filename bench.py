@@ -568,8 +568,11 @@ def main():
         roll_ms, gram_ms, ar_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]), ev[2].elapsed_time(ev[3])
         # independent check of the summed blocks: their x-x corners are plain sums over all pairs of the ensemble,
         # recomputed here with torch matmuls on every rank's shard and summed over the ranks
-        Xa, Xb = X4[:, :-1, :].reshape(-1, n), X4[:, 1:, :].reshape(-1, n)
-        chk = torch.cat([(Xa.T @ Xa).reshape(-1), (Xa.T @ Xb).reshape(-1)])
+        chk = torch.zeros(2 * n * n, dtype=torch.float64, device=dev)
+        for i0 in range(0, Bl, 32768):                     # in slices: the strided views have to be copied to be multiplied
+            Xa, Xb = X4[i0:i0 + 32768, :-1, :].reshape(-1, n), X4[i0:i0 + 32768, 1:, :].reshape(-1, n)
+            chk[: n * n] += (Xa.T @ Xa).reshape(-1)
+            chk[n * n:] += (Xa.T @ Xb).reshape(-1)
         allreduce_sum_(chk)
         cgg, cgy = chk[: n * n].view(n, n), chk[n * n:].view(n, n)
         e_gg = float(((G4[:n, :n] - cgg).norm() / cgg.norm()).item())
@@ -596,7 +599,7 @@ def main():
                 "config": {"workload": f"BASELINE config 4: {Bt} rollouts x {T4} RK4 steps in total (AR(1) commands, stream 0xC0F4), contiguous shards over the "
                                        f"ranks, trajectories stored [B][T+1][12], local lift + G^T[G|Y] (k=512) per rank, one all-reduce of {p4 * p4 + p4 * d4} doubles"},
             }
-        del U4, X4, GG4, G4, Y4, Xa, Xb
+        del U4, X4, GG4, G4, Y4, Xa, Xb, chk
         torch.cuda.empty_cache()
 
     if rank == 0 and not a.no_cpu and world == 1:

@@ -1,7 +1,7 @@
 // brov2_fast.h -- the time-loop form of the Fossen model used by the rollout / window kernels.
 //
 // Same equations as brov2_device.h (which is the literal per-call form used by brov_rhs), re-arranged
-// so that one RK4 step costs ~1.1k fp64 instructions instead of ~3k:
+// so that one RK4 step costs ~760 fp64 instructions instead of ~3k:
 //
 //  * Minv is folded into everything: the kernels integrate nu_dot = a_thr - c(nu) - d(nu_r) - g(eta)
 //    with a_thr = Minv tau, c = Minv C(nu) nu written as 12 products with 12 pre-multiplied constants
@@ -15,7 +15,8 @@
 //  * sin/cos: 3-term Cody-Waite reduction + the fdlibm kernel polynomials (~1 ulp for |x| < 3e9),
 //    instead of OCML's double-double reduction (fossen/BlueROV2.py:28-33,47-50,342-345 call
 //    np.sin/np.cos three times per call on the same angles; here once).  RK4 stages 2-4 get theirs from the
-//    first stage's by the addition theorem on the small angle increment (trig_delta).
+//    first stage's by the addition theorem on the small angle increment (trig_delta), and so does the NEXT step's first
+//    stage from the step's total increment (integrate_fast's carry; a full evaluation every 64 steps).
 //  * The lag bank is carried in the observer basis of its next three outputs (LagZ::to_observer): stages 1-3
 //    of a step read the thrust with one FMA per channel.
 //  * The hottest constants live in VGPRs (uniform values, pinned with an empty asm) and the rest is

@@ -1,10 +1,14 @@
 // rollout.hip -- time-loop kernels: batched RHS, Euler/RK4 rollouts, sliding-window
 // endpoint error with the reference's carried thruster-lag state.
 //
-// Mapping: one wavefront lane = one trajectory (or one evaluation window).  256-thread
-// workgroups = 4 waves, one per SIMD of a CU.  All state lives in VGPRs; vehicle constants
-// arrive as a by-value kernel argument (scalar loads).  Control rows are prefetched one
-// step ahead so the HBM/L2 latency sits under the ~1.5k fp64 instructions of a step.
+// Mapping: one wavefront lane = one trajectory (or one evaluation window); all state lives in VGPRs, nothing in scratch.
+// Vehicle constants sit in a small device buffer (FastParams) read through the constant address space, i.e. as scalar
+// loads.  Two forms of the rollout:
+//   rollout_pair_kernel  thruster model, time-major layouts (the benchmark): every step split over the two waves of a SIMD
+//                        -- thrust half and body half, LDS hand-over (K1p below);
+//   rollout_kernel       every model, every layout: the whole step in one lane, control rows prefetched one step ahead;
+//                        256-thread workgroups = one wave per SIMD at BASELINE config 2.
+// One RK4 step of the thruster model executes ~760 fp64 VALU instructions per 64 trajectories (brov2_fast.h).
 #include "brov2_device.h"
 #include "brov2_fast.h"
 #include "brov2_kernels.h"

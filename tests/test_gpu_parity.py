@@ -1135,6 +1135,42 @@ def test_timed_config2_launch_is_the_references_trajectories(eng, fc):
     assert torch.isfinite(xT).all()
 
 
+def test_two_wave_rollout_kernel_edge_cases(eng, fc):
+    """rollout_pair_kernel (thruster model, time-major layouts) at the edges: zero and one step, one trajectory, batches that
+    are not a multiple of the 256 trajectories of a workgroup, strided trajectory storage, both integrators, both lag modes,
+    both time-major layouts, lag state in and out -- against the C oracle; and against the one-lane kernel
+    (BROV2_ROLLOUT_SINGLE_LANE, read at context creation) on the same data."""
+    import os
+    from bluerov2_dynamics_amd import _lib
+    rng = np.random.default_rng(77)
+    dt = 0.02
+    os.environ["BROV2_ROLLOUT_SINGLE_LANE"] = "1"
+    ctx1 = _lib.Context(0)
+    del os.environ["BROV2_ROLLOUT_SINGLE_LANE"]
+    ctx2 = _lib.Context(0)
+    for B, T, stride in ((1, 0, 1), (1, 1, 1), (3, 7, 1), (257, 5, 2), (300, 64, 7), (513, 130, 1)):
+        X0 = rng.uniform(-0.4, 0.4, (B, 12))
+        U = rng.uniform(-1, 1, (B, T, 8))
+        lag0 = rng.uniform(-1, 1, (B, 8, 3))
+        Ut = np.ascontiguousarray(U.transpose(1, 2, 0))                                  # [T][8][B]
+        Up = np.ascontiguousarray(U.reshape(B, T, 4, 2).transpose(1, 2, 0, 3))           # [T][4][B][2]
+        for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
+            for lag_mode in ((0, 1) if integ == "rk4" else (0,)):
+                o = fc.rollout(0, oi, X0, U, dt, lag=lag0, lag_mode=lag_mode, sub=stride, nthreads=4)
+                for lay, Ul in (("tub", Ut), ("tpb", Up)):
+                    r = eng.rollout(0, integ, X0, Ul, dt, lag=lag0, lag_mode=lag_mode, layout=lay, stride=stride, ctx=ctx2)
+                    tr = r["traj"].transpose(2, 0, 1) if lay == "tub" else r["traj"].transpose(2, 0, 1, 3).reshape(B, -1, 12)
+                    assert tr.shape == o["traj"].shape, (B, T, stride, lay)
+                    assert rel_err(tr, o["traj"]) < 1e-11 and rel_err(r["xT"], o["xT"]) < 1e-11, (B, T, integ, lag_mode, lay)
+                    assert rel_err(r["lag"], o["lag"]) < 1e-11
+                    r1 = eng.rollout(0, integ, X0, Ul, dt, lag=lag0, lag_mode=lag_mode, layout=lay, stride=stride, ctx=ctx1)
+                    assert rel_err(r["traj"], r1["traj"]) < 1e-13 and rel_err(r["xT"], r1["xT"]) < 1e-13
+                    if T == 0:
+                        assert np.array_equal(r["xT"], X0)
+    ctx1.close()
+    ctx2.close()
+
+
 def test_config4_shard_rollouts_and_gram(eng, fc):
     """BASELINE config 4 at the per-GPU shard of the 8-GPU run: 131 072 rollouts x 500 RK4 steps (AR(1) commands, global
     trajectory indices of rank 3), trajectories stored [B][T+1][12], local lift + G^T[G|Y].

@@ -13,7 +13,7 @@ import json
 import sys
 
 root = sys.argv[1]
-NAMES = {"rollout_kernel<0, 1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
+NAMES = {"rollout_pair_kernel<1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
           "gram_kernel": "gram", "lift_rows_kernel": "lift", "kmeans_assign_kernel": "kmeans_assign",
          "propagate_kernel": "propagate", "pp_candidates_kernel": "kmeanspp_candidates", "pp_update_chunksum_kernel": "kmeanspp_update"}
 pats = sys.argv[2:] or list(NAMES)
