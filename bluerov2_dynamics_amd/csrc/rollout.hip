@@ -17,6 +17,16 @@ namespace brov {
 
 constexpr int TRIG_REFRESH = 64;   // steps between full sin/cos evaluations of the carried attitude trig (power of two)
 
+#if BROV_CLOCK_STAMPS
+// Diagnostic build only (tools/clock_probe.py; never in the shipped library): the body wave of every workgroup stamps the
+// shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) around its time loop; the ratio is the clock the
+// chip holds under this launch.  The stamps go to a buffer of their own, no output value is computed from them.
+__device__ unsigned long long g_clock_stamps[4096][4];
+extern "C" __attribute__((visibility("default"))) int brov_debug_clock_stamps(unsigned long long* host, int nblocks) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_clock_stamps), sizeof(unsigned long long) * 4 * nblocks, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 // ---------------------------------------------------------------------------------------
 // global <-> register movement for one row of NX/NU doubles
 // ---------------------------------------------------------------------------------------
@@ -237,6 +247,9 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
     if (traj) store_state();
     int64_t countdown = stride;
     Trig tcarry;           // sin/cos of the attitude angles, carried from step to step (integrate_fast)
+#if BROV_CLOCK_STAMPS
+    const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int64_t t = 0; t < T; ++t) {
         double u[NU];
 #pragma unroll
@@ -255,6 +268,12 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
             store_state();
         }
     }
+#if BROV_CLOCK_STAMPS
+    if (threadIdx.x == 0 && blockIdx.x < 4096) {
+        g_clock_stamps[blockIdx.x][0] = st0; g_clock_stamps[blockIdx.x][1] = sr0;
+        g_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime(); g_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (XT) store_row<NX>(XT + b * NX, x);
     if constexpr (MODEL == MODEL_THRUSTER_EULER && TRACK) store_row<24>(lag_io + b * 24, &Xl[0][0]);
 }
@@ -361,6 +380,9 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
         if (traj) store_state();
         int64_t countdown = stride;
         Trig tcarry;
+#if BROV_CLOCK_STAMPS
+        const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int64_t t = 0; t < T; ++t) {
             pair_barrier();
             const double2* src = &xch[t & 1][pair][0][lane];
@@ -373,6 +395,12 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
                 store_state();
             }
         }
+#if BROV_CLOCK_STAMPS
+        if (wave == 0 && lane == 0 && blockIdx.x < 4096) {
+            g_clock_stamps[blockIdx.x][0] = st0; g_clock_stamps[blockIdx.x][1] = sr0;
+            g_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime(); g_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
         if (XT && live) store_row<NX>(XT + b * NX, x);
     }
 }
