@@ -82,7 +82,9 @@ PropShape prop_shape(int n, int r, int k, int64_t nw);
 hipError_t launch_lift_t(hipStream_t st, const PropShape& s, double gamma, int64_t xstride, const double* X, const double* C, double* Zt);
 hipError_t launch_transpose(hipStream_t st, int64_t rows, int64_t cols, const double* src, int64_t lds_, double* dst, int64_t ldd);
 hipError_t launch_set_input_rows(hipStream_t st, const PropShape& s, const double* U, int64_t ldu, double* Zt);
-hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Unext, int64_t ldu, double* Zout);
+int64_t prop_window_blocks(const PropShape& s);
+hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Unext, int64_t ldu, double* Zout,
+                            int64_t wb0 = 0, int64_t nwb = -1);
 hipError_t launch_endpoint_se(hipStream_t st, const PropShape& s, int64_t xstride, const double* Xref, const double* Zt, double* se, double* xhat);
 hipError_t launch_extract_state(hipStream_t st, const PropShape& s, int64_t T1, int64_t t, const double* Zt, double* Xp);
 hipError_t launch_useq_t(hipStream_t st, const PropShape& s, int64_t T, const double* Us, double* Ust);

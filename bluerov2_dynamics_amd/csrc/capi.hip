@@ -50,6 +50,9 @@ struct brov_ctx {
     size_t partial_cap = 0;
     size_t tasks_cap[2] = {0, 0};     // bytes behind d_tasks[]
     hipEvent_t ev_handover = nullptr; // orders the work queued on the previous stream before the next one (brov_set_stream)
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams of edmdc_multistep_se (window groups advance independently), created on demand
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
     char arch[64] = {0};
 };
@@ -420,6 +423,7 @@ int brov_create(int device_id, brov_ctx** out) {
     // L2.  That placement is observed behaviour, not a HIP guarantee: probe it once and remember (speed only, never correctness).
     c->xcd_round_robin = probe_xcd_round_robin(nullptr);
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
+    if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
                              "the XCD-aware block mappings lose their L2 sharing (results unaffected)\n", device_id, c->xcd_round_robin);
@@ -439,6 +443,11 @@ void brov_destroy(brov_ctx* c) {
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 3; ++i) {
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+        if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
+    }
     delete c;
 }
 
@@ -1081,11 +1090,31 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
         HIPCK(c, launch_lift_t(c->stream, s, gamma, n, dX, dC, dZ0));
         HIPCK(c, launch_set_input_rows(c->stream, s, dUt, NUt, dZ0));                 // u_0 of every window: U[w]
         double *zin = dZ0, *zout = dZ1;
+        // A window block's step t+1 needs that block's step t only, so the recurrence runs in G groups of window blocks on G
+        // streams: at G = 2 each launch is one round of waves (3 938 -> 2 x 1 969 for 2 048 slots at the recorded size) and
+        // the ramp and tail of one group's launch are covered by the other's.
+        const int64_t nwb = prop_window_blocks(s);
+        const int G = (c->prop_groups > 1 && nwb >= 8 * c->prop_groups && H > 1) ? c->prop_groups : 1;
+        if (G > 1 && !c->ev_fork) HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int g = 1; g < G; ++g)
+            if (!c->side[g - 1]) {
+                HIPCK(c, hipStreamCreateWithFlags(&c->side[g - 1], hipStreamNonBlocking));
+                HIPCK(c, hipEventCreateWithFlags(&c->ev_join[g - 1], hipEventDisableTiming));
+            }
+        if (G > 1) {
+            HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
+            for (int g = 1; g < G; ++g) HIPCK(c, hipStreamWaitEvent(c->side[g - 1], c->ev_fork, 0));
+        }
         for (int64_t t = 0; t < H; ++t) {
             // window w at step t+1 reads U[w + t + 1]: the transposed input array shifted by t + 1
-            HIPCK(c, launch_propagate(c->stream, s, dABt, zin, t + 1 < H ? dUt + t + 1 : nullptr, NUt, zout));
+            const double* un = t + 1 < H ? dUt + t + 1 : nullptr;
+            for (int g = 0; g < G; ++g) {
+                const int64_t w0 = nwb * g / G, w1 = nwb * (g + 1) / G;
+                HIPCK(c, launch_propagate(g == 0 ? c->stream : c->side[g - 1], s, dABt, zin, un, NUt, zout, w0, w1 - w0));
+            }
             std::swap(zin, zout);
         }
+        for (int g = 1; g < G; ++g) { HIPCK(c, hipEventRecord(c->ev_join[g - 1], c->side[g - 1])); HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join[g - 1], 0)); }
         HIPCK(c, launch_endpoint_se(c->stream, s, n, dX + H * n, zin, dse, xhat_end ? dxh : nullptr));
         HIPCK(c, launch_sum(c->stream, nw, dse, dtot));
     }

@@ -73,12 +73,14 @@ __global__ void __launch_bounds__(256) transpose_kernel(int64_t rows, int64_t co
 //    its own padding rows (>= d) alone.
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 propagate_kernel(int d, int r, int ksteps, int64_t ldab, const double* __restrict__ ABt, int64_t nwp, const double* __restrict__ Zin,
-                 const double* __restrict__ Unext, int64_t ldu, double* __restrict__ Zout, int nfb, int64_t nitems, int64_t items_per_xcd) {
+                 const double* __restrict__ Unext, int64_t ldu, double* __restrict__ Zout, int nfb, int64_t nitems, int64_t items_per_xcd,
+                 int64_t wb0) {
     const int64_t bid = blockIdx.x;
     const int64_t item = (bid & 7) * items_per_xcd + (bid >> 3);
     if ((bid >> 3) >= items_per_xcd || item >= nitems) return;
-    const int64_t wb = item / nfb;
-    const int fb = (int)(item - wb * nfb);
+    const int64_t wbl = item / nfb;
+    const int fb = (int)(item - wbl * nfb);
+    const int64_t wb = wb0 + wbl;                        // window blocks [wb0, wb0 + nitems / nfb) of this launch
     const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
     const int64_t w0 = wb * (PTB * 16);
     const int i0 = fb * (PTA * 16);
@@ -213,13 +215,18 @@ hipError_t launch_set_input_rows(hipStream_t st, const PropShape& s, const doubl
     hipLaunchKernelGGL(set_input_rows_kernel, dim3((unsigned)((s.nwp + 255) / 256)), dim3(256), 0, st, s.d, s.r, s.nwp, U, ldu, Zt);
     return hipGetLastError();
 }
-// Zin rows d..d+r-1 must hold this step's inputs; Unext (may be NULL) = the next step's input rows [r][ldu], written into Zout
-hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Unext, int64_t ldu, double* Zout) {
+// Zin rows d..d+r-1 must hold this step's inputs; Unext (may be NULL) = the next step's input rows [r][ldu], written into Zout.
+// [wb0, wb0 + nwb): the window blocks (128 windows each) this launch advances; nwb < 0 = all of them.
+int64_t prop_window_blocks(const PropShape& s) { return s.nwp / (PTB * 16); }
+hipError_t launch_propagate(hipStream_t st, const PropShape& s, const double* ABt, const double* Zin, const double* Unext, int64_t ldu, double* Zout,
+                            int64_t wb0, int64_t nwb) {
     const int nfb = s.dpad / (PTA * 16);
-    const int64_t nitems = (s.nwp / (PTB * 16)) * nfb;
+    if (nwb < 0) { wb0 = 0; nwb = prop_window_blocks(s); }
+    if (nwb == 0) return hipSuccess;
+    const int64_t nitems = nwb * nfb;
     const int64_t per_xcd = (nitems + 7) / 8;
     hipLaunchKernelGGL(propagate_kernel, dim3((unsigned)(8 * per_xcd)), dim3(64), 0, st, s.d, s.r, s.ksteps, (int64_t)s.dpad, ABt, s.nwp, Zin, Unext,
-                       ldu, Zout, nfb, nitems, per_xcd);
+                       ldu, Zout, nfb, nitems, per_xcd, wb0);
     return hipGetLastError();
 }
 hipError_t launch_endpoint_se(hipStream_t st, const PropShape& s, int64_t xstride, const double* Xref, const double* Zt, double* se, double* xhat) {
