@@ -102,6 +102,21 @@ __device__ __forceinline__ void rbf_row(int n, double gamma, const double* __res
 #pragma unroll
     for (int q = 0; q < NC; ++q) out[q] = exp_fast(-gamma * ((x2 + c2[q]) - 2.0 * dot[q]));   // Koopman/koopmanEDMDc.py:46-48
 }
+// the same for a state row already in registers (wave-uniform values: scalar registers)
+template <int NS, int NC>
+__device__ __forceinline__ void rbf_vals(double gamma, const double* xr, const double (*c)[LIFT_NMAX], const double* c2, double* out) {
+    double x2 = 0.0, dot[NC];
+#pragma unroll
+    for (int q = 0; q < NC; ++q) dot[q] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NS; ++j) {
+        x2 = fma(xr[j], xr[j], x2);
+#pragma unroll
+        for (int q = 0; q < NC; ++q) dot[q] = fma(xr[j], c[q][j], dot[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < NC; ++q) out[q] = exp_fast(-gamma * ((x2 + c2[q]) - 2.0 * dot[q]));   // Koopman/koopmanEDMDc.py:46-48
+}
 template <int NS>
 __device__ __forceinline__ double rbf_one(int n, double gamma, const double* __restrict__ xrow, const double* c, double c2) {
     double o;
@@ -138,9 +153,11 @@ hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma
 // Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (+1 block row for the tail);
 // 128-thread blocks.  A lane owns FOUR adjacent centres (their 4 x 12 coordinates in VGPRs): |x|^2 and the row's scalar
 // loads are paid once per four RBF values (40 instructions per value instead of 65 with two centres per lane), and a lane's
-// results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  The kernel is bound by its stores, not
-// by the exp: with the stores removed a 10^7-row lift takes 5.5 ms, with the arithmetic removed 14.4 ms (43.6 GB at
-// 3.0 TB/s, against 6.6 TB/s for a plain fill on the same box; nontemporal stores and other row-tile heights change nothing).
+// results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  The kernel is bound by latency, not by
+// the exp or the store bandwidth: per 10^7 rows the arithmetic alone takes 5.5 ms and the same stores from a store-only
+// kernel 8 ms (5.4 TB/s, tools/store_probe.hip), but a loop that fetched a row's state, lifted it and stored it took 15.9 ms
+// at three waves per SIMD (132 VGPRs).  Fetching the next row's state while the current one is lifted, and letting the tail
+// block work on four rows at a time, brought it to 12.5 ms.
 constexpr int LIFT_NC = 4;          // centres per lane
 constexpr int LIFT_BLOCK = 128;     // threads per block: 128 x 4 = 512 centres per block row
 template <int NS>
@@ -171,11 +188,28 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
         const double* xp = X + (g0 < total_rows ? g0 : total_rows - 1) * n;
         double* zp = Zrows + l0 * W + c0;
         const bool store = c0 < s.kp;                  // kp is a multiple of 16: a lane's four columns are inside or outside together
+        // the next row's state is fetched (scalar loads) while the current row is lifted: the loop is otherwise one exposed
+        // scalar-load latency per row (the kernel spends 63 % of its wave-cycles waiting, three waves per SIMD)
+        constexpr int NSP = NS > 0 ? NS : 1;
+        double xcur[NSP], xnext[NSP];
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int j = 0; j < NS; ++j) xcur[j] = xp[j];
+        }
 #pragma unroll 1
         for (int64_t l = l0; l < lend; ++l) {
             const int64_t g = row0 + l;
             double z[NC];
-            rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
+            if constexpr (NS > 0) {
+                const double* xq = (g + 1 < total_rows) ? xp + n : xp;      // clamp: rows past the end are masked
+#pragma unroll
+                for (int j = 0; j < NS; ++j) xnext[j] = xq[j];
+                rbf_vals<NS, NC>(gamma, xcur, cc, c2, z);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) xcur[j] = xnext[j];
+            } else {
+                rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
+            }
             const bool valid = g < total_rows && t <= L;                     // wave-uniform
 #pragma unroll
             for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
@@ -188,19 +222,27 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
             if (++t == xs) { t = 0; ++bag; }
         }
     } else {
-        // tail block: [x | u | 0], and the pair weight
-        for (int64_t l = l0; l < lend; ++l) {
-            const int64_t g = row0 + l;
-            for (int j = threadIdx.x; j < s.tailp; j += LIFT_BLOCK) {
-                double v = 0.0;
-                if (g < total_rows && t <= L) {
-                    if (j < n) v = X[g * n + j];
-                    else if (j < n + s.r && t < L) v = U[(bag * us + t) * s.r + (j - n)];
+        // tail block: [x | u | 0] and the pair weight; a thread = one (row, column) of a group of LIFT_BLOCK / tailp rows, so that
+        // the loads of several rows are in flight together (one row per trip was one exposed global-load latency per row)
+        const int tp = s.tailp, rpp = tp <= LIFT_BLOCK ? LIFT_BLOCK / tp : 1;     // rows per pass
+        const int jr = threadIdx.x / tp, j = threadIdx.x - jr * tp;
+        for (int64_t lb = l0; lb < lend; lb += rpp) {
+            const int64_t l = lb + jr;
+            if (jr < rpp && l < lend) {
+                const int64_t g = row0 + l;
+                // (bag, step) of this row from the block's first row: at most a few wraps per 64 rows
+                int64_t tt = t + (l - l0), bb = bag;
+                while (tt >= xs) { tt -= xs; ++bb; }
+                for (int jj = j; jj < tp; jj += (tp <= LIFT_BLOCK ? tp : LIFT_BLOCK)) {
+                    double v = 0.0;
+                    if (g < total_rows && tt <= L) {
+                        if (jj < n) v = X[g * n + jj];
+                        else if (jj < n + s.r && tt < L) v = U[(bb * us + tt) * s.r + (jj - n)];
+                    }
+                    Zrows[l * W + s.kp + jj] = v;
                 }
-                Zrows[l * W + s.kp + j] = v;
+                if (j == 0) wrow[l] = (g < total_rows && tt < L) ? 1.0 : 0.0;
             }
-            if (threadIdx.x == 0) wrow[l] = (g < total_rows && t < L) ? 1.0 : 0.0;
-            if (++t == xs) { t = 0; ++bag; }
         }
     }
 }

@@ -18,4 +18,4 @@ for rep in range(3):
     e0.record()
     engine.gram_dev(X.view(-1, n), U.view(-1, r), C, 1.0, nb, L, L + 1, L, G, Y, ctx=ctx)
     e1.record(); torch.cuda.synchronize()
-    print("%s rep %d: lift+gram %.2f ms" % (os.environ.get("BROV2_LIBRARY", "shipped").split("/")[-2], rep, e0.elapsed_time(e1)))
+    print("%s rep %d: lift+gram %.2f ms" % (os.path.basename(os.path.dirname(os.environ.get("BROV2_LIBRARY", "shipped/libbrov2.so"))), rep, e0.elapsed_time(e1)))
