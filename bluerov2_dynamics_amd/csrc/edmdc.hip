@@ -158,8 +158,11 @@ hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma
 // kernel 8 ms (5.4 TB/s, tools/store_probe.hip), but a loop that fetched a row's state, lifted it and stored it took 15.9 ms
 // at three waves per SIMD (132 VGPRs).  Fetching the next row's state while the current one is lifted, and letting the tail
 // block work on four rows at a time, brought it to 12.5 ms.
-constexpr int LIFT_NC = 4;          // centres per lane
-constexpr int LIFT_BLOCK = 128;     // threads per block: 128 x 4 = 512 centres per block row
+#ifndef LIFT_NC_
+#define LIFT_NC_ 4
+#endif
+constexpr int LIFT_NC = LIFT_NC_;              // centres per lane (even)
+constexpr int LIFT_BLOCK = 512 / LIFT_NC;      // threads per block: 512 centres per block row
 template <int NS>
 __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
                                                         int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
@@ -214,8 +217,8 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
 #pragma unroll
             for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
             if (store) {
-                *reinterpret_cast<double2*>(zp) = make_double2(z[0], z[1]);
-                *reinterpret_cast<double2*>(zp + 2) = make_double2(z[2], z[3]);
+#pragma unroll
+                for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(zp + q) = make_double2(z[q], z[q + 1]);
             }
             zp += W;
             if (g + 1 < total_rows) xp += n;                                 // clamp: rows past the end are masked
