@@ -265,31 +265,64 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
 // ---------------------------------------------------------------------------------------
 // K5: Gram
 // ---------------------------------------------------------------------------------------
-// One task = GRAM_TA A-tiles x GRAM_TB B-tiles.  A tile ta: columns [16 ta, 16 ta + 16) of row t.
-// B tile: tb >= 0 -> columns [16 tb, ..) of row t (G^T G part); encoded (tb | 0x10000) -> row t+1
-// (G^T Y part).  -1 = empty slot.
-struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; };
+// One task = GRAM_TA A-tiles x GRAM_TB B-tiles of 16 features.  A tile code: t >= 0 -> columns [16 t, 16 t + 16) of row t of
+// the K-step ("G tile": phi(x_t), x_t, u_t); (t | 0x10000) -> the same columns of row t+1 ("Y tile": phi(x_{t+1})); -1 = empty
+// slot.  The A operand carries the pair weight.  `want` bit (a * GRAM_TB + b) marks the tile products the finish kernel
+// keeps: every needed product is computed by exactly one task.
+struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; unsigned want; };
 
-// mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T)
+// mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T).
+// Mode 0 is a staircase: number the columns of [G | Y] 0 .. nt + nty - 1 (G tiles, then Y tiles); by symmetry row-tile i
+// needs columns i .. nt + nty - 1 only.  Bands of 4 row-tiles are cut into 4 x 6 blocks (A = the band's rows, B = 6 columns);
+// when nt = 2 mod 4 the last band has SIX row-tiles and is cut into 6 x 4 blocks the other way round (A = 4 COLUMN tiles,
+// weighted, G or Y; B = the band's six row tiles), because the weight may sit on either factor of w g y^T.  k = 512: 78 tasks
+// (68 + 10) instead of the 81 of all-4-row bands whose last band is half empty; 72 would be perfect packing.  Every wave
+// still runs the same instruction stream (4 + 6 + 1 loads, 24 MFMAs per K-step), which is what keeps the waves of a slab
+// together in the L2.
 static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, int mode) {
     const int nt = s.width / 16;                     // G tiles
     const int nty = s.kp / 16 + (s.n + 15) / 16;     // Y tiles: rbf block + the x part of the tail
     tasks.clear();
-    for (int a0 = 0; a0 < nt; a0 += GRAM_TA) {
-        std::vector<int> bl;
-        if (mode == 0) for (int tb = a0; tb < nt; ++tb) bl.push_back(tb);   // upper triangle of G^T G (block granularity)
-        for (int tb = 0; tb < nty; ++tb) bl.push_back(tb | 0x10000);        // all of G^T Y
-        for (size_t o = 0; o < bl.size(); o += GRAM_TB) {
-            GramTask t;
-            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < nt) ? a0 + i : -1;
-            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (o + j < bl.size()) ? bl[o + j] : -1;
+    auto code = [&](int c) { return c < nt ? c : ((c - nt) | 0x10000); };     // column number -> tile code
+    if (mode == 1) {                                 // rectangle nt x nty, 4-row bands
+        for (int a0 = 0; a0 < nt; a0 += GRAM_TA)
+            for (int c0 = 0; c0 < nty; c0 += GRAM_TB) {
+                GramTask t; t.want = 0;
+                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < nt) ? a0 + i : -1;
+                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < nty) ? ((c0 + j) | 0x10000) : -1;
+                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j) if (t.a[i] >= 0 && t.b[j] >= 0) t.want |= 1u << (i * GRAM_TB + j);
+                tasks.push_back(t);
+            }
+        return;
+    }
+    const int ncol = nt + nty;
+    const bool six = (nt % 4 == 2) && nt >= 6;
+    const int rows4 = six ? nt - 6 : nt;             // row-tiles handled by 4-row bands
+    for (int a0 = 0; a0 < rows4; a0 += GRAM_TA)
+        for (int c0 = a0; c0 < ncol; c0 += GRAM_TB) {
+            GramTask t; t.want = 0;
+            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < rows4) ? a0 + i : -1;
+            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < ncol) ? code(c0 + j) : -1;
+            for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                if (t.a[i] >= 0 && t.b[j] >= 0 && c0 + j >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
+            tasks.push_back(t);
+        }
+    if (six) {
+        const int r0 = nt - 6;
+        static_assert(GRAM_TB == 6 && GRAM_TA == 4, "the six-row band is cut into TB x TA blocks");
+        for (int c0 = r0; c0 < ncol; c0 += GRAM_TA) {
+            GramTask t; t.want = 0;
+            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < ncol) ? code(c0 + i) : -1;       // A = column tiles (weighted)
+            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = r0 + j;                                     // B = the band's row tiles
+            for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                if (t.a[i] >= 0 && c0 + i >= r0 + j) t.want |= 1u << (i * GRAM_TB + j);
             tasks.push_back(t);
         }
     }
 }
 
 // K-slabs per chunk: as many as keep tasks x slabs within the 2048 wave slots of the chip at 2 waves/SIMD
-// (k = 512: 81 tasks x 25 slabs = 2025 waves, one resident round, 98.9 % of the slots busy)
+// (k = 512: 78 tasks x 26 slabs = 2028 waves, one resident round, 99.0 % of the slots busy)
 constexpr int GRAM_WAVE_SLOTS = 2048;
 static int gram_nslab(int ntasks) {
     int ns = GRAM_WAVE_SLOTS / (ntasks > 0 ? ntasks : 1);
@@ -329,7 +362,7 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
             int accumulate) {
     // ZA: rows the A tiles are cut from (== Z for the Gram; the rows of W = G P^T for edmdc_pinv_apply), same width W
     // XCD-aware item mapping: blocks b and b+8 share an XCD (observed round-robin, speed only); items are
-    // ordered slab-major and each XCD takes a contiguous run, so the ~81 task-waves of a slab share one L2.
+    // ordered slab-major and each XCD takes a contiguous run, so the ~80 task-waves of a slab share one L2.
     const int bid = blockIdx.x;
     const int item = (bid & 7) * items_per_xcd + (bid >> 3);
     if ((bid >> 3) >= items_per_xcd || item >= ntasks * nslab) return;
@@ -347,7 +380,11 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
     // pointer the loads take the "SGPR base + 32-bit VGPR offset" form, one address register per operand instead of two
     unsigned aoff[GRAM_TA], boff[GRAM_TB];
 #pragma unroll
-    for (int a = 0; a < GRAM_TA; ++a) { const int ta = tasks[task].a[a]; aoff[a] = 8u * (unsigned)(kq * W + (ta < 0 ? 0 : ta * 16) + col); }
+    for (int a = 0; a < GRAM_TA; ++a) {
+        const int tae = tasks[task].a[a];
+        const int ta = tae < 0 ? 0 : tae;
+        aoff[a] = 8u * (unsigned)((kq + ((ta >> 16) & 1)) * W + (ta & 0xFFFF) * 16 + col);
+    }
 #pragma unroll
     for (int b = 0; b < GRAM_TB; ++b) {
         const int tbe = tasks[task].b[b];
@@ -515,20 +552,23 @@ __device__ __forceinline__ int dev_to_ref_feature(const EdmdcShape& s, int f, bo
 __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntasks, int nslab, const GramTask* __restrict__ tasks,
                                                           const double* __restrict__ partial, int accumulate_out,
                                                           double* __restrict__ GtG, double* __restrict__ GtY) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over ntasks * 32 tiles * 256
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over ntasks * 24 tiles * 256
     const int64_t total = (int64_t)ntasks * GRAM_TA * GRAM_TB * 256;
     if (idx >= total) return;
     const int e = (int)(idx & 255), tile = (int)((idx >> 8) % (GRAM_TA * GRAM_TB)), task = (int)(idx / (GRAM_TA * GRAM_TB * 256));
+    if (!((tasks[task].want >> tile) & 1u)) return;     // empty slot, or a product another task owns
     const int lane = e >> 2, reg = e & 3;
     const int a = tile / GRAM_TB, b = tile % GRAM_TB;
-    const int ta = tasks[task].a[a], tbe = tasks[task].b[b];
-    if (ta < 0 || tbe < 0) return;
-    const bool is_y = (tbe >> 16) & 1;
-    const int tb = tbe & 0xFFFF;
-    if (!is_y && tb < ta) return;                       // redundant lower-triangle tile
-    const int fi = ta * 16 + (lane >> 4) + 4 * reg;     // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg
-    const int fj = tb * 16 + (lane & 15);               //                                          col = lane & 15
-    const int ri = dev_to_ref_feature(s, fi, false), rj = dev_to_ref_feature(s, fj, is_y);
+    const int tae = tasks[task].a[a], tbe = tasks[task].b[b];
+    const bool ya = (tae >> 16) & 1, yb = (tbe >> 16) & 1;
+    const int ta = tae & 0xFFFF, tb = tbe & 0xFFFF;
+    const int fa = ta * 16 + (lane >> 4) + 4 * reg;     // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg (A side)
+    const int fb = tb * 16 + (lane & 15);               //                                          col = lane & 15 (B side)
+    if (!ya && !yb && ta == tb && fb < fa) return;      // diagonal G x G tile: the upper half is written, and mirrored below
+    // which of the two is the G^T-side (row of the output) feature
+    const int fg = ya ? fb : fa, fo = ya ? fa : fb;     // A = Y tile: the task is the transposed product (w y)^T ... g
+    const bool is_y = ya || yb;
+    const int ri = dev_to_ref_feature(s, fg, false), rj = dev_to_ref_feature(s, fo, is_y);
     if (ri < 0 || rj < 0) return;
     double sum = 0.0;
     const double* pp = partial + (int64_t)task * nslab * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;
@@ -537,7 +577,6 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntas
         double* o = GtY + (int64_t)ri * s.d + rj;
         *o = accumulate_out ? *o + sum : sum;
     } else {
-        if (tb == ta && fj < fi) return;                // diagonal tile: write the upper half, mirror below
         double* o = GtG + (int64_t)ri * s.p + rj;
         const double v = accumulate_out ? *o + sum : sum;
         *o = v;
