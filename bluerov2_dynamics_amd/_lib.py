@@ -105,6 +105,7 @@ SIGNATURES = {
                                         i64, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_pinv_apply_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                             i64, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edmdc_gram_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "brov_comm_available": (ctypes.c_int, []),
     "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
     "brov_comm_init_rank": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void_p)]),

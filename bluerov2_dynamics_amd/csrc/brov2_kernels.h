@@ -32,6 +32,8 @@ struct EdmdcShape {
     int tailp;   // (n + r) padded to a multiple of 16
     int width;   // kp + tailp  (doubles per lifted row)
     int d, p;    // n + k, n + k + r
+    int xplus;   // 1: the padding of the tail is wide enough for x_{t+1} (n + r + n <= tailp); lift_rows writes it there and the
+                 //    Gram takes the x part of Y from the row's own last tile instead of from a 33rd Y tile of the next row
 };
 inline EdmdcShape edmdc_shape(int n, int r, int k) {
     EdmdcShape s;
@@ -40,6 +42,7 @@ inline EdmdcShape edmdc_shape(int n, int r, int k) {
     s.tailp = (n + r + 15) / 16 * 16;
     s.width = s.kp + s.tailp;
     s.d = n + k; s.p = n + k + r;
+    s.xplus = (n + r + n <= s.tailp) ? 1 : 0;
     return s;
 }
 // Reference-order lift Z[N][n+k] = [x, rbf]  (edmdc_lift C entry point)

@@ -907,6 +907,12 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
     return BROV_OK;
 }
 
+int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
+    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    (void)gram_partial_doubles(edmdc_shape(n, r, k), 0, ntasks, nslabs);
+    return BROV_OK;
+}
+
 // ---- fit()'s own association: M = (P G^T) Y  (Koopman/koopmanEDMDc.py:97) ------------------------------------------
 int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
                          int64_t xs, int64_t us, const double* d_X, const double* d_U, const double* P_host, double* d_M) {

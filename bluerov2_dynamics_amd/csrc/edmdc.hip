@@ -4,7 +4,7 @@
 //
 // Data flow per chunk of state rows (chunk sized by the host, default 2^20 rows):
 //   lift_rows_kernel : X,U  ->  Zrows[row][W]   (W = kp + tailp doubles, e.g. 544)
-//                               row = [ rbf_0..rbf_{kp-1} | x_0..x_{n-1} u_0..u_{r-1} 0.. ]
+//                               row = [ rbf_0..rbf_{kp-1} | x_0..x_{n-1} u_0..u_{r-1} x+_0..x+_{n-1} 0.. ]   (x+ = next state, when it fits)
 //                               wrow[row] = 1 if (row, row+1) is a pair inside one bag else 0
 //   gram_kernel      : partial[task][slab] += sum_{row in slab} w[row] Z[row]^T [ Z[row] | Z[row+1] ]
 //   gram_finish      : fixed-order sum over slabs, scatter to reference feature order.
@@ -225,7 +225,7 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
             if (++t == xs) { t = 0; ++bag; }
         }
     } else {
-        // tail block: [x | u | 0] and the pair weight; a thread = one (row, column) of a group of LIFT_BLOCK / tailp rows, so that
+        // tail block: [x | u | x_next (xplus shapes, pair rows only) | 0] and the pair weight; a thread = one (row, column) of a group of LIFT_BLOCK / tailp rows, so that
         // the loads of several rows are in flight together (one row per trip was one exposed global-load latency per row)
         const int tp = s.tailp, rpp = tp <= LIFT_BLOCK ? LIFT_BLOCK / tp : 1;     // rows per pass
         const int jr = threadIdx.x / tp, j = threadIdx.x - jr * tp;
@@ -240,7 +240,8 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
                     double v = 0.0;
                     if (g < total_rows && tt <= L) {
                         if (jj < n) v = X[g * n + jj];
-                        else if (jj < n + s.r && tt < L) v = U[(bb * us + tt) * s.r + (jj - n)];
+                        else if (jj < n + s.r) { if (tt < L) v = U[(bb * us + tt) * s.r + (jj - n)]; }
+                        else if (s.xplus && jj < n + s.r + n && tt < L && g + 1 < total_rows) v = X[(g + 1) * n + (jj - n - s.r)];
                     }
                     Zrows[l * W + s.kp + jj] = v;
                 }
@@ -273,18 +274,20 @@ struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; unsigned want; };
 
 // mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T).
 // Mode 0 is a staircase: number the columns of [G | Y] 0 .. nt + nty - 1 (G tiles, then Y tiles); by symmetry row-tile i
-// needs columns i .. nt + nty - 1 only.  Bands of 4 row-tiles are cut into 4 x 6 blocks (A = the band's rows, B = 6 columns);
-// when nt = 2 mod 4 the last band has SIX row-tiles and is cut into 6 x 4 blocks the other way round (A = 4 COLUMN tiles,
-// weighted, G or Y; B = the band's six row tiles), because the weight may sit on either factor of w g y^T.  k = 512: 78 tasks
-// (68 + 10) instead of the 81 of all-4-row bands whose last band is half empty; 72 would be perfect packing.  Every wave
-// still runs the same instruction stream (4 + 6 + 1 loads, 24 MFMAs per K-step), which is what keeps the waves of a slab
-// together in the L2.
+// needs columns i .. nt + nty - 1 only.  The row-tiles are cut into bands of 4 or 6: a 4-band into 4 x 6 blocks (A = the band's
+// rows, B = 6 columns), a 6-band into 6 x 4 blocks the other way round (A = 4 COLUMN tiles, weighted, G or Y; B = the band's
+// six row tiles), because the weight may sit on either factor of w g y^T.  The band sizes are chosen to minimise the number
+// of blocks (a small DP: a band that starts at row a0 has ncol - a0 columns, cut in sixes or in fours).
+// s.xplus (the tail tile has room for x_{t+1}: n + r + n <= tailp): the x part of Y rides in the last G tile of the SAME row, so
+// the Y tiles are the rbf tiles only.  k = 512: 34 + 32 = 66 columns, 75 tasks (seven 4-bands and a 6-band); with the x part
+// of Y as a 33rd Y tile every band has an odd number of columns and none divides: 78 tasks.  1683 wanted tile products in
+// 75 x 24 = 1800 slots; 71 would be perfect packing.  Every wave still runs the same instruction stream (4 + 6 + 1 loads,
+// 24 MFMAs per K-step), which is what keeps the waves of a slab together in the L2.
 static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, int mode) {
     const int nt = s.width / 16;                     // G tiles
-    const int nty = s.kp / 16 + (s.n + 15) / 16;     // Y tiles: rbf block + the x part of the tail
     tasks.clear();
-    auto code = [&](int c) { return c < nt ? c : ((c - nt) | 0x10000); };     // column number -> tile code
-    if (mode == 1) {                                 // rectangle nt x nty, 4-row bands
+    if (mode == 1) {                                 // rectangle nt x nty, 4-row bands; Y = rbf tiles + the x part of the next row's tail
+        const int nty = s.kp / 16 + (s.n + 15) / 16;
         for (int a0 = 0; a0 < nt; a0 += GRAM_TA)
             for (int c0 = 0; c0 < nty; c0 += GRAM_TB) {
                 GramTask t; t.want = 0;
@@ -295,34 +298,48 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
             }
         return;
     }
+    static_assert(GRAM_TB == 6 && GRAM_TA == 4, "a 6-band is cut into TB x TA blocks");
+    const int nty = s.xplus ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16;
     const int ncol = nt + nty;
-    const bool six = (nt % 4 == 2) && nt >= 6;
-    const int rows4 = six ? nt - 6 : nt;             // row-tiles handled by 4-row bands
-    for (int a0 = 0; a0 < rows4; a0 += GRAM_TA)
-        for (int c0 = a0; c0 < ncol; c0 += GRAM_TB) {
-            GramTask t; t.want = 0;
-            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < rows4) ? a0 + i : -1;
-            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < ncol) ? code(c0 + j) : -1;
-            for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                if (t.a[i] >= 0 && t.b[j] >= 0 && c0 + j >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
-            tasks.push_back(t);
+    auto code = [&](int c) { return c < nt ? c : ((c - nt) | 0x10000); };     // column number -> tile code
+    // cost[a0] = fewest blocks for the rows a0 .. nt-1; band[a0] = size of the band that starts there
+    std::vector<int> cost(nt + 1, 0), band(nt + 1, 0);
+    for (int a0 = nt - 1; a0 >= 0; --a0) {
+        const int L = ncol - a0, rem = nt - a0;
+        const int r4 = rem < 4 ? rem : 4;
+        cost[a0] = (L + GRAM_TB - 1) / GRAM_TB + cost[a0 + r4];
+        band[a0] = r4;
+        if (rem >= 6) {
+            const int c6 = (L + GRAM_TA - 1) / GRAM_TA + cost[a0 + 6];
+            if (c6 < cost[a0]) { cost[a0] = c6; band[a0] = 6; }
         }
-    if (six) {
-        const int r0 = nt - 6;
-        static_assert(GRAM_TB == 6 && GRAM_TA == 4, "the six-row band is cut into TB x TA blocks");
-        for (int c0 = r0; c0 < ncol; c0 += GRAM_TA) {
-            GramTask t; t.want = 0;
-            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < ncol) ? code(c0 + i) : -1;       // A = column tiles (weighted)
-            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = r0 + j;                                     // B = the band's row tiles
-            for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                if (t.a[i] >= 0 && c0 + i >= r0 + j) t.want |= 1u << (i * GRAM_TB + j);
-            tasks.push_back(t);
+    }
+    for (int a0 = 0; a0 < nt; a0 += band[a0]) {
+        if (band[a0] == 6) {
+            for (int c0 = a0; c0 < ncol; c0 += GRAM_TA) {
+                GramTask t; t.want = 0;
+                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < ncol) ? code(c0 + i) : -1;       // A = column tiles (weighted)
+                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = a0 + j;                                     // B = the band's row tiles
+                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                    if (t.a[i] >= 0 && c0 + i >= a0 + j) t.want |= 1u << (i * GRAM_TB + j);
+                tasks.push_back(t);
+            }
+        } else {
+            const int rows = band[a0];
+            for (int c0 = a0; c0 < ncol; c0 += GRAM_TB) {
+                GramTask t; t.want = 0;
+                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (i < rows) ? a0 + i : -1;
+                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < ncol) ? code(c0 + j) : -1;
+                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                    if (t.a[i] >= 0 && t.b[j] >= 0 && c0 + j >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
+                tasks.push_back(t);
+            }
         }
     }
 }
 
 // K-slabs per chunk: as many as keep tasks x slabs within the 2048 wave slots of the chip at 2 waves/SIMD
-// (k = 512: 78 tasks x 26 slabs = 2028 waves, one resident round, 99.0 % of the slots busy)
+// (k = 512: 75 tasks x 27 slabs = 2025 waves, one resident round, 98.9 % of the slots busy)
 constexpr int GRAM_WAVE_SLOTS = 2048;
 static int gram_nslab(int ntasks) {
     int ns = GRAM_WAVE_SLOTS / (ntasks > 0 ? ntasks : 1);
@@ -541,12 +558,16 @@ int edmdc_dev_to_ref_feature(const EdmdcShape& s, int f) {
 
 // Finish: one thread per (task, tile, lane, reg); sums the slabs in index order and scatters to the
 // reference feature order: G = [x (n) | rbf (k) | u (r)], Y = [x (n) | rbf (k)].
-__device__ __forceinline__ int dev_to_ref_feature(const EdmdcShape& s, int f, bool is_y) {
+// Column f of a tile -> reference index and side.  ytile: the tile is cut from row t+1 (everything in it that is not padding
+// or u is a Y feature); a G tile of an xplus shape carries x_{t+1} behind u: Y features in a G tile.
+__device__ __forceinline__ int dev_to_ref_feature(const EdmdcShape& s, int f, bool ytile, bool& yfeat) {
+    yfeat = ytile;
     if (f < s.k) return s.n + f;
     if (f < s.kp) return -1;
     const int j = f - s.kp;
     if (j < s.n) return j;
-    if (j < s.n + s.r) return is_y ? -1 : s.d + (j - s.n);
+    if (j < s.n + s.r) return ytile ? -1 : s.d + (j - s.n);
+    if (!ytile && s.xplus && j < s.n + s.r + s.n) { yfeat = true; return j - s.n - s.r; }
     return -1;
 }
 __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntasks, int nslab, const GramTask* __restrict__ tasks,
@@ -565,11 +586,11 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntas
     const int fa = ta * 16 + (lane >> 4) + 4 * reg;     // C/D layout of v_mfma_f64_16x16x4_f64: row = (lane>>4) + 4 reg (A side)
     const int fb = tb * 16 + (lane & 15);               //                                          col = lane & 15 (B side)
     if (!ya && !yb && ta == tb && fb < fa) return;      // diagonal G x G tile: the upper half is written, and mirrored below
-    // which of the two is the G^T-side (row of the output) feature
-    const int fg = ya ? fb : fa, fo = ya ? fa : fb;     // A = Y tile: the task is the transposed product (w y)^T ... g
-    const bool is_y = ya || yb;
-    const int ri = dev_to_ref_feature(s, fg, false), rj = dev_to_ref_feature(s, fo, is_y);
-    if (ri < 0 || rj < 0) return;
+    bool fya, fyb;
+    const int ra = dev_to_ref_feature(s, fa, ya, fya), rb = dev_to_ref_feature(s, fb, yb, fyb);
+    if (ra < 0 || rb < 0 || (fya && fyb)) return;       // padding, or a Y x Y product nobody asked for
+    const bool is_y = fya || fyb;
+    const int ri = fya ? rb : ra, rj = fya ? ra : rb;   // row of the output = the G-side feature (A = Y feature: transposed product)
     double sum = 0.0;
     const double* pp = partial + (int64_t)task * nslab * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;
     for (int sl = 0; sl < nslab; ++sl) sum += pp[(int64_t)sl * (GRAM_TA * GRAM_TB * 256)];

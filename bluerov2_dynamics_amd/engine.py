@@ -211,6 +211,15 @@ def gram(X_list, U_list, C, gamma, ctx=None):
     return GtG, GtY, npairs
 
 
+def gram_decomposition(n, r, k):
+    """(ntasks, nslabs) of the device Gram for a shape: ntasks blocks of 4 x 6 tiles of 16 x 16 outputs per slab of rows."""
+    nt, ns = ctypes.c_int(0), ctypes.c_int(0)
+    rc = _lib.load_library().edmdc_gram_decomposition(int(n), int(r), int(k), ctypes.byref(nt), ctypes.byref(ns))
+    if rc:
+        raise ValueError(f"edmdc_gram_decomposition: unsupported shape n={n} r={r} k={k}")
+    return nt.value, ns.value
+
+
 def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, accumulate=False, ctx=None):
     """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h)."""
     ctx = ctx or default_context(X.device.index)

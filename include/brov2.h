@@ -251,6 +251,11 @@ BROV_API int edmdc_pinv_apply_dev(brov_ctx* ctx, int n, int r, int k, double gam
                                   int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
                                   const double* d_X, const double* d_U, const double* P_host, double* d_M);
 
+/* Work decomposition of edmdc_gram / edmdc_gram_dev for a shape (no device work; for roofline accounting): the normal
+ * equations G^T[G|Y] (Koopman/koopmanEDMDc.py:129-147) are computed as ntasks blocks of 4 x 6 tiles of 16 x 16 per slab of
+ * rows, nslabs slabs per chunk; a task executes 24 x 16 x 16 x 2 = 12 288 flop per sample whether a tile is wanted or not. */
+BROV_API int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs);
+
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over
  * ranks of the local [GtG | GtY] blocks (4.5 MB at k = 512), after which every rank solves the same p x p system.

@@ -1016,7 +1016,7 @@ def test_multistep_accepts_inputs_one_row_shorter_than_states(eng):
 
 
 def test_gram_with_more_than_256_tasks(eng):
-    """k = 1024 needs 295 Gram tasks: the task table is sized from the shape (it used to be a fixed 256-entry buffer)."""
+    """k = 1024 needs 278 Gram tasks: the task table is sized from the shape (it used to be a fixed 256-entry buffer)."""
     from oracle import edmdc_numpy as ek
     rng = np.random.default_rng(2)
     n, r, k, N = 12, 8, 1024, 1500
@@ -1027,6 +1027,24 @@ def test_gram_with_more_than_256_tasks(eng):
     Go, Yo, _ = ek.gram([X], [U], C, 0.5)
     assert npairs == N - 1
     assert np.linalg.norm(GtG - Go) / np.linalg.norm(Go) < 1e-12 and np.linalg.norm(GtY - Yo) / np.linalg.norm(Yo) < 1e-12
+
+
+def test_gram_tail_layouts(eng):
+    """The x part of Y rides in the padding of the row's own tail tile when n + r + n fits there (12 + 8 + 12 = 32: the
+    benchmark shape) and comes from a Y tile of the next row otherwise; odd tile counts, several bags, every entry of both
+    blocks against the oracle (GtY's x columns and u rows are the ones that move)."""
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(21)
+    for n, r, k in ((12, 8, 48), (13, 8, 40), (12, 10, 33), (9, 4, 100), (5, 2, 16), (13, 6, 200), (12, 8, 500)):
+        Xs = [rng.normal(0, 0.5, (m, n)) for m in (37, 2, 160)]
+        Us = [rng.uniform(-1, 1, (m, r)) for m in (37, 2, 160)]
+        C = rng.normal(0, 0.5, (k, n))
+        GtG, GtY, npairs = eng.gram(Xs, Us, C, 0.7)
+        Go, Yo, _ = ek.gram(Xs, Us, C, 0.7)
+        assert npairs == 36 + 1 + 159
+        assert np.abs(GtG - Go).max() <= 1e-12 * np.abs(Go).max(), (n, r, k)
+        assert np.abs(GtY - Yo).max() <= 1e-12 * np.abs(Yo).max(), (n, r, k)
+        assert np.array_equal(GtG, GtG.T)
 
 
 def test_fit_keeps_the_references_own_product_order(eng):
