@@ -104,10 +104,10 @@ hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const
                                 const int* block_changed, double* C, double* c2, double* stats);
 
 int kmeanspp_chunks(int64_t N);
-int kmeanspp_blocks(int64_t N);
+size_t kmeanspp_sum_doubles(int64_t N);
 size_t kmeanspp_state_bytes();
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
-                           long long first, const double* u, double* Xt, double* xsq, double* closest, double* chunk_sum, double* partial,
+                           long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
                            void* state, double* C, long long* indices);
 
 }  // namespace brov

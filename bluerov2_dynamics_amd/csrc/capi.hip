@@ -1236,28 +1236,27 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
         n_trials < 1 || n_trials > 16 || (k > 1 && !uniforms_host) || N > 30000000)
         return fail(c, BROV_ERR_ARG, "edmdc_kmeanspp_dev: bad argument (need 1<=n<=16, 1<=n_trials<=16, k<=N<=3e7)");
     DeviceGuard g(c);
-    const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
-    const size_t nu = (size_t)(k > 1 ? k - 1 : 1) * n_trials;
+    const size_t nsum = kmeanspp_sum_doubles(N);
+    const size_t nu = (size_t)(k > 1 ? k : 1) * n_trials;        // one spare row: the last round's (unused) draw pointer stays in bounds
     Arena a(c);
-    int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al((size_t)nchunks * 8) + Arena::al((size_t)nblk * 16 * 8) + Arena::al(nu * 8) +
+    int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) +
                        Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + 8192);
     if (rc) return rc;
     double* Xt = a.take<double>((size_t)N * n);
     double* xsq = a.take<double>(N);
     double* closest = a.take<double>(N);
-    double* chunk_sum = a.take<double>(nchunks);
-    double* partial = a.take<double>((size_t)nblk * 16);
+    double* dsum = a.take<double>(nsum);
     double* du = a.take<double>(nu);
     long long* dind = a.take<long long>(k);
     char* state = a.take<char>(kmeanspp_state_bytes());
     double* dmean = a.take<double>(16);
     if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
-    if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, nu * 8, hipMemcpyHostToDevice, c->stream));
+    if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
         HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
-                                 closest, chunk_sum, partial, state, d_C, dind));
+                                 closest, dsum, state, d_C, dind));
     }
     if (indices_host) {
         static_assert(sizeof(long long) == sizeof(int64_t), "index width");

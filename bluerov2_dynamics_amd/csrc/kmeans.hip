@@ -174,20 +174,32 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
 // The running sum is formed per 4096-sample chunk (tree) + a sequential pass over the chunk sums + a sequential pass
 // inside the chunk that contains the value, not as one sequential np.cumsum: a candidate could differ from
 // scikit-learn's only if a drawn value fell within ~1e-13 (relative) of a running-sum boundary.
-// Per centre: pp_update_chunksum (1 pass over X), pp_pick (1 block), pp_candidates (1 pass over X), pp_select (1 block);
-// nothing returns to the host until all k centres are chosen.
+//
+// ONE pass over the samples per centre (the loop is bound by HBM: 112 bytes per sample and pass).  Round c (centre c is
+// being chosen, its L candidates are known):
+//   pp_round  (one block per chunk)   closest_i <- min(closest_i, d(x_i, centre c-1))  -- the update the previous round owed --
+//                                     and S[t][chunk] = sum over the chunk of min(closest_i, d(x_i, cand_t)) for every trial t
+//   pp_decide (one block per trial)   pot_t = sum of S[t][.]; winner = first smallest; centre c = its sample.  The candidates of
+//                                     round c+1 are drawn from the running sum of min(closest_i, d(x_i, centre c)): its chunk
+//                                     sums are S[winner][.], and inside the one chunk a drawn value falls into, the 4096 values
+//                                     are recomputed on the fly -- so the updated closest[] is never needed before the next
+//                                     pp_round writes it.
+// (The first version made two passes per centre: update + chunk sums, then the candidates' potentials; 535 us per centre at
+// N = 1e7 against 270 us now.)  Nothing returns to the host until all k centres are chosen.
 constexpr int PP_CHUNK = 4096;
 constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
 constexpr int PP_THREADS = 256;
+constexpr int PD_THREADS = 1024;      // pp_decide: 4 samples of the chunk per thread
+constexpr int PP_SROWS = PP_LMAX + 1; // rows of S: one per trial + the chunk sums of closest itself (used for the first draw)
 
 struct PPState {                      // device-resident scalars of the seeding loop
     double pot;                       // current potential
-    long long cand[PP_LMAX];          // candidate sample indices of this round
+    long long cand[2][PP_LMAX];       // candidate sample indices: round c reads [(c - 1) & 1], draws the next round's into [c & 1]
     long long last;                   // sample index of the centre chosen last
     int pad[2];
 };
 
-// The seeding makes 2 (k - 1) passes over the data, so the rows are first copied, centred, into a coordinate-major
+// The seeding makes k - 1 passes over the data, so the rows are first copied, centred, into a coordinate-major
 // array Xt[j][i] (one strided read of X; every later access is a coalesced 512-byte wave load), with |x_i|^2 alongside
 // (sklearn: row_norms(X, squared=True)).
 template <int NS>
@@ -213,204 +225,224 @@ __device__ __forceinline__ void pp_load_col(const double* __restrict__ Xt, int64
     for (int j = 0; j < KM_NMAX; ++j) x[j] = (NS > 0 ? (j < NS) : (j < n)) ? Xt[(int64_t)j * N + i] : 0.0;
 }
 
-// closest_i = min(closest_i, d(x_i, x_last))  (first = 1: closest_i = d) and the sum of every 4096-sample chunk.
-// One block per chunk, 256 threads x 16 samples, fixed reduction tree.
+// d(x, c) = max(0, (-2 x.c + |c|^2) + |x|^2), the dot product accumulated in coordinate order: the one formula every kernel
+// of the seeding uses, so that a value recomputed by pp_decide is bit-identical to what pp_round stores later
+template <int NS, class Row>
+__device__ __forceinline__ double pp_dist(const double x[KM_NMAX], Row&& crow, double cn, double xx) {
+    constexpr int NJ = NS > 0 ? NS : KM_NMAX;                // coordinates beyond n are zero on both sides
+    double dot = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) dot = fma(x[j], crow(j), dot);
+    const double d = (-2.0 * dot + cn) + xx;
+    return d > 0.0 ? d : 0.0;
+}
+
+// upd: 0 = closest stands (round 1: it already holds d(., centre 0)); 1 = closest_i = d(x_i, x_last) (before round 1);
+//      2 = closest_i = min(closest_i, d(x_i, x_last)).
+// S[t][chunk] = sum over the chunk of min(closest_i, d(x_i, cand_t)), t < L;  S[PP_LMAX][chunk] = sum of closest_i.
+// One block per 4096-sample chunk, 256 threads x 16 samples, fixed reduction tree.
 template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_update_chunksum_kernel(int64_t N, int n, const double* __restrict__ Xt,
-                                                                       const double* __restrict__ xsq, const PPState* __restrict__ st, int first,
-                                                                       double* __restrict__ closest, double* __restrict__ chunk_sum) {
-    __shared__ double sh[PP_THREADS];
-    const int64_t last = st->last;
-    double c[KM_NMAX];
-    pp_load_col<NS>(Xt, N, n, last, c);
-    const double cc = xsq[last];
-    double acc = 0.0;
+__global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
+                                                             const double* __restrict__ xsq, const PPState* __restrict__ st, int par, int upd,
+                                                             double* __restrict__ closest, double* __restrict__ S) {
+    // candidate rows in LDS: [trial][16 coordinates | norm | pad]; row L = the centre chosen last.  A compiler-level memory
+    // barrier in front of every trial keeps their reads where they are used: as plain loop invariants the compiler hoisted
+    // all 16 x 17 of them into registers (256 VGPRs + scratch, one wave per SIMD).
+    constexpr int CSW = KM_NMAX + 2;
+    __shared__ double cs[(PP_LMAX + 1) * CSW];
+    __shared__ double red[PP_THREADS / 64][PP_LMAX + 1];
+    for (int e = threadIdx.x; e < (L + 1) * CSW; e += PP_THREADS) {
+        const int t = e / CSW, j = e % CSW;
+        const int64_t ci = t < L ? st->cand[par][t] : st->last;
+        cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
+    }
+    __syncthreads();
+    double acc[PP_LMAX], acc0 = 0.0;
+#pragma unroll
+    for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
     const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
 #pragma unroll 1
     for (int q = 0; q < PP_CHUNK / PP_THREADS; ++q) {
         const int64_t i = base + q * PP_THREADS + threadIdx.x;
         if (i < N) {
-            double x[KM_NMAX], dot = 0.0;
+            double x[KM_NMAX];
             pp_load_col<NS>(Xt, N, n, i, x);
+            const double xx = xsq[i];
+            double old = upd == 1 ? 0.0 : closest[i];
+            if (upd) {
+                asm volatile("" ::: "memory");
+                const double* row = cs + L * CSW;
+                const double d = pp_dist<NS>(x, [&](int j) { return row[j]; }, row[KM_NMAX], xx);
+                old = (upd == 1 || d < old) ? d : old;        // np.minimum(closest, d)
+                closest[i] = old;
+            }
+            acc0 += old;
 #pragma unroll
-            for (int j = 0; j < KM_NMAX; ++j) dot = fma(x[j], c[j], dot);
-            double d = (-2.0 * dot + cc) + xsq[i];
-            d = d > 0.0 ? d : 0.0;
-            if (!first) { const double o = closest[i]; d = o < d ? o : d; }
-            closest[i] = d;
-            acc += d;
+            for (int t = 0; t < PP_LMAX; ++t) {
+                if (t < L) {
+                    asm volatile("" ::: "memory");
+                    const double* row = cs + t * CSW;
+                    const double d = pp_dist<NS>(x, [&](int j) { return row[j]; }, row[KM_NMAX], xx);
+                    acc[t] += old < d ? old : d;
+                }
+            }
         }
     }
-    sh[threadIdx.x] = acc;
-    __syncthreads();
-    for (int off = PP_THREADS / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-        __syncthreads();
+#pragma unroll
+    for (int t = 0; t <= PP_LMAX; ++t) {
+        double a = t < PP_LMAX ? acc[t] : acc0;
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
     }
-    if (threadIdx.x == 0) chunk_sum[blockIdx.x] = sh[0];
+    __syncthreads();
+    if (threadIdx.x <= PP_LMAX && (threadIdx.x < L || threadIdx.x == PP_LMAX)) {
+        double a = 0.0;
+        for (int w = 0; w < PP_THREADS / 64; ++w) a += red[w][threadIdx.x];
+        S[(int64_t)threadIdx.x * nchunks + blockIdx.x] = a;
+    }
 }
 
-// One block, one wave per trial: pot = sum of the chunk sums (round 0 only, else the winner's potential stands);
-// value = u * pot; chunk = first chunk whose running sum reaches it; inside the chunk lane l owns 64 consecutive
-// samples.  cand = first index with running sum >= value, clipped to N - 1 (np.searchsorted + np.clip).
-__global__ void __launch_bounds__(64 * PP_LMAX) pp_pick_kernel(int64_t N, int nchunks, int L, const double* __restrict__ u,
-                                                              const double* __restrict__ closest, const double* __restrict__ chunk_sum,
-                                                              PPState* __restrict__ st, int set_pot) {
-    extern __shared__ double prefix[];            // [nchunks + 1] exclusive running sums of the chunks
-    __shared__ double seg[64 * PP_LMAX];
-    {
-        // running sums of the chunk sums, in chunk order: every thread adds up a contiguous segment, thread 0 chains the
-        // segment totals, every thread then writes its segment's prefixes (fixed grouping -> same result every run)
-        const int nt = blockDim.x, per = (nchunks + nt - 1) / nt;
-        const int b0 = threadIdx.x * per, b1 = b0 + per < nchunks ? b0 + per : nchunks;
-        double a = 0.0;
-        for (int b = b0; b < b1; ++b) a += chunk_sum[b];
-        seg[threadIdx.x] = a;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double run = 0.0;
-            for (int t = 0; t < nt; ++t) { const double v = seg[t]; seg[t] = run; run += v; }
-            prefix[nchunks] = run;
-            if (set_pot) st->pot = run;
+// One block per trial of the NEXT round (one block when nothing is drawn); every block repeats the cheap global part.
+//   c > 0: winner = first trial with the smallest potential (np.argmin) among the candidates cand[(c-1)&1]; block 0 records it
+//          as centre c.  Potentials: one wave per trial, a lane takes every 64th chunk sum, then a fixed tree.
+//   draw : value = u[trial] * pot (pot = the winner's potential; before round 1 the sum of the chunk sums of closest);
+//          chunk = first chunk whose running sum reaches it (running sums of S[winner][.]); inside the chunk thread th
+//          owns 4 consecutive samples, whose values min(closest_i, d(x_i, centre c)) are recomputed here.
+//          cand = first index with running sum >= value, clipped to N - 1 (np.searchsorted + np.clip).
+template <int NS>
+__global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n, int nchunks, int L, int c, int draw, const double* __restrict__ u,
+                                                              const double* __restrict__ Xt, const double* __restrict__ xsq,
+                                                              const double* __restrict__ closest, const double* __restrict__ S,
+                                                              const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                                                              PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+    extern __shared__ double dyn[];               // prefix[nchunks + 1] | vals[PP_CHUNK]
+    double* prefix = dyn;
+    double* vals = dyn + (nchunks + 1);
+    __shared__ double pots[PP_LMAX];
+    __shared__ double wtot[PD_THREADS / 64];
+    __shared__ int wfirst[PD_THREADS / 64];
+    __shared__ long long s_last, s_found;
+    __shared__ double s_pot;
+    __shared__ int s_row;
+    const int tid = threadIdx.x;
+    if (c > 0) {
+        // one wave per trial: lane l adds every 64th chunk sum, then a fixed shuffle tree
+        const int t = tid >> 6, l = tid & 63;
+        if (t < L) {
+            double a = 0.0;
+            for (int b = l; b < nchunks; b += 64) a += S[(int64_t)t * nchunks + b];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+            if (l == 0) pots[t] = a;
         }
         __syncthreads();
-        double run = seg[threadIdx.x];
-        for (int b = b0; b < b1; ++b) { prefix[b] = run; run += chunk_sum[b]; }
+        if (tid == 0) {
+            int best = 0;
+            for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
+            const long long win = st->cand[(c - 1) & 1][best];
+            s_row = best; s_last = win; s_pot = pots[best];
+            if (blockIdx.x == 0) { st->pot = pots[best]; st->last = win; indices[c] = win; }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < n) C[(int64_t)c * n + tid] = X[s_last * xstride + tid] - (mean ? mean[tid] : 0.0);
+    } else {
+        if (tid == 0) { s_row = PP_LMAX; s_last = -1; s_pot = 0.0; }
+        __syncthreads();
+    }
+    if (!draw) return;
+    const double* cs = S + (int64_t)s_row * nchunks;
+    {
+        // running sums of the chunk sums, in chunk order: every thread adds up a contiguous segment; the segment totals are
+        // scanned in thread order (shuffle scan inside a wave, the 16 wave totals chained) -- fixed grouping, same result every run
+        const int per = (nchunks + PD_THREADS - 1) / PD_THREADS;
+        const int b0 = tid * per < nchunks ? tid * per : nchunks, b1 = b0 + per < nchunks ? b0 + per : nchunks;
+        double a = 0.0;
+        for (int b = b0; b < b1; ++b) a += cs[b];
+        const int lane = tid & 63, w = tid >> 6;
+        double incl = a;
+        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        double woff = 0.0;
+        for (int q = 0; q < w; ++q) woff += wtot[q];
+        double run = woff + (incl - a);
+        for (int b = b0; b < b1; ++b) { prefix[b] = run; run += cs[b]; }
+        if (tid == PD_THREADS - 1) {
+            prefix[nchunks] = run;
+            if (c == 0) { s_pot = run; if (blockIdx.x == 0) st->pot = run; }
+        }
+        __syncthreads();                          // wtot is reused below
     }
     __syncthreads();
-    const int trial = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (trial >= L) return;
-    const double pot = set_pot ? prefix[nchunks] : st->pot;
-    const double v = u[trial] * pot;
-    // first chunk b with prefix[b + 1] >= v (binary search, wave-uniform)
+    const int trial = blockIdx.x;
+    const double v = u[trial] * s_pot;
+    // first chunk b with prefix[b + 1] >= v (binary search, block-uniform)
     int lo = 0, hi = nchunks;                     // answer in [lo, hi]; hi = nchunks means "beyond the end"
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (prefix[mid + 1] >= v) hi = mid; else lo = mid + 1;
     }
-    long long found = N - 1;
+    if (tid == 0) s_found = N - 1;
     if (lo < nchunks) {
-        const int64_t base = (int64_t)lo * PP_CHUNK + lane * 64;
-        double seg = 0.0;
-        for (int q = 0; q < 64; ++q) { const int64_t i = base + q; if (i < N) seg += closest[i]; }
-        // exclusive prefix of the 64 segment sums, in lane order
-        double incl = seg;
+        const int64_t base = (int64_t)lo * PP_CHUNK;
+        const long long last = s_last;
+        double cl[KM_NMAX], cn = 0.0;
+        if (last >= 0) { pp_load_col<NS>(Xt, N, n, last, cl); cn = xsq[last]; }
+#pragma unroll
+        for (int q = 0; q < PP_CHUNK / PD_THREADS; ++q) {
+            const int sidx = q * PD_THREADS + tid;
+            const int64_t i = base + sidx;
+            double val = 0.0;
+            if (i < N) {
+                val = closest[i];
+                if (last >= 0) {
+                    double x[KM_NMAX];
+                    pp_load_col<NS>(Xt, N, n, i, x);
+                    const double d = pp_dist<NS>(x, [&](int j) { return cl[j]; }, cn, xsq[i]);
+                    val = d < val ? d : val;
+                }
+            }
+            vals[sidx] = val;
+        }
+        __syncthreads();
+        constexpr int PER = PP_CHUNK / PD_THREADS;    // consecutive samples per thread
+        double mine[PER], sg = 0.0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) { mine[q] = vals[tid * PER + q]; sg += mine[q]; }
+        const int lane = tid & 63, w = tid >> 6;
+        double incl = sg;
         for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        const double start = prefix[lo] + (incl - seg);
-        // the crossing segment: first lane whose inclusive running sum reaches v
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        double woff = 0.0;
+        for (int q = 0; q < w; ++q) woff += wtot[q];
+        incl += woff;
+        const double start = prefix[lo] + (incl - sg);
         const unsigned long long reach = __ballot(prefix[lo] + incl >= v);
-        if (reach) {
-            const int owner = __ffsll((long long)reach) - 1;
-            long long idx = -1;
-            if (lane == owner) {
+        if (lane == 0) wfirst[w] = reach ? __ffsll((long long)reach) - 1 : -1;
+        __syncthreads();
+        int ow = -1;
+        for (int q = 0; q < PD_THREADS / 64; ++q) if (wfirst[q] >= 0) { ow = q; break; }
+        if (ow >= 0) {
+            if (w == ow && lane == wfirst[ow]) {
+                const int64_t b4 = base + (int64_t)tid * PER;
                 double run = start;
-                idx = base + 63 < N ? base + 63 : N - 1;
-                for (int q = 0; q < 64; ++q) {
-                    const int64_t i = base + q;
+                long long idx = b4 + PER - 1 < N ? b4 + PER - 1 : N - 1;
+                for (int q = 0; q < PER; ++q) {
+                    const int64_t i = b4 + q;
                     if (i >= N) break;
-                    run += closest[i];
+                    run += mine[q];
                     if (run >= v) { idx = i; break; }
                 }
+                s_found = idx;
             }
-            found = __shfl(idx, owner);
-        } else {
+        } else if (tid == 0) {
             // rounding between the chunk's tree sum and its sequential sum: the value lies just past this chunk
             const long long nxt = (long long)(lo + 1) * PP_CHUNK;
-            found = nxt < N ? nxt : N - 1;
+            s_found = nxt < N ? nxt : N - 1;
         }
     }
-    if (lane == 0) st->cand[trial] = found;
-}
-
-// partial[block][trial] = sum over the block's samples of min(closest_i, d(x_i, x_cand[trial]))
-template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_candidates_kernel(int64_t N, int n, int L, const double* __restrict__ Xt,
-                                                                  const double* __restrict__ xsq, const double* __restrict__ closest,
-                                                                  const PPState* __restrict__ st, double* __restrict__ partial) {
-    // candidate rows in LDS: [trial][16 coordinates | norm | pad].  A compiler-level memory barrier in front of every
-    // trial keeps their reads where they are used: as plain loop invariants the compiler hoisted all 16 x 17 of them
-    // into registers (256 VGPRs + scratch, one wave per SIMD, 1.2 ms per pass over 1e7 rows).
-    constexpr int CSW = KM_NMAX + 2;
-    __shared__ double cs[PP_LMAX * CSW];
-    __shared__ double red[PP_THREADS / 64][PP_LMAX];
-    for (int e = threadIdx.x; e < L * CSW; e += PP_THREADS) {
-        const int t = e / CSW, j = e % CSW;
-        const int64_t ci = st->cand[t];
-        cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
-    }
     __syncthreads();
-    const double2* csv = reinterpret_cast<const double2*>(cs);
-    double acc[PP_LMAX];
-#pragma unroll
-    for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x; i < N; i += (int64_t)gridDim.x * PP_THREADS) {
-        double x[KM_NMAX];
-        pp_load_col<NS>(Xt, N, n, i, x);
-        const double xx = xsq[i], old = closest[i];
-#pragma unroll
-        for (int t = 0; t < PP_LMAX; ++t) {
-            if (t < L) {
-                asm volatile("" ::: "memory");
-                double dot = 0.0, dot1 = 0.0;
-                constexpr int NJ = NS > 0 ? (NS + 1) / 2 * 2 : KM_NMAX;     // coordinates beyond n are zero on both sides
-#pragma unroll
-                for (int j = 0; j < NJ; j += 2) {
-                    const double cx = csv[(t * CSW + j) / 2].x, cy = csv[(t * CSW + j) / 2].y;
-                    dot = fma(x[j], cx, dot);
-                    dot1 = fma(x[j + 1], cy, dot1);
-                }
-                const double cn = csv[(t * CSW + KM_NMAX) / 2].x;
-                double d = (-2.0 * (dot + dot1) + cn) + xx;
-                d = d > 0.0 ? d : 0.0;
-                acc[t] += old < d ? old : d;
-            }
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < PP_LMAX; ++t) {
-        double a = acc[t];
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < L) {
-        double a = 0.0;
-        for (int w = 0; w < PP_THREADS / 64; ++w) a += red[w][threadIdx.x];
-        partial[(int64_t)blockIdx.x * PP_LMAX + threadIdx.x] = a;
-    }
-}
-
-// winner = first trial with the smallest potential (np.argmin); records it as centre c.  The per-block partial
-// potentials are summed in a fixed order: 16 threads per trial take every 16th block, then a fixed tree.
-__global__ void __launch_bounds__(16 * PP_LMAX) pp_select_kernel(int nblocks, int n, int L, int c, const double* __restrict__ X, int64_t xstride,
-                                                                const double* __restrict__ mean, const double* __restrict__ partial,
-                                                                PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
-    __shared__ double part[PP_LMAX][16];
-    __shared__ double pots[PP_LMAX];
-    __shared__ long long win;
-    const int t = threadIdx.x >> 4, l = threadIdx.x & 15;
-    if (t < L) {
-        double a = 0.0;
-        for (int b = l; b < nblocks; b += 16) a += partial[(int64_t)b * PP_LMAX + t];
-        part[t][l] = a;
-    }
-    __syncthreads();
-    if (threadIdx.x < L) {
-        const double* q = part[threadIdx.x];
-        pots[threadIdx.x] = (((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]))) +
-                            (((q[8] + q[9]) + (q[10] + q[11])) + ((q[12] + q[13]) + (q[14] + q[15])));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int best = 0;
-        for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
-        st->pot = pots[best];
-        st->last = st->cand[best];
-        indices[c] = st->cand[best];
-        win = st->cand[best];
-    }
-    __syncthreads();
-    if (threadIdx.x < n) C[(int64_t)c * n + threadIdx.x] = X[win * xstride + threadIdx.x] - (mean ? mean[threadIdx.x] : 0.0);
+    if (tid == 0) st->cand[c & 1][trial] = s_found;
 }
 
 __global__ void pp_first_kernel(int n, long long first, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
@@ -421,30 +453,33 @@ __global__ void pp_first_kernel(int n, long long first, const double* __restrict
 }
 
 int kmeanspp_chunks(int64_t N) { return (int)((N + PP_CHUNK - 1) / PP_CHUNK); }
-int kmeanspp_blocks(int64_t N) {
-    const int64_t need = (N + PP_THREADS - 1) / PP_THREADS;
-    return (int)(need < 2048 ? (need > 0 ? need : 1) : 2048);
-}
+size_t kmeanspp_sum_doubles(int64_t N) { return (size_t)PP_SROWS * kmeanspp_chunks(N); }
 size_t kmeanspp_state_bytes() { return sizeof(PPState); }
 
-// the whole seeding loop, stream ordered; u: device [(k-1) * L] uniforms; Xt: device scratch [n][N]; C: device [k][n];
-// indices: device [k] (int64)
+// the whole seeding loop, stream ordered; u: device [(k-1) * L] uniforms; Xt: device scratch [n][N]; S: device scratch
+// [kmeanspp_sum_doubles(N)]; C: device [k][n]; indices: device [k] (int64)
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
-                           long long first, const double* u, double* Xt, double* xsq, double* closest, double* chunk_sum, double* partial,
+                           long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
                            void* state, double* C, long long* indices) {
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
-    const int nchunks = kmeanspp_chunks(N), nblk = kmeanspp_blocks(N);
-    if ((size_t)(nchunks + 1) * 8 > 60 * 1024) return hipErrorInvalidValue;        // prefix table of pp_pick in LDS: N <= 3.1e7
+    const int nchunks = kmeanspp_chunks(N);
+    const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;      // prefix table + the chunk's values: N <= 3e7
+    if (lds > 100 * 1024) return hipErrorInvalidValue;
     PPState* ps = reinterpret_cast<PPState*>(state);
     const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
 #define PP_DISPATCH(NS_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq); \
         hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
+        if (k > 1) { \
+            hipLaunchKernelGGL(pp_round_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
+            hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(L), dim3(PD_THREADS), lds, st, N, n, nchunks, L, 0, 1, u, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
+        } \
         for (int c = 1; c < k; ++c) { \
-            hipLaunchKernelGGL(pp_update_chunksum_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, Xt, xsq, ps, c == 1 ? 1 : 0, closest, chunk_sum); \
-            hipLaunchKernelGGL(pp_pick_kernel, dim3(1), dim3(64 * L), (size_t)(nchunks + 1) * 8, st, N, nchunks, L, u + (size_t)(c - 1) * L, closest, chunk_sum, ps, c == 1 ? 1 : 0); \
-            hipLaunchKernelGGL(pp_candidates_kernel<NS_>, dim3(nblk), dim3(PP_THREADS), 0, st, N, n, L, Xt, xsq, closest, ps, partial); \
-            hipLaunchKernelGGL(pp_select_kernel, dim3(1), dim3(16 * PP_LMAX), 0, st, nblk, n, L, c, X, xstride, mean, partial, ps, C, indices); \
+            const int draw = c + 1 < k ? 1 : 0; \
+            hipLaunchKernelGGL(pp_round_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
+            hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, L, c, draw, u + (size_t)c * L, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
 #undef PP_DISPATCH
