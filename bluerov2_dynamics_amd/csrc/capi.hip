@@ -52,6 +52,8 @@ struct brov_ctx {
     hipEvent_t ev_handover = nullptr; // orders the work queued on the previous stream before the next one (brov_set_stream)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams of edmdc_multistep_se (window groups advance independently), created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    double* h_stats = nullptr;        // pinned: per-iteration statistics of the Lloyd loop come back while the next E-step runs
+    hipEvent_t ev_stats = nullptr;
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
     char arch[64] = {0};
@@ -444,6 +446,8 @@ void brov_destroy(brov_ctx* c) {
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_stats) (void)hipEventDestroy(c->ev_stats);
+    if (c->h_stats) (void)hipHostFree(c->h_stats);
     for (int i = 0; i < 3; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -1202,27 +1206,37 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     }
     HIPCK(c, hipMemsetAsync(d_labels, 0xFF, N * sizeof(int32_t), c->stream));
     HIPCK(c, launch_kmeans_c2(c->stream, n, k, d_C, c2));
+    if (!c->h_stats) HIPCK(c, hipHostMalloc((void**)&c->h_stats, 8 * sizeof(double), hipHostMallocDefault));
+    if (!c->ev_stats) HIPCK(c, hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
     CallTimer t(c);
+    // The E-step of iteration it+1 is queued before the host looks at the statistics of iteration it: if the loop goes on it
+    // is the next E-step; if the shift criterion or max_iter ends it, it is the final E-step scikit-learn runs to make the
+    // labels consistent with the last centres; under strict convergence the centres did not move and it rewrites the same
+    // labels.  The read-back and the host's round trip hide behind it.
     bool strict = false;
     int it = 0;
     double hs[3] = {0, 0, 0};
+    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
         HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, d_C, c2, stats));
-        HIPCK(c, hipMemcpyAsync(hs, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
-        HIPCK(c, hipStreamSynchronize(c->stream));
+        HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+        HIPCK(c, hipEventSynchronize(c->ev_stats));
+        hs[0] = c->h_stats[0]; hs[1] = c->h_stats[1]; hs[2] = c->h_stats[2];
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
         if (hs[0] <= tol_abs) break;
     }
     if (it > max_iter) it = max_iter;
     double in = hs[1];
-    if (!strict) {   // labels / inertia consistent with the final centres
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+    if (!strict) {   // labels / inertia consistent with the final centres: the E-step already queued
         std::vector<double> hb(nb);
         HIPCK(c, hipMemcpyAsync(hb.data(), binert, nb * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         in = 0.0;
         for (double v : hb) in += v;
+    } else {
+        HIPCK(c, hipStreamSynchronize(c->stream));
     }
     if (inertia) *inertia = in;
     if (n_iter) *n_iter = it;

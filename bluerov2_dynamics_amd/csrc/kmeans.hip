@@ -19,6 +19,9 @@
 
 namespace brov {
 
+#ifndef KM_TWO_CHAINS
+#define KM_TWO_CHAINS 0
+#endif
 constexpr int KM_NMAX = 16;
 constexpr int KM_BLOCKS = 512;        // persistent blocks (2 per CU: each holds a 53 KB LDS table of member sums at k = 512)
 constexpr int KM_THREADS = 1024;      // 16 waves per block -> 8 waves per SIMD: the centre loop waits on its scalar loads once
@@ -61,13 +64,21 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
         double best = -1.0e300;
         int bi = 0;
         auto eval = [&](const Cen& t, int c) {
-            double dot = 0.0, dot1 = 0.0;                 // two chains: dependent fp64 FMAs do not issue back to back
+            // one FMA chain seeded with -|c|^2/2: n instructions per centre.  (Eight waves per SIMD: the other waves fill the
+            // slots a dependent chain leaves; the first version ran two chains and paid an add and an FMA to join them.)
             constexpr int NJ = NS > 0 ? NS : KM_CMAX;     // generic n: slots beyond n hold zeros (and the half norm, read below)
-#pragma unroll
-            for (int j = 0; j + 1 < NJ; j += 2) { dot = fma(x[j], t.v[j], dot); dot1 = fma(x[j + 1], t.v[j + 1], dot1); }
-            if constexpr (NJ & 1) dot = fma(x[NJ - 1], t.v[NJ - 1], dot);
             const double hn = NS > 0 ? t.v[NS] : t.v[n];
-            const double sc = fma(hn, -1.0, dot + dot1);
+#if KM_TWO_CHAINS
+            double dot = fma(x[0], t.v[0], -hn), dot1 = x[1] * t.v[1];
+#pragma unroll
+            for (int j = 2; j + 1 < NJ; j += 2) { dot = fma(x[j], t.v[j], dot); dot1 = fma(x[j + 1], t.v[j + 1], dot1); }
+            if constexpr (NJ & 1) dot = fma(x[NJ - 1], t.v[NJ - 1], dot);
+            const double sc = dot + dot1;
+#else
+            double sc = fma(x[0], t.v[0], -hn);
+#pragma unroll
+            for (int j = 1; j < NJ; ++j) sc = fma(x[j], t.v[j], sc);
+#endif
             bi = (sc <= best) ? bi : c;               // strict '>' to replace: the first extremum wins, like np.argmin
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));      // plain max: fmax() adds a canonicalising self-max
         };

@@ -10,3 +10,7 @@ ctx.set_timing(True)
 for rep in range(2):
     C, idx = engine.kmeanspp_dev(X, k, mean=X.mean(0).cpu().numpy(), random_state=0, ctx=ctx)
     print("kmeanspp ms", ctx.last_kernel_ms())
+
+tm = {}
+Ck, inertia, n_iter = engine.kmeans_centers_dev(X, k, random_state=0, max_iter=10, ctx=ctx, timings=tm)
+print("lloyd ms per iteration", tm["lloyd_ms"] / n_iter, "iterations", n_iter, "inertia", inertia)
