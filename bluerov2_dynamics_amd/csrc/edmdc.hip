@@ -150,14 +150,14 @@ hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma
     return hipGetLastError();
 }
 
-// Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (+1 block row for the tail);
-// 128-thread blocks.  A lane owns FOUR adjacent centres (their 4 x 12 coordinates in VGPRs): |x|^2 and the row's scalar
-// loads are paid once per four RBF values (40 instructions per value instead of 65 with two centres per lane), and a lane's
-// results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  The kernel is bound by latency, not by
-// the exp or the store bandwidth: per 10^7 rows the arithmetic alone takes 5.5 ms and the same stores from a store-only
-// kernel 8 ms (5.4 TB/s, tools/store_probe.hip), but a loop that fetched a row's state, lifted it and stored it took 15.9 ms
-// at three waves per SIMD (132 VGPRs).  Fetching the next row's state while the current one is lifted, and letting the tail
-// block work on four rows at a time, brought it to 12.5 ms.
+// Device-native lifted rows.  grid.x = row tiles of 64, grid.y = groups of 512 centres (the tail columns: lift_tail_kernel);
+// 128-thread blocks.  A lane owns FOUR adjacent centres (their 4 x 12 coordinates in VGPRs): |x|^2 and the row's state are
+// paid once per four RBF values (40 instructions per value instead of 65 with two centres per lane), and a lane's
+// results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  History of the loop "fetch a row's state,
+// lift it, store it" per 2^20-row chunk (180 VALU instructions per row and wave = 0.8 ms of issue slots, the stores alone
+// 0.8 ms at 5.4 TB/s, tools/store_probe.hip): state through scalar loads 1.65 ms; the next row's state fetched while the
+// current one is lifted, tail blocks four rows at a time 1.48 ms; the block's 64 state rows staged in LDS once 1.26 ms; the
+// tail columns in a kernel of their own 1.07 + 0.09 ms.
 #ifndef LIFT_NC_
 #define LIFT_NC_ 4
 #endif
@@ -165,7 +165,7 @@ constexpr int LIFT_NC = LIFT_NC_;              // centres per lane (even)
 constexpr int LIFT_BLOCK = 512 / LIFT_NC;      // threads per block: 512 centres per block row
 template <int NS>
 __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, double gamma, const double* __restrict__ C,
-                                                        int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
+                                                        int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs_, int64_t us,
                                                         const double* __restrict__ X, const double* __restrict__ U,
                                                         double* __restrict__ Zrows, double* __restrict__ wrow) {
     const int n = s.n, k = s.k, W = s.width;
@@ -176,9 +176,9 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
     // (bag, step) of the first row: one 64-bit division per block, then incremental (a division per row
     // costs ~130 scalar instructions, three times the useful work of a row)
     const int64_t g0 = row0 + l0;
-    int64_t bag = g0 / xs, t = g0 - bag * xs;
+    int64_t bag = g0 / xs_, t = g0 - bag * xs_;
     const int64_t lend = (l0 + RT < rows) ? l0 + RT : rows;
-    if ((int)blockIdx.y < ngroups) {
+    {
         const int c0 = (blockIdx.y * LIFT_BLOCK + threadIdx.x) * NC;       // first of this lane's four centres
         double cc[NC][LIFT_NMAX], c2[NC];
 #pragma unroll
@@ -191,62 +191,92 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
         const double* xp = X + (g0 < total_rows ? g0 : total_rows - 1) * n;
         double* zp = Zrows + l0 * W + c0;
         const bool store = c0 < s.kp;                  // kp is a multiple of 16: a lane's four columns are inside or outside together
-        // the next row's state is fetched (scalar loads) while the current row is lifted: the loop is otherwise one exposed
-        // scalar-load latency per row (the kernel spends 63 % of its wave-cycles waiting, three waves per SIMD)
-        constexpr int NSP = NS > 0 ? NS : 1;
-        double xcur[NSP], xnext[NSP];
         if constexpr (NS > 0) {
-#pragma unroll
-            for (int j = 0; j < NS; ++j) xcur[j] = xp[j];
-        }
+            // The block's 64 state rows are staged in LDS once (one exposed global-load latency per block) and every row is then
+            // read back as broadcast ds_reads: nothing in the row loop waits on HBM any more.  With the rows arriving through
+            // scalar loads -- even fetched one row ahead -- the loop waited on them 46 % of the time (SMEM can only be waited
+            // for with lgkmcnt(0), so the fetch distance cannot exceed one row, and a miss under the kernel's own 3.5 TB/s of
+            // stores takes longer than the 0.4 us a row's arithmetic lasts).
+            __shared__ __attribute__((aligned(16))) double xs[RT][LIFT_NMAX];
+            for (int e = threadIdx.x; e < RT * NS; e += LIFT_BLOCK) {
+                const int rr = e / NS, j = e - rr * NS;
+                const int64_t g = g0 + rr;
+                xs[rr][j] = X[(g < total_rows ? g : total_rows - 1) * n + j];      // clamp: rows past the end are masked
+            }
+            __syncthreads();
 #pragma unroll 1
-        for (int64_t l = l0; l < lend; ++l) {
-            const int64_t g = row0 + l;
-            double z[NC];
-            if constexpr (NS > 0) {
-                const double* xq = (g + 1 < total_rows) ? xp + n : xp;      // clamp: rows past the end are masked
-#pragma unroll
-                for (int j = 0; j < NS; ++j) xnext[j] = xq[j];
-                rbf_vals<NS, NC>(gamma, xcur, cc, c2, z);
-#pragma unroll
-                for (int j = 0; j < NS; ++j) xcur[j] = xnext[j];
-            } else {
-                rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
-            }
-            const bool valid = g < total_rows && t <= L;                     // wave-uniform
-#pragma unroll
-            for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
-            if (store) {
-#pragma unroll
-                for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(zp + q) = make_double2(z[q], z[q + 1]);
-            }
-            zp += W;
-            if (g + 1 < total_rows) xp += n;                                 // clamp: rows past the end are masked
-            if (++t == xs) { t = 0; ++bag; }
-        }
-    } else {
-        // tail block: [x | u | x_next (xplus shapes, pair rows only) | 0] and the pair weight; a thread = one (row, column) of a group of LIFT_BLOCK / tailp rows, so that
-        // the loads of several rows are in flight together (one row per trip was one exposed global-load latency per row)
-        const int tp = s.tailp, rpp = tp <= LIFT_BLOCK ? LIFT_BLOCK / tp : 1;     // rows per pass
-        const int jr = threadIdx.x / tp, j = threadIdx.x - jr * tp;
-        for (int64_t lb = l0; lb < lend; lb += rpp) {
-            const int64_t l = lb + jr;
-            if (jr < rpp && l < lend) {
+            for (int64_t l = l0; l < lend; ++l) {
                 const int64_t g = row0 + l;
-                // (bag, step) of this row from the block's first row: at most a few wraps per 64 rows
-                int64_t tt = t + (l - l0), bb = bag;
-                while (tt >= xs) { tt -= xs; ++bb; }
-                for (int jj = j; jj < tp; jj += (tp <= LIFT_BLOCK ? tp : LIFT_BLOCK)) {
-                    double v = 0.0;
-                    if (g < total_rows && tt <= L) {
-                        if (jj < n) v = X[g * n + jj];
-                        else if (jj < n + s.r) { if (tt < L) v = U[(bb * us + tt) * s.r + (jj - n)]; }
-                        else if (s.xplus && jj < n + s.r + n && tt < L && g + 1 < total_rows) v = X[(g + 1) * n + (jj - n - s.r)];
-                    }
-                    Zrows[l * W + s.kp + jj] = v;
+                double xr[NS], z[NC];
+                const double2* xl = reinterpret_cast<const double2*>(xs[l - l0]);
+#pragma unroll
+                for (int j = 0; j + 1 < NS; j += 2) { const double2 v = xl[j / 2]; xr[j] = v.x; xr[j + 1] = v.y; }
+                if constexpr (NS & 1) xr[NS - 1] = xs[l - l0][NS - 1];
+                rbf_vals<NS, NC>(gamma, xr, cc, c2, z);
+                const bool valid = g < total_rows && t <= L;                     // wave-uniform
+#pragma unroll
+                for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
+                if (store) {
+#pragma unroll
+                    for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(zp + q) = make_double2(z[q], z[q + 1]);
                 }
-                if (j == 0) wrow[l] = (g < total_rows && tt < L) ? 1.0 : 0.0;
+                zp += W;
+                if (++t == xs_) { t = 0; ++bag; }
             }
+        } else {
+#pragma unroll 1
+            for (int64_t l = l0; l < lend; ++l) {
+                const int64_t g = row0 + l;
+                double z[NC];
+                rbf_row<NS, NC>(n, gamma, xp, cc, c2, z);
+                const bool valid = g < total_rows && t <= L;                     // wave-uniform
+#pragma unroll
+                for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
+                if (store) {
+#pragma unroll
+                    for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(zp + q) = make_double2(z[q], z[q + 1]);
+                }
+                zp += W;
+                if (g + 1 < total_rows) xp += n;                                 // clamp: rows past the end are masked
+                if (++t == xs_) { t = 0; ++bag; }
+            }
+        }
+    }
+}
+
+// tail columns [x | u | x_next (xplus shapes, pair rows only) | 0] and the pair weight, as a kernel of its own: inside
+// lift_rows_kernel the tail blocks held wave slots at that kernel's 144 VGPRs while they waited on their loads (a quarter of
+// the slot time of the launch for 6 % of its bytes).  A thread = one (row, column) of a group of LIFT_TAIL_BLOCK / tailp rows.
+constexpr int LIFT_TAIL_BLOCK = 256;
+__global__ void __launch_bounds__(LIFT_TAIL_BLOCK) lift_tail_kernel(EdmdcShape s, int64_t row0, int64_t rows, int64_t total_rows, int64_t L,
+                                                                   int64_t xs_, int64_t us, const double* __restrict__ X,
+                                                                   const double* __restrict__ U, double* __restrict__ Zrows,
+                                                                   double* __restrict__ wrow) {
+    const int n = s.n, W = s.width;
+    constexpr int RT = 64;                             // rows per block
+    const int64_t l0 = (int64_t)blockIdx.x * RT;
+    const int64_t g0 = row0 + l0;
+    const int64_t bag = g0 / xs_, t = g0 - bag * xs_;  // one 64-bit division per block
+    const int64_t lend = (l0 + RT < rows) ? l0 + RT : rows;
+    const int tp = s.tailp, rpp = tp <= LIFT_TAIL_BLOCK ? LIFT_TAIL_BLOCK / tp : 1;     // rows per pass
+    const int jr = threadIdx.x / tp, j = threadIdx.x - jr * tp;
+    for (int64_t lb = l0; lb < lend; lb += rpp) {
+        const int64_t l = lb + jr;
+        if (jr < rpp && l < lend) {
+            const int64_t g = row0 + l;
+            // (bag, step) of this row from the block's first row: at most a few wraps per 64 rows
+            int64_t tt = t + (l - l0), bb = bag;
+            while (tt >= xs_) { tt -= xs_; ++bb; }
+            for (int jj = j; jj < tp; jj += (tp <= LIFT_TAIL_BLOCK ? tp : LIFT_TAIL_BLOCK)) {
+                double v = 0.0;
+                if (g < total_rows && tt <= L) {
+                    if (jj < n) v = X[g * n + jj];
+                    else if (jj < n + s.r) { if (tt < L) v = U[(bb * us + tt) * s.r + (jj - n)]; }
+                    else if (s.xplus && jj < n + s.r + n && tt < L && g + 1 < total_rows) v = X[(g + 1) * n + (jj - n - s.r)];
+                }
+                Zrows[l * W + s.kp + jj] = v;
+            }
+            if (j == 0) wrow[l] = (g < total_rows && tt < L) ? 1.0 : 0.0;
         }
     }
 }
@@ -256,7 +286,8 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
     if (rows <= 0) return hipSuccess;
     if (s.n > LIFT_NMAX || s.tailp > 256 || xs < 2 || total_rows < 1) return hipErrorInvalidValue;
     const int ngroups = (s.kp + LIFT_BLOCK * LIFT_NC - 1) / (LIFT_BLOCK * LIFT_NC);
-    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)(ngroups + 1));
+    const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)ngroups);
+    hipLaunchKernelGGL(lift_tail_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(LIFT_TAIL_BLOCK), 0, st, s, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     if (s.n == 12) hipLaunchKernelGGL(lift_rows_kernel<12>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     else if (s.n == 13) hipLaunchKernelGGL(lift_rows_kernel<13>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     else hipLaunchKernelGGL(lift_rows_kernel<0>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
