@@ -150,6 +150,23 @@ def test_arch_gate_and_comm_entry_points(lib):
     assert lib.brov_comm_nranks(None) == -1 and lib.edmdc_gram_allreduce_dev(None, None, 0, None, 0, None) == -1
 
 
+def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
+    """edmdc_gram_decomposition (no device work): the benchmark shape packs its 1 683 wanted tile products into 75 tasks (the x
+    part of Y rides in the tail tile's padding); a shape whose padding is too narrow keeps the 33rd Y tile (78 tasks); tasks x
+    slabs never exceeds the 2 048 wave slots of one resident round; bad shapes are refused."""
+    from bluerov2_dynamics_amd import engine
+    assert engine.gram_decomposition(12, 8, 512) == (75, 27)
+    assert engine.gram_decomposition(13, 8, 512) == (78, 26)
+    for n, r, k in ((12, 8, 48), (12, 8, 200), (12, 8, 500), (12, 6, 512), (13, 6, 512), (9, 4, 100), (12, 8, 1024), (5, 2, 16)):
+        nt, ns = engine.gram_decomposition(n, r, k)
+        tiles_g = ((k + 15) // 16 * 16 + (n + r + 15) // 16 * 16) // 16
+        assert nt * 24 >= tiles_g * (tiles_g + 1) // 2 + tiles_g * ((k + 15) // 16)        # at least the wanted products
+        assert 1 <= ns <= 256 and (nt * ns <= 2048 or ns == 1)
+    nt, ns = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.edmdc_gram_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns)) == -1
+    assert lib.edmdc_gram_decomposition(12, 8, 0, ctypes.byref(nt), ctypes.byref(ns)) == -1
+
+
 def test_bench_refuses_to_measure_fewer_gpus_than_asked():
     """`python bench.py --gpus N` outside torch.distributed.run launches its own ranks or fails loudly; with fewer than N GPUs
     visible (none here) it must exit non-zero before touching anything."""
