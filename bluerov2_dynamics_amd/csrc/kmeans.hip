@@ -210,6 +210,17 @@ struct PPState {                      // device-resident scalars of the seeding 
     int pad[2];
 };
 
+// |x|^2 accumulated in coordinate order with FMAs: pp_transpose stores it, pp_round recomputes it from the coordinates it has
+// loaded anyway (8 of the 112 bytes per sample and pass) -- one function, so that the two agree to the bit
+template <int NS>
+__device__ __forceinline__ double pp_norm2(const double x[KM_NMAX]) {
+    constexpr int NJ = NS > 0 ? NS : KM_NMAX;                // coordinates beyond n are zero
+    double s = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) s = fma(x[j], x[j], s);
+    return s;
+}
+
 // The seeding makes k - 1 passes over the data, so the rows are first copied, centred, into a coordinate-major
 // array Xt[j][i] (one strided read of X; every later access is a coalesced 512-byte wave load), with |x_i|^2 alongside
 // (sklearn: row_norms(X, squared=True)).
@@ -218,16 +229,16 @@ __global__ void __launch_bounds__(PP_THREADS) pp_transpose_kernel(int64_t N, int
                                                                  const double* __restrict__ mean, double* __restrict__ Xt, double* __restrict__ xsq) {
     const int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
     if (i >= N) return;
-    double s = 0.0;
+    double x[KM_NMAX];
 #pragma unroll
     for (int j = 0; j < KM_NMAX; ++j) {
+        x[j] = 0.0;
         if (NS > 0 ? (j < NS) : (j < n)) {
-            const double v = X[i * xstride + j] - (mean ? mean[j] : 0.0);
-            Xt[(int64_t)j * N + i] = v;
-            s += v * v;
+            x[j] = X[i * xstride + j] - (mean ? mean[j] : 0.0);
+            Xt[(int64_t)j * N + i] = x[j];
         }
     }
-    xsq[i] = s;
+    xsq[i] = pp_norm2<NS>(x);
 }
 
 template <int NS>
@@ -278,14 +289,13 @@ __global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, 
         if (i < N) {
             double x[KM_NMAX];
             pp_load_col<NS>(Xt, N, n, i, x);
-            const double xx = xsq[i];
+            const double xx = pp_norm2<NS>(x);
             double old = upd == 1 ? 0.0 : closest[i];
             if (upd) {
                 asm volatile("" ::: "memory");
                 const double* row = cs + L * CSW;
                 const double d = pp_dist<NS>(x, [&](int j) { return row[j]; }, row[KM_NMAX], xx);
-                old = (upd == 1 || d < old) ? d : old;        // np.minimum(closest, d)
-                closest[i] = old;
+                if (upd == 1 || d < old) { old = d; closest[i] = d; }     // np.minimum(closest, d); unchanged values are not rewritten
             }
             acc0 += old;
 #pragma unroll
