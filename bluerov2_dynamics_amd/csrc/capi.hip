@@ -52,6 +52,8 @@ struct brov_ctx {
     hipEvent_t ev_handover = nullptr; // orders the work queued on the previous stream before the next one (brov_set_stream)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams of edmdc_multistep_se (window groups advance independently), created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    double* h_io = nullptr;           // pinned, device-mapped staging of the per-call entry points (brov_rhs / brov_thruster_forces with a
+    double* d_io = nullptr;           // handful of vehicles): the kernel reads and writes host memory, no copy calls; d_io = its device alias
     double* h_stats = nullptr;        // pinned: per-iteration statistics of the Lloyd loop come back while the next E-step runs
     hipEvent_t ev_stats = nullptr;
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
@@ -448,6 +450,7 @@ void brov_destroy(brov_ctx* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_stats) (void)hipEventDestroy(c->ev_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
+    if (c->h_io) (void)hipHostFree(c->h_io);
     for (int i = 0; i < 3; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -572,6 +575,20 @@ int brov_memset(brov_ctx* c, void* dst, int value, size_t bytes) {
 }
 
 // ---- RHS ---------------------------------------------------------------------------------------
+// The reference's scripts call dynamics() once per vehicle and step (fossen/BlueROV2.py:357-400 from the loops at
+// training/train_tank_brov2_full_comparison.py:453-466): one launch whose cost is latency.  Up to SMALL_B vehicles go through a
+// pinned, device-mapped staging block: the host packs the operands, the kernel reads and writes that block over the bus,
+// the host unpacks -- one launch and one synchronisation, no copy calls (five of them cost more than the launch).
+constexpr int64_t SMALL_B = 16;
+constexpr size_t IO_DOUBLES = SMALL_B * (13 + 8 + 24 + 13) + 64;
+static int ensure_io(brov_ctx* c) {
+    if (c->h_io) return BROV_OK;
+    HIPCK(c, hipHostMalloc((void**)&c->h_io, IO_DOUBLES * sizeof(double), hipHostMallocMapped));
+    hipError_t e = hipHostGetDevicePointer((void**)&c->d_io, c->h_io, 0);
+    if (e != hipSuccess) { (void)hipHostFree(c->h_io); c->h_io = nullptr; return hip_fail(c, e, "hipHostGetDevicePointer"); }
+    return BROV_OK;
+}
+
 int brov_rhs(brov_ctx* c, int model, int64_t B, const double* x, const double* u, double dt, double* lag_io, double* xdot) {
     if (!c || !model_ok(model) || model_is_di_h(model) || B < 0 || (B && (!x || !u || !xdot)))
         return fail(c, BROV_ERR_ARG, "brov_rhs: bad argument (the double-integrator models have rollouts only)");
@@ -582,6 +599,22 @@ int brov_rhs(brov_ctx* c, int model, int64_t B, const double* x, const double* u
     if (rc) return rc;
     const int nx = NX(model), nu = NU(model);
     const bool lag = lag_io && model == BROV_THRUSTER_EULER;
+    if (B <= SMALL_B) {
+        rc = ensure_io(c);
+        if (rc) return rc;
+        const size_t ox = 0, ou = ox + B * nx, ol = ou + B * nu, od = ol + (lag ? B * 24 : 0);
+        std::memcpy(c->h_io + ox, x, B * nx * 8);
+        std::memcpy(c->h_io + ou, u, B * nu * 8);
+        if (lag) std::memcpy(c->h_io + ol, lag_io, B * 24 * 8);
+        {
+            CallTimer t(c);
+            HIPCK(c, launch_rhs(c->stream, *dp, model, B, c->d_io + ox, c->d_io + ou, lag ? c->d_io + ol : nullptr, c->d_io + od));
+        }
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(xdot, c->h_io + od, B * nx * 8);
+        if (lag) std::memcpy(lag_io, c->h_io + ol, B * 24 * 8);
+        return BROV_OK;
+    }
     Arena a(c);
     rc = a.reserve(Arena::al(B * nx * 8) * 2 + Arena::al(B * nu * 8) + Arena::al(B * 24 * 8));
     if (rc) return rc;
@@ -609,6 +642,21 @@ int brov_thruster_forces(brov_ctx* c, int64_t B, const double* u, double dt, dou
     const DevParams* dp;
     int rc = get_dp(c, dt, &dp);
     if (rc) return rc;
+    if (B <= SMALL_B) {
+        rc = ensure_io(c);
+        if (rc) return rc;
+        const size_t ou = 0, ol = ou + B * 8, ot = ol + B * 24;
+        std::memcpy(c->h_io + ou, u, B * 8 * 8);
+        std::memcpy(c->h_io + ol, lag_io, B * 24 * 8);
+        {
+            CallTimer t(c);
+            HIPCK(c, launch_thruster_forces(c->stream, *dp, B, c->d_io + ou, c->d_io + ol, c->d_io + ot));
+        }
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        std::memcpy(tau, c->h_io + ot, B * 6 * 8);
+        std::memcpy(lag_io, c->h_io + ol, B * 24 * 8);
+        return BROV_OK;
+    }
     Arena a(c);
     rc = a.reserve(Arena::al(B * 8 * 8) + Arena::al(B * 24 * 8) + Arena::al(B * 6 * 8));
     if (rc) return rc;

@@ -78,6 +78,30 @@ class ThrusterLag:
         return float(self._Cc[0] @ self._x)
 
 
+class _ThrusterEntry(dict):
+    """thrusters_r[i] of the reference is a dict {"r": array(3), "dir": array(3)} (fossen/BlueROV2.py:172-232).  Here the two
+    arrays are views of one row of the vehicle's [8,2,3] geometry block, and assigning a new array to either key copies it
+    into that view: edits in place and by assignment both land in the block, whose bytes the per-call check compares."""
+
+    def __init__(self, block_row):
+        dict.__init__(self, r=block_row[0], dir=block_row[1])
+        self._row = block_row
+
+    def __setitem__(self, key, value):
+        if key == "r" or key == "dir":
+            self._row[0 if key == "r" else 1][...] = np.asarray(value, dtype=float).reshape(3)
+        else:
+            dict.__setitem__(self, key, value)
+
+
+class _ThrusterList(list):
+    def __setitem__(self, i, entry):
+        if isinstance(i, slice):
+            raise TypeError("thrusters_r: assign one thruster at a time")
+        self[i]["r"] = entry["r"]
+        self[i]["dir"] = entry["dir"]
+
+
 class BlueROV2(VehicleBase):
     MODEL = _lib.THRUSTER_EULER
 
@@ -85,7 +109,9 @@ class BlueROV2(VehicleBase):
         self._init_common(rho, current_speed, device)
         self.n_thrusters = 8
         p = self._params
-        self.thrusters_r = [{"r": np.array(p.thr_r[i][:]), "dir": np.array(p.thr_dir[i][:])} for i in range(8)]
+        self._geom = np.array([[p.thr_r[i][:], p.thr_dir[i][:]] for i in range(8)], dtype=float)      # [8][r | dir][3]
+        self._geom_pushed = None
+        self._thrusters = _ThrusterList(_ThrusterEntry(self._geom[i]) for i in range(8))
         self._lag = np.zeros((8, 3))
         self.thruster_lags = [ThrusterLag(self._lag, i) for i in range(8)]
         self.use_tether = False
@@ -93,15 +119,33 @@ class BlueROV2(VehicleBase):
         self.tether_state = None
         self.anchor_pos = np.zeros(3)
 
+    @property
+    def thrusters_r(self):
+        return self._thrusters
+
+    @thrusters_r.setter
+    def thrusters_r(self, entries):
+        entries = list(entries)
+        if len(entries) != 8:
+            raise ValueError("thrusters_r holds the 8 thrusters of the BlueROV2 Heavy")
+        for i, e in enumerate(entries):
+            self._thrusters[i] = e
+
     def _push_extra(self, p):
-        for i, th in enumerate(self.thrusters_r):
+        for i in range(8):
             for k in range(3):
-                p.thr_r[i][k] = float(th["r"][k])
-                p.thr_dir[i][k] = float(th["dir"][k])
+                p.thr_r[i][k] = float(self._geom[i, 0, k])
+                p.thr_dir[i][k] = float(self._geom[i, 1, k])
 
     def _extra_key(self):
         # thruster geometry is part of the change key: editing rov.thrusters_r[i]["r" | "dir"] takes effect on the next call
-        return tuple(float(v) for th in self.thrusters_r for name in ("r", "dir") for v in np.asarray(th[name], dtype=float).reshape(3))
+        return self._geom.tobytes()
+
+    def _extra_clean(self):
+        return self._geom.tobytes() == self._geom_pushed
+
+    def _extra_mark_clean(self):
+        self._geom_pushed = self._geom.tobytes()
 
     def _thruster_rotational_matrix(self, alpha):
         s, c = np.sin(alpha), np.cos(alpha)

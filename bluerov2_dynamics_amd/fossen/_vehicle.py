@@ -8,12 +8,25 @@ from .. import _lib, engine
 
 _ATTR6 = ("Xu_dot", "Yv_dot", "Zw_dot", "Kp_dot", "Mq_dot", "Nr_dot")
 _LIN6 = ("Xu", "Yv", "Zw", "Kp", "Mq", "Nr")
+# attributes whose assignment has to reach the device before the next call
+_TRACKED = frozenset(("rho", "m", "g", "volume", "xb", "yb", "zb", "Ix", "Iy", "Iz", "current_speed") + _ATTR6 + _LIN6 +
+                     tuple(l + "_abs" for l in _LIN6))
 
 
 class VehicleBase:
     """Holds the vehicle constants as plain attributes (same names as the reference objects,
     fossen/BlueROV2.py:81-140) and mirrors them into the device context before each call."""
     MODEL = None
+    _dirty = True
+    _cs_pushed = None
+
+    def __setattr__(self, name, value):
+        # the reference reads its attributes on every dynamics() call, so an assignment takes effect on the next one; here it
+        # marks the object dirty, and a call on a clean object skips the comparison of all constants (the per-call entry
+        # points are latency: 40 attribute reads cost as much as the launch)
+        if name in _TRACKED:
+            object.__setattr__(self, "_dirty", True)
+        object.__setattr__(self, name, value)
 
     def _init_common(self, rho, current_speed, device=None):
         if device is None:
@@ -79,27 +92,41 @@ class VehicleBase:
     Minv = Minv.setter(lambda self, v: self._derived_readonly("Minv"))
 
     def _sync_params(self):
-        """Push attribute values that differ from what the device context holds."""
-        cur = np.zeros(3) if self.current_speed is None else np.asarray(self.current_speed, dtype=float).reshape(3)
+        """Push attribute values that differ from what the device context holds.  Fast path: nothing was assigned since the
+        last push and the arrays that can be edited in place (current_speed, the thruster geometry) still hold the same bytes."""
+        cs = self.current_speed
+        csb = b"" if cs is None else np.asarray(cs, dtype=float).tobytes()
+        if not self._dirty and csb == self._cs_pushed and self._extra_clean():
+            return
+        cur = np.zeros(3) if cs is None else np.asarray(cs, dtype=float).reshape(3)
         key = (float(self.rho), float(self.m), float(self.g), float(self.volume), float(self.zb), tuple(cur),
                tuple(float(getattr(self, a)) for a in _ATTR6),
                tuple(float(getattr(self, l)) for l in _LIN6), tuple(float(getattr(self, l + "_abs")) for l in _LIN6),
                float(self.Ix), float(self.Iy), float(self.Iz), float(self.xb), float(self.yb), self._extra_key())
-        if key == self._pushed:
-            return
-        p = self._params
-        p.rho, p.m, p.g, p.volume = self.rho, self.m, self.g, self.volume
-        p.xb, p.yb, p.zb = self.xb, self.yb, self.zb
-        p.Ix, p.Iy, p.Iz = self.Ix, self.Iy, self.Iz
-        for i, (a, l) in enumerate(zip(_ATTR6, _LIN6)):
-            p.added_mass[i] = getattr(self, a)
-            p.lin_damp[i] = getattr(self, l)
-            p.quad_damp[i] = getattr(self, l + "_abs")
-        for i in range(3):
-            p.current[i] = cur[i]
-        self._push_extra(p)
-        self._ctx.set_params(p)
-        self._pushed = key
+        if key != self._pushed:
+            p = self._params
+            p.rho, p.m, p.g, p.volume = self.rho, self.m, self.g, self.volume
+            p.xb, p.yb, p.zb = self.xb, self.yb, self.zb
+            p.Ix, p.Iy, p.Iz = self.Ix, self.Iy, self.Iz
+            for i, (a, l) in enumerate(zip(_ATTR6, _LIN6)):
+                p.added_mass[i] = getattr(self, a)
+                p.lin_damp[i] = getattr(self, l)
+                p.quad_damp[i] = getattr(self, l + "_abs")
+            for i in range(3):
+                p.current[i] = cur[i]
+            self._push_extra(p)
+            self._ctx.set_params(p)
+            self._pushed = key
+        object.__setattr__(self, "_dirty", False)
+        object.__setattr__(self, "_cs_pushed", csb)
+        self._extra_mark_clean()
+
+    def _extra_clean(self):
+        """Model-specific part of the fast check (the thruster model compares its geometry block)."""
+        return True
+
+    def _extra_mark_clean(self):
+        pass
 
     def _push_extra(self, p):
         pass

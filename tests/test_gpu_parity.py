@@ -986,6 +986,32 @@ def test_vehicle_attribute_edits_reach_the_device(fc):
     for name in ("W", "Minv", "M", "MRB", "MA"):
         with pytest.raises(AttributeError):
             setattr(rov3, name, 1.0)
+    # every way of editing reaches the next call -- after calls that found the object clean (the per-call path skips the
+    # comparison of all constants unless something was assigned or an array's bytes changed)
+    rov4 = BlueROV2()
+    assert np.array_equal(rov4.dynamics(x, u, 0.02), a) and rov4._dirty is False
+    rov4.thrusters_r[0]["r"][0] += 0.05                                                   # in place, element-wise
+    rov4._lag[...] = 0.0
+    assert np.array_equal(rov4.dynamics(x, u, 0.02), b)
+    rov4.thrusters_r[0] = {"r": rov.thrusters_r[0]["r"].copy(), "dir": rov.thrusters_r[0]["dir"].copy()}      # entry replaced
+    rov4._lag[...] = 0.0
+    assert np.array_equal(rov4.dynamics(x, u, 0.02), a)
+    rov4.thrusters_r = [dict(t) for t in rov2.thrusters_r]                                # whole list replaced
+    rov4._lag[...] = 0.0
+    assert np.array_equal(rov4.dynamics(x, u, 0.02), b)
+    rov4.thrusters_r = [dict(t) for t in rov.thrusters_r]
+    rov4.current_speed = np.zeros(3)                                                      # (the default array is shared between objects)
+    rov4._lag[...] = 0.0
+    assert np.array_equal(rov4.dynamics(x, u, 0.02), a)
+    rov4.current_speed[0] = 0.2                                                           # edited in place
+    rov4._lag[...] = 0.0
+    d1 = rov4.dynamics(x, u, 0.02)
+    assert np.max(np.abs(d1 - a)) > 1e-4
+    rov4.current_speed = np.zeros(3)
+    rov4.Xu = rov4.Xu * 2.0                                                               # scalar assignment
+    rov4._lag[...] = 0.0
+    d2 = rov4.dynamics(x, u, 0.02)
+    assert abs(d2[6] - a[6]) > 1e-4 and np.array_equal(d2[7:], a[7:])
 
 
 def test_multistep_accepts_inputs_one_row_shorter_than_states(eng):

@@ -15,7 +15,7 @@ import sys
 root = sys.argv[1]
 NAMES = {"rollout_pair_kernel<1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
           "gram_kernel": "gram", "lift_rows_kernel": "lift", "kmeans_assign_kernel": "kmeans_assign",
-         "propagate_kernel": "propagate", "pp_candidates_kernel": "kmeanspp_candidates", "pp_update_chunksum_kernel": "kmeanspp_update"}
+         "propagate_kernel": "propagate", "pp_round_kernel": "kmeanspp_round", "pp_decide_kernel": "kmeanspp_decide", "lift_tail_kernel": "lift_tail"}
 pats = sys.argv[2:] or list(NAMES)
 out = {p: {} for p in pats}
 for f in glob.glob(root + "/*/**/*counter_collection.csv", recursive=True):
