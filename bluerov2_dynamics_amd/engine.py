@@ -256,8 +256,18 @@ def kmeanspp_draws(N, k, random_state=0):
     (cumsum of p, normalise, searchsorted side='right' of one random_sample)."""
     rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
     L = 2 + int(np.log(k))
-    w = np.ones(N)
-    first = int(rs.choice(N, p=w / w.sum()))
+    # choice(N, p=1/N): cdf = cumsum(p) / cdf[-1], index = searchsorted(cdf, one random_sample, side="right") = floor(u N)
+    # unless u N lies within the rounding error of the sequential cumsum (<= 2 N^2 eps index units) of an integer: only then
+    # is the N-element cdf actually formed (0.05-2 s of host time at N = 1e7, as long as the whole device seeding)
+    u0 = rs.random_sample()
+    t = u0 * N
+    thr = 4.0 * float(N) * float(N) * 2.3e-16
+    if thr < 0.25 and thr < t - np.floor(t) < 1.0 - thr:
+        first = int(t)
+    else:
+        cdf = np.full(N, 1.0 / N).cumsum()
+        cdf /= cdf[-1]
+        first = int(cdf.searchsorted(u0, side="right"))
     U = np.empty((max(k - 1, 0), L))
     for c in range(k - 1):
         U[c] = rs.uniform(size=L)
