@@ -5,6 +5,7 @@ Device path: torch CUDA tensors (fp64, contiguous) -- only their data_ptr() and 
              torch stream cross the C ABI; results stay in HBM.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -371,12 +372,61 @@ def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
     return M
 
 
+def usable_cores():
+    """Cores this process may actually use: the scheduler affinity capped by the cgroup CPU quota (a container that sees
+    256 logical CPUs and is granted 16 is common on GPU hosts)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0 and per > 0:
+            n = min(n, max(1, int(q / per + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+class _blas_threads:
+    """The host `pinv` of the p x p normal matrix is the one BLAS/LAPACK call left on the fit path.  The reference caps its
+    BLAS at 4 threads on import (Koopman/koopmanEDMDc.py:23-25); left alone, OpenBLAS starts one thread per VISIBLE CPU, and
+    in a container that is granted fewer cores than it sees the solve takes 60-200 ms instead of 33 (p = 532).  Cap the pool
+    at the granted cores (at most 8) for the duration of the solve; no-op when threadpoolctl is missing."""
+    _limit = None
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            from threadpoolctl import threadpool_limits
+        except ImportError:
+            return self
+        if _blas_threads._limit is None:
+            _blas_threads._limit = min(8, usable_cores())
+        self._ctx = threadpool_limits(limits=_blas_threads._limit, user_api="blas")
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
 def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None):
     """(A, B) exactly as KoopmanEDMDc.fit associates the product (Koopman/koopmanEDMDc.py:97-101):
     M = (pinv(G^T G + ridge I) @ G.T) @ Y, the pinv on the host (numpy, like the reference), the two large products on
     the GPU.  Better conditioned than fit_multi's pinv(.) @ (G^T Y): at the class defaults (k = 200, ridge = 1e-8) the two
     differ by 1e-6 in the H = 100 RMSE."""
-    P = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0]))
+    with _blas_threads():
+        P = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0]))
     M = pinv_apply(X_list, U_list, C, gamma, P, ctx=ctx).T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
 
@@ -384,7 +434,8 @@ def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None):
 def solve_AB(GtG, GtY, ridge, d):
     """Host solve of the ridge normal equations exactly as the reference does it
     (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
-    M = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0])) @ GtY
+    with _blas_threads():
+        M = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0])) @ GtY
     M = M.T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
 
