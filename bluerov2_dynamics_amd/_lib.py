@@ -134,6 +134,9 @@ def load_library():
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
         # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is
         # loaded first serves both; with /opt/rocm's first, torch later finds no GPU.  So torch, when installed, goes first.
+        # (Pre-loading only torch's libamdhip64 and leaving `import torch` to whoever needs it was measured and dropped:
+        # once the runtime is initialised, a later `import torch` registers its code objects eagerly and takes 10.4 s instead
+        # of 0.76 s -- tools/time_late_torch.py.)
         try:
             import torch  # noqa: F401
         except ImportError:
