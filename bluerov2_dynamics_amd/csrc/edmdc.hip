@@ -333,44 +333,85 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
     const int nty = s.xplus ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16;
     const int ncol = nt + nty;
     auto code = [&](int c) { return c < nt ? c : ((c - nt) | 0x10000); };     // column number -> tile code
-    // cost[a0] = fewest blocks for the rows a0 .. nt-1; band[a0] = size of the band that starts there
-    std::vector<int> cost(nt + 1, 0), band(nt + 1, 0);
-    for (int a0 = nt - 1; a0 >= 0; --a0) {
-        const int L = ncol - a0, rem = nt - a0;
-        const int r4 = rem < 4 ? rem : 4;
-        cost[a0] = (L + GRAM_TB - 1) / GRAM_TB + cost[a0 + r4];
-        band[a0] = r4;
-        if (rem >= 6) {
-            const int c6 = (L + GRAM_TA - 1) / GRAM_TA + cost[a0 + 6];
-            if (c6 < cost[a0]) { cost[a0] = c6; band[a0] = 6; }
-        }
+    // Ragged ends.  A band whose column count does not divide by its block width ends in a partly empty block.  The last
+    // columns are Y tiles, which every row-tile needs: up to three SHARED SETS of four of them (set g = columns
+    // ncol-4(g+1) .. ncol-4g-1) can be left out of a band's own blocks and handed to shared transposed blocks
+    // (A = the set's four Y tiles, B = six row-tiles taken across the bands that left the set out).  Band sizes and the sets
+    // each band leaves out are chosen together by a DP over (first row of the band, rows so far in each shared set mod 6).
+    // k = 512: bands 4 4 4 4 4 4 4 6, sets left out {-, 01, 1, -, 01, 0, -, -}: 69 own + 2 + 2 shared = 73 tasks (75 without
+    // the shared sets, 78 with the x part of Y as a 33rd Y tile); 1 683 wanted tile products, 71 would be perfect packing.
+    const int G = nty / GRAM_TA < 3 ? nty / GRAM_TA : 3;
+    const int NM = 1 << G, NR = 216;                  // masks, (r0, r1, r2) in base 6
+    struct Choice { int size = 0, mask = 0, next_r = 0; };
+    const int INF = 1 << 28;
+    std::vector<int> cost((size_t)(nt + 1) * NR, INF);
+    std::vector<Choice> pick((size_t)(nt + 1) * NR);
+    for (int r = 0; r < NR; ++r) {                    // all rows placed: a started shared block counts as one more task
+        const int r0 = r % 6, r1 = (r / 6) % 6, r2 = r / 36;
+        cost[(size_t)nt * NR + r] = (r0 > 0) + (r1 > 0) + (r2 > 0);
     }
-    for (int a0 = 0; a0 < nt; a0 += band[a0]) {
-        if (band[a0] == 6) {
-            for (int c0 = a0; c0 < ncol; c0 += GRAM_TA) {
-                GramTask t; t.want = 0;
-                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < ncol) ? code(c0 + i) : -1;       // A = column tiles (weighted)
-                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = a0 + j;                                     // B = the band's row tiles
-                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                    if (t.a[i] >= 0 && c0 + i >= a0 + j) t.want |= 1u << (i * GRAM_TB + j);
-                tasks.push_back(t);
-            }
-        } else {
-            const int rows = band[a0];
-            for (int c0 = a0; c0 < ncol; c0 += GRAM_TB) {
-                GramTask t; t.want = 0;
-                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (i < rows) ? a0 + i : -1;
-                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < ncol) ? code(c0 + j) : -1;
-                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                    if (t.a[i] >= 0 && t.b[j] >= 0 && c0 + j >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
-                tasks.push_back(t);
+    for (int a0 = nt - 1; a0 >= 0; --a0)
+        for (int r = 0; r < NR; ++r) {
+            const int rem = nt - a0;
+            const int rr[3] = {r % 6, (r / 6) % 6, r / 36};
+            for (int size : {4, 6}) {
+                int sz = size;
+                if (size == 6 && rem < 6) continue;
+                if (size == 4 && rem < 4) sz = rem;
+                const int width = size == 6 ? GRAM_TA : GRAM_TB;
+                for (int m = 0; m < NM; ++m) {
+                    int pop = 0, extra = 0, nr[3] = {rr[0], rr[1], rr[2]};
+                    for (int g = 0; g < G; ++g) if ((m >> g) & 1) { ++pop; extra += (nr[g] + sz) / 6; nr[g] = (nr[g] + sz) % 6; }
+                    const int cols = ncol - a0 - GRAM_TA * pop;
+                    if (cols < sz) continue;          // the band keeps at least its diagonal block
+                    const int nxt = nr[0] + 6 * nr[1] + 36 * nr[2];
+                    const int c = (cols + width - 1) / width + extra + cost[(size_t)(a0 + sz) * NR + nxt];
+                    if (c < cost[(size_t)a0 * NR + r]) { cost[(size_t)a0 * NR + r] = c; pick[(size_t)a0 * NR + r] = Choice{sz == size ? size : sz, m, nxt}; }
+                }
             }
         }
+    std::vector<int> shared[3];                       // row-tiles whose products with set g go to the shared blocks
+    for (int a0 = 0, r = 0; a0 < nt;) {
+        const Choice ch = pick[(size_t)a0 * NR + r];
+        const bool six = ch.size == 6;
+        std::vector<int> cols;                        // the band's own columns
+        for (int c = a0; c < ncol; ++c) {
+            const int g = (ncol - 1 - c) / GRAM_TA;   // shared set the column belongs to (if any)
+            if (c >= nt && g < G && ((ch.mask >> g) & 1)) continue;
+            cols.push_back(c);
+        }
+        for (int g = 0; g < G; ++g) if ((ch.mask >> g) & 1) for (int i = 0; i < ch.size; ++i) shared[g].push_back(a0 + i);
+        const int width = six ? GRAM_TA : GRAM_TB;
+        for (size_t c0 = 0; c0 < cols.size(); c0 += width) {
+            GramTask t; t.want = 0;
+            if (six) {
+                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < cols.size()) ? code(cols[c0 + i]) : -1;       // A = column tiles (weighted)
+                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = a0 + j;                                                  // B = the band's row tiles
+                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                    if (t.a[i] >= 0 && cols[c0 + i] >= a0 + j) t.want |= 1u << (i * GRAM_TB + j);
+            } else {
+                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (i < ch.size) ? a0 + i : -1;
+                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < cols.size()) ? code(cols[c0 + j]) : -1;
+                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
+                    if (t.a[i] >= 0 && t.b[j] >= 0 && cols[c0 + j] >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
+            }
+            tasks.push_back(t);
+        }
+        a0 += ch.size;
+        r = ch.next_r;
     }
+    for (int g = 0; g < G; ++g)
+        for (size_t r0 = 0; r0 < shared[g].size(); r0 += GRAM_TB) {
+            GramTask t; t.want = 0;
+            for (int i = 0; i < GRAM_TA; ++i) t.a[i] = code(ncol - GRAM_TA * (g + 1) + i);                          // the set's four Y tiles (weighted)
+            for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (r0 + j < shared[g].size()) ? shared[g][r0 + j] : -1;
+            for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j) if (t.b[j] >= 0) t.want |= 1u << (i * GRAM_TB + j);
+            tasks.push_back(t);
+        }
 }
 
 // K-slabs per chunk: as many as keep tasks x slabs within the 2048 wave slots of the chip at 2 waves/SIMD
-// (k = 512: 75 tasks x 27 slabs = 2025 waves, one resident round, 98.9 % of the slots busy)
+// (k = 512: 73 tasks x 28 slabs = 2044 waves, one resident round, 99.8 % of the slots busy)
 constexpr int GRAM_WAVE_SLOTS = 2048;
 static int gram_nslab(int ntasks) {
     int ns = GRAM_WAVE_SLOTS / (ntasks > 0 ? ntasks : 1);

@@ -1042,7 +1042,7 @@ def test_multistep_accepts_inputs_one_row_shorter_than_states(eng):
 
 
 def test_gram_with_more_than_256_tasks(eng):
-    """k = 1024 needs 278 Gram tasks: the task table is sized from the shape (it used to be a fixed 256-entry buffer)."""
+    """k = 1024 needs 273 Gram tasks: the task table is sized from the shape (it used to be a fixed 256-entry buffer)."""
     from oracle import edmdc_numpy as ek
     rng = np.random.default_rng(2)
     n, r, k, N = 12, 8, 1024, 1500
