@@ -163,7 +163,4 @@ class BlueROV2(VehicleBase):
         if self.use_tether:
             raise NotImplementedError("the tether model of the reference is not part of this engine")
         self._sync_params()
-        xd, lag = engine.rhs(self.MODEL, np.asarray(x, dtype=float).reshape(1, 12), np.asarray(u_thrust, dtype=float).reshape(1, 8),
-                             dt, lag=self._lag[None], ctx=self._ctx)
-        self._lag[...] = lag[0]
-        return xd[0]
+        return self._rhs_single(x, u_thrust, dt, lag=self._lag)      # the lag state [8,3] is advanced in place

@@ -16,8 +16,5 @@ class BlueROV2(VehicleBase):
 
     def dynamics(self, x, tau_body, dt=0.02):
         """xdot (12,); raises ValueError on wrongly sized inputs like the reference's reshape (:245-246)."""
-        x = np.asarray(x, dtype=float).reshape(12,)
-        tau_body = np.asarray(tau_body, dtype=float).reshape(6,)
         self._sync_params()
-        xd, _ = engine.rhs(self.MODEL, x[None], tau_body[None], 0.02, ctx=self._ctx)
-        return xd[0]
+        return self._rhs_single(x, tau_body, 0.02)

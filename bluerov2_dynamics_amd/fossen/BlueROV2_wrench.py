@@ -69,8 +69,5 @@ class BlueROV2(VehicleBase):
 
     def dynamics(self, x, tau_body, dt=0.02):
         """xdot (13,) for x = [pos(3), q(4), nu(6)]; the quaternion is normalised on entry (:337)."""
-        x = np.asarray(x, dtype=float).reshape(13,)
-        tau_body = np.asarray(tau_body, dtype=float).reshape(6,)
         self._sync_params()
-        xd, _ = engine.rhs(self.MODEL, x[None], tau_body[None], 0.02, ctx=self._ctx)
-        return xd[0]
+        return self._rhs_single(x, tau_body, 0.02)

@@ -121,6 +121,27 @@ class VehicleBase:
         object.__setattr__(self, "_cs_pushed", csb)
         self._extra_mark_clean()
 
+    def _rhs_single(self, x, u, dt, lag=None):
+        """One dynamics() call through preallocated buffers and cached ctypes pointers (the per-call path is latency: the
+        generic batched wrapper spends more time converting and allocating than the launch takes).  x, u: anything that
+        reshapes to (nx,), (nu,) -- ValueError otherwise, like the reference's reshape.  lag: [8,3] array advanced in place."""
+        io = self.__dict__.get("_io")
+        if io is None:
+            nx, nu = _lib.NX[self.MODEL], _lib.NU[self.MODEL]
+            xb, ub, out = np.zeros(nx), np.zeros(nu), np.zeros(nx)
+            io = (xb, ub, out, xb.ctypes.data, ub.ctypes.data, out.ctypes.data, nx, nu, self._ctx.lib.brov_rhs)
+            object.__setattr__(self, "_io", io)
+        xb, ub, out, xp, up, op, nx, nu, fn = io
+        xb[...] = np.asarray(x, dtype=float).reshape(nx)
+        ub[...] = np.asarray(u, dtype=float).reshape(nu)
+        ctx = self._ctx
+        if ctx._stream:
+            ctx.set_stream(0)          # host path: back to the null stream (see Context.use_null_stream)
+        rc = fn(ctx.h, self.MODEL, 1, xp, up, float(dt), lag.ctypes.data if lag is not None else None, op)
+        if rc:
+            ctx.check(rc, "brov_rhs")
+        return out.copy()
+
     def _extra_clean(self):
         """Model-specific part of the fast check (the thruster model compares its geometry block)."""
         return True
