@@ -9,9 +9,11 @@
 
 namespace brov {
 
+// done / seq: when done != nullptr every row's thread stores seq to done[row] (system scope, release) after its results
 hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u,
-                      double* lag, double* xd);
-hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau);
+                      double* lag, double* xd, unsigned long long* done = nullptr, unsigned long long seq = 0);
+hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau,
+                                  unsigned long long* done = nullptr, unsigned long long seq = 0);
 hipError_t launch_rollout(hipStream_t st, const FastParams* d_fp, int model, int integ, int lag_mode, int layout, int64_t B,
                           int64_t T, double dt, const double* x0, const double* U, double* lag, double* traj,
                           int64_t stride, double* xT, int btu_staging);

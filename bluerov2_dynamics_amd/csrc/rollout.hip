@@ -139,7 +139,7 @@ __device__ __forceinline__ void integrate_step(const DevParams& p, double dt, do
 template <int MODEL>
 __global__ void __launch_bounds__(256) rhs_kernel(DevParams p, int64_t B, const double* __restrict__ X,
                                                   const double* __restrict__ U, double* __restrict__ lag_io,
-                                                  double* __restrict__ XD) {
+                                                  double* __restrict__ XD, unsigned long long* done, unsigned long long seq) {
     constexpr int NX = Dims<MODEL>::NX, NU = Dims<MODEL>::NU;
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
@@ -166,11 +166,15 @@ __global__ void __launch_bounds__(256) rhs_kernel(DevParams p, int64_t B, const 
     }
     rhs_state<MODEL>(p, x, tau, xd);
     store_row<NX>(XD + b * NX, xd);
+    // per-call path (capi.hip: brov_rhs with a handful of vehicles): the results live in host memory and the host spins on
+    // done[b] instead of synchronising the stream -- release at system scope, after the row's stores
+    if (done) __hip_atomic_store(done + b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // compute_thruster_forces (fossen/BlueROV2.py:265-278), batched
 __global__ void __launch_bounds__(256) thruster_forces_kernel(DevParams p, int64_t B, const double* __restrict__ U,
-                                                              double* __restrict__ lag_io, double* __restrict__ TAU) {
+                                                              double* __restrict__ lag_io, double* __restrict__ TAU,
+                                                              unsigned long long* done, unsigned long long seq) {
     const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     double u[8], fcmd[8], F[8], tau[6];
@@ -184,6 +188,7 @@ __global__ void __launch_bounds__(256) thruster_forces_kernel(DevParams p, int64
     lag.advance(p, 1, fcmd);
     store_row<24>(lag_io + b * 24, &lag.x[0][0]);
     store_row<6>(TAU + b * 6, tau);
+    if (done) __hip_atomic_store(done + b, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -674,21 +679,24 @@ static inline unsigned nblk(int64_t n, int bs) { return (unsigned)((n + bs - 1) 
 #define BROV_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return e_; } while (0)
 
 template <int MODEL>
-static hipError_t launch_rhs_m(hipStream_t st, const DevParams& p, int64_t B, const double* x, const double* u, double* lag, double* xd) {
-    hipLaunchKernelGGL(rhs_kernel<MODEL>, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, x, u, lag, xd);
+static hipError_t launch_rhs_m(hipStream_t st, const DevParams& p, int64_t B, const double* x, const double* u, double* lag, double* xd,
+                               unsigned long long* done, unsigned long long seq) {
+    hipLaunchKernelGGL(rhs_kernel<MODEL>, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, x, u, lag, xd, done, seq);
     return hipGetLastError();
 }
-hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u, double* lag, double* xd) {
+hipError_t launch_rhs(hipStream_t st, const DevParams& p, int model, int64_t B, const double* x, const double* u, double* lag, double* xd,
+                      unsigned long long* done, unsigned long long seq) {
     if (B <= 0) return hipSuccess;
     switch (model) {
-        case MODEL_THRUSTER_EULER: return launch_rhs_m<MODEL_THRUSTER_EULER>(st, p, B, x, u, lag, xd);
-        case MODEL_WRENCH_EULER: return launch_rhs_m<MODEL_WRENCH_EULER>(st, p, B, x, u, lag, xd);
-        default: return launch_rhs_m<MODEL_WRENCH_QUAT>(st, p, B, x, u, lag, xd);
+        case MODEL_THRUSTER_EULER: return launch_rhs_m<MODEL_THRUSTER_EULER>(st, p, B, x, u, lag, xd, done, seq);
+        case MODEL_WRENCH_EULER: return launch_rhs_m<MODEL_WRENCH_EULER>(st, p, B, x, u, lag, xd, done, seq);
+        default: return launch_rhs_m<MODEL_WRENCH_QUAT>(st, p, B, x, u, lag, xd, done, seq);
     }
 }
-hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau) {
+hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B, const double* u, double* lag, double* tau,
+                                  unsigned long long* done, unsigned long long seq) {
     if (B <= 0) return hipSuccess;
-    hipLaunchKernelGGL(thruster_forces_kernel, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, u, lag, tau);
+    hipLaunchKernelGGL(thruster_forces_kernel, dim3(nblk(B, 256)), dim3(256), 0, st, p, B, u, lag, tau, done, seq);
     return hipGetLastError();
 }
 

@@ -25,3 +25,10 @@ xx = x.copy()
 for k in range(2000):
     xx = xx + 0.02 * rov.dynamics(xx, u, 0.02)
 print("python Euler loop: %.0f steps/s" % (2000 / (time.perf_counter() - t0)))
+
+# long run: 300 000 calls without an explicit synchronisation in between (the per-call path spins on completion flags)
+t0 = time.perf_counter()
+xx = x.copy()
+for k in range(300000):
+    xd = rov.dynamics(xx, u, 0.02)
+print("300k calls: %.2f s, last xdot finite: %s" % (time.perf_counter() - t0, bool(np.isfinite(xd).all())))
