@@ -184,7 +184,10 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
 //   candidate with the smallest new potential sum_i min(closest_i, d(x_i, cand)) wins.
 // The running sum is formed per 4096-sample chunk (tree) + a sequential pass over the chunk sums + a sequential pass
 // inside the chunk that contains the value, not as one sequential np.cumsum: a candidate could differ from
-// scikit-learn's only if a drawn value fell within ~1e-13 (relative) of a running-sum boundary.
+// scikit-learn's only if a drawn value fell within ~1e-13 (relative) of a running-sum boundary -- or if two candidates of a
+// round tie in exact arithmetic (two mutually nearest uncovered points both drawn: pot - closest[a] - closest[b] + d(a, b)
+// either way; seen at N = 50, k = 16): the winner is then decided by the summation order of the potentials, scikit-learn's
+// own by that of a BLAS matrix-vector product (tools/stress_parity.py checks that every mismatch is such a tie).
 //
 // ONE pass over the samples per centre (the loop is bound by HBM: 112 bytes per sample and pass).  Round c (centre c is
 // being chosen, its L candidates are known):

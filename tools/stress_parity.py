@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box (not part of the test suite: minutes, not seconds): random shapes, layouts,
+strides, bag structures and chunk sizes through the C ABI against the oracle.  Prints the worst relative error per family
+and exits non-zero on the first violation.
+
+    python tools/stress_parity.py [seconds per family = 40] [seed = 0]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from bluerov2_dynamics_amd import _lib, engine
+from oracle import fossen_c, edmdc_numpy as ek
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 40.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+NX, NU = _lib.NX, _lib.NU
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def rollouts():
+    worst, n, t0 = 0.0, 0, time.time()
+    while time.time() - t0 < budget:
+        model = int(rng.integers(0, 3))
+        integ = str(rng.choice(["euler", "rk4"]))
+        B = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 700]))
+        T = int(rng.choice([1, 2, 3, 17, 64, 65, 130, 257]))
+        stride = int(rng.choice([1, 1, 2, 5, T]))
+        layout = str(rng.choice(["btu", "tub"]))
+        lag_mode = int(rng.integers(0, 2))
+        nx, nu = NX[model], NU[model]
+        x0 = rng.normal(0, 0.3, (B, nx))
+        if nx == 13:
+            x0[:, 3:7] /= np.linalg.norm(x0[:, 3:7], axis=1, keepdims=True)
+        U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 8.0)
+        lag = rng.normal(0, 0.2, (B, 8, 3)) if (model == 0 and rng.random() < 0.5) else None
+        ref = fossen_c.rollout(model, 0 if integ == "euler" else 1, x0, U, 0.02, lag=lag, lag_mode=lag_mode, sub=stride)
+        Ud = U if layout == "btu" else np.ascontiguousarray(U.transpose(1, 2, 0))
+        got = engine.rollout(model, integ, x0, Ud, 0.02, lag=lag, lag_mode=lag_mode, layout=layout, stride=stride)
+        tr = got["traj"] if layout == "btu" else got["traj"].transpose(2, 0, 1)
+        # lanes that pass within 0.05 rad of the Euler-angle singularity amplify the last bit by 1 / cos(theta)^2 (up to the
+        # reference's 1e-7 clamp) in BOTH implementations: there only finiteness is compared, everywhere else 1e-9
+        scale = np.abs(ref["traj"][np.isfinite(ref["traj"])]).max()
+        lane_err = np.nan_to_num(np.abs(tr - ref["traj"]), nan=0.0, posinf=0.0).max(axis=(1, 2)) / scale
+        if nx == 12:
+            full = ref if stride == 1 else fossen_c.rollout(model, 0 if integ == "euler" else 1, x0, U, 0.02, lag=lag, lag_mode=lag_mode, sub=1)
+            near = np.abs(np.cos(full["traj"][:, :, 4])).min(axis=1) < 0.05
+        else:
+            near = np.zeros(B, dtype=bool)
+        assert np.array_equal(np.isfinite(tr), np.isfinite(ref["traj"])), ("rollout finiteness", model, integ, B, T)
+        keep = ~near
+        e = float(lane_err[keep].max()) if keep.any() else 0.0
+        e = max(e, relerr(got["xT"][keep], ref["xT"][keep]) if keep.any() else 0.0)
+        if model == 0 and got["lag"] is not None:
+            e = max(e, relerr(got["lag"], ref["lag"]))
+        tol = 1e-9
+        if not (np.isfinite(e) and e < tol):
+            err = np.abs(tr - ref["traj"])
+            per_lane = err.max(axis=(1, 2)); b = int(per_lane.argmax())
+            print("  worst lane", b, "abs err", err.max(), "lanes above 1e-11:", int((per_lane > 1e-11).sum()), "of", B,
+                  "median lane err", float(np.median(per_lane)))
+            print("  err over time (every 16 rows):", err[b].max(axis=1)[::16])
+            print("  theta of that lane: min %.4f max %.4f; max |state| %.3f" % (ref["traj"][b, :, 4].min(), ref["traj"][b, :, 4].max(), np.abs(ref["traj"][b]).max()))
+        assert np.isfinite(e) and e < tol, ("rollout", model, integ, B, T, stride, layout, lag_mode, e)
+        worst, n = max(worst, e), n + 1
+    print(f"rollouts   : {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
+def grams():
+    worst, n, t0 = 0.0, 0, time.time()
+    ctx = _lib.default_context()
+    while time.time() - t0 < budget:
+        n_, r = [(12, 8), (12, 6), (13, 6), (9, 4), (5, 2), (13, 8), (12, 10)][int(rng.integers(0, 7))]
+        k = int(rng.choice([1, 7, 16, 17, 48, 100, 200, 257, 500, 512]))
+        nb = int(rng.integers(1, 5))
+        lens = [int(rng.choice([2, 3, 5, 33, 100, 257, 1000])) for _ in range(nb)]
+        chunk = int(rng.choice([64, 100, 257, 4096, 1 << 20]))
+        ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, chunk), "edmdc_set_chunk_rows")
+        Xs = [np.cumsum(rng.normal(0, 0.05, (m, n_)), 0) for m in lens]
+        Us = [rng.uniform(-1, 1, (m, r)) for m in lens]
+        C = rng.normal(0, 0.4, (k, n_))
+        g = float(rng.choice([0.3, 1.0, 3.0]))
+        GtG, GtY, npairs = engine.gram(Xs, Us, C, g)
+        Go, Yo, npo = ek.gram(Xs, Us, C, g)
+        e = max(np.abs(GtG - Go).max() / np.abs(Go).max(), np.abs(GtY - Yo).max() / max(1e-300, np.abs(Yo).max()))
+        assert npairs == npo and np.isfinite(e) and e < 1e-11, ("gram", n_, r, k, lens, chunk, e)
+        worst, n = max(worst, float(e)), n + 1
+    ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, 1 << 20), "edmdc_set_chunk_rows")
+    print(f"Gram       : {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
+def multistep():
+    worst, n, t0 = 0.0, 0, time.time()
+    while time.time() - t0 < budget:
+        n_, r = [(12, 8), (13, 6), (9, 4)][int(rng.integers(0, 3))]
+        k = int(rng.choice([8, 40, 100, 200]))
+        N = int(rng.choice([30, 129, 300, 1500]))
+        H = int(rng.choice([1, 2, 10, 29]))
+        if H >= N:
+            continue
+        X = np.cumsum(rng.normal(0, 0.02, (N, n_)), 0)
+        U = rng.uniform(-1, 1, (N, r))
+        C = X[rng.choice(N, k, replace=k > N)]
+        A, B_ = ek.fit([X], [U], C, 1.0, 1e-2)
+        se, _ = engine.multistep_se(X, U, C, 1.0, A, B_, H)
+        ref = ek.multistep_rmse(X, U, C, 1.0, A, B_, H)
+        got = np.sqrt(se / ((N - H) * n_))
+        e = abs(got - ref) / max(ref, 1e-300)
+        assert np.isfinite(e) and e < 1e-9, ("multistep", n_, r, k, N, H, got, ref)
+        worst, n = max(worst, float(e)), n + 1
+    print(f"multistep  : {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
+def kmeanspp():
+    """Seed indices equal to scikit-learn's -- except where two candidates of a round tie in exact arithmetic (two mutually
+    nearest uncovered points both drawn: pot - closest[a] - closest[b] + d(a, b) either way), which happens at tiny N with
+    k ~ N / 3.  There the winner is decided by the summation order of the potentials (scikit-learn's own comes out of a BLAS
+    matrix-vector product), so a mismatch is accepted iff the two choices' potentials agree to 1e-10 at the first differing
+    round (replayed here with NumPy)."""
+    import torch
+    from sklearn.cluster import kmeans_plusplus
+    from sklearn.metrics.pairwise import euclidean_distances
+    from sklearn.utils.extmath import row_norms, stable_cumsum
+    ties, n, t0 = 0, 0, time.time()
+    while time.time() - t0 < budget:
+        N = int(rng.choice([50, 4095, 4096, 4097, 9000, 20000, 50000]))
+        n_ = int(rng.choice([5, 12, 13]))
+        k = int(rng.choice([2, 3, 16, 64, 200]))
+        if k > N:
+            continue
+        X = np.concatenate([rng.normal(m, 0.5, (N // 4 + 1, n_)) for m in rng.uniform(-2, 2, (4, n_))])[:N]
+        seed = int(rng.integers(0, 1000))
+        mean = X.mean(0)
+        Xc = X - mean
+        C_ref, idx_ref = kmeans_plusplus(Xc, k, random_state=np.random.RandomState(seed))
+        C, idx = engine.kmeanspp_dev(torch.from_numpy(X).cuda(), k, mean=mean, random_state=seed)
+        n += 1
+        if np.array_equal(idx, idx_ref):
+            continue
+        j = int(np.argmax(idx != idx_ref))
+        rs = np.random.RandomState(seed)
+        xsq = row_norms(Xc, squared=True)
+        first = rs.choice(N, p=np.full(N, 1.0 / N))
+        closest = euclidean_distances(Xc[first, None], Xc, Y_norm_squared=xsq, squared=True)[0]
+        pot = closest.sum()
+        L = 2 + int(np.log(k))
+        for c in range(1, j + 1):
+            cand = np.searchsorted(stable_cumsum(closest), rs.uniform(size=L) * pot)
+            np.clip(cand, None, N - 1, out=cand)
+            d = euclidean_distances(Xc[cand], Xc, Y_norm_squared=xsq, squared=True)
+            np.minimum(closest, d, out=d)
+            pots = d.sum(axis=1)
+            if c == j:
+                assert idx[j] in cand and idx_ref[j] in cand, ("kmeans++ pick is not a candidate", N, n_, k, seed, j)
+                pa, pb = pots[list(cand).index(idx[j])], pots[list(cand).index(idx_ref[j])]
+                assert abs(pa - pb) <= 1e-10 * abs(pb), ("kmeans++ differs without a tie", N, n_, k, seed, j, pa, pb)
+            best = list(cand).index(idx_ref[c])
+            pot, closest = pots[best], d[best]
+        ties += 1
+    print(f"k-means++  : {n} cases, seed indices equal to scikit-learn's except {ties} exact-arithmetic ties", flush=True)
+
+
+if __name__ == "__main__":
+    rollouts()
+    grams()
+    multistep()
+    kmeanspp()
+    print("stress parity: ok")
