@@ -27,7 +27,7 @@ def rollouts():
         B = int(rng.choice([1, 2, 63, 64, 65, 255, 256, 257, 700]))
         T = int(rng.choice([1, 2, 3, 17, 64, 65, 130, 257]))
         stride = int(rng.choice([1, 1, 2, 5, T]))
-        layout = str(rng.choice(["btu", "tub"]))
+        layout = str(rng.choice(["btu", "tub", "tpb"]))
         lag_mode = int(rng.integers(0, 2))
         nx, nu = NX[model], NU[model]
         x0 = rng.normal(0, 0.3, (B, nx))
@@ -36,9 +36,19 @@ def rollouts():
         U = rng.uniform(-1, 1, (B, T, nu)) * (1.0 if model == 0 else 8.0)
         lag = rng.normal(0, 0.2, (B, 8, 3)) if (model == 0 and rng.random() < 0.5) else None
         ref = fossen_c.rollout(model, 0 if integ == "euler" else 1, x0, U, 0.02, lag=lag, lag_mode=lag_mode, sub=stride)
-        Ud = U if layout == "btu" else np.ascontiguousarray(U.transpose(1, 2, 0))
+        if layout == "btu":
+            Ud = U
+        elif layout == "tub":
+            Ud = np.ascontiguousarray(U.transpose(1, 2, 0))
+        else:                                                     # [T][nu/2][B][2]
+            Ud = np.ascontiguousarray(U.reshape(B, T, nu // 2, 2).transpose(1, 2, 0, 3))
         got = engine.rollout(model, integ, x0, Ud, 0.02, lag=lag, lag_mode=lag_mode, layout=layout, stride=stride)
-        tr = got["traj"] if layout == "btu" else got["traj"].transpose(2, 0, 1)
+        if layout == "btu":
+            tr = got["traj"]
+        elif layout == "tub":
+            tr = got["traj"].transpose(2, 0, 1)
+        else:                                                     # [rows][ceil(nx/2)][B][2]
+            tr = got["traj"].transpose(2, 0, 1, 3).reshape(B, got["traj"].shape[0], -1)[:, :, :nx]
         # lanes that pass within 0.05 rad of the Euler-angle singularity amplify the last bit by 1 / cos(theta)^2 (up to the
         # reference's 1e-7 clamp) in BOTH implementations: there only finiteness is compared, everywhere else 1e-9
         scale = np.abs(ref["traj"][np.isfinite(ref["traj"])]).max()
@@ -112,6 +122,34 @@ def multistep():
     print(f"multistep  : {n} cases, worst rel err {worst:.2e}", flush=True)
 
 
+def windows():
+    worst, n, t0 = 0.0, 0, time.time()
+    while time.time() - t0 < budget:
+        model = int(rng.integers(0, 6))                           # incl. the double-integrator baselines (3..5)
+        integ = str(rng.choice(["euler", "rk4"]))
+        N = int(rng.choice([12, 70, 200, 1000, 4200]))
+        H = int(rng.choice([1, 2, 10, 33]))
+        if H >= N:
+            continue
+        nx, nu = NX[model], NU[model]
+        X = np.cumsum(rng.normal(0, 0.01, (N, nx)), 0)
+        X[:, 3:6] *= 0.2
+        if nx == 13:
+            X[:, 3:7] = rng.normal(0, 1, (N, 4)); X[:, 3:7] /= np.linalg.norm(X[:, 3:7], axis=1, keepdims=True)
+        U = rng.uniform(-1, 1, (N, nu)) * (1.0 if nu == 8 else 5.0)
+        carry = bool(rng.integers(0, 2))
+        if model >= 3:
+            Kl, Ka = rng.normal(0, 0.5, (nu, 3)), rng.normal(0, 0.5, (nu, 3))
+            fossen_c.set_di_gains(Kl, Ka)
+            _lib.default_context().set_di_gains(Kl, Ka)
+        se_ref, per_ref = fossen_c.window_endpoint_se(model, 0 if integ == "euler" else 1, X, U, H, 0.02, carry_lag=carry)
+        se, per = engine.window_endpoint_se(model, integ, X, U, H, 0.02, carry_lag=carry)
+        e = max(abs(se - se_ref) / max(se_ref, 1e-300), float(np.max(np.abs(per - per_ref)) / max(1e-300, np.max(np.abs(per_ref)))))
+        assert np.isfinite(e) and e < 1e-9, ("window", model, integ, N, H, carry, e)
+        worst, n = max(worst, e), n + 1
+    print(f"windows    : {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
 def kmeanspp():
     """Seed indices equal to scikit-learn's -- except where two candidates of a round tie in exact arithmetic (two mutually
     nearest uncovered points both drawn: pot - closest[a] - closest[b] + d(a, b) either way), which happens at tiny N with
@@ -163,6 +201,7 @@ def kmeanspp():
 
 if __name__ == "__main__":
     rollouts()
+    windows()
     grams()
     multistep()
     kmeanspp()
