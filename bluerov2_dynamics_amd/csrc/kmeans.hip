@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
 // scikit-learn's only if a drawn value fell within ~1e-13 (relative) of a running-sum boundary -- or if two candidates of a
 // round tie in exact arithmetic (two mutually nearest uncovered points both drawn: pot - closest[a] - closest[b] + d(a, b)
 // either way; seen at N = 50, k = 16): the winner is then decided by the summation order of the potentials, scikit-learn's
-// own by that of a BLAS matrix-vector product (tools/stress_parity.py checks that every mismatch is such a tie).
+// own by that of a BLAS matrix-vector product (tests/stress_parity.py checks that every mismatch is such a tie).
 //
 // ONE pass over the samples per centre (the loop is bound by HBM: 112 bytes per sample and pass).  Round c (centre c is
 // being chosen, its L candidates are known):

@@ -3,7 +3,9 @@
 strides, bag structures and chunk sizes through the C ABI against the oracle.  Prints the worst relative error per family
 and exits non-zero on the first violation.
 
-    python tools/stress_parity.py [seconds per family = 40] [seed = 0]"""
+    python tests/stress_parity.py [seconds per family = 40] [seed = 0]
+
+Lives under tests/ because it checks against oracle/ (test infrastructure); tests/test_gpu_parity.py runs a short sweep."""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1305,3 +1305,14 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert len(c4["per_rank_ms"]) == 1 and c4["rollout_steps_per_s"] > 0 and c4["gram_samples_per_s"] > 0
     assert d["cpu_baseline_reference_shape"]["cores"] == 1 and d["cpu_baseline_reference_shape"]["value"] > 0
     assert d["roofline"]["bound"] == "valu_fp64_issue" and 0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_randomised_parity_sweep_short(eng):
+    """tests/stress_parity.py for a few seconds per family: random shapes, layouts, strides, bag structures, chunk sizes
+    and models (rollouts, window evaluator, Gram, multistep, k-means++ seeding) against the oracle / scikit-learn."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    out = subprocess.run([sys.executable, os.path.join(REPO, "tests", "stress_parity.py"), "3", "11"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "stress parity: ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
