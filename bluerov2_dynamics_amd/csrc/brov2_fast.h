@@ -74,6 +74,9 @@ struct HotConstsT {
 typedef HotConstsT<false> HotConsts;
 typedef HotConstsT<true> HotConstsResident;
 
+#ifndef BROV_PSI_FRAME
+#define BROV_PSI_FRAME 1
+#endif
 #define BROV_PIN_V(x) asm volatile("" : "+v"(x))
 #define BROV_PIN_S(x) asm volatile("" : "+s"(x))
 #define BROV_SC(h, p, f) (HC::RESIDENT ? (h).f : (p)->f)
@@ -163,7 +166,7 @@ __device__ __forceinline__ void trig_full(const double* ang, Trig& t, const doub
 //                version had one per stage: its literals cost 36 SGPR spill reloads and 40 AGPR moves per step).
 //   |d| >= 2^37 or not finite: NaN (np.sin gives NaN for inf/NaN; for finite arguments of that size the reference's
 //                values carry no information about the trajectory either).
-__device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Trig& t) {
+__device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Trig& t, double* dpsi = nullptr) {
     double dd[3] = {d[0], d[1], d[2]};
     int k = 0;
     const double m = fmax(fmax(fabs(d[0]), fabs(d[1])), fabs(d[2]));
@@ -202,6 +205,7 @@ __device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Tri
     t.sphi = fma(b.cphi, sd[0], fma(b.sphi, cm[0], b.sphi)); t.cphi = fma(-b.sphi, sd[0], fma(b.cphi, cm[0], b.cphi));
     t.sth = fma(b.cth, sd[1], fma(b.sth, cm[1], b.sth));     t.cth = fma(-b.sth, sd[1], fma(b.cth, cm[1], b.cth));
     t.spsi = fma(b.cpsi, sd[2], fma(b.spsi, cm[2], b.spsi)); t.cpsi = fma(-b.spsi, sd[2], fma(b.cpsi, cm[2], b.cpsi));
+    if (dpsi) { dpsi[0] = sd[2]; dpsi[1] = cm[2]; }           // sin(d psi), cos(d psi) - 1 (BROV_PSI_FRAME: see integrate_fast)
 }
 
 // 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps
@@ -255,7 +259,8 @@ __device__ __forceinline__ void nu_dot_fast(const HC& h, CFP p, const double R[9
 }
 
 // xdot for the Euler-angle state; a = Minv tau
-template <bool GENERIC, class HC>
+// PFRAME: xd[0..1] are left in the frame of the yaw angle (the last of the three plane rotations is not applied)
+template <bool GENERIC, class HC, bool PFRAME = false>
 __device__ __forceinline__ void rhs_fast_euler(const HC& h, CFP p, const double x[12], const double a[6], double xd[12], const Trig& tg) {
     const double sphi = tg.sphi, cphi = tg.cphi, sth = tg.sth, cth = tg.cth, spsi = tg.spsi, cpsi = tg.cpsi;   // x[3..5] enter only through these
     const double* nu = x + 6;
@@ -275,8 +280,11 @@ __device__ __forceinline__ void rhs_fast_euler(const HC& h, CFP p, const double 
         // forming the nine entries of R (14) and a 3x3 product (9)
         const double y1 = fma(cphi, nu[1], -(sphi * nu[2])), z1 = fma(sphi, nu[1], cphi * nu[2]);
         const double x2 = fma(cth, nu[0], sth * z1), z2 = fma(cth, z1, -(sth * nu[0]));
-        xd[0] = fma(cpsi, x2, -(spsi * y1));
-        xd[1] = fma(spsi, x2, cpsi * y1);
+        if constexpr (PFRAME) { xd[0] = x2; xd[1] = y1; }
+        else {
+            xd[0] = fma(cpsi, x2, -(spsi * y1));
+            xd[1] = fma(spsi, x2, cpsi * y1);
+        }
         xd[2] = z2;
     }
     double cc = cth;
@@ -343,12 +351,12 @@ __device__ __forceinline__ void rhs_di_quat(const double x[13], const double a[6
 }
 
 // tg: sin/cos of x[3..5] for the Euler-angle models (ignored by the quaternion ones)
-template <int MODEL, bool GENERIC, class HC>
+template <int MODEL, bool GENERIC, class HC, bool PFRAME = false>
 __device__ __forceinline__ void rhs_fast(const HC& h, CFP p, const double* x, const double a[6], double* xd, const Trig& tg) {
     if constexpr (MODEL == MODEL_DI_WRENCH_QUAT) rhs_di_quat(x, a, xd);
     else if constexpr (model_is_di(MODEL)) rhs_di_euler(x, a, xd, tg);
     else if constexpr (MODEL == MODEL_WRENCH_QUAT) rhs_fast_quat<GENERIC>(h, p, x, a, xd);
-    else rhs_fast_euler<GENERIC>(h, p, x, a, xd, tg);
+    else rhs_fast_euler<GENERIC, HC, PFRAME>(h, p, x, a, xd, tg);
 }
 
 // ---- thruster lag in acceleration space ---------------------------------------------------------
@@ -526,6 +534,12 @@ __device__ __forceinline__ void integrate_fast(const HC& h, CFP p, double dt, do
     } else {
         double k[NX], xn[NX], xs[NX], dl[3];
         const double h2 = 0.5 * dt, h6 = dt / 6.0, h3 = dt / 3.0;
+        // PSIF (the reference vehicle's Euler-angle models): the horizontal position increment is accumulated in the frame of
+        // the step's initial yaw.  A stage's p_dot arrives in ITS yaw frame (rhs_fast_euler<PFRAME>), is turned by the stage's
+        // yaw increment -- whose sin and cos - 1 trig_delta has anyway -- and the sum is turned by the initial yaw once at the
+        // end: the stages' own sin/cos(psi) are never formed and stage 1 needs no rotation (12 instructions fewer per step).
+        constexpr bool PSIF = BROV_PSI_FRAME && ANG && !GENERIC && !model_is_di(MODEL);
+        double dps[2] = {0.0, 0.0};
         // stage state xs = x + c k; for the Euler-angle models the angles enter the RHS only through their sin/cos,
         // which come from the angle increments dl = c k[3..5] (trig_delta), so xs[3..5] is never formed
         auto stage_state = [&](double c) {
@@ -534,36 +548,49 @@ __device__ __forceinline__ void integrate_fast(const HC& h, CFP p, double dt, do
                 if (ANG && i >= 3 && i < 6) dl[i - 3] = c * k[i];
                 else xs[i] = fma(c, k[i], x[i]);
             }
-            if constexpr (ANG) trig_delta(tb, dl, ts);
+            if constexpr (ANG) trig_delta(tb, dl, ts, PSIF ? dps : nullptr);
+        };
+        // horizontal position increment of a later stage: turn its p_dot by the stage's yaw increment, then weight it
+        auto add_turned = [&](double w) {
+            const double r0 = fma(dps[1], k[0], fma(-dps[0], k[1], k[0])), r1 = fma(dps[0], k[0], fma(dps[1], k[1], k[1]));
+            xn[0] = fma(w, r0, xn[0]);
+            xn[1] = fma(w, r1, xn[1]);
         };
         accel(1, a);
-        rhs_fast<MODEL, GENERIC>(h, p, x, a, k, tb);
+        rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, x, a, k, tb);
         // with a carry the three angles accumulate their INCREMENT in xn (x is added at the end), so that the increment is
-        // available for the addition theorem
+        // available for the addition theorem; PSIF does the same with the horizontal position
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xn[i] = (CARRY && i >= 3 && i < 6) ? h6 * k[i] : fma(h6, k[i], x[i]);
+        for (int i = 0; i < NX; ++i) xn[i] = ((CARRY && i >= 3 && i < 6) || (PSIF && i < 2)) ? h6 * k[i] : fma(h6, k[i], x[i]);
         stage_state(h2);
         accel(2, a);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
+        rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        for (int i = PSIF ? 2 : 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        if constexpr (PSIF) add_turned(h3);
         stage_state(h2);
         accel(3, a);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
+        rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
 #pragma unroll
-        for (int i = 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        for (int i = PSIF ? 2 : 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
+        if constexpr (PSIF) add_turned(h3);
         stage_state(dt);
         accel(4, a);
-        rhs_fast<MODEL, GENERIC>(h, p, xs, a, k, ts);
+        rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
+        if constexpr (PSIF) {
+            add_turned(h6);
+            x[0] = fma(tb.cpsi, xn[0], fma(-tb.spsi, xn[1], x[0]));
+            x[1] = fma(tb.spsi, xn[0], fma(tb.cpsi, xn[1], x[1]));
+        }
         if (CARRY) {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) {
+            for (int i = PSIF ? 2 : 0; i < NX; ++i) {
                 if (i >= 3 && i < 6) { dang[i - 3] = fma(h6, k[i], xn[i]); x[i] += dang[i - 3]; }
                 else x[i] = fma(h6, k[i], xn[i]);
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
+            for (int i = PSIF ? 2 : 0; i < NX; ++i) x[i] = fma(h6, k[i], xn[i]);
         }
     }
     if constexpr (ANG) { if (CARRY) trig_delta(tb, dang, *carry); }
