@@ -74,6 +74,9 @@ struct HotConstsT {
 typedef HotConstsT<false> HotConsts;
 typedef HotConstsT<true> HotConstsResident;
 
+#ifndef BROV_CLAMP_BRANCH
+#define BROV_CLAMP_BRANCH 1
+#endif
 #ifndef BROV_PSI_FRAME
 #define BROV_PSI_FRAME 1
 #endif
@@ -288,7 +291,15 @@ __device__ __forceinline__ void rhs_fast_euler(const HC& h, CFP p, const double 
         xd[2] = z2;
     }
     double cc = cth;
-    if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));   // fossen/BlueROV2.py:52-54
+    // fossen/BlueROV2.py:52-54.  As plain code the compiler turns the clamp into nine select / convert instructions per stage;
+    // behind a wave-level test (is ANY lane that close to the singularity?) the common path pays one compare and a scalar branch
+#if BROV_CLAMP_BRANCH
+    if (__builtin_amdgcn_ballot_w64(fabs(cc) < 1e-7) != 0) {
+        if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));
+    }
+#else
+    if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));
+#endif
     const double ic = recip_fast(cc);
     const double m = fma(sphi, nu[4], cphi * nu[5]);   // sin(phi) q + cos(phi) r
     xd[3] = fma(sth * ic, m, nu[3]);

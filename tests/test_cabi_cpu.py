@@ -206,7 +206,7 @@ def test_bench_instruction_counts_match_the_compiler_listing(tmp_path):
         loops = [ast.literal_eval(l.split("):", 1)[1].strip()) for l in out.splitlines() if l.startswith("loop lines")]
         assert len(loops) >= 2, out
         static = loops[0]["f64"] + loops[1]["f64"]
-        rare = 81 + (45 if integ == "rk4" else 15)          # refresh block + cold range-extension code, give or take
+        rare = 81 + (45 + 20 if integ == "rk4" else 15 + 5)  # refresh block + cold range-extension code + the cos(theta) clamp behind its wave-level test, give or take
         assert static - rare - 25 <= bench.ROLLOUT_EXEC_FP64_INSTR[integ] <= static - rare + 25, (integ, static, out)
         # the two waves of a SIMD keep nothing in scratch and no accumulator-file spills
         assert all(l.get("acc", 0) == 0 and l.get("lane", 0) <= 4 for l in loops[:2]), out
