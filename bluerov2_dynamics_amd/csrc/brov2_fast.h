@@ -295,6 +295,7 @@ __device__ __forceinline__ void rhs_fast_euler(const HC& h, CFP p, const double 
     // behind a wave-level test (is ANY lane that close to the singularity?) the common path pays one compare and a scalar branch
 #if BROV_CLAMP_BRANCH
     if (__builtin_amdgcn_ballot_w64(fabs(cc) < 1e-7) != 0) {
+        asm volatile("; cos(theta) clamp, rare" ::: "memory");      // not speculatable: keeps the block behind its branch
         if (fabs(cc) < 1e-7) cc = 1e-7 * ((cc > 0.0) - (cc < 0.0));
     }
 #else
