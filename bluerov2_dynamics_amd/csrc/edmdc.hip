@@ -198,6 +198,7 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
             // for with lgkmcnt(0), so the fetch distance cannot exceed one row, and a miss under the kernel's own 3.5 TB/s of
             // stores takes longer than the 0.4 us a row's arithmetic lasts).
             __shared__ __attribute__((aligned(16))) double xs[RT][LIFT_NMAX];
+            const bool partial_wave = __builtin_amdgcn_ballot_w64(c0 + NC > k) != 0;       // some lane of the wave holds padding centres
             for (int e = threadIdx.x; e < RT * NS; e += LIFT_BLOCK) {
                 const int rr = e / NS, j = e - rr * NS;
                 const int64_t g = g0 + rr;
@@ -214,8 +215,13 @@ __global__ void __launch_bounds__(LIFT_BLOCK) lift_rows_kernel(EdmdcShape s, dou
                 if constexpr (NS & 1) xr[NS - 1] = xs[l - l0][NS - 1];
                 rbf_vals<NS, NC>(gamma, xr, cc, c2, z);
                 const bool valid = g < total_rows && t <= L;                     // wave-uniform
+                // rows past the end / gap rows and the padding centres (k <= c < kp) are written as zeros; both are rare
+                // and wave-uniform tests (as per-value selects they were 8 of the row's 180 VALU instructions)
+                if (!valid || partial_wave) {
+                    asm volatile("; lift: zero rows / padding centres, rare" ::: "memory");      // keeps the block behind its branch
 #pragma unroll
-                for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
+                    for (int q = 0; q < NC; ++q) z[q] = (valid && c0 + q < k) ? z[q] : 0.0;
+                }
                 if (store) {
 #pragma unroll
                     for (int q = 0; q < NC; q += 2) *reinterpret_cast<double2*>(zp + q) = make_double2(z[q], z[q + 1]);
