@@ -140,3 +140,25 @@ def test_driver_entry_points_exist_and_bench_parses_its_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def test_thruster_geometry_entries_are_views_of_one_block():
+    """thrusters_r[i]["r" | "dir"] of the drop-in vehicle (fossen/BlueROV2.py:172-232 holds plain dicts of arrays): edits in
+    place, assignment of a new array to a key, and replacement of a whole entry all land in the one [8,2,3] block whose bytes
+    the per-call path compares -- no GPU needed to check the container classes."""
+    from bluerov2_dynamics_amd.fossen.BlueROV2 import _ThrusterEntry, _ThrusterList
+    geom = np.arange(48, dtype=float).reshape(8, 2, 3)
+    lst = _ThrusterList(_ThrusterEntry(geom[i]) for i in range(8))
+    before = geom.tobytes()
+    lst[2]["r"][1] += 0.5                                         # in place
+    assert geom[2, 0, 1] == 13.5 + 0.0 and geom.tobytes() != before
+    lst[3]["dir"] = [9.0, 8.0, 7.0]                               # key assignment copies into the view
+    assert np.array_equal(geom[3, 1], [9.0, 8.0, 7.0]) and lst[3]["dir"].base is not None
+    lst[0] = {"r": np.ones(3), "dir": np.zeros(3)}                # entry replacement copies too
+    assert np.array_equal(geom[0], [[1, 1, 1], [0, 0, 0]]) and isinstance(lst[0], _ThrusterEntry)
+    lst[1]["label"] = "front-left"                                # other keys behave like a dict
+    assert lst[1]["label"] == "front-left" and set(lst[1]) == {"r", "dir", "label"}
+    with np.testing.assert_raises(ValueError):
+        lst[4]["r"] = np.zeros(4)
+    with np.testing.assert_raises(TypeError):
+        lst[0:2] = []
