@@ -51,14 +51,40 @@ CLOCK_HZ = 2.4e9                     # nominal; the chip holds 1.9-2.1 GHz under
 SIMDS = 1024
 
 
-def pmc_traffic(kernel, launches=1):
-    """HBM bytes per launch from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
-    command, FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  PMC counters cannot be read from inside the timed
-    process, so this is the recorded figure, not a live one."""
-    for name in ("r02_pmc_summary.json", "r01_pmc_summary.json"):
+# ceilings measured on this pool with the committed microbenchmarks (profiles/r02_ubench_fp64.txt: v_fma_f64 streams at 2-4
+# waves per SIMD 56.9-58.7 TFLOP/s under the board's power cap; MI355X_MICROARCH.md: ~6.3 TB/s achievable HBM)
+MEASURED_FP64_VALU_TFLOPS = 57.0
+MEASURED_HBM_GBS = 6300.0
+
+
+def kernel_source_sha():
+    """sha256 (16 hex) over the kernel sources: recorded next to a PMC summary (tools/pmc_summary.py) so that a traffic
+    figure taken from an older build of the kernels is visible as stale."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.join(REPO, "bluerov2_dynamics_amd", "csrc")
+    for f in sorted(os.listdir(root)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(parts):
+    """HBM bytes from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
+    FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  parts: {kernel name in the summary: launches}; the figure is
+    the sum over ALL of them (a fit = lift + tail + Gram per chunk).  PMC counters cannot be read from inside the timed
+    process, so this is the recorded figure, not a live one: `kernel_source_sha` of the run it came from is printed beside
+    the current one and `stale` says whether the kernels changed since."""
+    for name in ("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json"):
         try:
-            d = json.load(open(os.path.join(REPO, "profiles", name)))[kernel]
-            return {"bytes": d["hbm_total_GB_per_launch"] * 1e9 * launches, "source": f"profiles/{name} (rocprofv3 --pmc, recorded run)"}
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            tot = sum(d[k]["hbm_total_GB_per_launch"] * 1e9 * n for k, n in parts.items())
+            rec = d.get("_kernel_source_sha")
+            cur = kernel_source_sha()
+            return {"bytes": tot, "per_kernel_GB_per_launch": {k: d[k]["hbm_total_GB_per_launch"] for k in parts}, "launches": dict(parts),
+                    "source": f"profiles/{name} (rocprofv3 --pmc, recorded run)", "recorded_kernel_source_sha": rec,
+                    "current_kernel_source_sha": cur, "stale": (rec != cur) if rec else None}
         except Exception:
             continue
     return None
@@ -76,9 +102,11 @@ def parse():
     ap.add_argument("--integrator", default="rk4", choices=["rk4", "euler"])
     ap.add_argument("--controls", default="iid", choices=["iid", "ar1"], help="command stream of the timed rollout leg")
     ap.add_argument("--no-ar1", action="store_true", help="skip the AR(1) (dist B) rollout variant")
+    ap.add_argument("--no-variants", action="store_true", help="skip config 2's other runs (endpoint-only, Euler stored / endpoint-only)")
+    ap.add_argument("--no-fit", action="store_true", help="skip the KoopmanEDMDc.fit() / fit_multi() end-to-end leg")
     ap.add_argument("--edmdc-samples", type=int, default=10_000_000, help="(x,u,x+) pairs per GPU for the Gram leg")
     ap.add_argument("--edmdc-steps", type=int, default=2)
-    ap.add_argument("--kmeans-iters", type=int, default=30, help="cap on Lloyd iterations for the centres of the EDMDc leg")
+    ap.add_argument("--kmeans-iters", type=int, default=300, help="cap on Lloyd iterations (scikit-learn's KMeans default: 300, tol 1e-4)")
     ap.add_argument("--no-edmdc", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the config-4 ensemble leg")
     ap.add_argument("--cfg4-rollouts", type=int, default=1 << 20, help="TOTAL rollouts of the config-4 ensemble (all ranks together)")
@@ -337,6 +365,17 @@ def main():
     issue_frac = issue_tflops / PEAK_FP64_VALU_TFLOPS             # == issue_rate / (SIMDS * CLOCK_HZ / 4) up to the datasheet's rounding
     assert torch.isfinite(xT).all()
 
+    # the binding term is max(issue, hbm).  After round 2's instruction trims the kernel sits across the ridge
+    # (1 450 executed flop / 160 B = 9.1 < 9.8): both are printed, `bound` / `frac` name the larger one.
+    hbm_frac = byte_rate / PEAK_HBM_GBS
+    issue_term = {"bound": "valu_fp64_issue", "achieved": issue_tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": issue_frac,
+                  "frac_of_measured_ceiling": issue_tflops / MEASURED_FP64_VALU_TFLOPS, "executed_fp64_instr_per_step": instr,
+                  "note": "fp64 VALU instructions issued x 64 lanes x 2 flop (every slot priced as an FMA) / kernel time; frac = share "
+                          "of the chip's fp64 issue slots (1024 SIMDs x 2.4 GHz / 4) the kernel fills"}
+    hbm_term = {"bound": "hbm", "achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_frac,
+                "frac_of_measured_ceiling": byte_rate / MEASURED_HBM_GBS, "bytes_per_step": bytes_per_step}
+    binding = hbm_term if hbm_frac >= issue_frac else issue_term
+    traffic = (pmc_traffic({"rollout": 1}) if (a.integrator == "rk4" and not a.no_store and lay != "btu" and B == 65536 and T == 5000) else None)
     out = {
         "metric": "rk4_rollout_steps_per_s" if a.integrator == "rk4" else "euler_rollout_steps_per_s",
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -347,23 +386,19 @@ def main():
                                + f" (splitmix64 stream 0x5EED), layout {lay}, "
                                + ("all states stored" if traj is not None else "endpoint only"),
                    "trajectories_per_gpu": B, "horizon": T, "parallelism": f"{world} x independent shards, no collective"},
-        "roofline": {"kernel": f"rollout_pair_kernel<{a.integrator.upper()},{lay.upper()}> (thruster model, two waves per SIMD)", "bound": "valu_fp64_issue",
-                     "achieved": issue_tflops, "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": issue_frac,
+        "roofline": {"kernel": f"rollout_pair_kernel<{a.integrator.upper()},{lay.upper()}> (thruster model, two waves per SIMD)",
+                     "bound": binding["bound"], "achieved": binding["achieved"], "peak": binding["peak"], "unit": binding["unit"],
+                     "frac": binding["frac"], "frac_of_measured_ceiling": binding["frac_of_measured_ceiling"],
+                     "measured_ceilings": {"fp64_valu_TFLOPs": MEASURED_FP64_VALU_TFLOPS, "hbm_GBs": MEASURED_HBM_GBS,
+                                           "source": "profiles/r02_ubench_fp64.txt, MI355X_MICROARCH.md"},
                      "kernel_ms": kern_s * 1e3, "kernel_ms_each": kern_ms,
-                     "executed_fp64_instr_per_step": instr,
-                     "note": "achieved = fp64 VALU instructions issued x 64 lanes x 2 flop (every slot priced as an FMA) / kernel time; "
-                             "frac = share of the chip's fp64 issue slots (1024 SIMDs x 2.4 GHz / 4) the kernel fills",
-                     "algorithmic": {"achieved": flop_rate, "frac": flop_rate / PEAK_FP64_VALU_TFLOPS, "flop_per_step": flop_per_step,
+                     "terms": {"valu_fp64_issue": issue_term, "hbm": hbm_term,
+                               "note": "SURVEY 8(d): roofline.achieved = max(issue term, HBM term); both are fractions of datasheet peaks"},
+                     "algorithmic": {"achieved": flop_rate, "flop_per_step": flop_per_step, "unit": "TFLOP/s",
                                      "note": "SURVEY 8(d) figure: the reference's dense 6x6 algebra per step / kernel time -- credit for "
-                                             "algebra, can exceed what the pipe executes"},
-                     "hbm": {"achieved": byte_rate, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS,
-                             "bytes_per_step": bytes_per_step},
-                     "traffic": pmc_traffic("rollout") if (a.integrator == "rk4" and not a.no_store and lay != "btu" and B == 65536 and T == 5000) else None},
+                                             "algebra; NOT a roofline fraction (the kernel executes 1 450 flop per step, not 3 100)"},
+                     "traffic": traffic},
     }
-    # the same kernel against the HBM roofline (second, not binding: intensity 19 flop/B > ridge 9.8), in the plain schema
-    out["roofline_hbm"] = {"kernel": out["roofline"]["kernel"], "bound": "hbm", "achieved": byte_rate, "peak": PEAK_HBM_GBS,
-                           "unit": "GB/s", "frac": byte_rate / PEAK_HBM_GBS, "kernel_ms": kern_s * 1e3,
-                           "bytes_per_step": bytes_per_step, "traffic": out["roofline"]["traffic"]}
 
     # ------------------------------------------------------------------ what did the timed launches write?
     if traj is not None and rank == 0:
@@ -403,6 +438,76 @@ def main():
         out["rollout_ar1"] = {"value": world * B * T * len(k2) / w2, "unit": "steps/s", "kernel_ms": float(np.mean(k2)),
                               "finite": bool(torch.isfinite(xT).all().item()),
                               "note": "same kernel and sizes on the AR(1) command stream u_t = clip(0.98 u_{t-1} + 0.02 xi_t) (dist B)"}
+
+    # ------------------------------------------------------------------ config 2's other runs (SURVEY 8(d) cfg 2: "trajectories stored
+    # in one run and endpoint-only in another"; the reference's comparison script integrates with Euler,
+    # training/train_tank_brov2_full_comparison.py:453-466): same commands, same sizes, each verified
+    if not a.no_variants and a.controls == "iid" and a.integrator == "rk4" and traj is not None:
+        engine.fill_controls_dev(U, lay, "iid", seed=0x5EED, b0=rank * B, T_total=T, ctx=ctx)     # back to dist A
+        xT_stored = {}
+        variants = {}
+        gpath = os.path.join(REPO, "tests", "golden", "fossen_rollouts.npz")
+        for integ, store in (("rk4", True), ("rk4", False), ("euler", True), ("euler", False)):
+            tr = traj if store else None
+
+            def vstep():
+                engine.rollout_dev(_lib.THRUSTER_EULER, integ, x0, U, dt, traj=tr, xT=xT, layout=lay, stride=1, ctx=ctx)
+
+            vstep()
+            if integ == "rk4" and store:               # the headline launch again: only its end states are needed (for the endpoint-only check)
+                torch.cuda.synchronize()
+                xT_stored[integ] = xT.clone()
+                continue
+            barrier()
+            nrep = max(1, min(3, a.steps))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(nrep + 1)]
+            t0 = time.perf_counter()
+            ev[0].record()
+            for i in range(nrep):
+                vstep()
+                ev[i + 1].record()
+            barrier()
+            wv = max_over_ranks(time.perf_counter() - t0)
+            kms = float(np.mean([ev[i].elapsed_time(ev[i + 1]) for i in range(nrep)]))
+            bps = 160.0 if store else 64.0
+            ninstr = ROLLOUT_EXEC_FP64_INSTR[integ]
+            it = -(-B // 64) * T * ninstr * 128 / (kms * 1e-3) / 1e12
+            hb = B * T * bps / (kms * 1e-3) / 1e9
+            leg = {"value": world * B * T * nrep / wv, "unit": "steps/s", "kernel_ms": kms, "bytes_per_step": bps,
+                   "roofline": {"bound": "hbm" if hb / PEAK_HBM_GBS >= it / PEAK_FP64_VALU_TFLOPS else "valu_fp64_issue",
+                                "frac": max(hb / PEAK_HBM_GBS, it / PEAK_FP64_VALU_TFLOPS),
+                                "hbm_GBs": hb, "hbm_frac": hb / PEAK_HBM_GBS, "issue_TFLOPs": it, "issue_frac": it / PEAK_FP64_VALU_TFLOPS,
+                                "peak_hbm_GBs": PEAK_HBM_GBS, "peak_fp64_TFLOPs": PEAK_FP64_VALU_TFLOPS}}
+            if rank == 0:
+                ver = {}
+                if store:
+                    xT_stored[integ] = xT.clone()
+                    if os.path.exists(gpath) and B >= 8:
+                        g = np.load(gpath)
+                        sub, Tg = int(g["cfg2_sub"]), int(g["cfg2_T"])
+                        if T == Tg and float(g["cfg2_dt"]) == dt:
+                            got = lanes_from_traj(traj, lay, list(range(8)), list(range(0, T + 1, sub)))
+                            ver["vs_reference_fixture"] = rel_err(got, g["cfg2_" + integ])
+                    rng = np.random.default_rng(11)
+                    lanes = sorted(set(int(v) for v in rng.integers(0, B, 5)) | {B - 1})
+                    rows = list(range(0, T + 1, max(1, T // 20)))
+                    got = lanes_from_traj(traj, lay, lanes, rows)
+                    Ul = torch.empty((len(lanes), T, nu), dtype=torch.float64, device=dev)
+                    for i, b in enumerate(lanes):
+                        engine.fill_controls_dev(Ul[i:i + 1], "btu", "iid", seed=0x5EED, b0=rank * B + b, T_total=T, ctx=ctx)
+                    tl = torch.empty((len(lanes), T + 1, nx), dtype=torch.float64, device=dev)
+                    engine.rollout_dev(_lib.THRUSTER_EULER, integ, x0[: len(lanes)].contiguous(), Ul, dt, traj=tl, layout="btu", stride=1, ctx=ctx)
+                    ver["random_lanes_vs_single_lane_runs"] = rel_err(got, tl[:, rows].cpu().numpy())
+                    del Ul, tl
+                else:
+                    # the endpoint-only launch against the end states of the stored launch of the same integrator
+                    ver["xT_vs_stored_run"] = rel_err(xT.cpu().numpy(), xT_stored[integ].cpu().numpy())
+                ver["max_rel_err"] = max(ver.values())
+                ver["ok"] = bool(ver["max_rel_err"] <= 1e-9)
+                leg["verified"] = ver
+            variants[f"{integ}_{'stored' if store else 'endpoint_only'}"] = leg
+        out["rollout_variants"] = variants
+        del xT_stored
 
     # ------------------------------------------------------------------ EDMDc leg (config 3)
     del traj, U
@@ -475,24 +580,68 @@ def main():
         solve_s = time.perf_counter() - t1
         eflops = pairs * EDMDC_FLOP_PER_SAMPLE / ekern_s / 1e12
         gram_tasks, gram_slabs = engine.gram_decomposition(n, r, k)
+        xflops = pairs * gram_tasks * 12288.0 / ekern_s / 1e12          # MFMA flop the kernel issues / (lift + Gram) time
+        chunks = -(-(pairs + nb) // (1 << 20))
         out["edmdc"] = {
             "metric": "edmdc_gram_samples_per_s", "value": world * pairs * a.edmdc_steps / ewall, "unit": "samples/s",
             "pairs_per_gpu": pairs, "ms_per_fit_gram": ewall / a.edmdc_steps * 1e3, "host_pinv_solve_s": solve_s,
-            "end_to_end_fit_samples_per_s": world * pairs / (ewall / a.edmdc_steps + solve_s),
+            "gram_plus_host_solve_samples_per_s": world * pairs / (ewall / a.edmdc_steps + solve_s),
             "config": {"workload": f"BASELINE config 3: {pairs} (x,u,x+) pairs/GPU from {nb} Euler rollouts x {L} steps, "
                                    f"n=12 r=8 k=512 gamma={gamma}, lift + G^T[G|Y] on device, centres from GPU Lloyd k-means over all states"},
-            "roofline": {"kernel": "gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": eflops,
-                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": eflops / PEAK_FP64_MFMA_TFLOPS,
-                         "kernel_ms": ekern_s * 1e3, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE,
-                         "executed": {"achieved": pairs * gram_tasks * 12288.0 / ekern_s / 1e12,
-                                      "frac": pairs * gram_tasks * 12288.0 / ekern_s / 1e12 / PEAK_FP64_MFMA_TFLOPS,
-                                      "tasks": gram_tasks, "slabs_per_chunk": gram_slabs, "flop_per_sample": gram_tasks * 12288.0,
-                                      "note": "MFMA flop the kernel issues (tasks x 24 tiles x 16 x 16 x 2 per sample; symmetry and the "
-                                              "packing of the staircase make it less than the algorithmic figure) / (lift + Gram) time"},
-                         "traffic": pmc_traffic("gram", launches=-(-(pairs + nb) // (1 << 20))) if pairs == 10_000_000 else None},
+            "roofline": {"kernel": "lift_rows_kernel + gram_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": xflops,
+                         "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": xflops / PEAK_FP64_MFMA_TFLOPS,
+                         "kernel_ms": ekern_s * 1e3, "flop_per_sample": gram_tasks * 12288.0,
+                         "tasks": gram_tasks, "slabs_per_chunk": gram_slabs,
+                         "note": "achieved = MFMA flop the kernel EXECUTES (tasks x 24 tiles x 16 x 16 x 2 per sample; symmetry and the "
+                                 "packing of the staircase make it less than the algorithmic figure) / (lift + Gram) time: a fraction of "
+                                 "the pipe, <= 1",
+                         "algorithmic": {"achieved": eflops, "flop_per_sample": EDMDC_FLOP_PER_SAMPLE, "unit": "TFLOP/s",
+                                         "note": "SURVEY 8(d) figure 2p^2 + 2pd (the reference's full G.T@G + G.T@Y) / time -- credit for "
+                                                 "symmetry, NOT a roofline fraction (can exceed the peak)"},
+                         "traffic": pmc_traffic({"lift": chunks, "lift_tail": chunks, "gram": chunks}) if pairs == 10_000_000 else None},
             "A_finite": bool(np.isfinite(A_).all() and np.isfinite(B_).all()),
             "kmeans": kmeans_info,
         }
+        # ---- the call the reference's scripts make: KoopmanEDMDc.fit() (Koopman/koopmanEDMDc.py:72-103; caller
+        # training/train_tank_brov2_full_comparison.py:921-930) end to end on the same device-resident data -- centres with
+        # scikit-learn's stopping rule, G^T[G|Y], host pinv, then fit()'s own product order (P G^T) Y as two MFMA passes
+        # (edmdc_pinv_apply_dev: rows of W = G P^T, then W^T Y); and fit_multi() (:113-152: P (G^T Y), no apply pass)
+        if not a.no_fit and world == 1:
+            fit_legs = {}
+            dec = engine.apply_decomposition(n, r, k)
+            W_ = (k + 15) // 16 * 16 + (n + r + 15) // 16 * 16
+            wrows_flop = dec["wrows_items_per_192_rows"] * 24 * 512.0 * W_ / 192.0          # executed MFMA flop per row of W
+            wty_flop = dec["wty_tasks"] * 12288.0                                           # executed MFMA flop per pair of W^T Y
+            for order in ("fit", "fit_multi"):
+                tmf = {}
+                ctx.set_timing(True)
+                A_f, B_f, _ = engine.fit_dev(Xe.view(-1, n), Ue.view(-1, r), nb, L, k, gamma, ridge, order=order, max_iter=a.kmeans_iters,
+                                             ctx=ctx, timings=tmf)
+                apply_kernel_ms = ctx.last_kernel_ms() if order == "fit" else None
+                ctx.set_timing(False)
+                leg = {"fit_samples_per_s": pairs / tmf["total_s"], "wall_s": tmf["total_s"],
+                       "stages_ms": {"centres_kmeanspp_plus_lloyd": tmf["centres_s"] * 1e3, "lift_plus_gram_plus_download": tmf["gram_s"] * 1e3,
+                                     "host_pinv": tmf["pinv_s"] * 1e3,
+                                     ("apply_lift_wrows_wty_plus_download" if order == "fit" else "host_P_times_GtY"): tmf["apply_s"] * 1e3},
+                       "lloyd_iterations": tmf["lloyd_iterations"], "lloyd_max_iter": a.kmeans_iters, "lloyd_converged": tmf["lloyd_converged"],
+                       "kmeanspp_ms_device": tmf.get("kmeanspp_ms"), "lloyd_ms_device": tmf.get("lloyd_ms"),
+                       "finite": bool(np.isfinite(A_f).all() and np.isfinite(B_f).all()),
+                       "samples_per_s_excluding_centres": pairs / (tmf["total_s"] - tmf["centres_s"])}
+                if order == "fit":
+                    aflops = pairs * (wrows_flop + wty_flop) / (apply_kernel_ms * 1e-3) / 1e12
+                    leg["apply_kernel_ms"] = apply_kernel_ms
+                    leg["roofline"] = {"kernel": "lift_rows_kernel + wrows_kernel + gram_kernel<W^T Y> (v_mfma_f64_16x16x4_f64)", "bound": "mfma",
+                                       "achieved": aflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": aflops / PEAK_FP64_MFMA_TFLOPS,
+                                       "kernel_ms": apply_kernel_ms, "flop_per_sample": wrows_flop + wty_flop,
+                                       "wrows_flop_per_sample": wrows_flop, "wty_flop_per_sample": wty_flop, "decomposition": dec,
+                                       "note": "executed MFMA flop of the two passes of (P G^T) Y / time of the whole apply pass (re-lift included)",
+                                       "algorithmic": {"flop_per_sample": 2.0 * p * p + 2.0 * p * d, "unit": "TFLOP/s",
+                                                       "achieved": pairs * (2.0 * p * p + 2.0 * p * d) / (apply_kernel_ms * 1e-3) / 1e12}}
+                    leg["ratio_to_gram_ms"] = (tmf["total_s"] - tmf["centres_s"]) * 1e3 / (ewall / a.edmdc_steps * 1e3)
+                fit_legs[order] = leg
+            fit_legs["config"] = {"workload": f"BASELINE config 3 data ({pairs} pairs in {nb} bags, n=12 r=8 k=512 gamma={gamma} ridge={ridge}), device "
+                                              f"resident; KMeans stopping rule max_iter={a.kmeans_iters} tol=1e-4; wall clock incl. host pinv and downloads"}
+            out["edmdc_fit"] = fit_legs
         # f1: KoopmanEDMDc.multistep_rmse on the recorded-data size of the reference (45 823 samples, H = 100;
         # training/best_results.txt:801 logs 41.19 s for it on the authors' CPU) -- rank 0 only, host arrays in/out
         if rank == 0:

@@ -5,9 +5,10 @@ lift_dim_).
 
 What runs where:
   * RBF centres: the reference calls sklearn KMeans(n_clusters, n_init="auto", random_state=0) (:85,126).
-    Here scikit-learn provides the seeded k-means++ initialisation and the Lloyd E/M loop runs on the GPU
-    (csrc/kmeans.hip) with scikit-learn's stopping rules: same centres to rounding, tested.  `kmeans="sklearn"`
-    calls scikit-learn for the whole thing instead;
+    Here both halves run on the GPU (csrc/kmeans.hip): the k-means++ seeding restates scikit-learn's
+    `_kmeans_plusplus` and consumes numpy's RandomState(0) in scikit-learn's order (engine.kmeanspp_draws,
+    edmdc_kmeanspp_dev: same seed indices), then Lloyd's E/M loop with scikit-learn's stopping rules: same centres
+    to rounding, tested.  `kmeans="sklearn"` calls scikit-learn for the whole thing instead;
   * lift phi(x) = [x, exp(-gamma(|x|^2+|c|^2-2x.c))] and the G^T[G|Y] normal-equation blocks:
     HIP kernels (csrc/edmdc.hip, fp64 MFMA);
   * the p x p ridge solve: NumPy pinv on the host.  fit_multi associates M = pinv(G^T G + ridge I) (G^T Y) (:147) and so
@@ -57,7 +58,7 @@ class KoopmanEDMDc:
     A_: np.ndarray = None
     B_: np.ndarray = None
     lift_dim_: int = None
-    kmeans: str = "hip"                 # "hip" (GPU Lloyd, sklearn k-means++ init) or "sklearn"
+    kmeans: str = "hip"                 # "hip" (k-means++ seeding and Lloyd on the GPU) or "sklearn"
 
     # ------------------------------------------------------------------ fitting
     def fit(self, X, U, centers=None) -> None:

@@ -67,7 +67,10 @@ hipError_t upload_gram_tasks(hipStream_t st, const EdmdcShape& s, int mode, void
 hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, int64_t npairs,
                                    const double* Arows, const double* Zrows, const double* wrow, double* partial, int accumulate);
 // Wrows[rows][width] = Zrows . PdT  (PdT [width][width] = P^T in device feature order)
-hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows);
+// (PdT needs 8 extra rows of allocation: the tuned kernel prefetches two K-steps past the last feature; simple = the round-2 kernel)
+hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows,
+                                int simple = 0);
+void wrows_decomposition(const EdmdcShape& s, int* items_per_unit, int* tiles_wanted_per_unit);
 int edmdc_dev_to_ref_feature(const EdmdcShape& s, int f);
 // Sum partials over slabs (fixed order) and scatter into reference-order GtG [p][p], GtY [p][d].
 hipError_t launch_gram_finish_tasks(hipStream_t st, const EdmdcShape& s, int ntasks, const void* d_tasks, const double* partial,

@@ -42,6 +42,7 @@ struct brov_ctx {
     int btu_staging = 0;
     int single_lane = 0;          // 1: never use the two-wave rollout kernel (A/B measurements: BROV2_ROLLOUT_SINGLE_LANE=1)
     int64_t chunk_rows = (int64_t)1 << 20;
+    int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
     void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
     EdmdcShape task_shape[2] = {};
     int ntasks[2] = {0, 0};
@@ -428,6 +429,7 @@ int brov_create(int device_id, brov_ctx** out) {
     // L2.  That placement is observed behaviour, not a HIP guarantee: probe it once and remember (speed only, never correctness).
     c->xcd_round_robin = probe_xcd_round_robin(nullptr);
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
+    if (const char* e = std::getenv("BROV2_APPLY_SIMPLE")) c->apply_variant = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
@@ -1000,6 +1002,20 @@ int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
     return BROV_OK;
 }
 
+int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows, int* wrows_tiles_wanted, int* wty_tasks, int* wty_slabs) {
+    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    const EdmdcShape s = edmdc_shape(n, r, k);
+    wrows_decomposition(s, wrows_items_per_192_rows, wrows_tiles_wanted);
+    (void)gram_partial_doubles(s, 1, wty_tasks, wty_slabs);
+    return BROV_OK;
+}
+
+int edmdc_set_apply_variant(brov_ctx* c, int variant) {
+    if (!c || variant < 0 || variant > 1) return fail(c, BROV_ERR_ARG, "edmdc_set_apply_variant: variant must be 0 or 1");
+    c->apply_variant = variant;
+    return BROV_OK;
+}
+
 // ---- fit()'s own association: M = (P G^T) Y  (Koopman/koopmanEDMDc.py:97) ------------------------------------------
 int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
                          int64_t xs, int64_t us, const double* d_X, const double* d_U, const double* P_host, double* d_M) {
@@ -1023,14 +1039,14 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
     if (chunk < 4) chunk = 4;
     const int W = s.width;
     Arena a(c);
-    rc = a.reserve(2 * Arena::al((size_t)(chunk + 8) * W * 8) + Arena::al((chunk + 8) * 8) + Arena::al((size_t)W * W * 8));
+    rc = a.reserve(2 * Arena::al((size_t)(chunk + 8) * W * 8) + Arena::al((chunk + 8) * 8) + Arena::al((size_t)(W + 8) * W * 8));
     if (rc) return rc;
     double* dZ = a.take<double>((size_t)(chunk + 8) * W);
     double* dWr = a.take<double>((size_t)(chunk + 8) * W);
     double* dw = a.take<double>(chunk + 8);
-    double* dPt = a.take<double>((size_t)W * W);
+    double* dPt = a.take<double>((size_t)(W + 8) * W);      // 8 rows of padding: wrows_kernel prefetches two K-steps past the last feature
     {   // PdT[f][j] = P[ref(j)][ref(f)]: P^T permuted to the device feature order, zero for padding features
-        std::vector<double> h((size_t)W * W, 0.0);
+        std::vector<double> h((size_t)(W + 8) * W, 0.0);
         const int p = s.p;
         for (int f = 0; f < W; ++f) {
             const int rf = edmdc_dev_to_ref_feature(s, f);
@@ -1051,7 +1067,7 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
         const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
         HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
-        HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, dZ, dPt, dWr));
+        HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, dZ, dPt, dWr, c->apply_variant));
         HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], npairs, dWr, dZ, dw, c->d_partial, first ? 0 : 1));
         first = 0;
     }

@@ -42,15 +42,26 @@ std::once_flag g_once;
 void load_rccl() {
     Rccl& r = g_rccl;
     const char* env = std::getenv("BROV2_RCCL_LIBRARY");
-    const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-    // a copy that is already mapped (PyTorch's) wins
-    for (const char* n : {"librccl.so.1", "librccl.so"}) {
-        r.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        if (r.handle) break;
+    const bool forced = env && env[0];             // an explicit library is the ONLY candidate (no fall-back to the defaults)
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    std::string why;
+    auto open = [&](const char* n, int flags) {
+        r.handle = dlopen(n, flags);
+        if (!r.handle && !(flags & RTLD_NOLOAD)) {
+            const char* e = dlerror();                 // dlerror() clears the message: read it exactly once
+            if (why.empty()) why = e ? e : "?";
+        }
+        return r.handle != nullptr;
+    };
+    if (forced) {
+        open(env, RTLD_NOW | RTLD_LOCAL);
+    } else {
+        // a copy that is already mapped (PyTorch's) wins
+        for (const char* n : {"librccl.so.1", "librccl.so"})
+            if (open(n, RTLD_NOW | RTLD_NOLOAD)) break;
+        for (size_t i = 0; !r.handle && i < sizeof names / sizeof names[0]; ++i) open(names[i], RTLD_NOW | RTLD_LOCAL);
     }
-    for (size_t i = 0; !r.handle && i < sizeof names / sizeof names[0]; ++i)
-        if (names[i] && names[i][0]) r.handle = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-    if (!r.handle) { r.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+    if (!r.handle) { r.err = std::string("librccl not found: ") + (why.empty() ? "?" : why); return; }
     auto sym = [&](const char* s) { void* p = dlsym(r.handle, s); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + s; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));

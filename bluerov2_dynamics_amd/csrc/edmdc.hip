@@ -308,6 +308,7 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
 // slot.  The A operand carries the pair weight.  `want` bit (a * GRAM_TB + b) marks the tile products the finish kernel
 // keeps: every needed product is computed by exactly one task.
 struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; unsigned want; };
+constexpr unsigned GRAM_SWAP = 1u << 31;     // (mode 1) transposed block: A tiles are cut from the lifted rows, B tiles from the rows of W
 
 // mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T).
 // Mode 0 is a staircase: number the columns of [G | Y] 0 .. nt + nty - 1 (G tiles, then Y tiles); by symmetry row-tile i
@@ -321,31 +322,25 @@ struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; unsigned want; };
 // 75 x 24 = 1800 slots; 71 would be perfect packing.  Every wave still runs the same instruction stream (4 + 6 + 1 loads,
 // 24 MFMAs per K-step), which is what keeps the waves of a slab together in the L2.
 static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, int mode) {
-    const int nt = s.width / 16;                     // G tiles
+    const int nt = s.width / 16;                     // G tiles (mode 1: tiles of a row of W = G P^T)
     tasks.clear();
-    if (mode == 1) {                                 // rectangle nt x nty, 4-row bands; Y = rbf tiles + the x part of the next row's tail
-        const int nty = s.kp / 16 + (s.n + 15) / 16;
-        for (int a0 = 0; a0 < nt; a0 += GRAM_TA)
-            for (int c0 = 0; c0 < nty; c0 += GRAM_TB) {
-                GramTask t; t.want = 0;
-                for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (a0 + i < nt) ? a0 + i : -1;
-                for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < nty) ? ((c0 + j) | 0x10000) : -1;
-                for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j) if (t.a[i] >= 0 && t.b[j] >= 0) t.want |= 1u << (i * GRAM_TB + j);
-                tasks.push_back(t);
-            }
-        return;
-    }
     static_assert(GRAM_TB == 6 && GRAM_TA == 4, "a 6-band is cut into TB x TA blocks");
-    const int nty = s.xplus ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16;
-    const int ncol = nt + nty;
-    auto code = [&](int c) { return c < nt ? c : ((c - nt) | 0x10000); };     // column number -> tile code
+    // mode 0: a staircase over the columns [G tiles | Y tiles]; mode 1: the full rectangle (W tiles) x (Y tiles), Y = the rbf
+    // tiles + the x part of the NEXT row's tail tile.  Both are cut by the same DP; only the column count of a band differs.
+    const bool stair = mode == 0;
+    const int nty = (stair && s.xplus) ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16;
+    const int ncol = stair ? nt + nty : nty;
+    auto code = [&](int c) { return stair ? (c < nt ? c : ((c - nt) | 0x10000)) : (c | 0x10000); };     // column number -> tile code
     // Ragged ends.  A band whose column count does not divide by its block width ends in a partly empty block.  The last
     // columns are Y tiles, which every row-tile needs: up to three SHARED SETS of four of them (set g = columns
     // ncol-4(g+1) .. ncol-4g-1) can be left out of a band's own blocks and handed to shared transposed blocks
     // (A = the set's four Y tiles, B = six row-tiles taken across the bands that left the set out).  Band sizes and the sets
     // each band leaves out are chosen together by a DP over (first row of the band, rows so far in each shared set mod 6).
-    // k = 512: bands 4 4 4 4 4 4 4 6, sets left out {-, 01, 1, -, 01, 0, -, -}: 69 own + 2 + 2 shared = 73 tasks (75 without
-    // the shared sets, 78 with the x part of Y as a 33rd Y tile); 1 683 wanted tile products, 71 would be perfect packing.
+    // k = 512, mode 0: bands 4 4 4 4 4 4 4 6, sets left out {-, 01, 1, -, 01, 0, -, -}: 69 own + 2 + 2 shared = 73 tasks (75
+    // without the shared sets, 78 with the x part of Y as a 33rd Y tile); 1 683 wanted tile products, 71 would be perfect.
+    // k = 512, mode 1: 34 x 33 = 1 122 products; plain 4 x 6 blocks need 9 x 6 = 54 tasks (round 2), the DP 49 (bands
+    // 4 4 4 4 4 4 4 6, six of the 4-bands leave set 0 to four shared blocks); 47 would be perfect packing.
+    // Transposed blocks of mode 1 read their A tiles (Y) from the lifted rows and their B tiles from the rows of W: GRAM_SWAP.
     const int G = nty / GRAM_TA < 3 ? nty / GRAM_TA : 3;
     const int NM = 1 << G, NR = 216;                  // masks, (r0, r1, r2) in base 6
     struct Choice { int size = 0, mask = 0, next_r = 0; };
@@ -368,22 +363,23 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
                 for (int m = 0; m < NM; ++m) {
                     int pop = 0, extra = 0, nr[3] = {rr[0], rr[1], rr[2]};
                     for (int g = 0; g < G; ++g) if ((m >> g) & 1) { ++pop; extra += (nr[g] + sz) / 6; nr[g] = (nr[g] + sz) % 6; }
-                    const int cols = ncol - a0 - GRAM_TA * pop;
-                    if (cols < sz) continue;          // the band keeps at least its diagonal block
+                    const int cols = (stair ? ncol - a0 : ncol) - GRAM_TA * pop;
+                    if (cols < (stair ? sz : 0)) continue;          // a staircase band keeps at least its diagonal block
                     const int nxt = nr[0] + 6 * nr[1] + 36 * nr[2];
                     const int c = (cols + width - 1) / width + extra + cost[(size_t)(a0 + sz) * NR + nxt];
                     if (c < cost[(size_t)a0 * NR + r]) { cost[(size_t)a0 * NR + r] = c; pick[(size_t)a0 * NR + r] = Choice{sz == size ? size : sz, m, nxt}; }
                 }
             }
         }
+    const unsigned swap = stair ? 0u : GRAM_SWAP;
     std::vector<int> shared[3];                       // row-tiles whose products with set g go to the shared blocks
     for (int a0 = 0, r = 0; a0 < nt;) {
         const Choice ch = pick[(size_t)a0 * NR + r];
         const bool six = ch.size == 6;
         std::vector<int> cols;                        // the band's own columns
-        for (int c = a0; c < ncol; ++c) {
+        for (int c = stair ? a0 : 0; c < ncol; ++c) {
             const int g = (ncol - 1 - c) / GRAM_TA;   // shared set the column belongs to (if any)
-            if (c >= nt && g < G && ((ch.mask >> g) & 1)) continue;
+            if ((!stair || c >= nt) && g < G && ((ch.mask >> g) & 1)) continue;
             cols.push_back(c);
         }
         for (int g = 0; g < G; ++g) if ((ch.mask >> g) & 1) for (int i = 0; i < ch.size; ++i) shared[g].push_back(a0 + i);
@@ -394,12 +390,13 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
                 for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (c0 + i < cols.size()) ? code(cols[c0 + i]) : -1;       // A = column tiles (weighted)
                 for (int j = 0; j < GRAM_TB; ++j) t.b[j] = a0 + j;                                                  // B = the band's row tiles
                 for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                    if (t.a[i] >= 0 && cols[c0 + i] >= a0 + j) t.want |= 1u << (i * GRAM_TB + j);
+                    if (t.a[i] >= 0 && (!stair || cols[c0 + i] >= a0 + j)) t.want |= 1u << (i * GRAM_TB + j);
+                t.want |= swap;
             } else {
                 for (int i = 0; i < GRAM_TA; ++i) t.a[i] = (i < ch.size) ? a0 + i : -1;
                 for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (c0 + j < cols.size()) ? code(cols[c0 + j]) : -1;
                 for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j)
-                    if (t.a[i] >= 0 && t.b[j] >= 0 && cols[c0 + j] >= a0 + i) t.want |= 1u << (i * GRAM_TB + j);
+                    if (t.a[i] >= 0 && t.b[j] >= 0 && (!stair || cols[c0 + j] >= a0 + i)) t.want |= 1u << (i * GRAM_TB + j);
             }
             tasks.push_back(t);
         }
@@ -412,6 +409,7 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
             for (int i = 0; i < GRAM_TA; ++i) t.a[i] = code(ncol - GRAM_TA * (g + 1) + i);                          // the set's four Y tiles (weighted)
             for (int j = 0; j < GRAM_TB; ++j) t.b[j] = (r0 + j < shared[g].size()) ? shared[g][r0 + j] : -1;
             for (int i = 0; i < GRAM_TA; ++i) for (int j = 0; j < GRAM_TB; ++j) if (t.b[j] >= 0) t.want |= 1u << (i * GRAM_TB + j);
+            t.want |= swap;
             tasks.push_back(t);
         }
 }
@@ -494,8 +492,11 @@ gram_kernel(int W, int ntasks, int nslab, int items_per_xcd, int64_t ksteps_tota
         for (int b = 0; b < GRAM_TB; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
     if (ks0 < ks1) {
-        const double* zp = Z + ks0 * 4 * W;       // wave-uniform base of the current 4 rows
-        const double* za = SEPARATE_A ? ZA + ks0 * 4 * W : zp;      // the Gram proper keeps a single row pointer
+        // wave-uniform bases of the current 4 rows: zp for the B tiles, za for the A tiles (the Gram proper keeps a single row
+        // pointer; a transposed block of W^T Y takes its A tiles -- Y -- from the lifted rows and its B tiles from the rows of W)
+        const bool swapped = SEPARATE_A && (tasks[task].want & GRAM_SWAP) != 0;
+        const double* zp = (swapped ? ZA : Z) + ks0 * 4 * W;
+        const double* za = SEPARATE_A ? (swapped ? Z : ZA) + ks0 * 4 * W : zp;
         const double* wp = wrow + ks0 * 4;
         // Operands are double-buffered by hand: two register sets, loop unrolled by two, the 11 loads of K-step k+1 issued
         // BEFORE the 24 MFMAs of K-step k, so that they have that whole K-step to arrive.  Left to the compiler the loop is
@@ -583,11 +584,14 @@ hipError_t launch_gram_chunk_tasks(hipStream_t st, const EdmdcShape& s, int ntas
 
 // W rows for edmdc_pinv_apply: Wrows[row][j] = sum_f Zrows[row][f] PdT[f][j]  (PdT = P^T in device feature order, [W][W],
 // zero rows / columns for padding features), i.e. row t of W is (P g_t)^T, the t-th column of P G^T
-// (Koopman/koopmanEDMDc.py:97 evaluated left to right).  One wave = 16 rows x RXP_TB column tiles;
-// v_mfma_f64_16x16x4_f64 with A[i][k] = Z[row0+i][f0+k], B[k][j] = PdT[f0+k][j0+j].
+// (Koopman/koopmanEDMDc.py:97 evaluated left to right).
+//
+// rows_times_pt_simple_kernel (round 2, kept as the second implementation the GPU suite compares with): one wave = 16 rows x
+// RXP_TB column tiles; v_mfma_f64_16x16x4_f64 with A[i][k] = Z[row0+i][f0+k], B[k][j] = PdT[f0+k][j0+j]; 18 loads for 17
+// MFMAs per K-step, nothing prefetched, every wave re-reads its half of PdT for 16 rows.
 constexpr int RXP_TB = 17;
-__global__ void __launch_bounds__(64) rows_times_pt_kernel(int W, int64_t rows, const double* __restrict__ Zrows,
-                                                           const double* __restrict__ PdT, double* __restrict__ Wrows) {
+__global__ void __launch_bounds__(64) rows_times_pt_simple_kernel(int W, int64_t rows, const double* __restrict__ Zrows,
+                                                                  const double* __restrict__ PdT, double* __restrict__ Wrows) {
     const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
     const int64_t row0 = (int64_t)blockIdx.x * 16;
     const int j0 = blockIdx.y * (RXP_TB * 16);
@@ -616,12 +620,173 @@ __global__ void __launch_bounds__(64) rows_times_pt_kernel(int W, int64_t rows, 
         }
     }
 }
-hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows) {
+
+// wrows_kernel (round 3): the Gram kernel's treatment for W = Z PdT.  One wave = one item = a 4 x 6 block of 16 x 16 output
+// tiles (96 accumulators = 192 VGPRs), K = the W features in steps of 4, operands double-buffered by hand exactly as in
+// gram_kernel (10 loads for 24 MFMAs per K-step, two register sets, explicit vmcnt waits).  The A and B operands of
+// v_mfma_f64_16x16x4_f64 have the same lane layout (lane & 15 = the non-K index, lane >> 4 = K), so the two sides of a block
+// are interchangeable and the nt column tiles of W are covered without a ragged end:
+//   type A item: A side = 4 row tiles of Z (64 rows),  B side = 6 column tiles of PdT  -> D[row][col]
+//   type B item: A side = the last nt % 6 (<= 4) column tiles of PdT, B side = 6 row tiles of Z (96 rows) -> D[col][row]
+// A unit = 12 row tiles = 192 rows: 3 x (nt / 6) type A items + 2 type B items; k = 512: nt = 34 = 5 x 6 + 4 -> 17 items of 24
+// tile products for the unit's 12 x 34 = 408 products: every MFMA issued is wanted (the round-2 kernel: 17 of 18 loads per 17
+// MFMAs, no reuse of PdT across row tiles).  Both types run the same instruction stream; what differs are two base pointers
+// with their K strides (Z: 4 doubles per K-step, PdT: 4 rows) and ten per-lane offsets, all fixed before the loop.
+// The items of a unit are consecutive on one XCD (blockIdx % 8 = XCD, as for the Gram): the unit's rows are fetched from HBM
+// once and shared through that L2, which also holds PdT (2.4 MB at k = 512).
+// Loads run up to two K-steps past the last feature: Z rows are followed by the next row (the buffers are padded by 8 rows),
+// PdT must be allocated with 8 extra rows.
+constexpr int WR_UNIT_TILES = 12;
+struct WrowsPlan { int nt, nA, remB, items_per_unit; };
+static WrowsPlan wrows_plan(const EdmdcShape& s) {
+    WrowsPlan p;
+    p.nt = s.width / 16;
+    const int rem = p.nt % GRAM_TB;
+    p.nA = p.nt / GRAM_TB + (rem > GRAM_TA ? 1 : 0);            // a remainder of 5 stays a (5/6 full) type A column group
+    p.remB = rem <= GRAM_TA ? rem : 0;
+    p.items_per_unit = (WR_UNIT_TILES / GRAM_TA) * p.nA + (p.remB ? WR_UNIT_TILES / GRAM_TB : 0);
+    return p;
+}
+
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+wrows_kernel(int W, int64_t rows, int nt, int nA, int remB, int items_per_unit, int64_t items_per_xcd, int64_t nitems,
+             const double* __restrict__ Zrows, const double* __restrict__ PdT, double* __restrict__ Wrows) {
+    const int64_t bid = blockIdx.x;
+    const int64_t idx = bid >> 3;
+    const int64_t item = (bid & 7) * items_per_xcd + idx;
+    if (idx >= items_per_xcd || item >= nitems) return;
+    const int64_t unit = item / items_per_unit;
+    const int sub = (int)(item - unit * items_per_unit);
+    const int lane = threadIdx.x, kq = lane >> 4, col = lane & 15;
+    const bool typeB = sub >= (WR_UNIT_TILES / GRAM_TA) * nA;
+    int64_t row0;
+    int j0, ncolt;                                         // first column of W, valid column tiles of this item
+    if (!typeB) {
+        const int rb = sub / nA, cg = sub - rb * nA;
+        row0 = unit * (WR_UNIT_TILES * 16) + rb * (GRAM_TA * 16);
+        j0 = cg * (GRAM_TB * 16);
+        ncolt = nt - cg * GRAM_TB < GRAM_TB ? nt - cg * GRAM_TB : GRAM_TB;
+    } else {
+        const int rb = sub - (WR_UNIT_TILES / GRAM_TA) * nA;
+        row0 = unit * (WR_UNIT_TILES * 16) + rb * (GRAM_TB * 16);
+        j0 = (nt - remB) * 16;
+        ncolt = remB;
+    }
+    if (row0 >= rows) return;
+    // per-lane BYTE offsets from the two wave-uniform bases (Z: first row of the item; PdT: first column of the item)
+    auto zoff = [&](int t) {
+        int64_t rr = row0 + 16 * t + col;
+        if (rr >= rows) rr = rows - 1;                     // clamp: never stored
+        return 8u * (unsigned)((rr - row0) * W + kq);
+    };
+    auto poff = [&](int t) { return 8u * (unsigned)(kq * W + 16 * (t < ncolt ? t : 0) + col); };
+    unsigned aoff[GRAM_TA], boff[GRAM_TB];
+#pragma unroll
+    for (int a = 0; a < GRAM_TA; ++a) aoff[a] = typeB ? poff(a) : zoff(a);
+#pragma unroll
+    for (int b = 0; b < GRAM_TB; ++b) boff[b] = typeB ? zoff(b) : poff(b);
+    const double* zb = Zrows + row0 * W;
+    const double* pbase = PdT + j0;
+    const double* pa = typeB ? pbase : zb;                 // A-side base and its stride per K-step (doubles)
+    const double* pb = typeB ? zb : pbase;
+    const int64_t sa = typeB ? 4 * (int64_t)W : 4, sb = typeB ? 4 : 4 * (int64_t)W;
+    v4d acc[GRAM_TA][GRAM_TB];
+#pragma unroll
+    for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+        for (int b = 0; b < GRAM_TB; ++b) acc[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+    {
+        static_assert(GRAM_TA + GRAM_TB == 10, "the vmcnt immediates below count 10 loads per register set");
+        double a0[GRAM_TA], b0[GRAM_TB], a1[GRAM_TA], b1[GRAM_TB];
+        auto gload = [](const double* base, unsigned byte_off) {
+            double v;
+            asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(v) : "v"(byte_off), "s"(base) : "memory");
+            return v;
+        };
+        auto load = [&](double* an, double* bn) {
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a) an[a] = gload(pa, aoff[a]);
+#pragma unroll
+            for (int b = 0; b < GRAM_TB; ++b) bn[b] = gload(pb, boff[b]);
+        };
+        auto advance = [&]() { pa += sa; pb += sb; };
+        auto mfma = [&](const double* an, const double* bn) {
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+                for (int b = 0; b < GRAM_TB; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(an[a], bn[b], acc[a][b], 0, 0, 0);
+        };
+        const int ksteps = W / 4;                          // W is a multiple of 16: an even number of K-steps
+        load(a0, b0);
+        for (int ks = 0; ks < ksteps; ks += 2) {
+            advance();
+            load(a1, b1);                                  // K-step ks + 1
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // set 0 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(a0, b0);
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            load(a0, b0);                                  // K-step ks + 2 (past the last feature on the last trip: padded, never consumed)
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");      // set 1 has landed
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(a1, b1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // drain: nothing may land in a register the epilogue reuses
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: A-side index = (lane >> 4) + 4 reg, B-side index = lane & 15
+    if (!typeB) {
+#pragma unroll
+        for (int a = 0; a < GRAM_TA; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = row0 + 16 * a + kq + 4 * r;
+                if (row >= rows) continue;
+                double* o = Wrows + row * W + j0 + col;
+#pragma unroll
+                for (int b = 0; b < GRAM_TB; ++b) if (b < ncolt) o[16 * b] = acc[a][b][r];
+            }
+    } else {
+#pragma unroll
+        for (int b = 0; b < GRAM_TB; ++b) {
+            const int64_t row = row0 + 16 * b + col;
+            if (row >= rows) continue;
+            double* o = Wrows + row * W + j0 + kq;
+#pragma unroll
+            for (int a = 0; a < GRAM_TA; ++a) {
+                if (a >= ncolt) continue;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[16 * a + 4 * r] = acc[a][b][r];
+            }
+        }
+    }
+}
+
+hipError_t launch_rows_times_pt(hipStream_t st, const EdmdcShape& s, int64_t rows, const double* Zrows, const double* PdT, double* Wrows,
+                                int simple) {
     if (rows <= 0) return hipSuccess;
     const int ntile = s.width / 16;
-    hipLaunchKernelGGL(rows_times_pt_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)((ntile + RXP_TB - 1) / RXP_TB)), dim3(64), 0, st,
-                       s.width, rows, Zrows, PdT, Wrows);
+    if (simple) {
+        hipLaunchKernelGGL(rows_times_pt_simple_kernel, dim3((unsigned)((rows + 15) / 16), (unsigned)((ntile + RXP_TB - 1) / RXP_TB)), dim3(64), 0, st,
+                           s.width, rows, Zrows, PdT, Wrows);
+        return hipGetLastError();
+    }
+    const WrowsPlan p = wrows_plan(s);
+    const int64_t units = (rows + WR_UNIT_TILES * 16 - 1) / (WR_UNIT_TILES * 16);
+    const int64_t nitems = units * p.items_per_unit;
+    const int64_t units_per_xcd = (units + 7) / 8;
+    const int64_t items_per_xcd = units_per_xcd * p.items_per_unit;
+    hipLaunchKernelGGL(wrows_kernel, dim3((unsigned)(8 * items_per_xcd)), dim3(64), 0, st, s.width, rows, p.nt, p.nA, p.remB, p.items_per_unit,
+                       items_per_xcd, nitems, Zrows, PdT, Wrows);
     return hipGetLastError();
+}
+// MFMA work of the W rows per row of Z: executed tile products (of 16 x 16 x 16 x 2 / 16 = 512 flop per row) and wanted ones
+void wrows_decomposition(const EdmdcShape& s, int* items_per_unit, int* tiles_wanted_per_unit) {
+    const WrowsPlan p = wrows_plan(s);
+    if (items_per_unit) *items_per_unit = p.items_per_unit;
+    if (tiles_wanted_per_unit) *tiles_wanted_per_unit = WR_UNIT_TILES * p.nt;
 }
 
 // device feature f (column of Zrows) -> reference feature index of G = [x | rbf | u] (or -1 for padding)

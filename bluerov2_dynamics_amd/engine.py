@@ -14,7 +14,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
@@ -221,6 +221,16 @@ def gram_decomposition(n, r, k):
     return nt.value, ns.value
 
 
+def apply_decomposition(n, r, k):
+    """Work decomposition of edmdc_pinv_apply for a shape: dict(wrows_items_per_192_rows, wrows_tiles_wanted, wty_tasks,
+    wty_slabs) -- see include/brov2.h (edmdc_apply_decomposition)."""
+    v = [ctypes.c_int(0) for _ in range(4)]
+    rc = _lib.load_library().edmdc_apply_decomposition(int(n), int(r), int(k), *[ctypes.byref(x) for x in v])
+    if rc:
+        raise ValueError(f"edmdc_apply_decomposition: unsupported shape n={n} r={r} k={k}")
+    return dict(zip(("wrows_items_per_192_rows", "wrows_tiles_wanted", "wty_tasks", "wty_slabs"), (x.value for x in v)))
+
+
 def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, accumulate=False, ctx=None):
     """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h)."""
     ctx = ctx or default_context(X.device.index)
@@ -370,6 +380,66 @@ def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
                                            _hptr(P), _hptr(Mi)), "edmdc_pinv_apply")
         M += Mi
     return M
+
+
+def pinv_apply_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, P, M, ctx=None):
+    """Device form of pinv_apply on torch tensors (bag layout as gram_dev): P [p,p] host array (the host's pinv), M [p,d]
+    CUDA tensor, overwritten with (P G^T) Y."""
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
+    P = as_f64(P)
+    assert P.shape == (n + k + r, n + k + r) and tuple(M.shape) == (n + k + r, n + k)
+    ctx.check(ctx.lib.edmdc_pinv_apply_dev(ctx.h, n, r, k, float(gamma), _dptr(C), int(nbags), int(L), int(x_bag_stride), int(u_bag_stride),
+                                           _dptr(X), _dptr(U), _hptr(P), _dptr(M)), "edmdc_pinv_apply_dev")
+
+
+def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
+            timings=None):
+    """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
+    states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
+    seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
+    two products of `(P G^T) Y` on the device (order="fit_multi": `P (G^T Y)` on the host).  Returns (A [d,d], B [d,r],
+    centres CUDA [k,n]); timings (dict) receives the stage wall times in seconds, the Lloyd iteration count and whether
+    the stopping rule fired before max_iter."""
+    import time
+    import torch
+    ctx = ctx or default_context(X.device.index)
+    n, r = X.shape[-1], U.shape[-1]
+    d, p = n + k, n + k + r
+    tm = {} if timings is None else timings
+
+    def tick():
+        torch.cuda.synchronize(X.device)
+        return time.perf_counter()
+
+    t0 = tick()
+    if centers is None:
+        C, _, n_iter = kmeans_centers_dev(X.view(-1, n), k, random_state=random_state, max_iter=max_iter, tol=tol, ctx=ctx, timings=tm)
+        tm["lloyd_iterations"], tm["lloyd_converged"] = n_iter, bool(n_iter < max_iter)
+    else:
+        C = centers
+    t1 = tick()
+    GG = torch.empty((p * p + p * d,), dtype=torch.float64, device=X.device)
+    GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+    gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
+    Gh = GtG.cpu().numpy()
+    t2 = tick()
+    with _blas_threads():
+        P = np.linalg.pinv(Gh + ridge * np.eye(p))
+    t3 = time.perf_counter()
+    if order == "fit":
+        M = torch.empty((p, d), dtype=torch.float64, device=X.device)
+        pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
+        Mt = M.cpu().numpy().T
+    elif order == "fit_multi":
+        with _blas_threads():
+            Mt = (P @ GtY.cpu().numpy()).T
+    else:
+        raise ValueError("order must be 'fit' or 'fit_multi'")
+    t4 = tick()
+    tm.update(centres_s=t1 - t0, gram_s=t2 - t1, pinv_s=t3 - t2, apply_s=t4 - t3, total_s=t4 - t0)
+    return np.ascontiguousarray(Mt[:, :d]), np.ascontiguousarray(Mt[:, d:]), C
 
 
 def usable_cores():

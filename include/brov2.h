@@ -255,12 +255,21 @@ BROV_API int edmdc_pinv_apply_dev(brov_ctx* ctx, int n, int r, int k, double gam
  * equations G^T[G|Y] (Koopman/koopmanEDMDc.py:129-147) are computed as ntasks blocks of 4 x 6 tiles of 16 x 16 per slab of
  * rows, nslabs slabs per chunk; a task executes 24 x 16 x 16 x 2 = 12 288 flop per sample whether a tile is wanted or not. */
 BROV_API int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs);
+/* The same for edmdc_pinv_apply(_dev), fit()'s own product order (Koopman/koopmanEDMDc.py:97): the rows of W = G P^T are
+ * formed per unit of 192 rows by `wrows_items_per_192_rows` blocks of 4 x 6 tiles (`wrows_tiles_wanted` of their tile products
+ * are wanted; a tile product is 16 x 16 x 16 x 2 flop per 16 rows = 512 flop per row), and W^T Y is accumulated by `wty_tasks`
+ * blocks of 4 x 6 tiles per slab of rows, `wty_slabs` slabs per chunk (12 288 flop per sample and task). */
+BROV_API int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows, int* wrows_tiles_wanted, int* wty_tasks, int* wty_slabs);
+/* Which kernel forms the rows of W in edmdc_pinv_apply(_dev): 0 = the tuned one (default), 1 = the plain one-row-tile-per-wave
+ * form (kept as an independent second implementation for the parity tests; BROV2_APPLY_SIMPLE=1 selects it at brov_create). */
+BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over
  * ranks of the local [GtG | GtY] blocks (4.5 MB at k = 512), after which every rank solves the same p x p system.
- * librccl is bound with dlopen at first use (BROV2_RCCL_LIBRARY overrides the search; a copy already mapped by the process,
- * e.g. PyTorch's, is reused).  Rank 0 calls brov_comm_unique_id and hands the 128 bytes to the other ranks out of band
+ * librccl is bound with dlopen at first use (a copy already mapped by the process, e.g. PyTorch's, is reused; with
+ * BROV2_RCCL_LIBRARY set that path is the ONLY candidate -- when it cannot be opened brov_comm_available() is 0 and the
+ * brov_comm_* calls return BROV_ERR_COMM, the rest of the library keeps working).  Rank 0 calls brov_comm_unique_id and hands the 128 bytes to the other ranks out of band
  * (file, socket, MPI, torch.distributed store ...); every rank then calls brov_comm_init_rank (collective, blocks until
  * all nranks have joined).  A communicator is bound to one device and is independent of any brov_ctx. */
 #define BROV_COMM_ID_BYTES 128

@@ -150,6 +150,26 @@ def test_arch_gate_and_comm_entry_points(lib):
     assert lib.brov_comm_nranks(None) == -1 and lib.edmdc_gram_allreduce_dev(None, None, 0, None, 0, None) == -1
 
 
+def test_missing_rccl_is_reported_not_a_crash(lib):
+    """A host without librccl: brov_comm_available() == 0 and the brov_comm_* entry points return BROV_ERR_COMM -- the
+    process must survive (round-2 advice: the not-found message called dlerror() twice and built a std::string from the
+    NULL the second call returns).  Fresh process, raw ctypes, BROV2_RCCL_LIBRARY (the only candidate when set) bogus."""
+    from bluerov2_dynamics_amd import _build
+    code = (
+        "import ctypes, sys\n"
+        f"lib = ctypes.CDLL({_build.LIB!r})\n"
+        "assert lib.brov_comm_available() == 0\n"
+        "ident = (ctypes.c_ubyte * 128)()\n"
+        "assert lib.brov_comm_unique_id(ident) == -5, lib.brov_comm_unique_id(ident)\n"
+        "h = ctypes.c_void_p()\n"
+        "assert lib.brov_comm_init_rank(0, ident, 1, 0, ctypes.byref(h)) == -5\n"
+        "assert lib.brov_abi_version() == 1\n"
+        "print('survived')\n")
+    env = dict(os.environ, BROV2_RCCL_LIBRARY="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "survived" in r.stdout, (r.returncode, r.stdout, r.stderr)
+
+
 def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
     """edmdc_gram_decomposition (no device work): the benchmark shape packs its 1 683 wanted tile products into 73 tasks (the x
     part of Y rides in the tail tile's padding); a shape whose padding is too narrow keeps the 33rd Y tile (76 tasks); tasks x

@@ -15,7 +15,9 @@ import sys
 root = sys.argv[1]
 NAMES = {"rollout_pair_kernel<1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
           "gram_kernel": "gram", "lift_rows_kernel": "lift", "kmeans_assign_kernel": "kmeans_assign",
-         "propagate_kernel": "propagate", "pp_round_kernel": "kmeanspp_round", "pp_decide_kernel": "kmeanspp_decide", "lift_tail_kernel": "lift_tail"}
+         "propagate_kernel": "propagate", "pp_round_kernel": "kmeanspp_round", "pp_decide_kernel": "kmeanspp_decide", "lift_tail_kernel": "lift_tail",
+         "gram_kernel<false>": "gram", "gram_kernel<true>": "wty_gram", "wrows_kernel": "wrows", "rows_times_pt_simple_kernel": "wrows_simple"}
+NAMES.pop("gram_kernel")
 pats = sys.argv[2:] or list(NAMES)
 out = {p: {} for p in pats}
 for f in glob.glob(root + "/*/**/*counter_collection.csv", recursive=True):
@@ -44,4 +46,11 @@ out = {NAMES.get(p, p): d for p, d in out.items()}
 out["_method"] = ("rocprofv3 --pmc <group> --kernel-trace, one pass per counter group (tools/profile_round.sh), python3 bench.py --steps 1 "
                   "--warmup 1 --edmdc-steps 1 --no-cpu; per-kernel means over the dispatches of each pass; FETCH_SIZE doubled per "
                   "MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); sizes in KiB; SQ_*_CYCLES in units of 4 clocks")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+try:
+    from bench import kernel_source_sha
+    out["_kernel_source_sha"] = kernel_source_sha()       # bench.py prints it next to the traffic figure: stale summaries show
+except Exception as e:                                    # noqa: BLE001
+    out["_kernel_source_sha"] = None
 json.dump(out, sys.stdout, indent=1)
