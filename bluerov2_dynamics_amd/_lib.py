@@ -285,6 +285,7 @@ class Context:
 
     def set_timing(self, on: bool):
         self.check(self.lib.brov_set_timing(self.h, int(bool(on))), "brov_set_timing")
+        self.timing = bool(on)
 
     def last_kernel_ms(self) -> float:
         ms = ctypes.c_float(0.0)

@@ -338,7 +338,7 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
         Xi = X[idx].contiguous()
     if init == "hip":
         C, _ = kmeanspp_dev(Xi, k, mean=mean_h, random_state=random_state, ctx=ctx)
-        if timings is not None:
+        if timings is not None and getattr(ctx, "timing", False):
             timings["kmeanspp_ms"] = ctx.last_kernel_ms()
     elif init == "sklearn":
         from sklearn.cluster import kmeans_plusplus
@@ -352,7 +352,7 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
     torch.cuda.current_stream(X.device).synchronize()
     ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _dptr(X), X.stride(0), _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
                                              labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
-    if timings is not None:
+    if timings is not None and getattr(ctx, "timing", False):
         timings["lloyd_ms"] = ctx.last_kernel_ms()
     return C + mean, inertia.value, n_iter.value
 
