@@ -62,6 +62,65 @@ __global__ void __launch_bounds__(256) fill_ar1_kernel(int64_t B, int64_t T, int
     }
 }
 
+// The caller layout [B][T][nu] at size (config 4: 33.5 GB): with one thread per (trajectory, channel) and lanes over
+// trajectories every 8-byte store of a wave hits its own cache line (0.3 TB/s, 112 ms for the block config 4's 28 ms rollout
+// reads).  Here a lane still owns one (trajectory, channel) recurrence, but a wave = 64 / nu trajectories x nu channels, values
+// are parked in LDS for FILL_TS steps and written out as 16-byte pieces along each trajectory's contiguous FILL_TS x nu x 8 bytes.
+constexpr int FILL_TS = 16;
+template <int NU>
+__global__ void __launch_bounds__(256) fill_ar1_btu_kernel(int64_t B, int64_t T, uint64_t seed, int64_t b0, int64_t T_total, Scale8 sc,
+                                                           double* __restrict__ U) {
+    constexpr int TPW = 64 / NU;                       // trajectories per wave (8 or 10; lanes beyond TPW * NU idle)
+    constexpr int SROW = 64 + 8;                       // doubles per parked step (64 lanes + padding: conflict-free 16-byte reads)
+    __shared__ __attribute__((aligned(16))) double park[4][FILL_TS * SROW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int bl = lane / NU, j = lane - bl * NU;
+    const int64_t bw = ((int64_t)blockIdx.x * 4 + wave) * TPW;       // first trajectory of this wave
+    const int64_t b = bw + bl;
+    const bool live = bl < TPW && b < B;
+    const uint64_t s2 = seed ^ 0xA5A5A5A5A5A5A5A5ull;
+    double* pk = park[wave];
+    double prev = 0.0;
+    for (int64_t t0 = 0; t0 < T; t0 += FILL_TS) {
+        const int ns = (int)(T - t0 < FILL_TS ? T - t0 : FILL_TS);
+        for (int s = 0; s < ns; ++s) {
+            const uint64_t c = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)(t0 + s)) * (uint64_t)NU + (uint64_t)j;
+            const double u1 = uniform01_at(s2, 2ull * c), u2 = uniform01_at(s2, 2ull * c + 1ull);
+            const double xi = sqrt(-2.0 * log1p(-u1)) * cos(6.283185307179586476925286766559 * u2);
+            prev = fmin(fmax(fma(0.98, prev, 0.02 * xi), -1.0), 1.0);
+            pk[s * SROW + lane] = prev * sc.s[j];
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // write-out: trajectory q of the wave owns ns * NU contiguous doubles; 16-byte pieces, lanes along the trajectory
+        const int pieces = ns * NU / 2;                // per trajectory (NU even)
+        for (int q = 0; q < TPW; ++q) {
+            if (bw + q >= B) break;
+            double* dst = U + ((bw + q) * T + t0) * NU;
+            for (int c = lane; c < pieces; c += 64) {
+                const int e = 2 * c, s = e / NU, jj = e - s * NU;
+                const double2 v = *reinterpret_cast<const double2*>(pk + s * SROW + q * NU + jj);
+                *reinterpret_cast<double2*>(dst + e) = v;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    (void)live;
+}
+
+// dist A in the caller layout: one thread per (trajectory, step) row with lanes along the flattened [B*T] rows, so that a
+// wave writes 64 x nu x 8 contiguous bytes
+__global__ void __launch_bounds__(256) fill_iid_btu_kernel(int64_t B, int64_t T, int nu, uint64_t seed, int64_t b0, int64_t T_total,
+                                                           Scale8 sc, double* __restrict__ U) {
+    const int64_t rows = B * T;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = r / T, t = r - b * T;
+        const uint64_t c0 = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)t) * (uint64_t)nu;
+        for (int j = 0; j < nu; ++j) U[r * nu + j] = (2.0 * uniform01_at(seed, c0 + j) - 1.0) * sc.s[j];
+    }
+}
+
 hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B, int64_t T, int nu, uint64_t seed,
                                 int64_t b0, int64_t T_total, const double* scale8, double* U) {
     if (B <= 0 || T <= 0) return hipSuccess;
@@ -70,14 +129,19 @@ hipError_t launch_fill_controls(hipStream_t st, int layout, int dist, int64_t B,
     const unsigned gx = (unsigned)((B + 255) / 256);
     if (dist == 0) {
         const unsigned gy = (unsigned)(T < 4096 ? T : 4096);
-        if (layout == LAYOUT_BTU)
-            hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_BTU>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
-        else if (layout == LAYOUT_TUB)
+        if (layout == LAYOUT_BTU) {
+            const int64_t nb = (B * T + 255) / 256;
+            hipLaunchKernelGGL(fill_iid_btu_kernel, dim3((unsigned)(nb < (1 << 20) ? nb : (1 << 20))), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
+        } else if (layout == LAYOUT_TUB)
             hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_TUB>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
         else
             hipLaunchKernelGGL(fill_iid_kernel<LAYOUT_TPB>, dim3(gx, gy), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
     } else {
-        if (layout == LAYOUT_BTU)
+        if (layout == LAYOUT_BTU && nu == 8)
+            hipLaunchKernelGGL(fill_ar1_btu_kernel<8>, dim3((unsigned)((B + 31) / 32)), dim3(256), 0, st, B, T, seed, b0, T_total, sc, U);
+        else if (layout == LAYOUT_BTU && nu == 6)
+            hipLaunchKernelGGL(fill_ar1_btu_kernel<6>, dim3((unsigned)((B + 39) / 40)), dim3(256), 0, st, B, T, seed, b0, T_total, sc, U);
+        else if (layout == LAYOUT_BTU)
             hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_BTU>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);
         else if (layout == LAYOUT_TUB)
             hipLaunchKernelGGL(fill_ar1_kernel<LAYOUT_TUB>, dim3(gx, (unsigned)nu), dim3(256), 0, st, B, T, nu, seed, b0, T_total, sc, U);

@@ -312,7 +312,10 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
                                                            const double* __restrict__ X0, const double* __restrict__ U,
                                                            double* __restrict__ lag_io, double* __restrict__ traj,
                                                            int64_t stride, double* __restrict__ XT) {
-    static_assert(LAYOUT != LAYOUT_BTU, "time-major layouts only");
+    // LAYOUT_BTU (the callers' layout, round 3): lane-per-row accesses -- the thrust wave reads its trajectory's 64-byte control
+    // row with four 16-byte loads, the body wave writes its 96-byte state row with six 16-byte stores.  A wave-instruction then
+    // touches 64 cache lines instead of 8, which costs address-pipeline cycles but no issue slots: the instruction counts are
+    // those of the time-major layouts, and the thrust wave's loads fall into its slack.
     constexpr int MODEL = MODEL_THRUSTER_EULER;
     constexpr int NX = 12, NU = 8, NXP = 6, NUP = 4;
     constexpr int NS = (INTEG == INTEG_RK4) ? 4 : 1;          // dynamics() calls per step
@@ -337,20 +340,24 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
         if constexpr (!GENERIC) lz.to_observer(p);
         const double* up;
         int64_t ustep;
-        if constexpr (LAYOUT == LAYOUT_TUB) { up = U + b; ustep = (int64_t)NU * B; }
+        if constexpr (LAYOUT == LAYOUT_BTU) { up = U + b * T * NU; ustep = NU; }
+        else if constexpr (LAYOUT == LAYOUT_TUB) { up = U + b; ustep = (int64_t)NU * B; }
         else { up = U + 2 * b; ustep = (int64_t)NUP * 2 * B; }
         double un[NU];
         int64_t tl = 0;                                       // step whose controls sit in `un`
-        if (T > 0) {
-            if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un); else load_pairs<NU>(up, 2 * B, un);
-        }
+        auto load_controls = [&]() {
+            if constexpr (LAYOUT == LAYOUT_BTU) load_row<NU>(up, un);
+            else if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un);
+            else load_pairs<NU>(up, 2 * B, un);
+        };
+        if (T > 0) load_controls();
         auto produce = [&](int slot) {
             double u[NU], fcmd[8], acmd[6], a[6];
 #pragma unroll
             for (int i = 0; i < NU; ++i) u[i] = un[i];
             up += (tl + 1 < T) ? ustep : 0;                   // prefetch the next row (the last step re-reads its own, unused)
             ++tl;
-            if constexpr (LAYOUT == LAYOUT_TUB) load_soa<NU>(up, B, un); else load_pairs<NU>(up, 2 * B, un);
+            load_controls();
             const CFP pp = relaunder(p);
             command_accel<MODEL, !GENERIC>(pp, u, fcmd, acmd);
 #pragma unroll
@@ -373,12 +380,15 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
         double* tp = nullptr;
         int64_t tstep = 0;
         if (traj) {
-            if constexpr (LAYOUT == LAYOUT_TUB) { tp = traj + b; tstep = (int64_t)NX * B; }
+            if constexpr (LAYOUT == LAYOUT_BTU) { tp = traj + b * (T / stride + 1) * NX; tstep = NX; }
+            else if constexpr (LAYOUT == LAYOUT_TUB) { tp = traj + b; tstep = (int64_t)NX * B; }
             else { tp = traj + 2 * b; tstep = (int64_t)NXP * 2 * B; }
         }
         auto store_state = [&]() {
             if (live) {
-                if constexpr (LAYOUT == LAYOUT_TUB) store_soa<NX>(tp, B, x); else store_pairs<NX>(tp, 2 * B, x);
+                if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x);
+                else if constexpr (LAYOUT == LAYOUT_TUB) store_soa<NX>(tp, B, x);
+                else store_pairs<NX>(tp, 2 * B, x);
             }
             tp += tstep;
         };
@@ -703,8 +713,11 @@ hipError_t launch_thruster_forces(hipStream_t st, const DevParams& p, int64_t B,
 template <int MODEL, int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
 static hipError_t launch_rollout_g(hipStream_t st, const FastParams* p, int64_t B, int64_t T, double dt, const double* x0,
                                    const double* U, double* lag, double* traj, int64_t stride, double* xT, bool want_lds, bool want_pair) {
-    if constexpr (MODEL == MODEL_THRUSTER_EULER && LAYOUT != LAYOUT_BTU) {
-        if (want_pair) {
+    if constexpr (MODEL == MODEL_THRUSTER_EULER) {
+        // the caller layout BTU takes the two-wave kernel where the one-lane kernel would use lane-per-row accesses anyway
+        // (RK4: instruction-bound); the memory-bound Euler case keeps its LDS-staged kernel
+        const bool staged_btu = LAYOUT == LAYOUT_BTU && (!traj || stride == 1) && T > 0 && want_lds;
+        if (want_pair && !staged_btu) {
             hipLaunchKernelGGL((rollout_pair_kernel<INTEG, LAYOUT, LAGMODE, TRACK, GENERIC>), dim3(nblk(B, 256)), dim3(512), 0, st,
                                p, B, T, dt, x0, U, lag, traj, stride, xT);
             return hipGetLastError();

@@ -409,9 +409,13 @@ def test_btu_lds_staged_and_direct_paths_agree(eng, fc):
                     r2 = eng.rollout(model, integ, X0, U, dt, lag=lag0, ctx=ctx, store=False)   # endpoint only
                     assert np.array_equal(r2["xT"], r["xT"])
                     res.append(r)
-                assert np.array_equal(res[0]["traj"], res[1]["traj"])
-                if model == 0:
-                    assert np.array_equal(res[0]["lag"], res[1]["lag"]) and rel_err(res[0]["lag"], o["lag"]) < 1e-11
+                if model != 0:
+                    assert np.array_equal(res[0]["traj"], res[1]["traj"])
+                else:
+                    # thruster model: mode 1 is the one-lane LDS-staged kernel, mode 2 the two-wave kernel with lane-per-row
+                    # accesses (round 3) -- the same step functions, separately compiled: equal to rounding, not bit for bit
+                    assert rel_err(res[0]["traj"], res[1]["traj"]) < 1e-13
+                    assert rel_err(res[0]["lag"], res[1]["lag"]) < 1e-13 and rel_err(res[0]["lag"], o["lag"]) < 1e-11
 
 
 def test_fill_controls_layouts_and_ar1(eng):
@@ -434,6 +438,16 @@ def test_fill_controls_layouts_and_ar1(eng):
     eng.fill_controls_dev(a, "btu", "ar1", seed=9, b0=0, T_total=T, scale=[2.0] * 8)
     torch.cuda.synchronize()
     assert rel_err(a.cpu().numpy(), 2.0 * controls.controls_ar1(9, 0, B, T)) < 1e-12
+    # the AR(1) stream in the caller layout goes through its own LDS-transposed kernel (round 3): bit-identical with the
+    # time-major fill for both channel counts, ragged last wave (B not a multiple of 32 / 40), T not a multiple of 16
+    for nu in (8, 6):
+        a = torch.empty((B, T, nu), dtype=torch.float64, device="cuda")
+        b = torch.empty((T, nu, B), dtype=torch.float64, device="cuda")
+        eng.fill_controls_dev(a, "btu", "ar1", seed=11, b0=77, T_total=T)
+        eng.fill_controls_dev(b, "tub", "ar1", seed=11, b0=77, T_total=T)
+        torch.cuda.synchronize()
+        assert torch.equal(a, b.permute(2, 0, 1)), nu
+        assert rel_err(a.cpu().numpy(), controls.controls_ar1(11, 77, B, T, nu=nu)) < 1e-12
 
 
 # ------------------------------------------------------------------------------------------ windows
@@ -1242,7 +1256,7 @@ def test_timed_config2_launch_is_the_references_trajectories(eng, fc):
 
 
 def test_two_wave_rollout_kernel_edge_cases(eng, fc):
-    """rollout_pair_kernel (thruster model, time-major layouts) at the edges: zero and one step, one trajectory, batches that
+    """rollout_pair_kernel (thruster model; time-major layouts and, round 3, the caller layout BTU) at the edges: zero and one step, one trajectory, batches that
     are not a multiple of the 256 trajectories of a workgroup, strided trajectory storage, both integrators, both lag modes,
     both time-major layouts, lag state in and out -- against the C oracle; and against the one-lane kernel
     (BROV2_ROLLOUT_SINGLE_LANE, read at context creation) on the same data."""
@@ -1263,9 +1277,9 @@ def test_two_wave_rollout_kernel_edge_cases(eng, fc):
         for integ, oi in (("euler", fc.INTEG_EULER), ("rk4", fc.INTEG_RK4)):
             for lag_mode in ((0, 1) if integ == "rk4" else (0,)):
                 o = fc.rollout(0, oi, X0, U, dt, lag=lag0, lag_mode=lag_mode, sub=stride, nthreads=4)
-                for lay, Ul in (("tub", Ut), ("tpb", Up)):
+                for lay, Ul in (("tub", Ut), ("tpb", Up), ("btu", U)):
                     r = eng.rollout(0, integ, X0, Ul, dt, lag=lag0, lag_mode=lag_mode, layout=lay, stride=stride, ctx=ctx2)
-                    tr = r["traj"].transpose(2, 0, 1) if lay == "tub" else r["traj"].transpose(2, 0, 1, 3).reshape(B, -1, 12)
+                    tr = r["traj"] if lay == "btu" else r["traj"].transpose(2, 0, 1) if lay == "tub" else r["traj"].transpose(2, 0, 1, 3).reshape(B, -1, 12)
                     assert tr.shape == o["traj"].shape, (B, T, stride, lay)
                     assert rel_err(tr, o["traj"]) < 1e-11 and rel_err(r["xT"], o["xT"]) < 1e-11, (B, T, integ, lag_mode, lay)
                     assert rel_err(r["lag"], o["lag"]) < 1e-11
