@@ -73,23 +73,52 @@ def _device_gram(X, U, C, gamma, nbags, L, xs, us):
     return GtG, GtY
 
 
-def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, deterministic=False):
+def _device_apply(X, U, C, gamma, nbags, L, xs, us, P):
+    """Local (P G^T) Y on this rank's GPU -> M [p, d] CUDA tensor."""
+    import torch
+    from . import engine
+    n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
+    M = torch.empty((n + k + r, n + k), dtype=torch.float64, device=X.device)
+    engine.pinv_apply_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, P, M)
+    return M
+
+
+def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, deterministic=False, order="fit_multi", apply_fn=None,
+                allreduce=None):
     """EDMDc fit over trajectories sharded across ranks.
 
     X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);
     C [k, n] centres (identical on all ranks -- broadcast them first).
     gram_fn(X, U, C, gamma, nbags, L, xs, us) -> (GtG, GtY) defaults to the HIP path; tests on CPU
     inject a host implementation to exercise the collective + solve plumbing under gloo.
+    order="fit_multi": M = P (G^T Y) (Koopman/koopmanEDMDc.py:147), ONE collective.
+    order="fit"      : M = (P G^T) Y (:97): P from the all-reduced Gram is identical on every rank, every rank forms its
+                       local sum over its own pairs (apply_fn, default the HIP path) and a second all-reduce of the p x d
+                       block adds them up.
+    allreduce(a, b)  : in-place sum over ranks of two tensors (default: torch.distributed through allreduce_gram_; the
+                       torch-free communicator of the C ABI passes _lib.Comm.allreduce_gram_).
     Returns (A [d,d], B [d,r]) as NumPy arrays, identical on every rank."""
+    import numpy as np
     from . import engine
     nb, L1, n = X_local.shape
     L = L1 - 1
     assert U_local.shape[0] == nb and U_local.shape[1] == L
     gram_fn = gram_fn or _device_gram
+    allreduce = allreduce or (lambda a, b: allreduce_gram_(a, b, group, deterministic=deterministic))
     GtG, GtY = gram_fn(X_local, U_local, C, gamma, nb, L, L + 1, L)
-    allreduce_gram_(GtG, GtY, group, deterministic=deterministic)
+    allreduce(GtG, GtY)
     d = n + C.shape[0]
-    return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d)
+    if order == "fit_multi":
+        return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d)
+    if order != "fit":
+        raise ValueError("order must be 'fit' or 'fit_multi'")
+    with engine._blas_threads():
+        P = np.linalg.pinv(GtG.cpu().numpy() + ridge * np.eye(GtG.shape[0]))
+    M = (apply_fn or _device_apply)(X_local, U_local, C, gamma, nb, L, L + 1, L, P)
+    pad = M.new_zeros(1)                                   # the collective takes two tensors; the second one is a dummy
+    allreduce(M, pad)
+    Mt = M.cpu().numpy().T
+    return np.ascontiguousarray(Mt[:, :d]), np.ascontiguousarray(Mt[:, d:])
 
 
 def rollout_sharded(model, integrator, B_total, T, dt, seed=0x5EED, layout="tub", stride=None, device=None):

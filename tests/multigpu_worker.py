@@ -1,0 +1,94 @@
+"""One rank of the multi-GPU rehearsal (child process of tests/test_multigpu.py; one process per GPU).
+
+    python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON]
+
+MODE "torch": torch.distributed (backend nccl = RCCL), RENDEZVOUS = TCP port on 127.0.0.1.
+MODE "brov" : the torch-free communicator of the C ABI (brov_comm_unique_id / brov_comm_init_rank /
+              edmdc_gram_allreduce_dev); RENDEZVOUS = a file path: rank 0 writes the 128-byte id there, the others wait for it.
+BASELINE config 4 at small size: TOTAL_ROLLOUTS x HORIZON RK4 steps in total, contiguous shards (dist.shard_range), commands
+a function of the GLOBAL trajectory index, trajectories stored [B][T+1][12], centres = seeded rows of the first 64 trajectories
+(which every rank rolls out for itself: no exchange), local lift + G^T[G|Y], all-reduce, identical host solve; both product
+orders (fit_multi: one collective; fit: a second one for the p x d block).  Writes OUT (npz): GtG, GtY, A, B, Af, Bf.
+The GPU is chosen (cuda:RANK) before anything initialises HIP in this process."""
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    mode, rank, world, rdv, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    Bt = int(sys.argv[6]) if len(sys.argv) > 6 else 1536
+    T = int(sys.argv[7]) if len(sys.argv) > 7 else 40
+    import torch
+    ndev = torch.cuda.device_count()                    # does not initialise the GPU on this image
+    dev_id = rank % max(ndev, 1)
+    torch.cuda.set_device(dev_id)
+    dev = torch.device("cuda", dev_id)
+    from bluerov2_dynamics_amd import _lib, engine
+    from bluerov2_dynamics_amd import dist as bd
+    ctx = _lib.default_context(dev_id)
+    n, r, k, gamma, ridge, dt = 12, 8, 48, 1.0, 1e-3, 0.02
+
+    def rollouts(b0, nb):
+        U = torch.empty((nb, T, r), dtype=torch.float64, device=dev)
+        engine.fill_controls_dev(U, "btu", "ar1", seed=0xC0F4, b0=b0, T_total=T, ctx=ctx)
+        X = torch.empty((nb, T + 1, n), dtype=torch.float64, device=dev)
+        x0 = torch.zeros((nb, n), dtype=torch.float64, device=dev)
+        x0[:, 2] = 5.0
+        engine.rollout_dev(_lib.THRUSTER_EULER, "rk4", x0, U, dt, traj=X, layout="btu", ctx=ctx)
+        return X, U
+
+    Xc, _ = rollouts(0, 64)
+    idx = torch.from_numpy(np.random.RandomState(0).choice(64 * (T + 1), k, replace=False)).to(dev)
+    C = Xc.view(-1, n)[idx].contiguous()
+    b0, b1 = bd.shard_range(Bt, rank, world)
+    X, U = rollouts(b0, b1 - b0)
+
+    comm = None
+    if mode == "torch":
+        import torch.distributed as dist
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=rdv, RANK=str(rank), WORLD_SIZE=str(world))
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        allreduce = None
+    else:
+        if rank == 0:
+            ident = _lib.Comm.unique_id()
+            with open(rdv + ".tmp", "wb") as f:
+                f.write(ident)
+            os.replace(rdv + ".tmp", rdv)
+        else:
+            t0 = time.time()
+            while not os.path.exists(rdv):
+                if time.time() - t0 > 120:
+                    raise TimeoutError("no communicator id from rank 0")
+                time.sleep(0.02)
+            ident = open(rdv, "rb").read()
+        comm = _lib.Comm(dev_id, ident, world, rank)
+        allreduce = comm.allreduce_gram_
+
+    # the exchange on its own (the summed blocks are part of the output), then both product orders end to end
+    GtG, GtY = bd._device_gram(X, U, C, gamma, b1 - b0, T, T + 1, T)
+    if allreduce is None:
+        bd.allreduce_gram_(GtG, GtY)
+    else:
+        allreduce(GtG, GtY)
+    A, B = bd.fit_sharded(X, U, C, gamma, ridge, allreduce=allreduce)
+    Af, Bf = bd.fit_sharded(X, U, C, gamma, ridge, order="fit", allreduce=allreduce)
+    torch.cuda.synchronize()
+    np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id)
+    if mode == "torch":
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        comm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,17 @@ def _oracle_gram(X, U, C, gamma, nbags, L, xs, us):
     return torch.from_numpy(GtG), torch.from_numpy(GtY)
 
 
+def _oracle_apply(X, U, C, gamma, nbags, L, xs, us, P):
+    """(P G^T) Y over this rank's bags, fit()'s own association (Koopman/koopmanEDMDc.py:97), NumPy."""
+    from oracle import edmdc_numpy as ek
+    Cn = C.numpy()
+    M = np.zeros((P.shape[0], Cn.shape[1] + Cn.shape[0]))
+    for Xb, Ub in zip(X.numpy(), U.numpy()):
+        G = np.hstack([ek.lift(Xb[:-1], Cn, gamma), Ub])
+        M += (P @ G.T) @ ek.lift(Xb[1:], Cn, gamma)
+    return torch.from_numpy(M)
+
+
 def _worker(rank, world, port, q):
     try:
         _worker_body(rank, world, port, q)
@@ -52,12 +63,16 @@ def _worker_body(rank, world, port, q):
     # fixed-order variant (all-gather + rank-order sum): same reduced system up to the order of two additions
     Ad, Bd = bd.fit_sharded(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, 1e-3, gram_fn=_oracle_gram, deterministic=True)
     assert np.max(np.abs(Ad - A)) < 1e-9 and np.max(np.abs(Bd - B)) < 1e-9
+    # fit()'s own product order on sharded data: P from the summed Gram, local (P G^T) Y, a second all-reduce
+    Af, Bf = bd.fit_sharded(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, 1e-3, gram_fn=_oracle_gram, order="fit",
+                            apply_fn=_oracle_apply)
+    assert np.max(np.abs(Af - A)) < 1e-7 and np.max(np.abs(Bf - B)) < 1e-7
     G1, Y1 = _oracle_gram(torch.from_numpy(Xb[b0:b1]), torch.from_numpy(Ub[b0:b1]), C, 1.0, b1 - b0, L, L + 1, L)
     G2, Y2 = G1.clone(), Y1.clone()
     bd.allreduce_gram_(G1, Y1, deterministic=True)
     bd.allreduce_gram_(G2, Y2, deterministic=True)
     assert torch.equal(G1, G2) and torch.equal(Y1, Y2)
-    q.put((rank, A, B))
+    q.put((rank, A, B, Af, Bf))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -76,8 +91,9 @@ def test_two_rank_fit_equals_single_process():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, A0, B0), (_, A1, B1) = res
+    (_, A0, B0, Af0, Bf0), (_, A1, B1, Af1, Bf1) = res
     assert np.array_equal(A0, A1) and np.array_equal(B0, B1)          # every rank solves the same reduced system
+    assert np.array_equal(Af0, Af1) and np.array_equal(Bf0, Bf1)      # ... and holds the same all-reduced (P G^T) Y
     from oracle import edmdc_numpy as ek
     g = load_golden("edmdc.npz")
     X, U = g["X"], g["U"]
@@ -85,3 +101,9 @@ def test_two_rank_fit_equals_single_process():
     Ul = [U[i * 200:(i + 1) * 200] for i in range(8)]
     A, B = ek.fit(Xl, Ul, g["centers"], 1.0, 1e-3)
     assert np.max(np.abs(A - A0)) < 1e-9 and np.max(np.abs(B - B0)) < 1e-9
+    # the sharded fit-order result == the single-process (P G^T) Y on all bags
+    GtG, _, _ = ek.gram(Xl, Ul, g["centers"], 1.0)
+    P = np.linalg.pinv(GtG + 1e-3 * np.eye(GtG.shape[0]))
+    M = _oracle_apply(torch.from_numpy(np.stack(Xl)), torch.from_numpy(np.stack([u[:-1] for u in Ul])), torch.from_numpy(g["centers"]), 1.0, 8, 199, 200, 199, P).numpy().T
+    d = 12 + g["centers"].shape[0]
+    assert np.max(np.abs(M[:, :d] - Af0)) < 1e-9 and np.max(np.abs(M[:, d:] - Bf0)) < 1e-9

@@ -810,6 +810,17 @@ def test_full_comparison_script_matches_reference_table(tmp_path):
     assert np.max(np.abs(r["table"][0] - g["table"][0])) < 1e-6
     assert np.max(np.abs(r["table"][1:] - g["table"][1:])) < 1e-10
     assert np.array_equal(np.argsort(r["table"], axis=0), np.argsort(g["table"], axis=0))
+    # BASELINE config 5's fourth row: the reference's PINc evaluator with its shipped checkpoint on the same test split
+    # (tests/golden/cfg5_pinc.npz, tools/gen_golden.py: gen_cfg5_pinc; the network itself is out of scope).  Our three rows +
+    # that row rank exactly as the reference's four rows do, per horizon: Fossen < ... << PINc (training/best_results.txt:790-793)
+    gp = load_golden("cfg5_pinc.npz")
+    assert int(gp["n_test"]) == len(g["X"]) - int(g["split"])
+    r4 = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]), centers=g["centers"], verbose=False,
+                      pinc_row=gp["pinc_row"])
+    ref4 = np.vstack([g["table"], gp["pinc_row"]])
+    assert r4["table"].shape == (4, 3) and r4["rows"][3].startswith("PINc")
+    assert np.array_equal(np.argsort(r4["table"], axis=0), np.argsort(ref4, axis=0))
+    assert np.array_equal(r4["ranking"][3], [3, 3, 3]) and np.array_equal(r4["ranking"][1], [0, 0, 0])      # PINc last, Fossen first
     r2 = fcmp.compare(csv, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]), verbose=False)
     assert rel_err(r2["model"].centers_, g["centers"]) < 1e-10
     assert np.max(np.abs(r2["table"][0] - g["table"][0])) < 1e-6

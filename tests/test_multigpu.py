@@ -1,0 +1,81 @@
+"""Multi-rank rehearsal of BASELINE config 4 on real GPUs: one child process per GPU (tests/multigpu_worker.py), run twice --
+through torch.distributed (nccl = RCCL) and through the torch-free communicator of the C ABI (brov_comm_*, id handed over a
+file).  The N-rank tests arm themselves when the box shows >= 2 GPUs (the development pool has one; the driver's 8-GPU node
+runs them); the one-rank test runs everywhere and keeps the worker itself honest.  SURVEY.md 8(e)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import REPO
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(REPO, "tests", "multigpu_worker.py")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(mode, world, tmp, total=1536, horizon=40):
+    rdv = str(_free_port()) if mode == "torch" else os.path.join(tmp, f"id_{mode}_{world}")
+    outs = [os.path.join(tmp, f"{mode}_{world}_{r}.npz") for r in range(world)]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), rdv, outs[r], str(total), str(horizon)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            logs.append(p.communicate(timeout=600)[0])
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+    for r, p in enumerate(procs):
+        assert p.returncode == 0, f"rank {r} of {world} ({mode}) failed:\n{logs[r][-3000:]}"
+    return [np.load(o) for o in outs]
+
+
+def _check(res, one):
+    scale_g, scale_y = np.linalg.norm(one["GtG"]), np.linalg.norm(one["GtY"])
+    for z in res:
+        # summed Gram == 1-rank Gram (the shards partition the ensemble; only the order of the additions differs)
+        assert np.linalg.norm(z["GtG"] - one["GtG"]) / scale_g < 1e-12
+        assert np.linalg.norm(z["GtY"] - one["GtY"]) / scale_y < 1e-12
+        # every rank solved the same reduced system: identical A, B bit for bit, both product orders
+        for key in ("A", "B", "Af", "Bf"):
+            assert np.array_equal(z[key], res[0][key]), key
+        assert np.max(np.abs(z["A"] - one["A"])) < 1e-8 and np.max(np.abs(z["Af"] - one["Af"])) < 1e-8
+    assert sorted(int(z["b0"]) for z in res)[0] == 0 and len({int(z["device"]) for z in res}) == len(res)
+
+
+def test_worker_single_rank_both_transports(tmp_path):
+    """The worker at world size 1, both transports: runs on any GPU box; the N-rank tests compare against this."""
+    a = _run("torch", 1, str(tmp_path))[0]
+    b = _run("brov", 1, str(tmp_path))[0]
+    for key in ("GtG", "GtY", "A", "B", "Af", "Bf"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.isfinite(a["A"]).all() and np.isfinite(a["Af"]).all()
+    assert np.max(np.abs(a["A"] - a["Af"])) < 1e-6            # the two product orders agree to the conditioning of the Gram
+
+
+def _ngpu():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.parametrize("mode", ["torch", "brov"])
+def test_n_rank_config4_equals_one_rank(mode, tmp_path):
+    n = _ngpu()
+    if n < 2:
+        pytest.skip(f"needs >= 2 GPUs, this box has {n}")
+    one = _run(mode, 1, str(tmp_path))[0]
+    for world in sorted({2, min(n, 4), min(n, 6)}):           # at most 6 processes may use the GPUs of a box together
+        _check(_run(mode, world, str(tmp_path)), one)

@@ -20,6 +20,7 @@ Fixtures (all float64):
   simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
   cfg5w_dataset.csv.gz + cfg5w.npz  the same recording with wrench inputs through the wrench_comp / wrench_quat scripts' functions
   cfg5_dataset.csv.gz + cfg5.npz   script-level run (loader, split, Koopman / Fossen / DI RMSE table)
+  cfg5_pinc.npz         the fourth row of that table: the reference's PINc evaluator with the shipped checkpoint (fixture only)
 """
 import argparse
 import os
@@ -433,6 +434,31 @@ def gen_cfg5():
     print(table)
 
 
+def gen_cfg5_pinc():
+    """Config 5's fourth row (fixture only; the PINc network itself is out of scope): the reference's
+    multistep_rmse_endpoint_pinc (training/train_tank_brov2_full_comparison.py:866-890) with the checkpoint the checkout ships
+    (models/pinc_best.pt, loaded as at :948-952) on the test split of cfg5_dataset.csv.gz, H = 1 / 10 / 100 in the script's
+    order with ONE thruster-map vehicle (`rov_old`, :947: its lag state carries from one horizon's evaluation into the next,
+    :992-994).  Stored next to cfg5.npz so that the ranking assertion covers four rows."""
+    import torch
+    import train_tank_brov2_full_comparison as ref
+    g = np.load(os.path.join(OUT, "cfg5.npz"))
+    X, U, dt, split = g["X"], g["U"], float(g["dt"]), int(g["split"])
+    Xte, Ute = X[split:], U[split:]
+    device = torch.device("cpu")
+    torch.manual_seed(0)
+    pinc = ref.PINcNet(hidden_sizes=ref.PINc_HIDDEN).to(device)
+    pinc.load_state_dict(torch.load(os.path.join(REF, "models", "pinc_best.pt"), map_location=device))
+    rov_old = RefThruster(dt=dt)
+    t0 = time.time()
+    row = np.array([ref.multistep_rmse_endpoint_pinc(Xte, Ute, H=H, dt=dt, model=pinc, old_model_for_map=rov_old, device=device)
+                    for H in (1, 10, 100)])
+    np.savez(os.path.join(OUT, "cfg5_pinc.npz"), pinc_row=row, H=np.array([1, 10, 100]), n_test=np.int64(len(Xte)),
+             row_name=np.array(["PINc (ResDNN)"]), checkpoint=np.array(["models/pinc_best.pt (reference checkout), float32 forward on CPU"]),
+             torch_version=np.array([torch.__version__]), versions=versions())
+    print("PINc row", row, f"({time.time() - t0:.1f} s); table of the other rows:\n", g["table"])
+
+
 def gen_torchrhs():
     """fossen/bluerov_torch.py: bluerov_compute and ssa on random batches (float64 and float32)."""
     import torch
@@ -519,7 +545,7 @@ def gen_simscript():
              pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
 
 
-GENS = dict(torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
+GENS = dict(cfg5_pinc=gen_cfg5_pinc, torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
