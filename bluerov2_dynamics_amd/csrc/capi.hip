@@ -42,6 +42,7 @@ struct brov_ctx {
     int btu_staging = 0;
     int single_lane = 0;          // 1: never use the two-wave rollout kernel (A/B measurements: BROV2_ROLLOUT_SINGLE_LANE=1)
     int64_t chunk_rows = (int64_t)1 << 20;
+    int kmeans_variant = 0;       // Lloyd E-step: 0 = candidate filter (triangle inequality, per wave), 1 = full scan (the second implementation)
     int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
     void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
     EdmdcShape task_shape[2] = {};
@@ -430,6 +431,7 @@ int brov_create(int device_id, brov_ctx** out) {
     c->xcd_round_robin = probe_xcd_round_robin(nullptr);
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_APPLY_SIMPLE")) c->apply_variant = (e[0] == '1');
+    if (const char* e = std::getenv("BROV2_KMEANS_PLAIN")) c->kmeans_variant = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
@@ -1010,6 +1012,12 @@ int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows
     return BROV_OK;
 }
 
+int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
+    if (!c || variant < 0 || variant > 1) return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0 or 1");
+    c->kmeans_variant = variant;
+    return BROV_OK;
+}
+
 int edmdc_set_apply_variant(brov_ctx* c, int variant) {
     if (!c || variant < 0 || variant > 1) return fail(c, BROV_ERR_ARG, "edmdc_set_apply_variant: variant must be 0 or 1");
     c->apply_variant = variant;
@@ -1291,10 +1299,14 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     DeviceGuard g(c);
     const int nb = kmeans_blocks(N);
     Arena a(c);
-    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) + 4096);
+    const bool filter = c->kmeans_variant == 0 && k >= 64;       // below one mask word there is nothing to skip
+    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + 2 * Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
+                       Arena::al(filter ? (size_t)k * k * 8 : 8) + 4096);
     if (rc) return rc;
     double* partial = a.take<double>((size_t)nb * k * (n + 1));
     double* binert = a.take<double>(nb);
+    double* bxmax = a.take<double>(nb);
+    double* Dc = a.take<double>(filter ? (size_t)k * k : 1);
     int* bchg = a.take<int>(nb);
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* stats = a.take<double>(8);
@@ -1315,12 +1327,17 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     bool strict = false;
     int it = 0;
     double hs[3] = {0, 0, 0};
-    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+    // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
+    double* prm = stats + 4;
+    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg, bxmax,
+                                  nullptr, nullptr));
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, d_C, c2, stats));
+        HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, bxmax, d_C, c2, stats, prm));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg));
+        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mean_host ? dmean : nullptr, d_C, c2, d_labels, partial, binert, bchg, bxmax,
+                                      filter ? Dc : nullptr, prm));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         hs[0] = c->h_stats[0]; hs[1] = c->h_stats[1]; hs[2] = c->h_stats[2];
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)

@@ -14,6 +14,20 @@
 // as wave-uniform scalar loads: 12 FMA + compare/select per (64 samples, centre).  Persistent 1024-thread blocks
 // accumulate member sums and counts with LDS fp64 atomics and write one partial per block; a second
 // kernel reduces the partials in block order and forms the new centres.
+//
+// Round 3: the E-step with a candidate filter (kmeans_assign_kernel<NS, true>).  With scikit-learn's stopping rule the config-3
+// centres need all 300 iterations (tol 1e-4 is not reached at N = 1e7, k = 512), so Lloyd is two thirds of a fit().  Exact
+// pruning by the triangle inequality, decided per WAVE so that every lane keeps running the same instruction stream:
+//   * a wave holds 64 consecutive samples; their labels of the previous iteration form a few groups (4.5 on trajectory data);
+//   * for a group with label a:  u = max over its lanes of d(x, c_a) (one distance per lane, rounded up);  a centre c with
+//     d(c_a, c) >= 2 u + margin is farther from every lane of the group than c_a is, by at least `margin`;
+//   * the wave evaluates the union over its groups of { c : d(c_a, c) < 2 u_a + margin } -- 131 of 512 centres on average --
+//     in increasing index order with the plain kernel's eval(), for all lanes (a superfluous candidate is harmless).
+// The labels are those of the full scan bit for bit: a skipped centre's exact score is below the group centre's by more than
+// margin^2 / 2 = 5e-13 R^2 while the FMA chain errs by < 1.1e-15 R^2 (R^2 = 2 max |x|^2), so it cannot be the computed argmax,
+// and ties among the candidates resolve to the lowest index as before.  The centre-centre distances come from
+// kmeans_cdist_kernel (k x k doubles, rebuilt after every M-step; 2 MB at k = 512, L2 resident).  Waves with a stale label
+// (first iteration), a non-finite sample or more than KM_GMAX label groups (shuffled data) take the full scan.
 #include "brov2_kernels.h"
 #include <cstdint>
 
@@ -33,21 +47,41 @@ constexpr int KM_CMAX = 15;
 struct __attribute__((aligned(128))) Cen { double v[16]; };
 typedef const Cen __attribute__((address_space(4)))* ccp;
 
-template <int NS>
+constexpr int KM_GMAX = 8;            // label groups per wave the candidate filter handles; more -> full scan
+// wave-wide maximum of a 32-bit unsigned value (all 64 lanes active): four DPP steps inside the rows of 16, then the row maxima
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false));    // row_half_mirror
+    v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false));    // row_mirror
+    const unsigned r0 = __builtin_amdgcn_readlane((int)v, 0), r1 = __builtin_amdgcn_readlane((int)v, 16);
+    const unsigned r2 = __builtin_amdgcn_readlane((int)v, 32), r3 = __builtin_amdgcn_readlane((int)v, 48);
+    return max(max(r0, r1), max(r2, r3));
+}
+
+// prm (device, written by kmeans_update_kernel): [0] = margin, [1] = eps2 (see the header comment); Dc: [k][k] centre distances
+template <int NS, bool PRUNE>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) kmeans_assign_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride,
                                                             const double* __restrict__ mean,
                                                             const double* __restrict__ Ct /* [k][16]: coordinates, |c|^2/2 at [n] */, int* __restrict__ labels,
                                                             double* __restrict__ partial /* [blocks][k][n+1] */,
-                                                            double* __restrict__ block_inertia, int* __restrict__ block_changed) {
+                                                            double* __restrict__ block_inertia, int* __restrict__ block_changed,
+                                                            double* __restrict__ block_xmax, const double* __restrict__ Dc,
+                                                            const double* __restrict__ prm) {
     extern __shared__ double sums[];                  // [k][n+1]: member sums and count
     const int np1 = n + 1;
     for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0.0;
     __shared__ double sh_inertia[KM_THREADS / 64];
     __shared__ int sh_changed[KM_THREADS / 64];
+    __shared__ double sh_xmax[KM_THREADS / 64];
     __syncthreads();
     const ccp T = (ccp)(unsigned long long)Ct;
-    double inertia = 0.0;
+    double inertia = 0.0, xmax = 0.0;
     int changed = 0;
+    double margin = 0.0, eps2 = 0.0;
+    bool centres_finite = true;
+    if constexpr (PRUNE) { margin = prm[0]; eps2 = prm[1]; centres_finite = prm[2] == 0.0; }
+    const int lane = threadIdx.x & 63;
     for (int64_t base = (int64_t)blockIdx.x * KM_THREADS; base < N; base += (int64_t)gridDim.x * KM_THREADS) {
         const int64_t i = base + threadIdx.x;
         const bool live = i < N;
@@ -82,25 +116,98 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
             bi = (sc <= best) ? bi : c;               // strict '>' to replace: the first extremum wins, like np.argmin
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));      // plain max: fmax() adds a canonicalising self-max
         };
-        // two centres per trip: their four 64-byte scalar loads go out together and are waited for once
-        int c = 0;
+        const int ol = labels[ii];                    // label of the previous iteration (-1 before the first)
+        bool filtered = false;
+        if constexpr (PRUNE) {
+            // ---- candidate filter (see the header comment); every branch below is wave-uniform
+            const bool usable = (unsigned)ol < (unsigned)k && (x2 - x2 == 0.0) && centres_finite;
+            if (__ballot(!usable) == 0ull) {
+                int ga[KM_GMAX];
+                double gthr[KM_GMAX];
+                int ng = 0;
+                unsigned long long remaining = ~0ull;
+#pragma unroll
+                for (int g = 0; g < KM_GMAX; ++g) {
+                    if (remaining != 0ull) {
+                        const int lead = __builtin_ctzll(remaining);
+                        const int a = __builtin_amdgcn_readlane(ol, lead);
+                        const bool mine = ol == a;
+                        Cen ca;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) ca.v[j] = T[a].v[j];
+                        constexpr int NJ = NS > 0 ? NS : KM_CMAX;
+                        double sc = fma(x[0], ca.v[0], -(NS > 0 ? ca.v[NS] : ca.v[n]));
+#pragma unroll
+                        for (int j = 1; j < NJ; ++j) sc = fma(x[j], ca.v[j], sc);
+                        const double d2 = fma(-2.0, sc, x2);                       // |x - c_a|^2 up to rounding
+                        // the group's squared radius as a float rounded UP (non-negative floats order like their bit patterns)
+                        float rf = mine ? (float)fmax(d2, 0.0) : 0.0f;
+                        rf = rf * 1.0000005f + 1.0e-37f;
+                        const unsigned rb = wave_max_u32(mine ? __float_as_uint(rf) : 0u);
+                        const double u = sqrt((double)__uint_as_float(rb) + eps2);
+                        ga[g] = a;
+                        gthr[g] = fma(2.0, u, margin);
+                        ng = g + 1;
+                        remaining &= ~__ballot(mine);
+                    }
+                }
+                if (remaining == 0ull) {
+                    filtered = true;
+                    const int kw = (k + 63) >> 6;
 #pragma unroll 1
-        for (; c + 1 < k; c += 2) {
-            Cen a, b;
+                    for (int w = 0; w < kw; ++w) {
+                        const int cw = (w << 6) + lane;
+                        const int cc = cw < k ? cw : k - 1;
+                        bool pred = false;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) { a.v[j] = T[c].v[j]; b.v[j] = T[c + 1].v[j]; }
-            eval(a, c);
-            eval(b, c + 1);
+                        for (int g = 0; g < KM_GMAX; ++g)
+                            if (g < ng) pred = pred || (Dc[(int64_t)ga[g] * k + cc] < gthr[g]);
+                        unsigned long long mw = __ballot(pred && cw < k);
+                        // candidates of this word in increasing index order, two per trip (their scalar loads go out together)
+                        while (mw != 0ull) {
+                            const int c0 = (w << 6) + __builtin_ctzll(mw);
+                            mw &= mw - 1ull;
+                            if (mw != 0ull) {
+                                const int c1 = (w << 6) + __builtin_ctzll(mw);
+                                mw &= mw - 1ull;
+                                Cen a, b;
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) { a.v[j] = T[c0].v[j]; b.v[j] = T[c1].v[j]; }
+                                eval(a, c0);
+                                eval(b, c1);
+                            } else {
+                                Cen a;
+#pragma unroll
+                                for (int j = 0; j < 16; ++j) a.v[j] = T[c0].v[j];
+                                eval(a, c0);
+                            }
+                        }
+                    }
+                }
+            }
         }
-        if (c < k) {
-            Cen a;
+        if (!filtered) {
+            // two centres per trip: their four 64-byte scalar loads go out together and are waited for once
+            int c = 0;
+#pragma unroll 1
+            for (; c + 1 < k; c += 2) {
+                Cen a, b;
 #pragma unroll
-            for (int j = 0; j < 16; ++j) a.v[j] = T[c].v[j];
-            eval(a, c);
+                for (int j = 0; j < 16; ++j) { a.v[j] = T[c].v[j]; b.v[j] = T[c + 1].v[j]; }
+                eval(a, c);
+                eval(b, c + 1);
+            }
+            if (c < k) {
+                Cen a;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a.v[j] = T[c].v[j];
+                eval(a, c);
+            }
         }
         if (live) {
-            if (labels[i] != bi) ++changed;
+            if (ol != bi) ++changed;
             labels[i] = bi;
+            xmax = fmax(xmax, x2);
             inertia += fma(-2.0, best, x2);
             double* s = sums + bi * np1;
             for (int j = 0; j < n; ++j) atomicAdd(&s[j], x[j]);
@@ -111,56 +218,85 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
         changed += __shfl_down(changed, off);
+        xmax = fmax(xmax, __shfl_down(xmax, off));
     }
-    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; }
+    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; sh_xmax[threadIdx.x >> 6] = xmax; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double in = 0.0;
+        double in = 0.0, xm = 0.0;
         int ch = 0;
-        for (int w = 0; w < KM_THREADS / 64; ++w) { in += sh_inertia[w]; ch += sh_changed[w]; }
+        for (int w = 0; w < KM_THREADS / 64; ++w) { in += sh_inertia[w]; ch += sh_changed[w]; xm = fmax(xm, sh_xmax[w]); }
         block_inertia[blockIdx.x] = in;
         block_changed[blockIdx.x] = ch;
+        block_xmax[blockIdx.x] = xm;
     }
     double* out = partial + (int64_t)blockIdx.x * k * np1;
     for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) out[i] = sums[i];
 }
 
-// thread per (c, j): sum partials over blocks (fixed order), new centre, accumulate squared shift.
-// stats[0] = sum of squared centre shifts, stats[1] = inertia, stats[2] = changed labels
+// One 256-thread block per centre: sums the block partials (thread = (coordinate slot j, sub-range s of the blocks); the 16
+// sub-range sums are added in index order: a fixed grouping, the same result for the same partials), forms the new centre and
+// the squared shift.  (Round 2: one wave per centre walked the 512 partials one dependent load after the other, 0.2 ms.)
+// stats[0] = sum of squared centre shifts, stats[1] = inertia, stats[2] = changed labels;
+// prm[0] = margin, prm[1] = eps2 of the candidate filter, from R^2 = 2 max |x|^2 (block_xmax); prm[2] != 0: some centre is not finite.
 __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, int k, const double* __restrict__ partial,
                                                             const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
-                                                            double* __restrict__ C, double* __restrict__ Ct, double* __restrict__ stats) {
+                                                            const double* __restrict__ block_xmax,
+                                                            double* __restrict__ C, double* __restrict__ Ct, double* __restrict__ stats,
+                                                            double* __restrict__ prm) {
     const int np1 = n + 1;
-    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per centre
-    const int j = threadIdx.x & 63;
-    double shift2 = 0.0;
-    if (c < k) {
-        double cnt = 0.0, sum = 0.0;
-        for (int b = 0; b < nblocks; ++b) {
-            const double* p = partial + ((int64_t)b * k + c) * np1;
-            cnt += p[n];
-            if (j < n) sum += p[j];
-        }
-        double nv = 0.0;
-        if (j < n) {
-            const double old = C[c * n + j];
-            nv = cnt > 0.0 ? sum / cnt : old;
-            C[c * n + j] = nv;
+    const int c = blockIdx.x;
+    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;       // slot (0..n: coordinates, n: count), sub-range of the blocks
+    __shared__ double part[16][17];
+    double a = 0.0;
+    if (j <= n)
+        for (int b = sr; b < nblocks; b += 16) a += partial[((int64_t)b * k + c) * np1 + j];
+    part[sr][j] = a;
+    __syncthreads();
+    __shared__ double tot[16];
+    if (threadIdx.x < 16) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int jj = threadIdx.x;
+        const double cnt = tot[n];
+        double nv = 0.0, shift2 = 0.0;
+        if (jj < n) {
+            const double old = C[c * n + jj];
+            nv = cnt > 0.0 ? tot[jj] / cnt : old;
+            C[c * n + jj] = nv;
             const double dd = nv - old;
             shift2 = dd * dd;
         }
         double q = nv * nv;
         for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); shift2 += __shfl_down(shift2, off); }
         q = __shfl(q, 0);
-        if (j < 16) Ct[c * 16 + j] = j < n ? nv : (j == n ? 0.5 * q : 0.0);
-        if (j == 0) atomicAdd(&stats[0], shift2);
+        if (jj < 16) Ct[c * 16 + jj] = jj < n ? nv : (jj == n ? 0.5 * q : 0.0);
+        if (jj == 0) atomicAdd(&stats[0], shift2);
+        if (jj == 0 && !(q - q == 0.0)) prm[2] = 1.0;         // a non-finite centre (NaN / inf data): the candidate filter stands down
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double in = 0.0;
+    if (blockIdx.x == 0 && threadIdx.x == 64) {
+        double in = 0.0, xm = 0.0;
         long long ch = 0;
-        for (int b = 0; b < nblocks; ++b) { in += block_inertia[b]; ch += block_changed[b]; }
+        for (int b = 0; b < nblocks; ++b) { in += block_inertia[b]; ch += block_changed[b]; xm = fmax(xm, block_xmax[b]); }
         stats[1] = in;
         stats[2] = (double)ch;
+        const double R2 = 2.0 * xm;                       // centres are means of samples: |c| <= max |x|
+        prm[0] = 1.0e-6 * sqrt(R2);                       // margin
+        prm[1] = 1.0e-13 * R2;                            // eps2: 30 x the rounding of a computed squared distance
+    }
+}
+
+// centre-centre distances Dc[a][c] (difference form), one block per row; rebuilt after every M-step for the candidate filter
+__global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, double* __restrict__ Dc) {
+    const int a = blockIdx.x;
+    for (int c = threadIdx.x; c < k; c += 256) {
+        double s = 0.0;
+        for (int j = 0; j < n; ++j) { const double d = Ct[a * 16 + j] - Ct[c * 16 + j]; s = fma(d, d, s); }
+        Dc[(int64_t)a * k + c] = sqrt(s);
     }
 }
 
@@ -518,21 +654,28 @@ hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, doubl
     return hipGetLastError();
 }
 
-// one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_update maintain
+// one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_update maintain.
+// Dc != nullptr: the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist, prm from launch_kmeans_update).
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
-                                const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed) {
+                                const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
+                                double* block_xmax, const double* Dc, const double* prm) {
     (void)C;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
     const size_t lds = (size_t)k * (n + 1) * sizeof(double) ;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N);
-#define KM_LAUNCH(NS_) do { \
-        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define KM_LAUNCH(NS_, PR_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_kernel<NS_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL(kmeans_assign_kernel<NS_>, dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, \
-                           block_inertia, block_changed); } while (0)
-    if (n == 12) KM_LAUNCH(12); else if (n == 13) KM_LAUNCH(13); else KM_LAUNCH(0);
+        hipLaunchKernelGGL((kmeans_assign_kernel<NS_, PR_>), dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, \
+                           block_inertia, block_changed, block_xmax, Dc, prm); } while (0)
+    if (Dc) { if (n == 12) KM_LAUNCH(12, true); else if (n == 13) KM_LAUNCH(13, true); else KM_LAUNCH(0, true); }
+    else { if (n == 12) KM_LAUNCH(12, false); else if (n == 13) KM_LAUNCH(13, false); else KM_LAUNCH(0, false); }
 #undef KM_LAUNCH
+    return hipGetLastError();
+}
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, double* Dc) {
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc);
     return hipGetLastError();
 }
 int kmeans_blocks(int64_t N) {
@@ -540,10 +683,13 @@ int kmeans_blocks(int64_t N) {
     return need < KM_BLOCKS ? (int)(need > 0 ? need : 1) : KM_BLOCKS;
 }
 hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
-                                const int* block_changed, double* C, double* c2, double* stats) {
+                                const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm) {
     hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3((k + 3) / 4), dim3(256), 0, st, nblocks, n, k, partial, block_inertia, block_changed, C, c2, stats);
+    e = hipMemsetAsync(prm + 2, 0, sizeof(double), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kmeans_update_kernel, dim3(k), dim3(256), 0, st, nblocks, n, k, partial, block_inertia, block_changed, block_xmax, C, c2,
+                       stats, prm);
     return hipGetLastError();
 }
 

@@ -263,6 +263,10 @@ BROV_API int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per
 /* Which kernel forms the rows of W in edmdc_pinv_apply(_dev): 0 = the tuned one (default), 1 = the plain one-row-tile-per-wave
  * form (kept as an independent second implementation for the parity tests; BROV2_APPLY_SIMPLE=1 selects it at brov_create). */
 BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
+/* Lloyd's E-step in edmdc_kmeans_lloyd(_dev): 0 = with the per-wave candidate filter (triangle inequality over the centre-centre
+ * distances; the same labels as the full scan bit for bit, 3-4 x fewer centre evaluations on trajectory-ordered data; default),
+ * 1 = full scan over all k centres (the independent second implementation; BROV2_KMEANS_PLAIN=1 selects it at brov_create). */
+BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over

@@ -631,6 +631,48 @@ def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
     assert np.array_equal(U[0], rs.uniform(size=L))
 
 
+def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
+    """Lloyd's E-step with the per-wave candidate filter (triangle inequality over centre-centre distances, csrc/kmeans.hip)
+    against the full scan over all k centres: the SAME labels bit for bit, the same iteration count, centres equal to the
+    rounding of the member sums (fp64 atomics, order not fixed).  Trajectory-ordered data (few label groups per wave),
+    shuffled data (more than 8 groups: the wave falls back to the full scan), duplicate centres (exact score ties: the lowest
+    index must win in both), k not a multiple of 64, n = 13, and a NaN row."""
+    from bluerov2_dynamics_amd import _lib
+    rng = np.random.default_rng(21)
+    ctxs = []
+    for v in (0, 1):
+        c = _lib.Context(0)
+        c.set_kmeans_variant(v)
+        ctxs.append(c)
+    cases = []
+    for (N, n, k, shuffle) in ((60000, 12, 512, False), (60000, 12, 512, True), (20011, 13, 100, False), (5000, 12, 70, False), (3000, 5, 64, False)):
+        X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0)                   # a random walk: consecutive samples are neighbours
+        X += 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))
+        if shuffle:
+            X = X[rng.permutation(N)]
+        C0 = X[rng.choice(N, k, replace=False)].copy()
+        cases.append((X, C0, None))
+    X, C0, _ = cases[0]
+    C0d = C0.copy()
+    C0d[7] = C0d[3]                                                     # duplicate centres: exact ties, index 3 must win
+    C0d[300] = C0d[3]
+    cases.append((X, C0d, None))
+    Xn = cases[3][0].copy()
+    Xn[1234, 5] = np.nan                                                # a NaN sample: its wave takes the full scan
+    cases.append((Xn, cases[3][1], None))
+    for ci, (X, C0, _) in enumerate(cases):
+        mean = np.nanmean(X, 0)
+        for max_iter in (1, 7):
+            out = [eng.kmeans_lloyd(X, C0 - mean, max_iter=max_iter, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
+            (Ca, la, ina, ita), (Cb, lb, inb, itb) = out
+            assert np.array_equal(la, lb), (ci, max_iter, int(np.sum(la != lb)))
+            assert ita == itb
+            if not np.isnan(X).any():
+                assert rel_err(Ca, Cb) < 1e-12 and abs(ina - inb) <= 1e-10 * abs(inb), (ci, max_iter)
+    for c in ctxs:
+        c.close()
+
+
 def test_gram_full_width_vs_oracle_chunked_and_bags(eng):
     """k = 512 (p = 532, the benchmark shape), several chunks, bag boundaries inside chunks."""
     import torch
