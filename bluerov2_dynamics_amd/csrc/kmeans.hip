@@ -113,7 +113,9 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 #pragma unroll
             for (int j = 1; j < NJ; ++j) sc = fma(x[j], t.v[j], sc);
 #endif
-            bi = (sc <= best) ? bi : c;               // strict '>' to replace: the first extremum wins, like np.argmin
+            // strict '>' to replace: the first extremum wins, like np.argmin.  (The wave-uniform index cannot be the scalar operand
+            // of the select: v_cndmask reads its condition over the constant bus as well, and gfx9 allows one scalar source.)
+            bi = (sc <= best) ? bi : c;
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));      // plain max: fmax() adds a canonicalising self-max
         };
         const int ol = labels[ii];                    // label of the previous iteration (-1 before the first)
@@ -123,7 +125,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
             const bool usable = (unsigned)ol < (unsigned)k && (x2 - x2 == 0.0) && centres_finite;
             if (__ballot(!usable) == 0ull) {
                 int ga[KM_GMAX];
-                double gthr[KM_GMAX];
+                double gthr2[KM_GMAX];                     // squared thresholds: Dc holds SQUARED centre distances (no square roots)
                 int ng = 0;
                 unsigned long long remaining = ~0ull;
 #pragma unroll
@@ -144,44 +146,73 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                         float rf = mine ? (float)fmax(d2, 0.0) : 0.0f;
                         rf = rf * 1.0000005f + 1.0e-37f;
                         const unsigned rb = wave_max_u32(mine ? __float_as_uint(rf) : 0u);
-                        const double u = sqrt((double)__uint_as_float(rb) + eps2);
+                        const double u2 = (double)__uint_as_float(rb) + eps2;      // >= the true squared radius u^2 of the group
                         ga[g] = a;
-                        gthr[g] = fma(2.0, u, margin);
+                        // (2 u + m)^2 <= 4.004 u^2 + 1001 m^2 (Young's inequality): the skip rule d(c_a, c)^2 >= this implies
+                        // d(c_a, c) >= 2 u + m
+                        // (wave-uniform: pinned into scalar registers -- left in VGPRs the eight thresholds were spilled to scratch and
+                        // re-read for every mask word)
+                        const double t2 = fma(4.004, u2, 1001.0 * margin * margin);
+                        gthr2[g] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t2)), __builtin_amdgcn_readfirstlane(__double2loint(t2)));
                         ng = g + 1;
                         remaining &= ~__ballot(mine);
                     }
                 }
+                const int kw = (k + 63) >> 6;
+                // candidate mask of word w: centres 64 w + lane within the threshold of some group
+                auto word_mask = [&](int w) {
+                    const int cw = (w << 6) + lane;
+                    const int cc = cw < k ? cw : k - 1;
+                    bool pred = false;
+#pragma unroll
+                    for (int g = 0; g < KM_GMAX; ++g)
+                        if (g < ng) pred = pred || (Dc[(int64_t)ga[g] * k + cc] < gthr2[g]);
+                    return __ballot(pred && cw < k);
+                };
+                // candidates of one word in increasing index order, two per trip (their scalar loads go out together)
+                auto scan_word = [&](int w, unsigned long long mw) {
+                    while (mw != 0ull) {
+                        const int c0 = (w << 6) + __builtin_ctzll(mw);
+                        mw &= mw - 1ull;
+                        if (mw != 0ull) {
+                            const int c1 = (w << 6) + __builtin_ctzll(mw);
+                            mw &= mw - 1ull;
+                            Cen a, b;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) { a.v[j] = T[c0].v[j]; b.v[j] = T[c1].v[j]; }
+                            eval(a, c0);
+                            eval(b, c1);
+                        } else {
+                            Cen a;
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) a.v[j] = T[c0].v[j];
+                            eval(a, c0);
+                        }
+                    }
+                };
                 if (remaining == 0ull) {
                     filtered = true;
-                    const int kw = (k + 63) >> 6;
-#pragma unroll 1
-                    for (int w = 0; w < kw; ++w) {
-                        const int cw = (w << 6) + lane;
-                        const int cc = cw < k ? cw : k - 1;
-                        bool pred = false;
+                    if (kw <= 8) {
+                        // k <= 512: all mask words first (the group table is dead before the first centre is evaluated: with both
+                        // alive the scalar registers did not fit and the hot loop carried 7 v_readlane / v_writelane per centre)
+                        unsigned long long mws[8];
 #pragma unroll
-                        for (int g = 0; g < KM_GMAX; ++g)
-                            if (g < ng) pred = pred || (Dc[(int64_t)ga[g] * k + cc] < gthr[g]);
-                        unsigned long long mw = __ballot(pred && cw < k);
-                        // candidates of this word in increasing index order, two per trip (their scalar loads go out together)
-                        while (mw != 0ull) {
-                            const int c0 = (w << 6) + __builtin_ctzll(mw);
-                            mw &= mw - 1ull;
-                            if (mw != 0ull) {
-                                const int c1 = (w << 6) + __builtin_ctzll(mw);
-                                mw &= mw - 1ull;
-                                Cen a, b;
-#pragma unroll
-                                for (int j = 0; j < 16; ++j) { a.v[j] = T[c0].v[j]; b.v[j] = T[c1].v[j]; }
-                                eval(a, c0);
-                                eval(b, c1);
-                            } else {
-                                Cen a;
-#pragma unroll
-                                for (int j = 0; j < 16; ++j) a.v[j] = T[c0].v[j];
-                                eval(a, c0);
-                            }
+                        for (int w = 0; w < 8; ++w) {
+                            mws[w] = w < kw ? word_mask(w) : 0ull;
+                            asm volatile("" ::: "memory");        // one word's distance loads at a time (64 VGPRs: hoisting all 8 x ng spills)
                         }
+                        // one copy of the evaluation loop (eight unrolled copies were 30 KB of code and slower than the interleaved
+                        // form); the word is picked with scalar selects
+#pragma unroll 1
+                        for (int w = 0; w < kw; ++w) {
+                            unsigned long long mw = 0ull;
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) mw = (w == q) ? mws[q] : mw;
+                            scan_word(w, mw);
+                        }
+                    } else {
+#pragma unroll 1
+                        for (int w = 0; w < kw; ++w) scan_word(w, word_mask(w));
                     }
                 }
             }
@@ -290,13 +321,13 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
     }
 }
 
-// centre-centre distances Dc[a][c] (difference form), one block per row; rebuilt after every M-step for the candidate filter
+// squared centre-centre distances Dc[a][c] (difference form), one block per row; rebuilt after every M-step for the candidate filter
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, double* __restrict__ Dc) {
     const int a = blockIdx.x;
     for (int c = threadIdx.x; c < k; c += 256) {
         double s = 0.0;
         for (int j = 0; j < n; ++j) { const double d = Ct[a * 16 + j] - Ct[c * 16 + j]; s = fma(d, d, s); }
-        Dc[(int64_t)a * k + c] = sqrt(s);
+        Dc[(int64_t)a * k + c] = s;                       // squared: the filter compares against squared thresholds
     }
 }
 

@@ -35,6 +35,9 @@ for it in its:
         D = ((xs * xs).sum(1)[:, None] - 2 * xs @ C.T + c2[None]).clamp_min(0)
         v, ix = D.min(1)
         lab[i0:i0 + (1 << 20)] = ix; da[i0:i0 + (1 << 20)] = v.sqrt()
+    if os.environ.get("SORT_BY_LABEL") == "1":          # what a label-sorted copy of the samples would give
+        order = torch.argsort(lab, stable=True)
+        lab, da = lab[order], da[order]
     Dc = torch.cdist(C, C)
     Ds, _ = Dc.sort(1)
     nw = N // 64
