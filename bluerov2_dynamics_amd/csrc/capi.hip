@@ -8,6 +8,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <ctime>
 #include <vector>
 
 #include "../../include/brov2.h"
@@ -423,6 +424,7 @@ int brov_create(int device_id, brov_ctx** out) {
         hipEventCreateWithFlags(&c->ev_handover, hipEventDisableTiming) != hipSuccess) {
         if (c->ev0) (void)hipEventDestroy(c->ev0);
         if (c->ev1) (void)hipEventDestroy(c->ev1);
+        if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
         delete c;
         return BROV_ERR_HIP;
     }
@@ -589,14 +591,32 @@ constexpr size_t IO_FLAGS = SMALL_B * (13 + 8 + 24 + 13);          // offset (in
 constexpr size_t IO_DOUBLES = IO_FLAGS + SMALL_B + 64;
 
 // Wait for the per-call kernel: every row's thread stores the call's sequence number to its flag after its results (release,
-// system scope), the host spins on the flags (acquire) -- 3-4 us less than hipStreamSynchronize.  If the flags do not arrive
-// within ~50 ms of spinning (a faulted kernel, a debugger) the stream is synchronised and its status reported.
+// system scope), the host spins on the flags (acquire) -- 3-4 us less than hipStreamSynchronize.  The spin is bounded by the
+// CLOCK, not by an iteration count (`pause` costs 10-140 cycles depending on the CPU): after 2 ms without the flags -- long
+// prior work on the stream, a faulted kernel, a debugger -- the stream is synchronised instead and its status reported.  A ctx
+// bound to a caller's stream (brov_set_stream) never spins: other work may be queued in front of the launch.
 static int wait_flags(brov_ctx* c, int64_t B, unsigned long long seq, const char* what) {
     volatile unsigned long long* f = reinterpret_cast<volatile unsigned long long*>(c->h_io + IO_FLAGS);
+    if (c->stream != nullptr) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e, what);
+        for (int64_t b = 0; b < B; ++b)
+            if (__atomic_load_n(const_cast<unsigned long long*>(&f[b]), __ATOMIC_ACQUIRE) != seq) return fail(c, BROV_ERR_HIP, what);
+        return BROV_OK;
+    }
+    timespec t0{};
+    bool timed = false;
     for (int64_t b = 0; b < B; ++b) {
         long spins = 0;
         while (__atomic_load_n(const_cast<unsigned long long*>(&f[b]), __ATOMIC_ACQUIRE) != seq) {
-            if (++spins > 20000000L) {
+            bool give_up = false;
+            if ((++spins & 0x3FF) == 0) {                 // look at the clock every 1024 polls
+                timespec t1{};
+                clock_gettime(CLOCK_MONOTONIC, &t1);
+                if (!timed) { t0 = t1; timed = true; }
+                give_up = (t1.tv_sec - t0.tv_sec) * 1000000000L + (t1.tv_nsec - t0.tv_nsec) > 2000000L;
+            }
+            if (give_up) {
                 hipError_t e = hipStreamSynchronize(c->stream);
                 if (e != hipSuccess) return hip_fail(c, e, what);
                 if (__atomic_load_n(const_cast<unsigned long long*>(&f[b]), __ATOMIC_ACQUIRE) != seq) return fail(c, BROV_ERR_HIP, what);
@@ -1210,6 +1230,13 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
             HIPCK(c, hipStreamCreateWithFlags(&c->side[g - 1], hipStreamNonBlocking));
             HIPCK(c, hipEventCreateWithFlags(&c->ev_join[g - 1], hipEventDisableTiming));
         }
+    // Any early return between the fork and the join below would leave side-stream kernels running on arena scratch that the
+    // Arena destructor hands to the next call: this guard (declared after the Arena, so destroyed before it) waits for the
+    // side streams on every path that did not reach the join.
+    struct SideJoin {
+        brov_ctx* c; int G; bool armed = false;
+        ~SideJoin() { if (armed) for (int g = 1; g < G; ++g) if (c->side[g - 1]) (void)hipStreamSynchronize(c->side[g - 1]); }
+    } side_join{c, G};
     {
         CallTimer t(c);
         HIPCK(c, launch_transpose(c->stream, N, r, dU, r, dUt, NUt));
@@ -1221,6 +1248,7 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
         // the ramp and tail of one group's launch are covered by the other's.
         if (G > 1) {
             HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
+            side_join.armed = true;
             for (int g = 1; g < G; ++g) HIPCK(c, hipStreamWaitEvent(c->side[g - 1], c->ev_fork, 0));
         }
         for (int64_t t = 0; t < H; ++t) {
@@ -1233,6 +1261,7 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
             std::swap(zin, zout);
         }
         for (int g = 1; g < G; ++g) { HIPCK(c, hipEventRecord(c->ev_join[g - 1], c->side[g - 1])); HIPCK(c, hipStreamWaitEvent(c->stream, c->ev_join[g - 1], 0)); }
+        side_join.armed = false;                     // joined: the ctx stream now orders everything behind the side streams
         HIPCK(c, launch_endpoint_se(c->stream, s, n, dX + H * n, zin, dse, xhat_end ? dxh : nullptr));
         HIPCK(c, launch_sum(c->stream, nw, dse, dtot));
     }

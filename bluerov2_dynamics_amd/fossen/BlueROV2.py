@@ -93,6 +93,40 @@ class _ThrusterEntry(dict):
         else:
             dict.__setitem__(self, key, value)
 
+    # dict.update / setdefault / |= bypass __setitem__ in CPython: route them through it, so that no foreign array can take
+    # the place of a view of the geometry block (the edit would never reach the device and the per-call check would see no change)
+    def update(self, *args, **kw):
+        for k, v in dict(*args, **kw).items():
+            self[k] = v
+
+    def setdefault(self, key, default=None):
+        if key in self:
+            return self[key]
+        self[key] = default
+        return self[key]
+
+    def __ior__(self, other):
+        self.update(other)
+        return self
+
+    def _keep(self, key):
+        if key in ("r", "dir"):
+            raise KeyError(f"thruster entry: {key!r} is a view of the vehicle's geometry block and cannot be removed")
+
+    def __delitem__(self, key):
+        self._keep(key)
+        dict.__delitem__(self, key)
+
+    def pop(self, key, *default):
+        self._keep(key)
+        return dict.pop(self, key, *default)
+
+    def popitem(self):
+        raise KeyError("thruster entry: items cannot be removed")
+
+    def clear(self):
+        raise KeyError("thruster entry: items cannot be removed")
+
 
 class _ThrusterList(list):
     def __setitem__(self, i, entry):

@@ -230,3 +230,28 @@ def test_bench_instruction_counts_match_the_compiler_listing(tmp_path):
         assert static - rare - 25 <= bench.ROLLOUT_EXEC_FP64_INSTR[integ] <= static - rare + 25, (integ, static, out)
         # the two waves of a SIMD keep nothing in scratch and no accumulator-file spills
         assert all(l.get("acc", 0) == 0 and l.get("lane", 0) <= 4 for l in loops[:2]), out
+
+
+def test_hand_scheduled_mfma_loops_have_no_copies_or_spills(tmp_path):
+    """gram_kernel and wrows_kernel issue their operand loads as inline-assembly global_load_dwordx2 and wait with explicit
+    s_waitcnt vmcnt(N): the compiler does not know the destination registers are written asynchronously (round-2 advice).
+    Check on the compiler's own listing of the shipped source that no copy, spill or accumulator-file move touches an
+    operand or accumulator register inside those loops, and that nothing reads a loaded register before the wait that
+    covers it (tools/isa_async_loads.py; a deliberately broken listing must be flagged)."""
+    import sys
+    from bluerov2_dynamics_amd import _build
+    asm = tmp_path / "edmdc.s"
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBROV2_BUILDING=1", "--offload-device-only", "-S",
+                           "-o", str(asm), os.path.join(_build.CSRC, "edmdc.hip")], stderr=subprocess.DEVNULL)
+    tool = os.path.join(REPO, "tools", "isa_async_loads.py")
+    r = subprocess.run([sys.executable, tool, str(asm), "gram_kernel", "wrows_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.count("1 hand-scheduled loop(s) checked, 0 problem(s)") == 3, r.stdout + r.stderr
+    # the checker itself: a copy of a load destination placed right behind the load must be reported
+    lines = asm.read_text().split("\n")
+    k = next(i for i, l in enumerate(lines) if l.startswith("_ZN4brov12wrows_kernel"))
+    j = next(i for i in range(k, len(lines)) if "global_load_dwordx2" in lines[i] and "Inner Loop" in "".join(lines[i - 8:i]))
+    dst = re.search(r"global_load_dwordx2 (v\[\d+:\d+\])", lines[j]).group(1)
+    bad = tmp_path / "bad.s"
+    bad.write_text("\n".join(lines[:j + 1] + [f"\tv_mov_b64_e32 v[2:3], {dst}"] + lines[j + 1:]))
+    r = subprocess.run([sys.executable, tool, str(bad), "wrows_kernel"], capture_output=True, text=True)
+    assert r.returncode == 1 and "PROBLEM" in r.stdout, r.stdout

@@ -162,3 +162,16 @@ def test_thruster_geometry_entries_are_views_of_one_block():
         lst[4]["r"] = np.zeros(4)
     with np.testing.assert_raises(TypeError):
         lst[0:2] = []
+    # round-2 advice: dict.update / setdefault / |= bypass __setitem__ in CPython -- they must land in the block too
+    lst[5].update(r=[0.1, 0.2, 0.3])
+    assert np.array_equal(geom[5, 0], [0.1, 0.2, 0.3]) and np.shares_memory(lst[5]["r"], geom)
+    lst[5].update({"dir": np.array([0.0, 0.0, -1.0])}, note="x")
+    assert np.array_equal(geom[5, 1], [0.0, 0.0, -1.0]) and lst[5]["note"] == "x" and np.shares_memory(lst[5]["dir"], geom)
+    lst[6] |= {"r": [3.0, 2.0, 1.0]}
+    assert np.array_equal(geom[6, 0], [3.0, 2.0, 1.0]) and isinstance(lst[6], _ThrusterEntry)
+    assert lst[6].setdefault("r", [0, 0, 0]) is lst[6]["r"] and np.array_equal(geom[6, 0], [3.0, 2.0, 1.0])
+    assert lst[6].setdefault("tag", 7) == 7
+    for bad in (lambda: lst[6].pop("r"), lambda: lst[6].clear(), lambda: lst[6].__delitem__("dir"), lambda: lst[6].popitem()):
+        with np.testing.assert_raises(KeyError):
+            bad()
+    assert lst[6].pop("tag") == 7
