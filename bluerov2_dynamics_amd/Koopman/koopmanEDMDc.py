@@ -68,8 +68,21 @@ class KoopmanEDMDc:
         U = np.asarray(U, dtype=float)
         N, n = X.shape
         assert U.shape[0] == N and U.shape[1] == self.input_dim
-        self.centers_ = _kmeans_centers(X, self.n_rbfs, self.kmeans) if centers is None else np.asarray(centers, dtype=float)
-        self._solve([X], [U], fit_order=True)
+        if N < 2 or (centers is None and self.kmeans == "sklearn"):
+            self.centers_ = _kmeans_centers(X, self.n_rbfs, self.kmeans) if centers is None else np.asarray(centers, dtype=float)
+            self._solve([X], [U], fit_order=True)
+            return
+        # one upload of the samples; centres, Gram and the two products of (P G^T) Y all read them where they lie in HBM
+        # (round 2 uploaded X three times and went through three host entry points)
+        import torch
+        dev = torch.device("cuda", engine.default_context().device)
+        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
+        Ud = torch.from_numpy(np.ascontiguousarray(U[:N - 1])).to(dev)
+        Cd = None if centers is None else torch.from_numpy(np.ascontiguousarray(np.asarray(centers, dtype=float))).to(dev)
+        k = self.n_rbfs if centers is None else Cd.shape[0]
+        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=engine.default_context())
+        self.centers_ = C.cpu().numpy() if centers is None else np.asarray(centers, dtype=float)
+        self.lift_dim_ = self.state_dim + self.centers_.shape[0]
 
     def fit_multi(self, X_list, U_list, centers=None) -> None:
         """Fit from several independent trajectories without cross-bag transitions (reference :113-152)."""

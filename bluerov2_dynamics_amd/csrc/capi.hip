@@ -43,6 +43,13 @@ struct brov_ctx {
     int btu_staging = 0;
     int single_lane = 0;          // 1: never use the two-wave rollout kernel (A/B measurements: BROV2_ROLLOUT_SINGLE_LANE=1)
     int64_t chunk_rows = (int64_t)1 << 20;
+    // lifted-row cache of fit(): edmdc_gram_dev lifts its chunks straight into it, edmdc_pinv_apply_dev with the same arguments
+    // reads them back instead of lifting again (edmdc_lift_cache; the caller promises not to touch X / U / C in between)
+    size_t lift_cache_max = 0;    // 0 = off
+    char* lift_cache = nullptr;
+    size_t lift_cache_cap = 0;
+    bool lift_cache_valid = false;
+    struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; } lift_key = {};
     int kmeans_variant = 0;       // Lloyd E-step: 0 = candidate filter (triangle inequality, per wave), 1 = full scan (the second implementation)
     int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
     void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
@@ -451,6 +458,7 @@ void brov_destroy(brov_ctx* c) {
     if (c->d_fp) (void)hipFree(c->d_fp);
     if (c->d_fp_di) (void)hipFree(c->d_fp_di);
     if (c->d_partial) (void)hipFree(c->d_partial);
+    if (c->lift_cache) (void)hipFree(c->lift_cache);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
@@ -966,6 +974,9 @@ static int ensure_tasks(brov_ctx* c, const EdmdcShape& s, int mode) {
     return BROV_OK;
 }
 
+// one cache slot = the lifted rows of a chunk (+ 8 rows of padding: the Gram kernel prefetches past the end) and their pair weights
+static size_t lift_slot_bytes(int64_t chunk, int width) { return ((size_t)(chunk + 8) * width + (size_t)(chunk + 8)) * 8; }
+
 static int ensure_partial(brov_ctx* c, size_t pdoubles) {
     if (pdoubles * 8 > c->partial_cap) {
         HIPCK(c, hipStreamSynchronize(c->stream));
@@ -1002,17 +1013,39 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
     if (rc) return rc;
     double* dZ = a.take<double>((size_t)(chunk + 8) * s.width);
     double* dw = a.take<double>(chunk + 8);
+    // lifted-row cache (edmdc_lift_cache): when every chunk of this call fits, lift straight into the cache slots
+    c->lift_cache_valid = false;
+    const int64_t nchunks = total_pairs_rows > 0 ? (total_pairs_rows + chunk - 1) / chunk : 0;
+    const size_t slot = lift_slot_bytes(chunk, s.width);
+    bool caching = false;
+    if (c->lift_cache_max && nchunks > 0 && (size_t)nchunks * slot <= c->lift_cache_max) {
+        if ((size_t)nchunks * slot > c->lift_cache_cap) {
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            if (c->lift_cache) (void)hipFree(c->lift_cache);
+            c->lift_cache = nullptr; c->lift_cache_cap = 0;
+            if (hipMalloc((void**)&c->lift_cache, (size_t)nchunks * slot) == hipSuccess) c->lift_cache_cap = (size_t)nchunks * slot;
+            else (void)hipGetLastError();                 // no room: carry on without the cache
+        }
+        caching = c->lift_cache != nullptr;
+    }
     CallTimer t(c);
     if (total_pairs_rows == 0) {
         HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
     }
     int first = 1;
-    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk) {
+    int64_t ci = 0;
+    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk, ++ci) {
         const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
-        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
-        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], npairs, dZ, dZ, dw, c->d_partial, first ? 0 : 1));
+        double* z = caching ? reinterpret_cast<double*>(c->lift_cache + (size_t)ci * slot) : dZ;
+        double* w = caching ? z + (size_t)(chunk + 8) * s.width : dw;
+        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], npairs, z, z, w, c->d_partial, first ? 0 : 1));
         first = 0;
+    }
+    if (caching) {
+        c->lift_key = {d_X, d_U, d_C, n, r, k, gamma, nbags, L, xs, us, chunk};
+        c->lift_cache_valid = true;
     }
     HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], c->d_partial, accumulate, d_GtG, d_GtY));
     return BROV_OK;
@@ -1029,6 +1062,19 @@ int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows
     const EdmdcShape s = edmdc_shape(n, r, k);
     wrows_decomposition(s, wrows_items_per_192_rows, wrows_tiles_wanted);
     (void)gram_partial_doubles(s, 1, wty_tasks, wty_slabs);
+    return BROV_OK;
+}
+
+int edmdc_lift_cache(brov_ctx* c, size_t max_bytes) {
+    if (!c) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    c->lift_cache_max = max_bytes;
+    c->lift_cache_valid = false;
+    if (max_bytes == 0 && c->lift_cache) {
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        (void)hipFree(c->lift_cache);
+        c->lift_cache = nullptr; c->lift_cache_cap = 0;
+    }
     return BROV_OK;
 }
 
@@ -1088,15 +1134,23 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     HIPCK(c, hipMemsetAsync(dWr, 0, (size_t)(chunk + 8) * W * 8, c->stream));   // the Gram kernel prefetches up to 8 rows past the chunk
+    // the lifted rows edmdc_gram_dev left in the cache for exactly these arguments (edmdc_lift_cache): no second lift
+    const brov_ctx::LiftKey& lk = c->lift_key;
+    const bool cached = c->lift_cache_valid && lk.X == d_X && lk.U == d_U && lk.C == d_C && lk.n == n && lk.r == r && lk.k == k &&
+                        lk.gamma == gamma && lk.nbags == nbags && lk.L == L && lk.xs == xs && lk.us == us && lk.chunk == chunk;
+    const size_t slot = lift_slot_bytes(chunk, W);
     CallTimer t(c);
     if (total_pairs_rows == 0) HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
     int first = 1;
-    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk) {
+    int64_t ci = 0;
+    for (int64_t r0 = 0; r0 < total_pairs_rows; r0 += chunk, ++ci) {
         const int64_t npairs = (total_pairs_rows - r0 < chunk) ? (total_pairs_rows - r0) : chunk;
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
-        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, dZ, dw));
-        HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, dZ, dPt, dWr, c->apply_variant));
-        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], npairs, dWr, dZ, dw, c->d_partial, first ? 0 : 1));
+        double* z = cached ? reinterpret_cast<double*>(c->lift_cache + (size_t)ci * slot) : dZ;
+        double* w = cached ? z + (size_t)(chunk + 8) * W : dw;
+        if (!cached) HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w));
+        HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, z, dPt, dWr, c->apply_variant));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], npairs, dWr, z, w, c->d_partial, first ? 0 : 1));
         first = 0;
     }
     HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], c->d_partial, 0, nullptr, d_M));

@@ -395,13 +395,14 @@ def pinv_apply_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, P, M, c
 
 
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None):
+            timings=None, lift_cache=True):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
     two products of `(P G^T) Y` on the device (order="fit_multi": `P (G^T Y)` on the host).  Returns (A [d,d], B [d,r],
     centres CUDA [k,n]); timings (dict) receives the stage wall times in seconds, the Lloyd iteration count and whether
-    the stopping rule fired before max_iter."""
+    the stopping rule fired before max_iter.  lift_cache: keep the lifted rows of the Gram pass in HBM for the apply pass
+    when they fit (edmdc_lift_cache; X, U, C are not touched in between)."""
     import time
     import torch
     ctx = ctx or default_context(X.device.index)
@@ -422,6 +423,15 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     t1 = tick()
     GG = torch.empty((p * p + p * d,), dtype=torch.float64, device=X.device)
     GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+    cache = False
+    if order == "fit" and lift_cache:
+        # keep the lifted rows of the Gram pass for the apply pass when HBM has room (rows x padded width x 8 B + slack)
+        W = (k + 15) // 16 * 16 + (n + r + 15) // 16 * 16
+        need = int(X.shape[0] * 1.01 + (1 << 21)) * (W + 1) * 8
+        free_b, _ = torch.cuda.mem_get_info(X.device)
+        if free_b > need + (4 << 30):
+            ctx.lift_cache(need)
+            cache = True
     gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
     Gh = GtG.cpu().numpy()
     t2 = tick()
@@ -432,6 +442,8 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
         M = torch.empty((p, d), dtype=torch.float64, device=X.device)
         pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
         Mt = M.cpu().numpy().T
+        if cache:
+            ctx.lift_cache(0)
     elif order == "fit_multi":
         with _blas_threads():
             Mt = (P @ GtY.cpu().numpy()).T
