@@ -433,8 +433,11 @@ __device__ __forceinline__ double pp_dist(const double x[KM_NMAX], Row&& crow, d
 //      2 = closest_i = min(closest_i, d(x_i, x_last)).
 // S[t][chunk] = sum over the chunk of min(closest_i, d(x_i, cand_t)), t < L;  S[PP_LMAX][chunk] = sum of closest_i.
 // One block per 4096-sample chunk, 256 threads x 16 samples, fixed reduction tree.
-template <int NS>
-__global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
+// BT threads per block: 256 at size (HBM-bound, many blocks per CU); 1024 when the whole sample set is a few chunks -- a thread then
+// walks 4 samples instead of 16, and at ~1.5 us of exposed load latency per sample that is a good part of a round (36 658 rows: 41 -> 34 us
+// per centre; the rest are the short dependent chains of staging, reduction and pp_decide)
+template <int NS, int BT>
+__global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
                                                              const double* __restrict__ xsq, const PPState* __restrict__ st, int par, int upd,
                                                              double* __restrict__ closest, double* __restrict__ S) {
     // candidate rows in LDS: [trial][16 coordinates | norm | pad]; row L = the centre chosen last.  A compiler-level memory
@@ -442,8 +445,8 @@ __global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, 
     // all 16 x 17 of them into registers (256 VGPRs + scratch, one wave per SIMD).
     constexpr int CSW = KM_NMAX + 2;
     __shared__ double cs[(PP_LMAX + 1) * CSW];
-    __shared__ double red[PP_THREADS / 64][PP_LMAX + 1];
-    for (int e = threadIdx.x; e < (L + 1) * CSW; e += PP_THREADS) {
+    __shared__ double red[BT / 64][PP_LMAX + 1];
+    for (int e = threadIdx.x; e < (L + 1) * CSW; e += BT) {
         const int t = e / CSW, j = e % CSW;
         const int64_t ci = t < L ? st->cand[par][t] : st->last;
         cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
@@ -454,8 +457,8 @@ __global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, 
     for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
     const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
 #pragma unroll 1
-    for (int q = 0; q < PP_CHUNK / PP_THREADS; ++q) {
-        const int64_t i = base + q * PP_THREADS + threadIdx.x;
+    for (int q = 0; q < PP_CHUNK / BT; ++q) {
+        const int64_t i = base + q * BT + threadIdx.x;
         if (i < N) {
             double x[KM_NMAX];
             pp_load_col<NS>(Xt, N, n, i, x);
@@ -488,7 +491,7 @@ __global__ void __launch_bounds__(PP_THREADS) pp_round_kernel(int64_t N, int n, 
     __syncthreads();
     if (threadIdx.x <= PP_LMAX && (threadIdx.x < L || threadIdx.x == PP_LMAX)) {
         double a = 0.0;
-        for (int w = 0; w < PP_THREADS / 64; ++w) a += red[w][threadIdx.x];
+        for (int w = 0; w < BT / 64; ++w) a += red[w][threadIdx.x];
         S[(int64_t)threadIdx.x * nchunks + blockIdx.x] = a;
     }
 }
@@ -658,18 +661,21 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     if (lds > 100 * 1024) return hipErrorInvalidValue;
     PPState* ps = reinterpret_cast<PPState*>(state);
     const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
+    const bool small = nchunks <= 256 && N > 2048;     // fewer chunks than CUs (and more than a few waves of samples): latency, not bandwidth
 #define PP_DISPATCH(NS_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq); \
         hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
         if (k > 1) { \
-            hipLaunchKernelGGL(pp_round_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(L), dim3(PD_THREADS), lds, st, N, n, nchunks, L, 0, 1, u, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } \
         for (int c = 1; c < k; ++c) { \
             const int draw = c + 1 < k ? 1 : 0; \
-            hipLaunchKernelGGL(pp_round_kernel<NS_>, dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, L, c, draw, u + (size_t)c * L, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
