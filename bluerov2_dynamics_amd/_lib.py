@@ -108,7 +108,7 @@ SIGNATURES = {
     "edmdc_gram_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "edmdc_apply_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
     "edmdc_set_apply_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
-    "edmdc_lift_cache": (ctypes.c_int, [c_void_p, ctypes.c_size_t]),
+    "edmdc_lift_cache": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "edmdc_set_kmeans_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "brov_comm_available": (ctypes.c_int, []),
     "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
@@ -278,9 +278,10 @@ class Context:
         """0 auto, 1 always stage BTU tiles through LDS, 2 never (see include/brov2.h)."""
         self.check(self.lib.brov_set_btu_staging(self.h, int(mode)), "brov_set_btu_staging")
 
-    def lift_cache(self, max_bytes: int):
-        """Lifted-row cache of the fit() sequence gram -> apply (include/brov2.h: edmdc_lift_cache); 0 frees it."""
-        self.check(self.lib.edmdc_lift_cache(self.h, int(max_bytes)), "edmdc_lift_cache")
+    def lift_cache(self, device_ptr, nbytes: int = 0):
+        """Lend the ctx a device buffer for the lifted rows of the fit() sequence gram -> apply (include/brov2.h:
+        edmdc_lift_cache); device_ptr None / 0 withdraws it."""
+        self.check(self.lib.edmdc_lift_cache(self.h, c_void_p(device_ptr or 0), int(nbytes if device_ptr else 0)), "edmdc_lift_cache")
 
     def set_kmeans_variant(self, variant: int):
         """Lloyd's E-step: 0 = per-wave candidate filter (default), 1 = full scan (see include/brov2.h)."""

@@ -45,8 +45,7 @@ struct brov_ctx {
     int64_t chunk_rows = (int64_t)1 << 20;
     // lifted-row cache of fit(): edmdc_gram_dev lifts its chunks straight into it, edmdc_pinv_apply_dev with the same arguments
     // reads them back instead of lifting again (edmdc_lift_cache; the caller promises not to touch X / U / C in between)
-    size_t lift_cache_max = 0;    // 0 = off
-    char* lift_cache = nullptr;
+    char* lift_cache = nullptr;   // caller-owned device buffer (edmdc_lift_cache), nullptr = off
     size_t lift_cache_cap = 0;
     bool lift_cache_valid = false;
     struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; } lift_key = {};
@@ -458,7 +457,6 @@ void brov_destroy(brov_ctx* c) {
     if (c->d_fp) (void)hipFree(c->d_fp);
     if (c->d_fp_di) (void)hipFree(c->d_fp_di);
     if (c->d_partial) (void)hipFree(c->d_partial);
-    if (c->lift_cache) (void)hipFree(c->lift_cache);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev_handover) (void)hipEventDestroy(c->ev_handover);
@@ -1017,17 +1015,7 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
     c->lift_cache_valid = false;
     const int64_t nchunks = total_pairs_rows > 0 ? (total_pairs_rows + chunk - 1) / chunk : 0;
     const size_t slot = lift_slot_bytes(chunk, s.width);
-    bool caching = false;
-    if (c->lift_cache_max && nchunks > 0 && (size_t)nchunks * slot <= c->lift_cache_max) {
-        if ((size_t)nchunks * slot > c->lift_cache_cap) {
-            HIPCK(c, hipStreamSynchronize(c->stream));
-            if (c->lift_cache) (void)hipFree(c->lift_cache);
-            c->lift_cache = nullptr; c->lift_cache_cap = 0;
-            if (hipMalloc((void**)&c->lift_cache, (size_t)nchunks * slot) == hipSuccess) c->lift_cache_cap = (size_t)nchunks * slot;
-            else (void)hipGetLastError();                 // no room: carry on without the cache
-        }
-        caching = c->lift_cache != nullptr;
-    }
+    const bool caching = c->lift_cache && nchunks > 0 && (size_t)nchunks * slot <= c->lift_cache_cap;
     CallTimer t(c);
     if (total_pairs_rows == 0) {
         HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
@@ -1065,16 +1053,11 @@ int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows
     return BROV_OK;
 }
 
-int edmdc_lift_cache(brov_ctx* c, size_t max_bytes) {
-    if (!c) return BROV_ERR_ARG;
-    DeviceGuard g(c);
-    c->lift_cache_max = max_bytes;
+int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
+    if (!c || (d_buffer && (reinterpret_cast<uintptr_t>(d_buffer) & 15))) return fail(c, BROV_ERR_ARG, "edmdc_lift_cache: buffer must be 16-byte aligned");
+    c->lift_cache = d_buffer ? static_cast<char*>(d_buffer) : nullptr;
+    c->lift_cache_cap = d_buffer ? bytes : 0;
     c->lift_cache_valid = false;
-    if (max_bytes == 0 && c->lift_cache) {
-        HIPCK(c, hipStreamSynchronize(c->stream));
-        (void)hipFree(c->lift_cache);
-        c->lift_cache = nullptr; c->lift_cache_cap = 0;
-    }
     return BROV_OK;
 }
 

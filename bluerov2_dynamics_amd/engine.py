@@ -395,14 +395,16 @@ def pinv_apply_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, P, M, c
 
 
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None, lift_cache=True):
+            timings=None, lift_cache=False):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
     two products of `(P G^T) Y` on the device (order="fit_multi": `P (G^T Y)` on the host).  Returns (A [d,d], B [d,r],
     centres CUDA [k,n]); timings (dict) receives the stage wall times in seconds, the Lloyd iteration count and whether
-    the stopping rule fired before max_iter.  lift_cache: keep the lifted rows of the Gram pass in HBM for the apply pass
-    when they fit (edmdc_lift_cache; X, U, C are not touched in between)."""
+    the stopping rule fired before max_iter.  lift_cache=True: keep the lifted rows of the Gram pass in HBM for the apply pass
+    when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
+    45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
+    so it pays for repeated fits in one process, not for a single one; off by default."""
     import time
     import torch
     ctx = ctx or default_context(X.device.index)
@@ -423,32 +425,42 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     t1 = tick()
     GG = torch.empty((p * p + p * d,), dtype=torch.float64, device=X.device)
     GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
-    cache = False
+    if order not in ("fit", "fit_multi"):
+        raise ValueError("order must be 'fit' or 'fit_multi'")
+    cache_buf = None
     if order == "fit" and lift_cache:
         # keep the lifted rows of the Gram pass for the apply pass when HBM has room (rows x padded width x 8 B + slack)
         W = (k + 15) // 16 * 16 + (n + r + 15) // 16 * 16
         need = int(X.shape[0] * 1.01 + (1 << 21)) * (W + 1) * 8
         free_b, _ = torch.cuda.mem_get_info(X.device)
         if free_b > need + (4 << 30):
-            ctx.lift_cache(need)
-            cache = True
-    gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
-    Gh = GtG.cpu().numpy()
-    t2 = tick()
-    with _blas_threads():
-        P = np.linalg.pinv(Gh + ridge * np.eye(p))
-    t3 = time.perf_counter()
-    if order == "fit":
-        M = torch.empty((p, d), dtype=torch.float64, device=X.device)
-        pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
-        Mt = M.cpu().numpy().T
-        if cache:
-            ctx.lift_cache(0)
-    elif order == "fit_multi":
+            # torch's caching allocator owns the block: a second fit() gets it back without a trip to the driver (a raw
+            # hipMalloc of 45 GB right after a hipFree of the same size was seen to take 2.4 s)
+            try:
+                cache_buf = torch.empty(need, dtype=torch.uint8, device=X.device)
+            except RuntimeError:
+                cache_buf = None
+    try:
+        if cache_buf is not None:
+            ctx.lift_cache(cache_buf.data_ptr(), need)
+        gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
+        Gh = GtG.cpu().numpy()
+        t2 = tick()
         with _blas_threads():
-            Mt = (P @ GtY.cpu().numpy()).T
-    else:
-        raise ValueError("order must be 'fit' or 'fit_multi'")
+            P = np.linalg.pinv(Gh + ridge * np.eye(p))
+        t3 = time.perf_counter()
+        if order == "fit":
+            M = torch.empty((p, d), dtype=torch.float64, device=X.device)
+            pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
+            Mt = M.cpu().numpy().T
+        else:
+            with _blas_threads():
+                Mt = (P @ GtY.cpu().numpy()).T
+    finally:
+        if cache_buf is not None:              # withdraw the buffer before it goes back to the allocator, whatever happened
+            torch.cuda.synchronize(X.device)
+            ctx.lift_cache(None)
+            del cache_buf
     t4 = tick()
     tm.update(centres_s=t1 - t0, gram_s=t2 - t1, pinv_s=t3 - t2, apply_s=t4 - t3, total_s=t4 - t0)
     return np.ascontiguousarray(Mt[:, :d]), np.ascontiguousarray(Mt[:, d:]), C

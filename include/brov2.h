@@ -260,12 +260,13 @@ BROV_API int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nsl
  * are wanted; a tile product is 16 x 16 x 16 x 2 flop per 16 rows = 512 flop per row), and W^T Y is accumulated by `wty_tasks`
  * blocks of 4 x 6 tiles per slab of rows, `wty_slabs` slabs per chunk (12 288 flop per sample and task). */
 BROV_API int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows, int* wrows_tiles_wanted, int* wty_tasks, int* wty_slabs);
-/* Lifted-row cache for the fit() sequence edmdc_gram_dev -> (host pinv) -> edmdc_pinv_apply_dev.  With max_bytes > 0 the next
- * edmdc_gram_dev whose lifted chunks fit in max_bytes lifts them straight into a cache owned by the ctx (rows x padded width x 8
- * bytes: 45.7 GB for 1e7 states at k = 512 -- what 288 GB of HBM are for), and an edmdc_pinv_apply_dev with the SAME pointers,
- * shape, gamma and bag layout reads them back instead of lifting again.  The caller promises not to modify X, U or C between the
- * two calls.  max_bytes = 0 switches the cache off and frees it.  Any other edmdc_gram_dev call invalidates the cached rows. */
-BROV_API int edmdc_lift_cache(brov_ctx* ctx, size_t max_bytes);
+/* Lifted-row cache for the fit() sequence edmdc_gram_dev -> (host pinv) -> edmdc_pinv_apply_dev.  The caller lends the ctx a
+ * device buffer (16-byte aligned; rows x (padded width + 1) x 8 bytes plus 8 rows of padding per chunk: 45.7 GB for 1e7 states at
+ * k = 512 -- what 288 GB of HBM are for).  The next edmdc_gram_dev whose lifted chunks fit lifts them straight into it, and an
+ * edmdc_pinv_apply_dev with the SAME pointers, shape, gamma and bag layout reads them back instead of lifting again.  The caller
+ * promises not to modify X, U or C between the two calls and keeps the buffer alive until it is withdrawn (d_buffer = NULL).
+ * Any other edmdc_gram_dev call invalidates the cached rows. */
+BROV_API int edmdc_lift_cache(brov_ctx* ctx, void* d_buffer, size_t bytes);
 /* Which kernel forms the rows of W in edmdc_pinv_apply(_dev): 0 = the tuned one (default), 1 = the plain one-row-tile-per-wave
  * form (kept as an independent second implementation for the parity tests; BROV2_APPLY_SIMPLE=1 selects it at brov_create). */
 BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);

@@ -1238,7 +1238,7 @@ def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):
     A_nc, B_nc, _ = eng.fit_dev(Xd, Ud, 1, ntr - 1, kk, 1.0, 1e-3, order="fit", centers=Cd, lift_cache=False)
     for order in ("fit", "fit_multi"):
         tm = {}
-        A, B, _ = eng.fit_dev(Xd, Ud, 1, ntr - 1, kk, 1.0, 1e-3, order=order, centers=Cd, timings=tm)
+        A, B, _ = eng.fit_dev(Xd, Ud, 1, ntr - 1, kk, 1.0, 1e-3, order=order, centers=Cd, timings=tm, lift_cache=True)
         if order == "fit":       # the apply pass on the lifted rows the Gram pass left in HBM == the apply pass that lifts again
             assert np.array_equal(A, A_nc) and np.array_equal(B, B_nc)
         m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=kk, gamma=1.0, ridge=1e-3)

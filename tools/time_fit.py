@@ -15,6 +15,8 @@ simple = len(sys.argv) > 3 and sys.argv[3] == "simple"
 dev = torch.device("cuda", 0)
 ctx = _lib.default_context(0)
 ctx.set_apply_variant(1 if simple else 0)
+if os.environ.get("BROV2_CHUNK_ROWS"):
+    ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, int(os.environ["BROV2_CHUNK_ROWS"])), "edmdc_set_chunk_rows")
 n, r, k, gamma, ridge, L = 12, 8, 512, 1.0, 1e-3, 500
 nb = max(1, pairs // L)
 Ue = torch.empty((nb, L, r), dtype=torch.float64, device=dev)
