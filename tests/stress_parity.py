@@ -201,7 +201,84 @@ def kmeanspp():
     print(f"k-means++  : {n} cases, seed indices equal to scikit-learn's except {ties} exact-arithmetic ties", flush=True)
 
 
+def applies():
+    """edmdc_pinv_apply (round 3: tuned W-rows kernel with both block orientations + the W^T Y task packing by DP) against NumPy's
+    (P G^T) Y and against the plain W-rows kernel, random shapes / bags / chunk sizes."""
+    worst, n, t0 = 0.0, 0, time.time()
+    ctx = _lib.default_context()
+    while time.time() - t0 < budget:
+        n_, r = [(12, 8), (12, 6), (13, 6), (9, 4), (5, 2), (13, 8)][int(rng.integers(0, 6))]
+        k = int(rng.choice([1, 7, 16, 17, 48, 80, 100, 200, 257, 500, 512]))
+        nb = int(rng.integers(1, 4))
+        lens = [int(rng.choice([2, 3, 33, 100, 193, 257, 1000])) for _ in range(nb)]
+        chunk = int(rng.choice([64, 100, 192, 257, 4096, 1 << 20]))
+        ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, chunk), "edmdc_set_chunk_rows")
+        Xs = [np.cumsum(rng.normal(0, 0.05, (m, n_)), 0) for m in lens]
+        Us = [rng.uniform(-1, 1, (m, r)) for m in lens]
+        C = rng.normal(0, 0.4, (k, n_))
+        g = float(rng.choice([0.3, 1.0, 3.0]))
+        p = n_ + k + r
+        P = rng.normal(0, 1, (p, p)) / np.sqrt(p)
+        got = []
+        for v in (0, 1):
+            ctx.set_apply_variant(v)
+            got.append(engine.pinv_apply(Xs, Us, C, g, P))
+        ctx.set_apply_variant(0)
+        Mo = np.zeros_like(got[0])
+        for Xb, Ub in zip(Xs, Us):
+            G = np.hstack([ek.lift(Xb[:-1], C, g), Ub[:-1]])
+            Mo += (P @ G.T) @ ek.lift(Xb[1:], C, g)
+        sc = max(1e-300, np.abs(Mo).max())
+        e = max(np.abs(got[0] - Mo).max() / sc, np.abs(got[0] - got[1]).max() / sc)
+        assert np.isfinite(e) and e < 1e-11, ("apply", n_, r, k, lens, chunk, e)
+        worst, n = max(worst, float(e)), n + 1
+    ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, 1 << 20), "edmdc_set_chunk_rows")
+    print(f"fit() apply: {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
+def lloyds():
+    """Lloyd with the per-wave candidate filter == Lloyd with the full scan: identical labels and iteration counts."""
+    n, ties, t0 = 0, 0, time.time()
+    ctxs = []
+    for v in (0, 1):
+        c = _lib.Context(0)
+        c.set_kmeans_variant(v)
+        ctxs.append(c)
+    while time.time() - t0 < budget:
+        N = int(rng.choice([70, 1000, 4097, 30000, 120000]))
+        n_ = int(rng.choice([3, 5, 12, 13, 15]))
+        k = int(rng.choice([2, 63, 64, 65, 128, 300, 512, 700]))
+        if k > N:
+            continue
+        X = np.cumsum(rng.normal(0, 0.05, (N, n_)), 0) * float(rng.choice([1e-3, 1.0, 50.0]))
+        if rng.random() < 0.3:
+            X = X[rng.permutation(N)]
+        rounded = rng.random() < 0.2
+        if rounded:
+            X = np.round(X, 1)                        # many exact duplicates / ties
+        C0 = X[rng.choice(N, k, replace=False)].copy()
+        mean = X.mean(0)
+        # tie-prone data: one M-step only (after a tie has fallen differently in the two runs their later iterations differ for real)
+        it = 1 if rounded else int(rng.choice([1, 3, 12]))
+        (Ca, la, ia, na), (Cb, lb, ib, nbb) = [engine.kmeans_lloyd(X, C0 - mean, max_iter=it, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
+        assert na == nbb, ("lloyd iterations", N, n_, k, it)
+        assert np.max(np.abs(Ca - Cb)) <= 1e-11 * max(1.0, np.abs(Cb).max()), ("lloyd centres", N, n_, k)
+        # the member sums are fp64 atomics (order not fixed): two RUNS differ by rounding in their centres, so a sample exactly
+        # between two centres (rounded data) may fall either way -- in either variant.  A differing label must be such a tie.
+        for i in np.nonzero(la != lb)[0]:
+            x = (X[i] - mean).astype(np.longdouble)
+            da, db = [float(((x - Cb[j].astype(np.longdouble)) ** 2).sum()) for j in (la[i], lb[i])]
+            assert abs(da - db) <= 1e-12 * max(da, db, float((x * x).sum())), ("lloyd label differs without a tie", N, n_, k, it, int(i), da, db)
+            ties += 1
+        n += 1
+    for c in ctxs:
+        c.close()
+    print(f"Lloyd      : {n} cases, candidate filter == full scan (labels, iterations) except {ties} exact-distance ties", flush=True)
+
+
 if __name__ == "__main__":
+    applies()
+    lloyds()
     rollouts()
     windows()
     grams()

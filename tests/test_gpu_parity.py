@@ -665,6 +665,8 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
         for max_iter in (1, 7):
             out = [eng.kmeans_lloyd(X, C0 - mean, max_iter=max_iter, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
             (Ca, la, ina, ita), (Cb, lb, inb, itb) = out
+            # (the member sums are fp64 atomics: two runs differ by rounding in their centres, so a sample at exactly equal
+            # distance from two centres could fall either way in either variant -- continuous data here: no such ties)
             assert np.array_equal(la, lb), (ci, max_iter, int(np.sum(la != lb)))
             assert ita == itb
             if not np.isnan(X).any():
