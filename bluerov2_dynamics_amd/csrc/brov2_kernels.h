@@ -103,11 +103,11 @@ hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 size_t kmeans_workspace_doubles(int n, int k);
 int kmeans_blocks(int64_t N);
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2);
-// E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist, prm [2] from launch_kmeans_update)
+// E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist, prm [3] from launch_kmeans_update)
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const double* Dc, const double* prm);
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, double* Dc);
+                                double* block_xmax, const float* Dc, const double* prm);
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc);
 hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
                                 const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm);
 

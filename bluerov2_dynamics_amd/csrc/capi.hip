@@ -1367,12 +1367,12 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     Arena a(c);
     const bool filter = c->kmeans_variant == 0 && k >= 64;       // below one mask word there is nothing to skip
     int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + 2 * Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
-                       Arena::al(filter ? (size_t)k * k * 8 : 8) + 4096);
+                       Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) + 4096);
     if (rc) return rc;
     double* partial = a.take<double>((size_t)nb * k * (n + 1));
     double* binert = a.take<double>(nb);
     double* bxmax = a.take<double>(nb);
-    double* Dc = a.take<double>(filter ? (size_t)k * k : 1);
+    float* Dc = a.take<float>(filter ? (size_t)k * ((k + 255) & ~255) : 1);
     int* bchg = a.take<int>(nb);
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* stats = a.take<double>(8);

@@ -26,7 +26,7 @@
 // The labels are those of the full scan bit for bit: a skipped centre's exact score is below the group centre's by more than
 // margin^2 / 2 = 5e-13 R^2 while the FMA chain errs by < 1.1e-15 R^2 (R^2 = 2 max |x|^2), so it cannot be the computed argmax,
 // and ties among the candidates resolve to the lowest index as before.  The centre-centre distances come from
-// kmeans_cdist_kernel (k x k doubles, rebuilt after every M-step; 2 MB at k = 512, L2 resident).  Waves with a stale label
+// kmeans_cdist_kernel (k x k floats rounded down, rebuilt after every M-step; 1 MB at k = 512, L2 resident).  Waves with a stale label
 // (first iteration), a non-finite sample or more than KM_GMAX label groups (shuffled data) take the full scan.
 #include "brov2_kernels.h"
 #include <cstdint>
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                                                             const double* __restrict__ Ct /* [k][16]: coordinates, |c|^2/2 at [n] */, int* __restrict__ labels,
                                                             double* __restrict__ partial /* [blocks][k][n+1] */,
                                                             double* __restrict__ block_inertia, int* __restrict__ block_changed,
-                                                            double* __restrict__ block_xmax, const double* __restrict__ Dc,
+                                                            double* __restrict__ block_xmax, const float* __restrict__ Dc,
                                                             const double* __restrict__ prm) {
     extern __shared__ double sums[];                  // [k][n+1]: member sums and count
     const int np1 = n + 1;
@@ -159,15 +159,27 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                     }
                 }
                 const int kw = (k + 63) >> 6;
-                // candidate mask of word w: centres 64 w + lane within the threshold of some group
-                auto word_mask = [&](int w) {
-                    const int cw = (w << 6) + lane;
-                    const int cc = cw < k ? cw : k - 1;
-                    bool pred = false;
+                const int kp = (k + 255) & ~255;                  // row length of Dc: blocks of 256 centres
+                // Candidate masks of one block of 256 centres: Dc holds the squared centre distances as floats rounded DOWN, permuted
+                // so that a lane's 16-byte load brings the centres 256 blk + 64 q + lane, q = 0..3 -- the four ballots are the
+                // four mask words of the block in natural bit order.  (Round 3, first form: doubles, one 8-byte load per group and
+                // 64-centre word -- 36 dependent load rounds per wave at k = 512 against 9 now.)
+                float tf[KM_GMAX];
+#pragma unroll
+                for (int g = 0; g < KM_GMAX; ++g) {
+                    // threshold as a float rounded UP, pinned in a scalar register
+                    const float t = g < ng ? fminf((float)(gthr2[g] * 1.0000001) + 1.0e-37f, 3.4028234e38f) : 0.0f;
+                    tf[g] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t)));
+                }
+                auto block_masks = [&](int blk, unsigned long long* m4) {
+                    bool p0 = false, p1 = false, p2 = false, p3 = false;
 #pragma unroll
                     for (int g = 0; g < KM_GMAX; ++g)
-                        if (g < ng) pred = pred || (Dc[(int64_t)ga[g] * k + cc] < gthr2[g]);
-                    return __ballot(pred && cw < k);
+                        if (g < ng) {
+                            const float4 v = *reinterpret_cast<const float4*>(Dc + (int64_t)ga[g] * kp + blk * 256 + lane * 4);
+                            p0 = p0 || v.x < tf[g]; p1 = p1 || v.y < tf[g]; p2 = p2 || v.z < tf[g]; p3 = p3 || v.w < tf[g];
+                        }
+                    m4[0] = __ballot(p0); m4[1] = __ballot(p1); m4[2] = __ballot(p2); m4[3] = __ballot(p3);
                 };
                 // candidates of one word in increasing index order, two per trip (their scalar loads go out together)
                 auto scan_word = [&](int w, unsigned long long mw) {
@@ -195,11 +207,11 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                     if (kw <= 8) {
                         // k <= 512: all mask words first (the group table is dead before the first centre is evaluated: with both
                         // alive the scalar registers did not fit and the hot loop carried 7 v_readlane / v_writelane per centre)
-                        unsigned long long mws[8];
-#pragma unroll
-                        for (int w = 0; w < 8; ++w) {
-                            mws[w] = w < kw ? word_mask(w) : 0ull;
-                            asm volatile("" ::: "memory");        // one word's distance loads at a time (64 VGPRs: hoisting all 8 x ng spills)
+                        unsigned long long mws[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+                        block_masks(0, mws);
+                        if (kw > 4) {
+                            asm volatile("" ::: "memory");        // one block's distance loads at a time (64 VGPRs)
+                            block_masks(1, mws + 4);
                         }
                         // one copy of the evaluation loop (eight unrolled copies were 30 KB of code and slower than the interleaved
                         // form); the word is picked with scalar selects
@@ -212,7 +224,12 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                         }
                     } else {
 #pragma unroll 1
-                        for (int w = 0; w < kw; ++w) scan_word(w, word_mask(w));
+                        for (int blk = 0; blk * 4 < kw; ++blk) {
+                            unsigned long long m4[4];
+                            block_masks(blk, m4);
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) scan_word(blk * 4 + q, m4[q]);
+                        }
                     }
                 }
             }
@@ -321,13 +338,21 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
     }
 }
 
-// squared centre-centre distances Dc[a][c] (difference form), one block per row; rebuilt after every M-step for the candidate filter
-__global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, double* __restrict__ Dc) {
+// squared centre-centre distances (difference form) for the candidate filter, one block per row, rebuilt after every M-step:
+// floats rounded DOWN (a candidate test that errs, errs towards evaluating), row length kp = k rounded up to 256, permuted inside
+// every block of 256 so that position 4 lane + q holds centre 64 q + lane (see block_masks); padding = +inf (never a candidate)
+__global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc) {
     const int a = blockIdx.x;
-    for (int c = threadIdx.x; c < k; c += 256) {
-        double s = 0.0;
-        for (int j = 0; j < n; ++j) { const double d = Ct[a * 16 + j] - Ct[c * 16 + j]; s = fma(d, d, s); }
-        Dc[(int64_t)a * k + c] = s;                       // squared: the filter compares against squared thresholds
+    const int kp = (k + 255) & ~255;
+    for (int c = threadIdx.x; c < kp; c += 256) {
+        float v = __builtin_inff();
+        if (c < k) {
+            double s = 0.0;
+            for (int j = 0; j < n; ++j) { const double d = Ct[a * 16 + j] - Ct[c * 16 + j]; s = fma(d, d, s); }
+            v = fminf((float)(s * 0.9999999), 3.0e38f);
+        }
+        const int r = c & 255;
+        Dc[(int64_t)a * kp + (c & ~255) + (r & 63) * 4 + (r >> 6)] = v;
     }
 }
 
@@ -695,7 +720,7 @@ hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, doubl
 // Dc != nullptr: the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist, prm from launch_kmeans_update).
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const double* Dc, const double* prm) {
+                                double* block_xmax, const float* Dc, const double* prm) {
     (void)C;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
     const size_t lds = (size_t)k * (n + 1) * sizeof(double) ;
@@ -711,7 +736,7 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 #undef KM_LAUNCH
     return hipGetLastError();
 }
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, double* Dc) {
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc) {
     hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc);
     return hipGetLastError();
 }
