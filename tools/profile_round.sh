@@ -5,7 +5,7 @@
 # trace only) and pmc_summary.json, fetch_probe.txt (known-bytes calibration of FETCH_SIZE / WRITE_SIZE).
 # Copy what should be judged into profiles/.
 set -e -o pipefail
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 root=$(pwd)
@@ -14,7 +14,7 @@ echo "bench done"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu > $root/$out/trace.log 2>&1 )
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 echo "trace done"
-short="--steps 1 --warmup 1 --edmdc-steps 1 --no-cpu --no-cfg4 --no-ar1"
+short="--steps 1 --warmup 1 --edmdc-steps 1 --no-cpu --no-cfg4 --no-ar1 --no-variants --no-fit --kmeans-iters 10"
 tools/pmc_pass.sh $out/pmc/fetch "FETCH_SIZE" -- python3 $root/bench.py $short
 tools/pmc_pass.sh $out/pmc/write "WRITE_SIZE" -- python3 $root/bench.py $short
 tools/pmc_pass.sh $out/pmc/sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES" -- python3 $root/bench.py $short
