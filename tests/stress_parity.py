@@ -3,7 +3,7 @@
 strides, bag structures and chunk sizes through the C ABI against the oracle.  Prints the worst relative error per family
 and exits non-zero on the first violation.
 
-    python tests/stress_parity.py [seconds per family = 40] [seed = 0]
+    python tests/stress_parity.py [seconds per family = 40] [seed = 0] [families, comma separated: applies,lloyds,rollouts,windows,grams,multistep,kmeanspp]
 
 Lives under tests/ because it checks against oracle/ (test infrastructure); tests/test_gpu_parity.py runs a short sweep."""
 import os, sys, time
@@ -208,7 +208,7 @@ def applies():
     ctx = _lib.default_context()
     while time.time() - t0 < budget:
         n_, r = [(12, 8), (12, 6), (13, 6), (9, 4), (5, 2), (13, 8)][int(rng.integers(0, 6))]
-        k = int(rng.choice([1, 7, 16, 17, 48, 80, 100, 200, 257, 500, 512]))
+        k = int(rng.choice([1, 7, 16, 17, 48, 64, 80, 96, 100, 160, 200, 257, 500, 512, 530, 600]))     # every nt mod 6 of the W-rows plan
         nb = int(rng.integers(1, 4))
         lens = [int(rng.choice([2, 3, 33, 100, 193, 257, 1000])) for _ in range(nb)]
         chunk = int(rng.choice([64, 100, 192, 257, 4096, 1 << 20]))
@@ -277,11 +277,7 @@ def lloyds():
 
 
 if __name__ == "__main__":
-    applies()
-    lloyds()
-    rollouts()
-    windows()
-    grams()
-    multistep()
-    kmeanspp()
+    fams = dict(applies=applies, lloyds=lloyds, rollouts=rollouts, windows=windows, grams=grams, multistep=multistep, kmeanspp=kmeanspp)
+    for name in (sys.argv[3].split(",") if len(sys.argv) > 3 else list(fams)):
+        fams[name]()
     print("stress parity: ok")
