@@ -90,6 +90,24 @@ def pmc_traffic(parts):
     return None
 
 
+def lloyd_roofline(rows, kk, ms_per_step):
+    """fp64 issue-slot roofline of the Lloyd E-step (csrc/kmeans.hip, candidate filter): VALU instructions one E-step executes
+    (SQ_INSTS_VALU of a recorded counter run over the same data, profiles/r03_lloyd_pmc_summary.json) x 64 lanes x 2 flop over
+    the measured time per E + M step, against the fp64 vector peak -- the share of the chip's issue slots the kernel fills."""
+    if rows != 10_020_000 or kk != 512 or not ms_per_step:
+        return None
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r03_lloyd_pmc_summary.json")))["kmeans_assign_kernel<12, true>"]
+    except Exception:
+        return None
+    tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
+    return {"kernel": "kmeans_assign_kernel<12, true> (+ update, distances)", "bound": "valu_fp64_issue", "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
+            "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
+            "note": "every VALU slot priced as an FMA; the full scan executes 2.7 x the instructions (1.38e9) in 2.0 x the time",
+            "traffic": None}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -628,6 +646,7 @@ def main():
                                      ("apply_lift_wrows_wty_plus_download" if order == "fit" else "host_P_times_GtY"): tmf["apply_s"] * 1e3},
                        "lloyd_iterations": tmf["lloyd_iterations"], "lloyd_max_iter": a.kmeans_iters, "lloyd_converged": tmf["lloyd_converged"],
                        "kmeanspp_ms_device": tmf.get("kmeanspp_ms"), "lloyd_ms_device": tmf.get("lloyd_ms"),
+                       "lloyd_roofline": lloyd_roofline(nb * (L + 1), k, (tmf.get("lloyd_ms") or 0.0) / (tmf["lloyd_iterations"] + 1)),
                        "finite": bool(np.isfinite(A_f).all() and np.isfinite(B_f).all()),
                        "samples_per_s_excluding_centres": pairs / (tmf["total_s"] - tmf["centres_s"])}
                 if order == "fit":
