@@ -182,6 +182,16 @@ def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
         tiles_g = ((k + 15) // 16 * 16 + (n + r + 15) // 16 * 16) // 16
         assert nt * 24 >= tiles_g * (tiles_g + 1) // 2 + tiles_g * ((k + 15) // 16)        # at least the wanted products
         assert 1 <= ns <= 256 and (nt * ns <= 2048 or ns == 1)
+    # fit()'s apply pass (round 3): W rows in 17 blocks per 192 rows with all 408 tile products wanted (34 tiles = 5 x 6 + 4: both
+    # block orientations), W^T Y in 49 tasks x 41 slabs (54 x 37 with plain 4 x 6 blocks); every shape keeps one resident round
+    assert engine.apply_decomposition(12, 8, 512) == dict(wrows_items_per_192_rows=17, wrows_tiles_wanted=408, wty_tasks=49, wty_slabs=41)
+    for n, r, k in ((12, 8, 48), (12, 8, 64), (12, 8, 96), (12, 8, 200), (13, 6, 500), (9, 4, 100), (12, 8, 1024), (5, 2, 16)):
+        dec = engine.apply_decomposition(n, r, k)
+        tiles_w = ((k + 15) // 16 * 16 + (n + r + 15) // 16 * 16) // 16
+        tiles_y = (k + 15) // 16 + (n + 15) // 16
+        assert dec["wrows_items_per_192_rows"] * 24 >= dec["wrows_tiles_wanted"] == 12 * tiles_w
+        assert dec["wrows_items_per_192_rows"] * 24 < dec["wrows_tiles_wanted"] + 4 * 24           # at most a ragged column group
+        assert dec["wty_tasks"] * 24 >= tiles_w * tiles_y and (dec["wty_tasks"] * dec["wty_slabs"] <= 2048 or dec["wty_slabs"] == 1)
     nt, ns = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.edmdc_gram_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns)) == -1
     assert lib.edmdc_gram_decomposition(12, 8, 0, ctypes.byref(nt), ctypes.byref(ns)) == -1
