@@ -11,7 +11,7 @@ mkdir -p $out
 root=$(pwd)
 python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
-( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu > $root/$out/trace.log 2>&1 )
+( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu --no-variants > $root/$out/trace.log 2>&1 )
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
 echo "trace done"
 short="--steps 1 --warmup 1 --edmdc-steps 1 --no-cpu --no-cfg4 --no-ar1 --no-variants --no-fit --kmeans-iters 10"
