@@ -193,6 +193,7 @@ def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
         assert dec["wrows_items_per_192_rows"] * 24 < dec["wrows_tiles_wanted"] + 4 * 24           # at most a ragged column group
         assert dec["wty_tasks"] * 24 >= tiles_w * tiles_y and (dec["wty_tasks"] * dec["wty_slabs"] <= 2048 or dec["wty_slabs"] == 1)
     nt, ns = ctypes.c_int(0), ctypes.c_int(0)
+    assert lib.edmdc_apply_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns), ctypes.byref(nt), ctypes.byref(ns)) == -1
     assert lib.edmdc_gram_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns)) == -1
     assert lib.edmdc_gram_decomposition(12, 8, 0, ctypes.byref(nt), ctypes.byref(ns)) == -1
 

@@ -59,6 +59,9 @@ def test_c_abi_rejects_bad_arguments_with_a_message():
         lib.brov_rhs(h, 0, -3, P(x), P(u), 0.02, None, P(xT)),
         lib.edmdc_lift(h, 4, 12, 0, 1.0, P(x), P(x), P(x)),                                       # k = 0
         lib.edmdc_lift(h, 4, 40, 8, 1.0, P(x), P(x), P(x)),                                       # n beyond the supported 16
+        lib.edmdc_set_apply_variant(h, 2), lib.edmdc_set_kmeans_variant(h, -1),                    # round 3: unknown variants
+        lib.edmdc_lift_cache(h, ctypes.c_void_p(8), 1 << 20),                                      # buffer not 16-byte aligned
+        lib.edmdc_pinv_apply_dev(h, 12, 8, 16, 1.0, None, 1, 3, 4, 3, None, None, None, None),      # NULL everything
     ]
     assert all(rc == -1 for rc in bad), bad
     assert b"" != lib.brov_last_error(h) and len(lib.brov_last_error(h)) > 10
