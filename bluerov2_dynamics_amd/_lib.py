@@ -106,6 +106,7 @@ SIGNATURES = {
     "edmdc_pinv_apply_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                             i64, i64, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_gram_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
+    "edmdc_gtg_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "edmdc_apply_decomposition": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 4),
     "edmdc_set_apply_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "edmdc_lift_cache": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_size_t]),

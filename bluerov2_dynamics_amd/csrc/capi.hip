@@ -51,13 +51,13 @@ struct brov_ctx {
     struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; } lift_key = {};
     int kmeans_variant = 0;       // Lloyd E-step: 0 = candidate filter (triangle inequality, per wave), 1 = full scan (the second implementation)
     int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
-    void* d_tasks[2] = {nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply)
-    EdmdcShape task_shape[2] = {};
-    int ntasks[2] = {0, 0};
+    void* d_tasks[3] = {nullptr, nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply), [2] G^T G alone
+    EdmdcShape task_shape[3] = {};
+    int ntasks[3] = {0, 0, 0};
     // persistent EDMDc workspaces (separate from the per-call arena so that accumulate works across calls)
     double* d_partial = nullptr;
     size_t partial_cap = 0;
-    size_t tasks_cap[2] = {0, 0};     // bytes behind d_tasks[]
+    size_t tasks_cap[3] = {0, 0, 0};  // bytes behind d_tasks[]
     hipEvent_t ev_handover = nullptr; // orders the work queued on the previous stream before the next one (brov_set_stream)
     hipStream_t side[3] = {nullptr, nullptr, nullptr};   // extra streams of edmdc_multistep_se (window groups advance independently), created on demand
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -453,7 +453,7 @@ void brov_destroy(brov_ctx* c) {
     DeviceGuard g(c);
     (void)hipStreamSynchronize(c->stream);
     if (c->scratch) (void)hipFree(c->scratch);
-    for (int m = 0; m < 2; ++m) if (c->d_tasks[m]) (void)hipFree(c->d_tasks[m]);
+    for (int m = 0; m < 3; ++m) if (c->d_tasks[m]) (void)hipFree(c->d_tasks[m]);
     if (c->d_fp) (void)hipFree(c->d_fp);
     if (c->d_fp_di) (void)hipFree(c->d_fp_di);
     if (c->d_partial) (void)hipFree(c->d_partial);
@@ -990,17 +990,18 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
                    int64_t xs, int64_t us, const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
     int rc = edmdc_shape_ok(c, n, r, k);
     if (rc) return rc;
-    if (nbags < 0 || L < 0 || !d_C || !d_GtG || !d_GtY || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+    if (nbags < 0 || L < 0 || !d_C || !d_GtG || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
         return fail(c, BROV_ERR_ARG, "edmdc_gram_dev: bad argument");
+    const int mode = d_GtY ? 0 : 2;                     // no G^T Y wanted (fit()'s Gram pass): the staircase over the G tiles alone
     DeviceGuard g(c);
     const EdmdcShape s = edmdc_shape(n, r, k);
-    rc = ensure_tasks(c, s, 0);
+    rc = ensure_tasks(c, s, mode);
     if (rc) return rc;
     if (nbags <= 1) { xs = L + 1; us = L; }
     const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
     const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;   // rows that can start a pair
     int nslab = 0, ntasks = 0;
-    const size_t pdoubles = gram_partial_doubles(s, 0, &ntasks, &nslab);
+    const size_t pdoubles = gram_partial_doubles(s, mode, &ntasks, &nslab);
     rc = ensure_partial(c, pdoubles);
     if (rc) return rc;
     int64_t chunk = c->chunk_rows;
@@ -1028,20 +1029,26 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
         double* z = caching ? reinterpret_cast<double*>(c->lift_cache + (size_t)ci * slot) : dZ;
         double* w = caching ? z + (size_t)(chunk + 8) * s.width : dw;
         HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w));
-        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], npairs, z, z, w, c->d_partial, first ? 0 : 1));
+        HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[mode], c->d_tasks[mode], npairs, z, z, w, c->d_partial, first ? 0 : 1));
         first = 0;
     }
     if (caching) {
         c->lift_key = {d_X, d_U, d_C, n, r, k, gamma, nbags, L, xs, us, chunk};
         c->lift_cache_valid = true;
     }
-    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[0], c->d_tasks[0], c->d_partial, accumulate, d_GtG, d_GtY));
+    HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[mode], c->d_tasks[mode], c->d_partial, accumulate, d_GtG, d_GtY));
     return BROV_OK;
 }
 
 int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
     if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
     (void)gram_partial_doubles(edmdc_shape(n, r, k), 0, ntasks, nslabs);
+    return BROV_OK;
+}
+
+int edmdc_gtg_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
+    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    (void)gram_partial_doubles(edmdc_shape(n, r, k), 2, ntasks, nslabs);
     return BROV_OK;
 }
 

@@ -310,7 +310,8 @@ hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double ga
 struct GramTask { int a[GRAM_TA]; int b[GRAM_TB]; unsigned want; };
 constexpr unsigned GRAM_SWAP = 1u << 31;     // (mode 1) transposed block: A tiles are cut from the lifted rows, B tiles from the rows of W
 
-// mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T).
+// mode 0: G^T [G | Y] (fit_multi's normal equations); mode 1: W^T Y only (edmdc_pinv_apply: A operand = rows of W = G P^T);
+// mode 2: G^T G only (fit()'s Gram pass).
 // Mode 0 is a staircase: number the columns of [G | Y] 0 .. nt + nty - 1 (G tiles, then Y tiles); by symmetry row-tile i
 // needs columns i .. nt + nty - 1 only.  The row-tiles are cut into bands of 4 or 6: a 4-band into 4 x 6 blocks (A = the band's
 // rows, B = 6 columns), a 6-band into 6 x 4 blocks the other way round (A = 4 COLUMN tiles, weighted, G or Y; B = the band's
@@ -326,9 +327,11 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
     tasks.clear();
     static_assert(GRAM_TB == 6 && GRAM_TA == 4, "a 6-band is cut into TB x TA blocks");
     // mode 0: a staircase over the columns [G tiles | Y tiles]; mode 1: the full rectangle (W tiles) x (Y tiles), Y = the rbf
-    // tiles + the x part of the NEXT row's tail tile.  Both are cut by the same DP; only the column count of a band differs.
-    const bool stair = mode == 0;
-    const int nty = (stair && s.xplus) ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16;
+    // tiles + the x part of the NEXT row's tail tile; mode 2 (round 3): the staircase over the G tiles alone -- G^T G without
+    // G^T Y, which is all KoopmanEDMDc.fit needs before its pinv (Koopman/koopmanEDMDc.py:97 never forms G^T Y): 595 tile products
+    // instead of 1 683 at k = 512.  All three are cut by the same DP; only the column count of a band differs.
+    const bool stair = mode != 1;
+    const int nty = mode == 2 ? 0 : ((stair && s.xplus) ? s.kp / 16 : s.kp / 16 + (s.n + 15) / 16);
     const int ncol = stair ? nt + nty : nty;
     auto code = [&](int c) { return stair ? (c < nt ? c : ((c - nt) | 0x10000)) : (c | 0x10000); };     // column number -> tile code
     // Ragged ends.  A band whose column count does not divide by its block width ends in a partly empty block.  The last
@@ -833,6 +836,7 @@ __global__ void __launch_bounds__(256) gram_finish_kernel(EdmdcShape s, int ntas
     const int ra = dev_to_ref_feature(s, fa, ya, fya), rb = dev_to_ref_feature(s, fb, yb, fyb);
     if (ra < 0 || rb < 0 || (fya && fyb)) return;       // padding, or a Y x Y product nobody asked for
     const bool is_y = fya || fyb;
+    if (is_y && !GtY) return;                           // G^T G alone (mode 2): the x+ columns riding in the tail tile are Y features
     const int ri = fya ? rb : ra, rj = fya ? ra : rb;   // row of the output = the G-side feature (A = Y feature: transposed product)
     double sum = 0.0;
     const double* pp = partial + (int64_t)task * nslab * (GRAM_TA * GRAM_TB * 256) + tile * 256 + e;

@@ -14,7 +14,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "gtg_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
@@ -231,8 +231,18 @@ def apply_decomposition(n, r, k):
     return dict(zip(("wrows_items_per_192_rows", "wrows_tiles_wanted", "wty_tasks", "wty_slabs"), (x.value for x in v)))
 
 
+def gtg_decomposition(n, r, k):
+    """(ntasks, nslabs) of the G^T G-only Gram (gram_dev with GtY=None: fit()'s Gram pass)."""
+    nt, ns = ctypes.c_int(0), ctypes.c_int(0)
+    rc = _lib.load_library().edmdc_gtg_decomposition(int(n), int(r), int(k), ctypes.byref(nt), ctypes.byref(ns))
+    if rc:
+        raise ValueError(f"edmdc_gtg_decomposition: unsupported shape n={n} r={r} k={k}")
+    return nt.value, ns.value
+
+
 def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, accumulate=False, ctx=None):
-    """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h)."""
+    """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h).
+    GtY=None: G^T G alone -- all KoopmanEDMDc.fit needs before its pinv (a third of the tile products)."""
     ctx = ctx or default_context(X.device.index)
     ctx.use_torch_stream()
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
@@ -425,6 +435,8 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     t1 = tick()
     GG = torch.empty((p * p + p * d,), dtype=torch.float64, device=X.device)
     GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+    if order == "fit":
+        GtY = None                  # fit() never forms G^T Y (Koopman/koopmanEDMDc.py:89-97): its Gram pass is G^T G alone
     if order not in ("fit", "fit_multi"):
         raise ValueError("order must be 'fit' or 'fit_multi'")
     cache_buf = None

@@ -255,6 +255,9 @@ BROV_API int edmdc_pinv_apply_dev(brov_ctx* ctx, int n, int r, int k, double gam
  * equations G^T[G|Y] (Koopman/koopmanEDMDc.py:129-147) are computed as ntasks blocks of 4 x 6 tiles of 16 x 16 per slab of
  * rows, nslabs slabs per chunk; a task executes 24 x 16 x 16 x 2 = 12 288 flop per sample whether a tile is wanted or not. */
 BROV_API int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs);
+/* The same for edmdc_gram_dev called with d_GtY = NULL: G^T G alone, the Gram pass of KoopmanEDMDc.fit (which never forms G^T Y,
+ * Koopman/koopmanEDMDc.py:89-97). */
+BROV_API int edmdc_gtg_decomposition(int n, int r, int k, int* ntasks, int* nslabs);
 /* The same for edmdc_pinv_apply(_dev), fit()'s own product order (Koopman/koopmanEDMDc.py:97): the rows of W = G P^T are
  * formed per unit of 192 rows by `wrows_items_per_192_rows` blocks of 4 x 6 tiles (`wrows_tiles_wanted` of their tile products
  * are wanted; a tile product is 16 x 16 x 16 x 2 flop per 16 rows = 512 flop per row), and W^T Y is accumulated by `wty_tasks`

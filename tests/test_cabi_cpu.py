@@ -192,6 +192,12 @@ def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
         assert dec["wrows_items_per_192_rows"] * 24 >= dec["wrows_tiles_wanted"] == 12 * tiles_w
         assert dec["wrows_items_per_192_rows"] * 24 < dec["wrows_tiles_wanted"] + 4 * 24           # at most a ragged column group
         assert dec["wty_tasks"] * 24 >= tiles_w * tiles_y and (dec["wty_tasks"] * dec["wty_slabs"] <= 2048 or dec["wty_slabs"] == 1)
+    # fit()'s Gram pass: G^T G alone, 595 wanted tile products in 30 tasks x 68 slabs (the full Gram: 1 683 in 73 x 28)
+    assert engine.gtg_decomposition(12, 8, 512) == (30, 68)
+    for n, r, k in ((12, 8, 48), (12, 8, 200), (13, 6, 500), (12, 8, 1024), (5, 2, 16)):
+        nt_, ns_ = engine.gtg_decomposition(n, r, k)
+        tiles_g = ((k + 15) // 16 * 16 + (n + r + 15) // 16 * 16) // 16
+        assert nt_ * 24 >= tiles_g * (tiles_g + 1) // 2 and (nt_ * ns_ <= 2048 or ns_ == 1) and nt_ <= engine.gram_decomposition(n, r, k)[0]
     nt, ns = ctypes.c_int(0), ctypes.c_int(0)
     assert lib.edmdc_apply_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns), ctypes.byref(nt), ctypes.byref(ns)) == -1
     assert lib.edmdc_gram_decomposition(0, 8, 512, ctypes.byref(nt), ctypes.byref(ns)) == -1

@@ -1234,6 +1234,24 @@ def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):
         assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all()
         assert np.linalg.norm(got[0] - got[1]) / scale < 1e-13, (n, r, k, np.linalg.norm(got[0] - got[1]) / scale)
         assert np.linalg.norm(got[0] - Mo) / scale < 1e-11, (n, r, k, np.linalg.norm(got[0] - Mo) / scale)
+    # G^T G alone (gram_dev with GtY=None: the Gram pass of fit(), which never forms G^T Y) == the G^T G of the full Gram, over
+    # several chunks and bags, for shapes with and without the x+ columns in the tail tile
+    for (n, r, k, nb, L, chunk) in ((12, 8, 512, 5, 401, 772), (13, 6, 100, 3, 97, 64), (12, 8, 48, 2, 300, 1 << 20), (5, 2, 16, 2, 50, 1 << 20)):
+        X = rng.normal(0, 0.4, (nb * (L + 1), n))
+        U = rng.uniform(-1, 1, (nb * L, r))
+        C = X[rng.choice(len(X), k, replace=False)]
+        p, d = n + k + r, n + k
+        Xd, Ud, Cd = (torch.from_numpy(a).cuda() for a in (X, U, C))
+        ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, chunk), "edmdc_set_chunk_rows")
+        try:
+            G0 = torch.zeros((p, p), dtype=torch.float64, device="cuda"); Y0 = torch.zeros((p, d), dtype=torch.float64, device="cuda")
+            G2 = torch.full((p, p), float("nan"), dtype=torch.float64, device="cuda")
+            eng.gram_dev(Xd, Ud, Cd, 0.7, nb, L, L + 1, L, G0, Y0, ctx=ctx)
+            eng.gram_dev(Xd, Ud, Cd, 0.7, nb, L, L + 1, L, G2, None, ctx=ctx)
+        finally:
+            ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, 1 << 20), "edmdc_set_chunk_rows")
+        assert torch.isfinite(G2).all() and float((G2 - G0).norm() / G0.norm()) < 1e-13, (n, r, k)
+        assert torch.equal(G2, G2.T)
     # device-resident fit == the drop-in class on host arrays (same centres), both product orders
     g = load_golden("edmdc_fit.npz")
     X, U, ntr = g["X"][:3000], g["U"][:3000], 3000
