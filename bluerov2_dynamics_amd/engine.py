@@ -457,6 +457,8 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
             ctx.lift_cache(cache_buf.data_ptr(), need)
         gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
         Gh = GtG.cpu().numpy()
+        if getattr(ctx, "timing", False):
+            tm["gram_kernel_ms"] = ctx.last_kernel_ms()
         t2 = tick()
         with _blas_threads():
             P = np.linalg.pinv(Gh + ridge * np.eye(p))
