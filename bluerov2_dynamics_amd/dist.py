@@ -73,6 +73,17 @@ def _device_gram(X, U, C, gamma, nbags, L, xs, us):
     return GtG, GtY
 
 
+def _device_gtg(X, U, C, gamma, nbags, L, xs, us):
+    """Local G^T G alone (fit()'s own order never forms G^T Y) -> (GtG, a one-element placeholder) CUDA tensors."""
+    import torch
+    from . import engine
+    n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
+    p = n + k + r
+    GtG = torch.zeros((p, p), dtype=torch.float64, device=X.device)
+    engine.gram_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, GtG, None)
+    return GtG, GtG.new_zeros(1)
+
+
 def _device_apply(X, U, C, gamma, nbags, L, xs, us, P):
     """Local (P G^T) Y on this rank's GPU -> M [p, d] CUDA tensor."""
     import torch
@@ -103,7 +114,7 @@ def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, det
     nb, L1, n = X_local.shape
     L = L1 - 1
     assert U_local.shape[0] == nb and U_local.shape[1] == L
-    gram_fn = gram_fn or _device_gram
+    gram_fn = gram_fn or (_device_gtg if order == "fit" else _device_gram)
     allreduce = allreduce or (lambda a, b: allreduce_gram_(a, b, group, deterministic=deterministic))
     GtG, GtY = gram_fn(X_local, U_local, C, gamma, nb, L, L + 1, L)
     allreduce(GtG, GtY)
