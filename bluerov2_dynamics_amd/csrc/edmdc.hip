@@ -344,7 +344,10 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
     // k = 512, mode 1: 34 x 33 = 1 122 products; plain 4 x 6 blocks need 9 x 6 = 54 tasks (round 2), the DP 49 (bands
     // 4 4 4 4 4 4 4 6, six of the 4-bands leave set 0 to four shared blocks); 47 would be perfect packing.
     // Transposed blocks of mode 1 read their A tiles (Y) from the lifted rows and their B tiles from the rows of W: GRAM_SWAP.
-    const int G = nty / GRAM_TA < 3 ? nty / GRAM_TA : 3;
+    // (mode 2 has no Y columns: the sets are its last G columns, and a band may leave one out only if all its rows lie before the
+    // set's first column -- then every product of the shared block is wanted, as with Y sets.  k = 512: 30 -> 28 tasks.)
+    const int gmax = mode == 2 ? ncol / GRAM_TA - 1 : nty / GRAM_TA;
+    const int G = gmax < 0 ? 0 : (gmax < 3 ? gmax : 3);
     const int NM = 1 << G, NR = 216;                  // masks, (r0, r1, r2) in base 6
     struct Choice { int size = 0, mask = 0, next_r = 0; };
     const int INF = 1 << 28;
@@ -365,7 +368,12 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
                 const int width = size == 6 ? GRAM_TA : GRAM_TB;
                 for (int m = 0; m < NM; ++m) {
                     int pop = 0, extra = 0, nr[3] = {rr[0], rr[1], rr[2]};
-                    for (int g = 0; g < G; ++g) if ((m >> g) & 1) { ++pop; extra += (nr[g] + sz) / 6; nr[g] = (nr[g] + sz) % 6; }
+                    bool allowed = true;
+                    for (int g = 0; g < G; ++g) if ((m >> g) & 1) {
+                        if (stair && a0 + sz > ncol - GRAM_TA * (g + 1)) allowed = false;       // a row of the band lies inside the set
+                        ++pop; extra += (nr[g] + sz) / 6; nr[g] = (nr[g] + sz) % 6;
+                    }
+                    if (!allowed) continue;
                     const int cols = (stair ? ncol - a0 : ncol) - GRAM_TA * pop;
                     if (cols < (stair ? sz : 0)) continue;          // a staircase band keeps at least its diagonal block
                     const int nxt = nr[0] + 6 * nr[1] + 36 * nr[2];
@@ -382,7 +390,7 @@ static void build_gram_tasks(const EdmdcShape& s, std::vector<GramTask>& tasks, 
         std::vector<int> cols;                        // the band's own columns
         for (int c = stair ? a0 : 0; c < ncol; ++c) {
             const int g = (ncol - 1 - c) / GRAM_TA;   // shared set the column belongs to (if any)
-            if ((!stair || c >= nt) && g < G && ((ch.mask >> g) & 1)) continue;
+            if (g < G && ((ch.mask >> g) & 1)) continue;
             cols.push_back(c);
         }
         for (int g = 0; g < G; ++g) if ((ch.mask >> g) & 1) for (int i = 0; i < ch.size; ++i) shared[g].push_back(a0 + i);

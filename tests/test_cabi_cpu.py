@@ -192,8 +192,8 @@ def test_gram_decomposition_is_host_only_and_fills_the_chip(lib):
         assert dec["wrows_items_per_192_rows"] * 24 >= dec["wrows_tiles_wanted"] == 12 * tiles_w
         assert dec["wrows_items_per_192_rows"] * 24 < dec["wrows_tiles_wanted"] + 4 * 24           # at most a ragged column group
         assert dec["wty_tasks"] * 24 >= tiles_w * tiles_y and (dec["wty_tasks"] * dec["wty_slabs"] <= 2048 or dec["wty_slabs"] == 1)
-    # fit()'s Gram pass: G^T G alone, 595 wanted tile products in 30 tasks x 68 slabs (the full Gram: 1 683 in 73 x 28)
-    assert engine.gtg_decomposition(12, 8, 512) == (30, 68)
+    # fit()'s Gram pass: G^T G alone, 595 wanted tile products in 28 tasks x 73 slabs (the full Gram: 1 683 in 73 x 28)
+    assert engine.gtg_decomposition(12, 8, 512) == (28, 73)
     for n, r, k in ((12, 8, 48), (12, 8, 200), (13, 6, 500), (12, 8, 1024), (5, 2, 16)):
         nt_, ns_ = engine.gtg_decomposition(n, r, k)
         tiles_g = ((k + 15) // 16 * 16 + (n + r + 15) // 16 * 16) // 16
