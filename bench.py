@@ -674,6 +674,34 @@ def main():
             fit_legs["config"] = {"workload": f"BASELINE config 3 data ({pairs} pairs in {nb} bags, n=12 r=8 k=512 gamma={gamma} ridge={ridge}), device "
                                               f"resident; KMeans stopping rule max_iter={a.kmeans_iters} tol=1e-4; wall clock incl. host pinv and downloads"}
             out["edmdc_fit"] = fit_legs
+        # ---- the same fit() sharded over the ranks (N > 1; weak scaling, 1e7 pairs per GPU): centres from rank 0's shard (already
+        # broadcast above), local G^T G, all-reduce, the same host pinv on every rank, local (P G^T) Y, a second all-reduce of the
+        # p x d block (dist.fit_sharded(order="fit")); identical A, B on every rank
+        if not a.no_fit and world > 1:
+            def ar2(x, y):
+                allreduce_sum_(x)
+                allreduce_sum_(y)
+            Xs, Us = Xe.view(nb, L + 1, n), Ue.view(nb, L, r)
+            bdist.fit_sharded(Xs, Us, Cc, gamma, ridge, order="fit", allreduce=ar2)       # warm-up (BLAS pool, task tables, code objects)
+            barrier()
+            t0 = time.perf_counter()
+            A_s, B_s = bdist.fit_sharded(Xs, Us, Cc, gamma, ridge, order="fit", allreduce=ar2)
+            barrier()
+            swall = max_over_ranks(time.perf_counter() - t0)
+            chk = torch.tensor([float(np.abs(A_s).sum()), float(np.abs(B_s).sum())], dtype=torch.float64, device=dev)
+            lo, hi = chk.clone(), chk.clone()
+            if backend == "nccl":
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            else:
+                lo, hi = lo.cpu(), hi.cpu()
+                dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            if rank == 0:
+                out["edmdc_fit_sharded"] = {
+                    "metric": "fit_order_samples_per_s_given_centres", "value": world * pairs / swall, "unit": "samples/s", "wall_s": swall,
+                    "pairs_per_gpu": pairs, "ranks": world, "collectives": 2, "finite": bool(np.isfinite(A_s).all() and np.isfinite(B_s).all()),
+                    "identical_on_all_ranks": bool(torch.equal(lo.cpu(), hi.cpu())),
+                    "note": "KoopmanEDMDc.fit's own product order on sharded data: G^T G per rank + all-reduce + host pinv + (P G^T) Y per rank + "
+                            "all-reduce; centres given (rank 0's k-means over its shard, timed in edmdc.kmeans)"}
         # f1: KoopmanEDMDc.multistep_rmse on the recorded-data size of the reference (45 823 samples, H = 100;
         # training/best_results.txt:801 logs 41.19 s for it on the authors' CPU) -- rank 0 only, host arrays in/out
         if rank == 0:
