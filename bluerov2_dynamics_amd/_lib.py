@@ -285,7 +285,7 @@ class Context:
         self.check(self.lib.edmdc_lift_cache(self.h, c_void_p(device_ptr or 0), int(nbytes if device_ptr else 0)), "edmdc_lift_cache")
 
     def set_kmeans_variant(self, variant: int):
-        """Lloyd's E-step: 0 = per-wave candidate filter (default), 1 = full scan (see include/brov2.h)."""
+        """Lloyd's loop: 0 = candidate filter on sorted samples (default), 1 = full scan, 2 = filter without sorting (include/brov2.h)."""
         self.check(self.lib.edmdc_set_kmeans_variant(self.h, int(variant)), "edmdc_set_kmeans_variant")
 
     def set_apply_variant(self, variant: int):

@@ -30,6 +30,8 @@
 // (first iteration), a non-finite sample or more than KM_GMAX label groups (shuffled data) take the full scan.
 #include "brov2_kernels.h"
 #include <cstdint>
+#include <type_traits>
+#include <utility>
 
 namespace brov {
 
@@ -59,6 +61,31 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return max(max(r0, r1), max(r2, r3));
 }
 
+// sum over the 8 lanes of half a DPP row, in every lane of it (all lanes active).  Three steps of two 32-bit DPP moves and one
+// add: __builtin_amdgcn_mov_dpp leaves the "old" operand undefined (every source lane is valid), where update_dpp(0, ...) cost
+// two more moves per step.
+__device__ __forceinline__ double half_row_sum_f64(double v) {
+    auto dpp = [](double x, auto ctrl) {
+        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), decltype(ctrl)::value, 0xF, 0xF, true);
+        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), decltype(ctrl)::value, 0xF, 0xF, true);
+        return __hiloint2double(hi, lo);
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+    return v;
+}
+
+#ifndef KM_PROFILE
+#define KM_PROFILE 0
+#endif
+#if KM_PROFILE
+__device__ unsigned long long km_prof[8];
+#define KM_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[slot] += now_ - t_prev; t_prev = now_; } while (0)
+#else
+#define KM_STAMP(slot) do { } while (0)
+#endif
+
 // prm (device, written by kmeans_update_kernel): [0] = margin, [1] = eps2 (see the header comment); Dc: [k][k] centre distances
 template <int NS, bool PRUNE>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) kmeans_assign_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride,
@@ -67,7 +94,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
                                                             double* __restrict__ partial /* [blocks][k][n+1] */,
                                                             double* __restrict__ block_inertia, int* __restrict__ block_changed,
                                                             double* __restrict__ block_xmax, const float* __restrict__ Dc,
-                                                            const double* __restrict__ prm) {
+                                                            const double* __restrict__ prm, float* __restrict__ d2out) {
     extern __shared__ double sums[];                  // [k][n+1]: member sums and count
     const int np1 = n + 1;
     for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0.0;
@@ -256,7 +283,28 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
             if (ol != bi) ++changed;
             labels[i] = bi;
             xmax = fmax(xmax, x2);
-            inertia += fma(-2.0, best, x2);
+            const double dmin2 = fma(-2.0, best, x2);     // squared distance to the chosen centre (up to rounding)
+            if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
+            inertia += dmin2;
+        }
+        // member sums.  A wave whose 64 samples all went to ONE centre (the rule once the loop keeps its samples sorted) would send
+        // 64 same-address fp64 atomics per coordinate through the LDS, one after the other: 13 x 64 LDS cycles per wave, more than
+        // the filtered evaluation itself.  Such a wave adds its rows up inside groups of 8 lanes first (DPP, three steps) and
+        // sends eight atomics per coordinate (the vector ALU is the scarcer unit: a fourth step costs more than it saves).
+        const int bi0 = __builtin_amdgcn_readfirstlane(bi);
+        if (__ballot(!live || bi != bi0) == 0ull) {
+            double* s = sums + bi0 * np1;
+            const bool leader = (lane & 7) == 0;
+#pragma unroll
+            for (int j = 0; j < KM_NMAX; ++j)
+                if (NS > 0 ? (j < NS) : (j < n)) x[j] = half_row_sum_f64(x[j]);       // (x is dead after this pass)
+            if (leader) {
+#pragma unroll
+                for (int j = 0; j < KM_NMAX; ++j)
+                    if (NS > 0 ? (j < NS) : (j < n)) atomicAdd(&s[j], x[j]);
+                atomicAdd(&s[n], 8.0);
+            }
+        } else if (live) {
             double* s = sums + bi * np1;
             for (int j = 0; j < n; ++j) atomicAdd(&s[j], x[j]);
             atomicAdd(&s[n], 1.0);
@@ -282,6 +330,332 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
     for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) out[i] = sums[i];
 }
 
+// ---- E-step, second form: centre records from the LDS through DPP ---------------------------------------------------------------
+// Phase timing of the kernel above on the config-3 data (tools/lloyd_phase_profile.py): the evaluation of the candidates is a
+// third to a half of a wave's pass; the rest is waiting -- for the wave's own rows (HBM, nothing else to do meanwhile), for the
+// group centres' records (scalar loads, one after the other), for the rows of the distance table, and in the evaluation loop
+// for the scalar loads of the records (two in flight per wave: 52 scalar registers).  Eight waves per SIMD were there to hide
+// that and left 64 vector registers per lane, not enough to prefetch anything.  This form needs fewer waves:
+//   * the packed centre table lives in the LDS (64 KB at k = 512, next to the 53 KB of member sums: one 1024-thread block per
+//     CU, 4 waves per SIMD, 128 vector registers);
+//   * a centre record reaches a wave as ONE ds_read_b64 -- lane l gets double l & 15 of the record, so every DPP row of 16 lanes
+//     holds the whole record -- and the FMA takes its centre operand through `row_newbcast:j` (v_fmac_f64_dpp: the broadcast
+//     costs nothing; tools/dpp64_probe.hip checks rate and bits against the scalar-operand form).  A record in flight costs 2
+//     vector registers instead of 26 scalar ones: KM2_DEPTH records are prefetched round the evaluation loop;
+//   * the candidates of all mask words form one list in the LDS (written by the lanes that hold the mask bits: mbcnt ranks), padded
+//     by repeating the last candidate (an equal score never replaces the best): the loop spends no scalar instructions on bit
+//     scanning -- a wave issues one instruction every four cycles, and with four waves per SIMD that rate is the budget;
+//   * the rows of the NEXT pass are loaded before the evaluation loop of this one (16-byte loads when the rows allow), the
+//     distance-table rows of all label groups are requested together;
+//   * the first / unfiltered E-step is the same loop with every mask bit set.
+// Same arithmetic as above, instruction for instruction (seed -|c|^2/2, then fma(x_j, c_j, .) in index order; candidates in
+// increasing index order, first maximum wins): labels and scores are bit-identical to the scalar-record kernel.
+constexpr int KM2_BLOCKS = 256;
+constexpr int KM2_DEPTH = 4;
+constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
+constexpr int KM2_KMAX = 512;        // 8 mask words
+constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// x.c - |c|^2/2 for the record held by the DPP rows of `rec`: the seed from slot 15, then fma(x_j, c_j, .) in index order -- one
+// asm block (between separate asm statements the compiler pads with s_nop, and a wave issues one instruction per four cycles).
+// s_nop 1: a DPP read needs two wait states after a VALU write of its source; the compiler does not see into the asm.
+#define KM2_SEED "s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define KM2_F(j, op) "v_fmac_f64_dpp %0, %1, %" #op " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+#define KM2_F12 KM2_F(0, 2) KM2_F(1, 3) KM2_F(2, 4) KM2_F(3, 5) KM2_F(4, 6) KM2_F(5, 7) KM2_F(6, 8) KM2_F(7, 9) KM2_F(8, 10) KM2_F(9, 11) KM2_F(10, 12) KM2_F(11, 13)
+__device__ __forceinline__ double score_bcast(double rec, const double (&x)[12]) {
+    double sc;
+    asm(KM2_SEED KM2_F12 : "=&v"(sc) : "v"(rec), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]),
+        "v"(x[9]), "v"(x[10]), "v"(x[11]));
+    return sc;
+}
+__device__ __forceinline__ double score_bcast(double rec, const double (&x)[13]) {
+    double sc;
+    asm(KM2_SEED KM2_F12 KM2_F(12, 14) : "=&v"(sc) : "v"(rec), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+        "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]));
+    return sc;
+}
+__device__ __forceinline__ double score_bcast(double rec, const double (&x)[15]) {
+    double sc;
+    asm(KM2_SEED KM2_F12 KM2_F(12, 14) KM2_F(13, 15) KM2_F(14, 16) : "=&v"(sc) : "v"(rec), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]),
+        "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]));
+    return sc;
+}
+#undef KM2_F12
+#undef KM2_F
+#undef KM2_SEED
+
+template <int NS>
+__global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                         const double* __restrict__ Ct, int* __restrict__ labels, double* __restrict__ partial,
+                         double* __restrict__ block_inertia, int* __restrict__ block_changed, double* __restrict__ block_xmax,
+                         const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out) {
+    extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums and count | candidate lists
+    double* tab = lds2;
+    double* sums = lds2 + k * 16;
+    unsigned short* cand = reinterpret_cast<unsigned short*>(sums + k * (n + 1));      // [16 waves][KM2_LIST]
+    const int np1 = n + 1;
+    for (int i = threadIdx.x; i < k * 16; i += KM_THREADS) tab[i] = Ct[i];
+    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0.0;
+    __shared__ double sh_inertia[KM_THREADS / 64];
+    __shared__ int sh_changed[KM_THREADS / 64];
+    __shared__ double sh_xmax[KM_THREADS / 64];
+    __syncthreads();
+    constexpr int NX = NS > 0 ? NS : KM_CMAX;         // coordinates in registers (generic n: slots beyond n hold zeros)
+    double inertia = 0.0, xmax = 0.0;
+    int changed = 0;
+    double margin = 0.0, eps2 = 0.0;
+    bool centres_finite = true;
+    if (Dc) { margin = prm[0]; eps2 = prm[1]; centres_finite = prm[2] == 0.0; }
+    const int lane = threadIdx.x & 63;
+    const unsigned laneoff = (unsigned)(lane & 15) * 8u;
+    auto record = [&](unsigned addr) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + addr); };
+    double mm[NX];
+#pragma unroll
+    for (int j = 0; j < NX; ++j) mm[j] = (mean && (NS > 0 || j < n)) ? mean[j] : 0.0;
+    const bool vec = NS > 0 && (NS & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (xstride & 1) == 0;
+    auto load_rows = [&](int64_t base, double (&xr)[NX], int& lab) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t ii = i < N ? i : N - 1;
+        const double* row = X + ii * xstride;
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j + 1 < NX; j += 2) { const v2d v = *reinterpret_cast<const v2d*>(row + j); xr[j] = v[0]; xr[j + 1] = v[1]; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NX; ++j) xr[j] = (NS > 0 || j < n) ? row[j] : 0.0;
+        }
+        lab = labels[ii];
+    };
+    const int kw = (k + 63) >> 6;
+    const int kp = (k + 255) & ~255;
+    const int64_t stride = (int64_t)gridDim.x * KM_THREADS;
+    double xn[NX];
+    int oln = -1;
+    int64_t base = (int64_t)blockIdx.x * KM_THREADS;
+    if (base < N) load_rows(base, xn, oln);
+#if KM_PROFILE
+    unsigned long long t_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+#endif
+    for (; base < N; base += stride) {
+#if KM_PROFILE
+        unsigned long long t_prev = __builtin_readcyclecounter();
+#endif
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < N;
+        double x[NX], x2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NX; ++j) { x[j] = xn[j] - mm[j]; x2 = fma(x[j], x[j], x2); }
+        const int ol = oln;                           // label of the previous iteration (-1 before the first)
+#if KM_PROFILE
+        asm volatile("; rows have arrived" :: "v"(x2), "v"(ol));
+        KM_STAMP(0);
+#endif
+        unsigned long long mws[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+        bool filtered = false;
+        if (Dc) {
+            // ---- candidate filter (header comment of this file); every branch below is wave-uniform
+            const bool usable = (unsigned)ol < (unsigned)k && (x2 - x2 == 0.0) && centres_finite;
+            if (__ballot(!usable) == 0ull) {
+                int ga[KM_GMAX] = {0, 0, 0, 0, 0, 0, 0, 0};
+                float tf[KM_GMAX] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                int ng = 0;
+                unsigned long long remaining = ~0ull;
+#pragma unroll
+                for (int g = 0; g < KM_GMAX; ++g) {
+                    if (remaining != 0ull) {
+                        const int lead = __builtin_ctzll(remaining);
+                        const int a = __builtin_amdgcn_readlane(ol, lead);
+                        const bool mine = ol == a;
+                        const double sc = score_bcast(record(((unsigned)a << 7) + laneoff), x);
+                        const double d2 = fma(-2.0, sc, x2);                       // |x - c_a|^2 up to rounding
+                        float rf = mine ? (float)fmax(d2, 0.0) : 0.0f;             // squared radius as a float rounded UP
+                        rf = rf * 1.0000005f + 1.0e-37f;
+                        const unsigned rb = wave_max_u32(mine ? __float_as_uint(rf) : 0u);
+                        const double u2 = (double)__uint_as_float(rb) + eps2;      // >= the true squared radius u^2 of the group
+                        const double t2 = fma(4.004, u2, 1001.0 * margin * margin);   // >= (2 u + margin)^2
+                        const float t = fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f);
+                        ga[g] = a;
+                        tf[g] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t)));
+                        ng = g + 1;
+                        remaining &= ~__ballot(mine);
+                    }
+                }
+                KM_STAMP(1);
+                if (remaining == 0ull) {
+                    filtered = true;
+                    // candidate masks: the distance-table rows of 2 or 4 groups (both blocks of 256 centres) are requested together;
+                    // groups beyond ng repeat group 0 with threshold 0 (no float is below it)
+                    auto masks = [&](auto NGc, auto TWOc, int g0) {
+                        constexpr int NG_ = decltype(NGc)::value;
+                        constexpr bool TWO_ = decltype(TWOc)::value;
+                        bool p0 = false, p1 = false, p2 = false, p3 = false, p4 = false, p5 = false, p6 = false, p7 = false;
+#pragma unroll
+                        for (int g = 0; g < NG_; ++g) {
+                            int a = ga[0];
+                            float t = 0.0f;
+#pragma unroll
+                            for (int q = 0; q < KM_GMAX; ++q)
+                                if (q == g0 + g && q < ng) { a = ga[q]; t = tf[q]; }
+                            const float* row = Dc + (int64_t)a * kp + lane * 4;
+                            const float4 v = *reinterpret_cast<const float4*>(row);
+                            p0 = p0 || v.x < t; p1 = p1 || v.y < t; p2 = p2 || v.z < t; p3 = p3 || v.w < t;
+                            if constexpr (TWO_) {
+                                const float4 w = *reinterpret_cast<const float4*>(row + 256);
+                                p4 = p4 || w.x < t; p5 = p5 || w.y < t; p6 = p6 || w.z < t; p7 = p7 || w.w < t;
+                            }
+                        }
+                        mws[0] |= __ballot(p0); mws[1] |= __ballot(p1); mws[2] |= __ballot(p2); mws[3] |= __ballot(p3);
+                        if constexpr (TWO_) { mws[4] |= __ballot(p4); mws[5] |= __ballot(p5); mws[6] |= __ballot(p6); mws[7] |= __ballot(p7); }
+                    };
+                    using std::integral_constant;
+                    if (kw > 4) {
+                        if (ng <= 2) masks(integral_constant<int, 2>{}, std::true_type{}, 0);
+                        else {
+                            masks(integral_constant<int, 4>{}, std::true_type{}, 0);
+                            if (ng > 4) masks(integral_constant<int, 4>{}, std::true_type{}, 4);
+                        }
+                    } else {
+                        if (ng <= 2) masks(integral_constant<int, 2>{}, std::false_type{}, 0);
+                        else {
+                            masks(integral_constant<int, 4>{}, std::false_type{}, 0);
+                            if (ng > 4) masks(integral_constant<int, 4>{}, std::false_type{}, 4);
+                        }
+                    }
+                }
+            }
+        }
+        KM_STAMP(2);
+        // rows of the next pass: in flight during the evaluation (which waits on the LDS only)
+        if (base + stride < N) load_rows(base + stride, xn, oln);
+        // ---- evaluation in increasing index order, KM2_DEPTH records in flight
+        double best = -1.0e300;
+        unsigned baddr = laneoff;                     // LDS address of the best record so far: the index is baddr >> 7
+        unsigned addr[KM2_DEPTH];
+        double rec[KM2_DEPTH];
+        auto eval = [&](int d) {
+            const double sc = score_bcast(rec[d], x);
+            // strict '>' to replace: the first maximum wins, like np.argmin on the distances
+            baddr = (sc <= best) ? baddr : addr[d];
+            asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));
+        };
+        if (filtered) {
+            // the candidates of the eight mask words as one list of LDS record offsets (128 c as 16 bits: k <= 512), written by
+            // the lanes that hold the bits; the tail repeats the last candidate (an equal score never replaces the best)
+            unsigned short* lst = cand + (threadIdx.x >> 6) * KM2_LIST;
+            int ncand = 0, lastc = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const unsigned long long m = mws[q];
+                if (m != 0ull) {
+                    const int rank = ncand + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                    if ((m >> lane) & 1ull) lst[rank] = (unsigned short)((q * 64 + lane) << 7);
+                    ncand += __builtin_popcountll(m);
+                    lastc = q * 64 + 63 - __builtin_clzll(m);
+                }
+            }
+            if (lane < 2 * KM2_DEPTH) lst[ncand + lane] = (unsigned short)(lastc << 7);
+            unsigned cn[KM2_DEPTH];
+#pragma unroll
+            for (int d = 0; d < KM2_DEPTH; ++d) { addr[d] = (unsigned)lst[d] + laneoff; rec[d] = record(addr[d]); cn[d] = lst[KM2_DEPTH + d]; }
+            const int trips = (ncand + KM2_DEPTH - 1) / KM2_DEPTH;
+            const unsigned short* lp = lst + 2 * KM2_DEPTH;
+#pragma unroll 1
+            for (int t = 0; t < trips; ++t, lp += KM2_DEPTH) {
+#pragma unroll
+                for (int d = 0; d < KM2_DEPTH; ++d) {
+                    eval(d);
+                    __builtin_amdgcn_sched_barrier(0);        // the refill stays here, KM2_DEPTH - 1 evaluations ahead of its use
+                    addr[d] = cn[d] + laneoff;
+                    rec[d] = record(addr[d]);
+                    cn[d] = lp[d];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        } else {
+            // all k centres
+#pragma unroll
+            for (int d = 0; d < KM2_DEPTH; ++d) { addr[d] = ((unsigned)min(d, k - 1) << 7) + laneoff; rec[d] = record(addr[d]); }
+            const int trips = (k + KM2_DEPTH - 1) / KM2_DEPTH;
+#pragma unroll 1
+            for (int t = 0; t < trips; ++t) {
+#pragma unroll
+                for (int d = 0; d < KM2_DEPTH; ++d) {
+                    eval(d);
+                    __builtin_amdgcn_sched_barrier(0);
+                    addr[d] = ((unsigned)min((t + 1) * KM2_DEPTH + d, k - 1) << 7) + laneoff;
+                    rec[d] = record(addr[d]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        const int bi = (int)(baddr >> 7);
+        KM_STAMP(3);
+        if (live) {
+            if (ol != bi) ++changed;
+            labels[i] = bi;
+            xmax = fmax(xmax, x2);
+            const double dmin2 = fma(-2.0, best, x2);     // squared distance to the chosen centre (up to rounding)
+            if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
+            inertia += dmin2;
+        }
+        // member sums (see the kernel above)
+        const int bi0 = __builtin_amdgcn_readfirstlane(bi);
+        if (__ballot(!live || bi != bi0) == 0ull) {
+            double* s = sums + bi0 * np1;
+            const bool leader = (lane & 7) == 0;
+#pragma unroll
+            for (int j = 0; j < NX; ++j) x[j] = half_row_sum_f64(x[j]);       // (x is dead after this pass)
+            if (leader) {
+#pragma unroll
+                for (int j = 0; j < NX; ++j)
+                    if (NS > 0 || j < n) atomicAdd(&s[j], x[j]);
+                atomicAdd(&s[n], 8.0);
+            }
+        } else if (live) {
+            double* s = sums + bi * np1;
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+                if (NS > 0 || j < n) atomicAdd(&s[j], x[j]);
+            atomicAdd(&s[n], 1.0);
+        }
+#if KM_PROFILE
+        KM_STAMP(4);
+        t_acc[7] += 1ull;
+#endif
+    }
+#if KM_PROFILE
+    if (threadIdx.x % 64 == 0) for (int q = 0; q < 8; ++q) atomicAdd(&km_prof[q], t_acc[q]);
+#endif
+    for (int off = 32; off > 0; off >>= 1) {
+        inertia += __shfl_down(inertia, off);
+        changed += __shfl_down(changed, off);
+        xmax = fmax(xmax, __shfl_down(xmax, off));
+    }
+    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; sh_xmax[threadIdx.x >> 6] = xmax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double in = 0.0, xm = 0.0;
+        int ch = 0;
+        for (int q = 0; q < KM_THREADS / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; xm = fmax(xm, sh_xmax[q]); }
+        block_inertia[blockIdx.x] = in;
+        block_changed[blockIdx.x] = ch;
+        block_xmax[blockIdx.x] = xm;
+    }
+    double* out = partial + (int64_t)blockIdx.x * k * np1;
+    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) out[i] = sums[i];
+}
+
+#if KM_PROFILE
+}  // namespace brov
+extern "C" __attribute__((visibility("default"))) int brov_debug_kmprof(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(brov::km_prof), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(brov::km_prof), z, 64) != hipSuccess) return -1; }
+    return 0;
+}
+namespace brov {
+#endif
 // One 256-thread block per centre: sums the block partials (thread = (coordinate slot j, sub-range s of the blocks); the 16
 // sub-range sums are added in index order: a fixed grouping, the same result for the same partials), forms the new centre and
 // the squared shift.  (Round 2: one wave per centre walked the 512 partials one dependent load after the other, 0.2 ms.)
@@ -322,7 +696,7 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
         double q = nv * nv;
         for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); shift2 += __shfl_down(shift2, off); }
         q = __shfl(q, 0);
-        if (jj < 16) Ct[c * 16 + jj] = jj < n ? nv : (jj == n ? 0.5 * q : 0.0);
+        if (jj < 16) Ct[c * 16 + jj] = jj < n ? nv : (jj == n ? 0.5 * q : ((jj == 15 && n <= KM2_NMAX) ? -0.5 * q : 0.0));
         if (jj == 0) atomicAdd(&stats[0], shift2);
         if (jj == 0 && !(q - q == 0.0)) prm[2] = 1.0;         // a non-finite centre (NaN / inf data): the candidate filter stands down
     }
@@ -362,7 +736,7 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
     if (c >= k) return;
     double s = 0.0;
     for (int j = 0; j < n; ++j) s = fma(C[c * n + j], C[c * n + j], s);
-    for (int j = 0; j < 16; ++j) Ct[c * 16 + j] = j < n ? C[c * n + j] : (j == n ? 0.5 * s : 0.0);
+    for (int j = 0; j < 16; ++j) Ct[c * 16 + j] = j < n ? C[c * n + j] : (j == n ? 0.5 * s : ((j == 15 && n <= KM2_NMAX) ? -0.5 * s : 0.0));
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -708,7 +1082,6 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     return hipGetLastError();
 }
 
-int kmeans_blocks(int64_t N);
 size_t kmeans_workspace_doubles(int n, int k) { return (size_t)KM_BLOCKS * k * (n + 1) + KM_BLOCKS + (size_t)k * 16 + 8; }
 
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2) {
@@ -718,19 +1091,33 @@ hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, doubl
 
 // one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_update maintain.
 // Dc != nullptr: the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist, prm from launch_kmeans_update).
+// `scalar_records`: the kernel with the centre records in scalar registers (the only one for k > 512 or n = 15); otherwise the
+// LDS / DPP kernel.  The block count -- the number of partial sums -- follows the kernel: kmeans_blocks(N, n, k, scalar_records).
+static bool kmeans_lds_form(int n, int k, bool scalar_records) { return !scalar_records && n <= KM2_NMAX && k <= KM2_KMAX; }
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const float* Dc, const double* prm) {
+                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records) {
     (void)C;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
+    const int blocks = kmeans_blocks(N, n, k, scalar_records);
+    if (kmeans_lds_form(n, k, scalar_records)) {
+        const size_t lds2 = (size_t)k * (16 + n + 1) * sizeof(double) + (KM_THREADS / 64) * KM2_LIST * sizeof(unsigned short);   // 133 KB at k = 512, n = 12
+#define KM2_LAUNCH(NS_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        if (e_ != hipSuccess) return e_; \
+        hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, \
+                           block_inertia, block_changed, block_xmax, Dc, prm, d2out); } while (0)
+        if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
+#undef KM2_LAUNCH
+        return hipGetLastError();
+    }
     const size_t lds = (size_t)k * (n + 1) * sizeof(double) ;
     if (lds > 150 * 1024) return hipErrorInvalidValue;
-    const int blocks = kmeans_blocks(N);
 #define KM_LAUNCH(NS_, PR_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_kernel<NS_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((kmeans_assign_kernel<NS_, PR_>), dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, \
-                           block_inertia, block_changed, block_xmax, Dc, prm); } while (0)
+                           block_inertia, block_changed, block_xmax, Dc, prm, d2out); } while (0)
     if (Dc) { if (n == 12) KM_LAUNCH(12, true); else if (n == 13) KM_LAUNCH(13, true); else KM_LAUNCH(0, true); }
     else { if (n == 12) KM_LAUNCH(12, false); else if (n == 13) KM_LAUNCH(13, false); else KM_LAUNCH(0, false); }
 #undef KM_LAUNCH
@@ -740,9 +1127,10 @@ hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, f
     hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc);
     return hipGetLastError();
 }
-int kmeans_blocks(int64_t N) {
+int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
     const int64_t need = (N + KM_THREADS - 1) / KM_THREADS;
-    return need < KM_BLOCKS ? (int)(need > 0 ? need : 1) : KM_BLOCKS;
+    const int cap = kmeans_lds_form(n, k, scalar_records) ? KM2_BLOCKS : KM_BLOCKS;
+    return need < cap ? (int)(need > 0 ? need : 1) : cap;
 }
 hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
                                 const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm) {

@@ -273,9 +273,14 @@ BROV_API int edmdc_lift_cache(brov_ctx* ctx, void* d_buffer, size_t bytes);
 /* Which kernel forms the rows of W in edmdc_pinv_apply(_dev): 0 = the tuned one (default), 1 = the plain one-row-tile-per-wave
  * form (kept as an independent second implementation for the parity tests; BROV2_APPLY_SIMPLE=1 selects it at brov_create). */
 BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
-/* Lloyd's E-step in edmdc_kmeans_lloyd(_dev): 0 = with the per-wave candidate filter (triangle inequality over the centre-centre
- * distances; the same labels as the full scan bit for bit, 3-4 x fewer centre evaluations on trajectory-ordered data; default),
- * 1 = full scan over all k centres (the independent second implementation; BROV2_KMEANS_PLAIN=1 selects it at brov_create). */
+/* Lloyd's loop in edmdc_kmeans_lloyd(_dev):
+ * 0 = E-step with the per-wave candidate filter (triangle inequality over the centre-centre distances; the same labels as the
+ *     full scan bit for bit) on a private copy of the samples kept sorted by (label, distance to the centre), re-sorted as labels
+ *     move (for >= 2^18 samples and k <= 1024; the labels are returned in the caller's order) -- default;
+ * 1 = full scan over all k centres in the caller's order (the independent second implementation; BROV2_KMEANS_PLAIN=1 at brov_create);
+ * 2 = candidate filter in the caller's order (no sorting).
+ * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
+ * still the one for k > 512 or n = 15) instead of the LDS-resident table read through DPP: same arithmetic, same labels. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------

@@ -237,16 +237,17 @@ def applies():
 
 
 def lloyds():
-    """Lloyd with the per-wave candidate filter == Lloyd with the full scan: identical labels and iteration counts."""
+    """Lloyd with the per-wave candidate filter (LDS / DPP kernel, sorted private copy from 2^18 samples on) == Lloyd with the full
+    scan in the scalar-record kernel: identical labels and iteration counts."""
     n, ties, t0 = 0, 0, time.time()
     ctxs = []
-    for v in (0, 1):
+    for v in (0, 5):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
     while time.time() - t0 < budget:
-        N = int(rng.choice([70, 1000, 4097, 30000, 120000]))
-        n_ = int(rng.choice([3, 5, 12, 13, 15]))
+        N = int(rng.choice([70, 1000, 4097, 30000, 120000, 270000]))
+        n_ = int(rng.choice([3, 5, 12, 13, 14, 15]))
         k = int(rng.choice([2, 63, 64, 65, 128, 300, 512, 700]))
         if k > N:
             continue

@@ -639,16 +639,19 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     against the full scan over all k centres: the SAME labels bit for bit, the same iteration count, centres equal to the
     rounding of the member sums (fp64 atomics, order not fixed).  Trajectory-ordered data (few label groups per wave),
     shuffled data (more than 8 groups: the wave falls back to the full scan), duplicate centres (exact score ties: the lowest
-    index must win in both), k not a multiple of 64, n = 13, and a NaN row."""
+    index must win in both), k not a multiple of 64, n = 13, and a NaN row.  Both E-step kernels: centre records from the LDS
+    through DPP (variants 0-2) and through scalar registers (variants 4-6); k = 600 and n = 15 only exist in the second."""
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(21)
     ctxs = []
-    for v in (0, 1):
+    for v in (0, 1, 2, 4, 5, 6):                                         # filter + sorted copy, full scan, filter in the caller's order
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
     cases = []
-    for (N, n, k, shuffle) in ((60000, 12, 512, False), (60000, 12, 512, True), (20011, 13, 100, False), (5000, 12, 70, False), (3000, 5, 64, False)):
+    for (N, n, k, shuffle) in ((60000, 12, 512, False), (60000, 12, 512, True), (20011, 13, 100, False), (5000, 12, 70, False), (3000, 5, 64, False),
+                               (300000, 12, 256, False), (270001, 13, 128, True),        # >= 2^18 samples: the loop sorts its private copy
+                               (30000, 12, 600, False), (9000, 15, 130, False), (9000, 14, 130, False), (7001, 3, 200, False)):
         X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0)                   # a random walk: consecutive samples are neighbours
         X += 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))
         if shuffle:
@@ -665,9 +668,11 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     cases.append((Xn, cases[3][1], None))
     for ci, (X, C0, _) in enumerate(cases):
         mean = np.nanmean(X, 0)
-        for max_iter in (1, 7):
+        for max_iter in (1, 7) if len(X) < 100000 else (12,):
             out = [eng.kmeans_lloyd(X, C0 - mean, max_iter=max_iter, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
-            (Ca, la, ina, ita), (Cb, lb, inb, itb) = out
+            (Ca, la, ina, ita), (Cb, lb, inb, itb) = out[:2]
+            for (_, lo, _, ito) in out[2:]:
+                assert np.array_equal(lo, lb) and ito == itb, (ci, max_iter, int(np.sum(lo != lb)))
             # (the member sums are fp64 atomics: two runs differ by rounding in their centres, so a sample at exactly equal
             # distance from two centres could fall either way in either variant -- continuous data here: no such ties)
             assert np.array_equal(la, lb), (ci, max_iter, int(np.sum(la != lb)))

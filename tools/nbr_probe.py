@@ -38,6 +38,16 @@ for it in its:
     if os.environ.get("SORT_BY_LABEL") == "1":          # what a label-sorted copy of the samples would give
         order = torch.argsort(lab, stable=True)
         lab, da = lab[order], da[order]
+    if os.environ.get("SORT_BY_LABEL") == "2":          # sorted by (label, distance to the centre): waves of homogeneous radius
+        order = torch.argsort(lab.double() * 1e6 + da.clamp_max(9e5), stable=True)
+        lab, da = lab[order], da[order]
+    # per-sample need (no wave effects): centres within 2 d_i + margin of the sample's own centre
+    Dc_ = torch.cdist(C, C); Ds_, _ = Dc_.sort(1)
+    need = torch.zeros(N, dtype=torch.float64, device=dev)
+    for i0 in range(0, N, 1 << 20):
+        sl = slice(i0, i0 + (1 << 20))
+        need[sl] = (Ds_[lab[sl]] < (2 * da[sl] + margin)[:, None]).sum(1).double()
+    print(f"                      per-sample candidates mean {need.mean():.1f} (median/p90/p99 {torch.quantile(need[::16], torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev)).tolist()})", flush=True)
     Dc = torch.cdist(C, C)
     Ds, _ = Dc.sort(1)
     nw = N // 64

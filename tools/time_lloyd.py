@@ -1,5 +1,5 @@
 """Lloyd on BASELINE config-3 data (1e7 trajectory-ordered states, k = 512): candidate-filtered E-step against the full scan,
-fixed iteration count, same seeds.   python3 tools/time_lloyd.py [pairs] [iters]"""
+fixed iteration count, same seeds.   python3 tools/time_lloyd.py [pairs] [iters] [all]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -21,7 +21,10 @@ sig = torch.tensor([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3, dtype=torc
 Xe += torch.randn(Xe.shape, generator=g, dtype=torch.float64, device=dev) * sig
 X = Xe.view(-1, n)
 res = {}
-for name, v in (("filtered", 0), ("full scan", 1), ("filtered", 0)):
+runs = (("filtered", 0), ("full scan", 1), ("filtered", 0))
+if len(sys.argv) > 3 and sys.argv[3] == "all":            # + the caller's order, and the scalar-record kernel (variant + 4)
+    runs += (("filtered, caller's order", 2), ("scalar records: filtered", 4), ("scalar records: full scan", 5), ("scalar records: caller's order", 6))
+for name, v in runs:
     ctx.set_kmeans_variant(v)
     tm = {}
     ctx.set_timing(True)
@@ -29,7 +32,7 @@ for name, v in (("filtered", 0), ("full scan", 1), ("filtered", 0)):
     C, inertia, n_iter = engine.kmeans_centers_dev(X, k, random_state=0, max_iter=iters, ctx=ctx, timings=tm)
     torch.cuda.synchronize(); wall = time.perf_counter() - t0
     ctx.set_timing(False)
-    print(f"{name:10s}: {n_iter} iterations, seeding {tm['kmeanspp_ms']:.1f} ms, Lloyd {tm['lloyd_ms']:.1f} ms = {tm['lloyd_ms'] / (n_iter + 1):.3f} ms per E+M step, "
+    print(f"{name:32s}: {n_iter} iterations, seeding {tm['kmeanspp_ms']:.1f} ms, Lloyd {tm['lloyd_ms']:.1f} ms = {tm['lloyd_ms'] / (n_iter + 1):.3f} ms per E+M step, "
           f"wall {wall * 1e3:.0f} ms, inertia {inertia:.9e}", flush=True)
     res[name] = C.cpu().numpy()
 print("centres filtered vs full scan: max rel diff", float(np.max(np.abs(res["filtered"] - res["full scan"]) / np.maximum(1, np.abs(res["full scan"])))))
