@@ -102,20 +102,21 @@ hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 // ---- k-means (kmeans.hip) ------------------------------------------------------------------
 size_t kmeans_workspace_doubles(int n, int k);
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records);
+bool kmeans_reads_through_perm(int n, int k, bool scalar_records);
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2);
 // E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist, prm [3] from launch_kmeans_update)
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records);
+                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records, const int* perm = nullptr);
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc);
 hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
                                 const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm);
 
 // sample order of the Lloyd loop (sortperm.hip): sort by (label, distance to the centre), gather rows / labels / permutation
 size_t kmeans_sort_temp_bytes(int64_t N);
-hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, int n, const double* Xold, int64_t xstride_old, double* Xnew, const int* labels_old,
-                                int* labels_new, const int* perm_old, int* perm_new, const float* d2, unsigned* keys_in, unsigned* keys_out,
-                                unsigned* vals_in, unsigned* vals_out, void* temp, size_t temp_bytes);
+hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old, int* labels_new, const int* perm_old, int* perm_new,
+                                const float* d2, unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, void* temp,
+                                size_t temp_bytes);
 hipError_t launch_kmeans_unpermute(hipStream_t st, int64_t N, const int* perm, const int* labels_sorted, int* labels_out);
 
 int kmeanspp_chunks(int64_t N);

@@ -1367,7 +1367,7 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 
 // ---- k-means (Lloyd) --------------------------------------------------------------------------------------
 #ifndef KM_SORT_MOVED
-#define KM_SORT_MOVED 0.02       // re-sort thresholds of the loop's private sample order, see below
+#define KM_SORT_MOVED 0.01       // re-sort thresholds of the loop's private sample order, see below
 #endif
 #ifndef KM_SORT_RATE
 #define KM_SORT_RATE 0.01
@@ -1382,13 +1382,14 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     const int nb = kmeans_blocks(N, n, k, scalar_records);
     Arena a(c);
     const bool filter = variant != 1 && k >= 64;       // below one mask word there is nothing to skip
-    // sample order (sortperm.hip): the filter decides per wave of 64 consecutive samples, so the loop keeps the samples sorted by
-    // (label, distance to the centre) -- a private copy of the rows, re-sorted when enough labels have moved.  Worth it only at size.
-    const bool sorting = filter && variant == 0 && k <= 1024 && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
+    // sample order (sortperm.hip): the filter decides per wave of 64 consecutive samples, so the loop keeps a permutation that orders the
+    // samples by (label, distance to the centre), re-sorted when enough labels have moved; the LDS / DPP kernel reads its rows
+    // through it.  Worth it only at size.
+    const bool sorting = filter && variant == 0 && kmeans_reads_through_perm(n, k, scalar_records) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
     const size_t sort_tmp = sorting ? kmeans_sort_temp_bytes(N) : 0;
     int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + 2 * Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
                        Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
-                       (sorting ? 2 * Arena::al((size_t)N * n * 8) + 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
+                       (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
     if (rc) return rc;
     double* partial = a.take<double>((size_t)nb * k * (n + 1));
     double* binert = a.take<double>(nb);
@@ -1398,13 +1399,12 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* stats = a.take<double>(8);
     double* dmean = a.take<double>(16);
-    double* Xs[2] = {nullptr, nullptr};
     int *Ls[2] = {nullptr, nullptr}, *Ps[2] = {nullptr, nullptr};
     float* d2 = nullptr;
     unsigned *kin = nullptr, *kout = nullptr, *vin = nullptr, *vout = nullptr;
     void* stmp = nullptr;
     if (sorting) {
-        for (int q = 0; q < 2; ++q) { Xs[q] = a.take<double>((size_t)N * n); Ls[q] = a.take<int>(N); Ps[q] = a.take<int>(N); }
+        for (int q = 0; q < 2; ++q) { Ls[q] = a.take<int>(N); Ps[q] = a.take<int>(N); }
         d2 = a.take<float>(N);
         kin = a.take<unsigned>(N); kout = a.take<unsigned>(N); vin = a.take<unsigned>(N); vout = a.take<unsigned>(N);
         stmp = a.take<char>(sort_tmp + 256);
@@ -1425,41 +1425,40 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     bool strict = false;
     int it = 0;
     double hs[3] = {0, 0, 0};
-    // current sample order: the caller's rows and label array until the first sort, then the private copies
-    const double* Xc = d_X;
-    int64_t xsc = xstride;
+    // current sample order: labels per position (the caller's label array until the first sort)
     int* Lc = d_labels;
-    const int* Pc = nullptr;                            // permutation to the caller's order (nullptr = identity)
+    const int* Pc = nullptr;                            // position -> row of the caller's X (nullptr = identity)
     int cur = 0;
     bool want_sort = false;
     double moved = 0.0;                                 // labels changed since the last sort
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
     double* prm = stats + 4;
     const double* mp = mean_host ? dmean : nullptr;
-    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, Xc, xsc, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, nullptr, nullptr, d2, scalar_records));
+    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, nullptr, nullptr, d2, scalar_records, nullptr));
     for (it = 1; it <= max_iter; ++it) {
         HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, bxmax, d_C, c2, stats, prm));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
         if (want_sort) {
-            // (label, distance) of the E-step that has just been summed up; rows, labels and permutation move together
-            HIPCK(c, launch_kmeans_resort(c->stream, N, n, Xc, xsc, Xs[cur], Lc, Ls[cur], Pc, Ps[cur], d2, kin, kout, vin, vout, stmp, sort_tmp));
-            Xc = Xs[cur]; xsc = n; Lc = Ls[cur]; Pc = Ps[cur];
+            // (label, distance) of the E-step that has just been summed up; labels and permutation move together
+            HIPCK(c, launch_kmeans_resort(c->stream, N, Lc, Ls[cur], Pc, Ps[cur], d2, kin, kout, vin, vout, stmp, sort_tmp));
+            Lc = Ls[cur]; Pc = Ps[cur];
             cur ^= 1;
             want_sort = false;
             moved = 0.0;
         }
         if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, Xc, xsc, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, filter ? Dc : nullptr, prm, d2, scalar_records));
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, filter ? Dc : nullptr, prm, d2, scalar_records, Pc));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         hs[0] = c->h_stats[0]; hs[1] = c->h_stats[1]; hs[2] = c->h_stats[2];
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
         if (hs[0] <= tol_abs) break;
         if (sorting) {
-            // hs[2] = labels changed by the E-step before the one just queued.  Sort once 2 % of the samples have changed label since
-            // the last sort (a fresh order costs ~55 candidates per wave, the caller's ~130; a sort costs about one E-step), but not
-            // while more than 1 % still change per iteration -- such an order is stale at once.  Thresholds from scans at
-            // 10^7 x 12, k = 512 (tools/run_lloyd_variants.sh): 330 ms per 300 iterations; 0.04 / 0.015: 349 ms; the caller's order: 423 ms.
+            // hs[2] = labels changed by the E-step before the one just queued.  Sort once 1 % of the samples have changed label since
+            // the last sort (a fresh order costs ~55 candidates per wave, the caller's ~130; a sort costs less than half an E-step),
+            // but not while more than 1 % still change per iteration -- such an order is stale at once.  Thresholds from scans at
+            // 10^7 x 12, k = 512 (tools/run_lloyd_variants.sh): 314 ms per 300 iterations; 0.02 / 0.01: 322 ms; 0.005 / 0.005: 331 ms;
+            // every iteration: 384 ms; the caller's order: 423 ms.
             moved += hs[2];
             if (moved >= KM_SORT_MOVED * (double)N && hs[2] <= KM_SORT_RATE * (double)N) want_sort = true;
         }

@@ -345,8 +345,9 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 //   * the candidates of all mask words form one list in the LDS (written by the lanes that hold the mask bits: mbcnt ranks), padded
 //     by repeating the last candidate (an equal score never replaces the best): the loop spends no scalar instructions on bit
 //     scanning -- a wave issues one instruction every four cycles, and with four waves per SIMD that rate is the budget;
-//   * the rows of the NEXT pass are loaded before the evaluation loop of this one (16-byte loads when the rows allow), the
-//     distance-table rows of all label groups are requested together;
+//   * the rows of the NEXT pass are loaded before the evaluation loop of this one (16-byte loads when the rows allow) -- through
+//     the loop's sample permutation when there is one (sortperm.hip: row perm[p] for position p, the index loaded a pass earlier
+//     still; labels and distances are per position) --, the distance-table rows of all label groups are requested together;
 //   * the first / unfiltered E-step is the same loop with every mask bit set.
 // Same arithmetic as above, instruction for instruction (seed -|c|^2/2, then fma(x_j, c_j, .) in index order; candidates in
 // increasing index order, first maximum wins): labels and scores are bit-identical to the scalar-record kernel.
@@ -390,7 +391,8 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
                          const double* __restrict__ Ct, int* __restrict__ labels, double* __restrict__ partial,
                          double* __restrict__ block_inertia, int* __restrict__ block_changed, double* __restrict__ block_xmax,
-                         const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out) {
+                         const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
+                         const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums and count | candidate lists
     double* tab = lds2;
     double* sums = lds2 + k * 16;
@@ -415,10 +417,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #pragma unroll
     for (int j = 0; j < NX; ++j) mm[j] = (mean && (NS > 0 || j < n)) ? mean[j] : 0.0;
     const bool vec = NS > 0 && (NS & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (xstride & 1) == 0;
-    auto load_rows = [&](int64_t base, double (&xr)[NX], int& lab) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t ii = i < N ? i : N - 1;
-        const double* row = X + ii * xstride;
+    auto position = [&](int64_t base) { const int64_t i = base + threadIdx.x; return i < N ? i : N - 1; };
+    auto load_rows = [&](int64_t base, int prow, double (&xr)[NX], int& lab) {
+        const int64_t ii = position(base);
+        const double* row = X + (perm ? (int64_t)prow : ii) * xstride;
         if (vec) {
 #pragma unroll
             for (int j = 0; j + 1 < NX; j += 2) { const v2d v = *reinterpret_cast<const v2d*>(row + j); xr[j] = v[0]; xr[j + 1] = v[1]; }
@@ -434,7 +436,12 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     double xn[NX];
     int oln = -1;
     int64_t base = (int64_t)blockIdx.x * KM_THREADS;
-    if (base < N) load_rows(base, xn, oln);
+    // sample order through `perm`: the row index of a pass is loaded one pass before its rows are
+    int pnext = 0;
+    if (base < N) {
+        load_rows(base, perm ? perm[position(base)] : 0, xn, oln);
+        if (perm && base + stride < N) pnext = perm[position(base + stride)];
+    }
 #if KM_PROFILE
     unsigned long long t_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #endif
@@ -528,7 +535,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         }
         KM_STAMP(2);
         // rows of the next pass: in flight during the evaluation (which waits on the LDS only)
-        if (base + stride < N) load_rows(base + stride, xn, oln);
+        if (base + stride < N) {
+            load_rows(base + stride, pnext, xn, oln);
+            if (perm && base + 2 * stride < N) pnext = perm[position(base + 2 * stride)];
+        }
         // ---- evaluation in increasing index order, KM2_DEPTH records in flight
         double best = -1.0e300;
         unsigned baddr = laneoff;                     // LDS address of the best record so far: the index is baddr >> 7
@@ -1094,10 +1104,12 @@ hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, doubl
 // `scalar_records`: the kernel with the centre records in scalar registers (the only one for k > 512 or n = 15); otherwise the
 // LDS / DPP kernel.  The block count -- the number of partial sums -- follows the kernel: kmeans_blocks(N, n, k, scalar_records).
 static bool kmeans_lds_form(int n, int k, bool scalar_records) { return !scalar_records && n <= KM2_NMAX && k <= KM2_KMAX; }
+bool kmeans_reads_through_perm(int n, int k, bool scalar_records) { return kmeans_lds_form(n, k, scalar_records); }
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records) {
+                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records, const int* perm) {
     (void)C;
+    if (perm && !kmeans_lds_form(n, k, scalar_records)) return hipErrorInvalidValue;      // only the LDS / DPP kernel reads through a permutation
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N, n, k, scalar_records);
     if (kmeans_lds_form(n, k, scalar_records)) {
@@ -1106,7 +1118,7 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, \
-                           block_inertia, block_changed, block_xmax, Dc, prm, d2out); } while (0)
+                           block_inertia, block_changed, block_xmax, Dc, prm, d2out, perm); } while (0)
         if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
 #undef KM2_LAUNCH
         return hipGetLastError();

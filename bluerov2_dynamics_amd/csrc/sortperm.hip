@@ -2,15 +2,19 @@
 //
 // The candidate filter of the E-step (kmeans.hip) decides per WAVE: 64 consecutive samples share one union of candidate
 // centres, and a group's radius is the largest distance of its lanes to their centre.  In trajectory order a wave holds 4.5
-// label groups and evaluates 131 of 512 centres; with the samples sorted by (label, distance to the centre) a wave is one
+// label groups and evaluates 131 of 512 centres; with the samples ordered by (label, distance to the centre) a wave is one
 // group of homogeneous radius and evaluates 55 -- the per-sample need (tools/nbr_probe.py, tools/sort_probe.py).  The order
 // decays as labels change (0.3-1.4 % of the samples per iteration: 57 -> 71 -> 80 -> 86 centres one to four iterations after a
 // sort early on, 55 -> 70 over six iterations late), so the loop re-sorts when enough labels have moved (capi.hip).
 //
-// A re-sort = keys (label << 22 | the top 22 bits of the float distance^2: non-negative floats order like their bit patterns),
-// rocPRIM's device radix sort of (key, source index) pairs -- a plain library primitive, like a library GEMM --, and a gather
-// of the sample rows, labels and the permutation to the original order.  Nothing here touches the arithmetic of the E / M
-// steps: the labels are those of the unsorted loop bit for bit, the member sums differ by the order of their additions.
+// The order is a permutation, not a copy: the E-step (kmeans_assign_lds_kernel) reads row perm[p] for position p -- its rows
+// are prefetched a pass ahead and the kernel is bound by the vector ALU, so the scattered 96-byte reads cost nothing measurable
+// (first form: a sorted private copy of the rows, 1.9 GB moved per re-sort; 330 -> 322 ms per 300 iterations without it, and a
+// re-sort fell from 1.0 to 0.45 ms).  A re-sort = keys (label << 22 | the top 22 bits of the float distance^2: non-negative floats
+// order like their bit patterns), rocPRIM's device radix sort of (key, position) pairs -- a plain library primitive, like a
+// library GEMM --, and a gather of labels and permutation.  Labels and distances live per POSITION; the labels go back to the
+// caller's order at the end.  Nothing here touches the arithmetic of the E / M steps: the labels are those of the unsorted loop
+// bit for bit, the member sums differ by the order of their additions.
 #include <cstdint>
 #include <cstring>
 #include <hip/hip_runtime.h>
@@ -30,28 +34,15 @@ __global__ void __launch_bounds__(256) sort_keys_kernel(int64_t N, const int* __
     vals[i] = (unsigned)i;
 }
 
-// row j of the new order = row src[j] of the old one; perm_old == nullptr: the old order is the caller's.  One thread per piece of
-// W doubles of a row (W = 2: 16-byte accesses, when n is even and both arrays are 16-byte aligned)
-template <int W>
-__global__ void __launch_bounds__(256) sort_gather_kernel(int64_t N, int n, const unsigned* __restrict__ src, const double* __restrict__ Xold,
-                                                          int64_t xstride_old, double* __restrict__ Xnew, const int* __restrict__ labels_old,
-                                                          int* __restrict__ labels_new, const int* __restrict__ perm_old, int* __restrict__ perm_new) {
-    const int pieces = n / W;
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= N * pieces) return;
-    const int64_t j = e / pieces;
-    const int c = (int)(e - j * pieces) * W;
+// position j of the new order = position src[j] of the old one: labels and the permutation to the caller's rows move, the rows
+// themselves stay where they are (perm_old == nullptr: the old order is the caller's)
+__global__ void __launch_bounds__(256) sort_gather_index_kernel(int64_t N, const unsigned* __restrict__ src, const int* __restrict__ labels_old,
+                                                                int* __restrict__ labels_new, const int* __restrict__ perm_old, int* __restrict__ perm_new) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= N) return;
     const int64_t s = src[j];
-    if constexpr (W == 2) {
-        typedef double v2d __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<v2d*>(Xnew + j * n + c) = *reinterpret_cast<const v2d*>(Xold + s * xstride_old + c);
-    } else {
-        Xnew[j * n + c] = Xold[s * xstride_old + c];
-    }
-    if (c == 0) {
-        labels_new[j] = labels_old[s];
-        perm_new[j] = perm_old ? perm_old[s] : (int)s;
-    }
+    labels_new[j] = labels_old[s];
+    perm_new[j] = perm_old ? perm_old[s] : (int)s;
 }
 
 __global__ void __launch_bounds__(256) sort_unpermute_kernel(int64_t N, const int* __restrict__ perm, const int* __restrict__ labels_sorted,
@@ -67,22 +58,15 @@ size_t kmeans_sort_temp_bytes(int64_t N) {
     return bytes;
 }
 
-hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, int n, const double* Xold, int64_t xstride_old, double* Xnew, const int* labels_old,
-                                int* labels_new, const int* perm_old, int* perm_new, const float* d2, unsigned* keys_in, unsigned* keys_out,
-                                unsigned* vals_in, unsigned* vals_out, void* temp, size_t temp_bytes) {
+hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old, int* labels_new, const int* perm_old, int* perm_new,
+                                const float* d2, unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, void* temp,
+                                size_t temp_bytes) {
     if (N <= 0) return hipSuccess;
     if (N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, labels_old, d2, keys_in, vals_in);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, 32, st);
     if (e != hipSuccess) return e;
-    const bool wide = (n & 1) == 0 && (xstride_old & 1) == 0 && ((reinterpret_cast<uintptr_t>(Xold) | reinterpret_cast<uintptr_t>(Xnew)) & 15) == 0;
-    const int64_t total = wide ? N * (n / 2) : N * n;
-    if (wide)
-        hipLaunchKernelGGL(sort_gather_kernel<2>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, n, vals_out, Xold, xstride_old, Xnew,
-                           labels_old, labels_new, perm_old, perm_new);
-    else
-        hipLaunchKernelGGL(sort_gather_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, N, n, vals_out, Xold, xstride_old, Xnew,
-                           labels_old, labels_new, perm_old, perm_new);
+    hipLaunchKernelGGL(sort_gather_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, vals_out, labels_old, labels_new, perm_old, perm_new);
     return hipGetLastError();
 }
 

@@ -275,8 +275,8 @@ BROV_API int edmdc_lift_cache(brov_ctx* ctx, void* d_buffer, size_t bytes);
 BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
 /* Lloyd's loop in edmdc_kmeans_lloyd(_dev):
  * 0 = E-step with the per-wave candidate filter (triangle inequality over the centre-centre distances; the same labels as the
- *     full scan bit for bit) on a private copy of the samples kept sorted by (label, distance to the centre), re-sorted as labels
- *     move (for >= 2^18 samples and k <= 1024; the labels are returned in the caller's order) -- default;
+ *     full scan bit for bit), visiting the samples in an order kept sorted by (label, distance to the centre) -- a permutation,
+ *     re-sorted as labels move; for >= 2^18 samples, k <= 512 and n <= 14; the labels are returned in the caller's order -- default;
  * 1 = full scan over all k centres in the caller's order (the independent second implementation; BROV2_KMEANS_PLAIN=1 at brov_create);
  * 2 = candidate filter in the caller's order (no sorting).
  * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
