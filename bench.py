@@ -97,14 +97,14 @@ def lloyd_roofline(rows, kk, ms_per_step):
     if rows != 10_020_000 or kk != 512 or not ms_per_step:
         return None
     try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r03_lloyd_pmc_summary.json")))["kmeans_assign_kernel<12, true>"]
+        d = json.load(open(os.path.join(REPO, "profiles", "r03_lloyd_pmc_summary.json")))["kmeans_assign_lds_kernel<12>"]
     except Exception:
         return None
     tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
-    return {"kernel": "kmeans_assign_kernel<12, true> (+ update, distances)", "bound": "valu_fp64_issue", "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS,
+    return {"kernel": "kmeans_assign_lds_kernel<12> (+ update, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS,
             "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
             "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
-            "note": "every VALU slot priced as an FMA; the full scan executes 2.7 x the instructions (1.38e9) in 2.0 x the time",
+            "note": "every VALU slot priced as an FMA; mean over the 300 E-steps of a recorded run of the shipped loop (sorted sample order)",
             "traffic": None}
 
 

@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 // Same arithmetic as above, instruction for instruction (seed -|c|^2/2, then fma(x_j, c_j, .) in index order; candidates in
 // increasing index order, first maximum wins): labels and scores are bit-identical to the scalar-record kernel.
 constexpr int KM2_BLOCKS = 256;
-constexpr int KM2_DEPTH = 4;
+constexpr int KM2_DEPTH = 4;         // records in flight round the evaluation loop: two pairs (the loop body is written for 4)
+static_assert(KM2_DEPTH == 4, "the evaluation loop of kmeans_assign_lds_kernel is written for two pairs");
 constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
 constexpr int KM2_KMAX = 512;        // 8 mask words
 constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
@@ -382,6 +383,27 @@ __device__ __forceinline__ double score_bcast(double rec, const double (&x)[15])
         "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]));
     return sc;
 }
+// two records at once, their chains interleaved: a dependent fp64 FMA cannot issue back to back, so one chain per wave fills
+// half of the vector ALU's slots and it takes four waves in this loop at the same time to fill them all (tools/dpp64_probe.hip:
+// 80 / 51 / 45 ns per evaluation and SIMD with 1 / 2 / 4 waves) -- with passes as short as 60 candidates they rarely are
+#define KM2_SEED2 "s_nop 1\n\tv_mov_b64_dpp %0, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %1, %3 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+#define KM2_G(j, op) "v_fmac_f64_dpp %0, %2, %" #op " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %3, %" #op " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+#define KM2_G12 KM2_G(0, 4) KM2_G(1, 5) KM2_G(2, 6) KM2_G(3, 7) KM2_G(4, 8) KM2_G(5, 9) KM2_G(6, 10) KM2_G(7, 11) KM2_G(8, 12) KM2_G(9, 13) KM2_G(10, 14) KM2_G(11, 15)
+__device__ __forceinline__ void score2_bcast(double ra, double rb, const double (&x)[12], double& sa, double& sb) {
+    asm(KM2_SEED2 KM2_G12 : "=&v"(sa), "=&v"(sb) : "v"(ra), "v"(rb), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]),
+        "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]));
+}
+__device__ __forceinline__ void score2_bcast(double ra, double rb, const double (&x)[13], double& sa, double& sb) {
+    asm(KM2_SEED2 KM2_G12 KM2_G(12, 16) : "=&v"(sa), "=&v"(sb) : "v"(ra), "v"(rb), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]),
+        "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]));
+}
+__device__ __forceinline__ void score2_bcast(double ra, double rb, const double (&x)[15], double& sa, double& sb) {
+    asm(KM2_SEED2 KM2_G12 KM2_G(12, 16) KM2_G(13, 17) KM2_G(14, 18) : "=&v"(sa), "=&v"(sb) : "v"(ra), "v"(rb), "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]),
+        "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "v"(x[8]), "v"(x[9]), "v"(x[10]), "v"(x[11]), "v"(x[12]), "v"(x[13]), "v"(x[14]));
+}
+#undef KM2_G12
+#undef KM2_G
+#undef KM2_SEED2
 #undef KM2_F12
 #undef KM2_F
 #undef KM2_SEED
@@ -544,11 +566,14 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         unsigned baddr = laneoff;                     // LDS address of the best record so far: the index is baddr >> 7
         unsigned addr[KM2_DEPTH];
         double rec[KM2_DEPTH];
-        auto eval = [&](int d) {
-            const double sc = score_bcast(rec[d], x);
+        auto eval2 = [&](int d) {                    // candidates d and d + 1 of the ring, in this order
+            double sa, sb;
+            score2_bcast(rec[d], rec[d + 1], x, sa, sb);
             // strict '>' to replace: the first maximum wins, like np.argmin on the distances
-            baddr = (sc <= best) ? baddr : addr[d];
-            asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));
+            baddr = (sa <= best) ? baddr : addr[d];
+            asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sa));
+            baddr = (sb <= best) ? baddr : addr[d + 1];
+            asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sb));
         };
         if (filtered) {
             // the candidates of the eight mask words as one list of LDS record offsets (128 c as 16 bits: k <= 512), written by
@@ -565,39 +590,46 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                     lastc = q * 64 + 63 - __builtin_clzll(m);
                 }
             }
-            if (lane < 2 * KM2_DEPTH) lst[ncand + lane] = (unsigned short)(lastc << 7);
+            if (lane < 2 * KM2_DEPTH + 2) lst[ncand + lane] = (unsigned short)(lastc << 7);
+            // The trip evaluates pair A = candidates (4t, 4t + 1), then pair B = (4t + 2, 4t + 3), and ENDS with an evaluation: the
+            // compiler waits for every LDS read at the loop head, so the reads issued last before it must be an evaluation old.
+            //   head: records of B (offsets cn[2..3], read a trip ago) | evaluate A | records of the next A | evaluate B
             unsigned cn[KM2_DEPTH];
 #pragma unroll
-            for (int d = 0; d < KM2_DEPTH; ++d) { addr[d] = (unsigned)lst[d] + laneoff; rec[d] = record(addr[d]); cn[d] = lst[KM2_DEPTH + d]; }
+            for (int d = 0; d < 2; ++d) { addr[d] = (unsigned)lst[d] + laneoff; rec[d] = record(addr[d]); cn[d] = lst[KM2_DEPTH + d]; cn[2 + d] = lst[2 + d]; }
             const int trips = (ncand + KM2_DEPTH - 1) / KM2_DEPTH;
-            const unsigned short* lp = lst + 2 * KM2_DEPTH;
+            const unsigned short* lp = lst + KM2_DEPTH + 2;
 #pragma unroll 1
             for (int t = 0; t < trips; ++t, lp += KM2_DEPTH) {
 #pragma unroll
-                for (int d = 0; d < KM2_DEPTH; ++d) {
-                    eval(d);
-                    __builtin_amdgcn_sched_barrier(0);        // the refill stays here, KM2_DEPTH - 1 evaluations ahead of its use
-                    addr[d] = cn[d] + laneoff;
-                    rec[d] = record(addr[d]);
-                    cn[d] = lp[d];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int e = 2; e < 4; ++e) { addr[e] = cn[e] + laneoff; rec[e] = record(addr[e]); cn[e] = lp[e - 2]; }
+                __builtin_amdgcn_sched_barrier(0);
+                eval2(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { addr[e] = cn[e] + laneoff; rec[e] = record(addr[e]); cn[e] = lp[e + 2]; }
+                __builtin_amdgcn_sched_barrier(0);
+                eval2(2);
+                __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            // all k centres
+            // all k centres, same schedule
+            auto off = [&](int c) { return ((unsigned)min(c, k - 1) << 7) + laneoff; };
 #pragma unroll
-            for (int d = 0; d < KM2_DEPTH; ++d) { addr[d] = ((unsigned)min(d, k - 1) << 7) + laneoff; rec[d] = record(addr[d]); }
+            for (int d = 0; d < 2; ++d) { addr[d] = off(d); rec[d] = record(addr[d]); }
             const int trips = (k + KM2_DEPTH - 1) / KM2_DEPTH;
 #pragma unroll 1
             for (int t = 0; t < trips; ++t) {
 #pragma unroll
-                for (int d = 0; d < KM2_DEPTH; ++d) {
-                    eval(d);
-                    __builtin_amdgcn_sched_barrier(0);
-                    addr[d] = ((unsigned)min((t + 1) * KM2_DEPTH + d, k - 1) << 7) + laneoff;
-                    rec[d] = record(addr[d]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                for (int e = 2; e < 4; ++e) { addr[e] = off(t * KM2_DEPTH + e); rec[e] = record(addr[e]); }
+                __builtin_amdgcn_sched_barrier(0);
+                eval2(0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) { addr[e] = off((t + 1) * KM2_DEPTH + e); rec[e] = record(addr[e]); }
+                __builtin_amdgcn_sched_barrier(0);
+                eval2(2);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         const int bi = (int)(baddr >> 7);

@@ -30,7 +30,7 @@ template <size_t... J> __device__ __forceinline__ double score_dpp(double rec, c
 template <int MODE, int DEPTH>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8)))
 probe(const double* __restrict__ X, const Cen* __restrict__ Tg, const int* __restrict__ list, int nlist, int reps, double* __restrict__ out, int* __restrict__ outi) {
-    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63;
     double x[12];
 #pragma unroll
@@ -92,7 +92,7 @@ template <typename F> float ms_of(F f) {
 
 int main() {
     const int64_t N = 512 * 1024;                        // 512 blocks x 1024 threads: 8 waves per SIMD on 256 CUs
-    const int k = 512, nlist = 128, reps = 16;
+    const int k = 512, nlist = 128, reps = 64;
     std::vector<double> hX(N * 12); std::vector<Cen> hT(k); std::vector<int> hl(16 * nlist);
     srand(1);
     for (auto& v : hX) v = rand() / (double)RAND_MAX - 0.5;
@@ -111,6 +111,17 @@ int main() {
 #define RUN(D) do { float t_ = ms_of([&] { hipLaunchKernelGGL((probe<1, D>), dim3(512), dim3(1024), 0, 0, X, T, l, nlist, reps, o1, i1); }); \
         report("DPP records, depth " #D, t_); } while (0)
     RUN(2); RUN(4); RUN(8);
+    // how many waves per SIMD does the dependent FMA chain need to fill the vector ALU?  256 blocks (one per CU) of 256 / 512 /
+    // 1024 threads = 1 / 2 / 4 waves per SIMD; the time per (wave, centre) per SIMD should stay at the 8-wave figure if one wave is enough
+    for (int tpb = 256; tpb <= 1024; tpb *= 2) {
+        const double ev = (double)(256 * tpb / 64) * nlist * reps;
+        float t_ = ms_of([&] { hipLaunchKernelGGL((probe<1, 4>), dim3(256), dim3(tpb), 0, 0, X, T, l, nlist, reps, o1, i1); });
+        printf("DPP records, depth 4, %d wave(s) per SIMD: %7.3f ms = %.1f ns per (wave, centre) per SIMD\n", tpb / 256, t_, t_ * 1e6 / (ev / 1024));
+        float t0_ = ms_of([&] { hipLaunchKernelGGL((probe<0, 2>), dim3(256), dim3(tpb), 0, 0, X, T, l, nlist, reps, o0, i0); });
+        printf("scalar records,       %d wave(s) per SIMD: %7.3f ms = %.1f ns per (wave, centre) per SIMD\n", tpb / 256, t0_, t0_ * 1e6 / (ev / 1024));
+    }
+    hipLaunchKernelGGL((probe<0, 2>), dim3(512), dim3(1024), 0, 0, X, T, l, nlist, reps, o0, i0);
+    hipLaunchKernelGGL((probe<1, 8>), dim3(512), dim3(1024), 0, 0, X, T, l, nlist, reps, o1, i1);
     std::vector<double> a(N), b(N); std::vector<int> ia(N), ib(N);
     hipMemcpy(a.data(), o0, N * 8, hipMemcpyDeviceToHost); hipMemcpy(b.data(), o1, N * 8, hipMemcpyDeviceToHost);
     hipMemcpy(ia.data(), i0, N * 4, hipMemcpyDeviceToHost); hipMemcpy(ib.data(), i1, N * 4, hipMemcpyDeviceToHost);
