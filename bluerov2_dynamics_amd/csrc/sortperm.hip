@@ -10,7 +10,7 @@
 // The order is a permutation, not a copy: the E-step (kmeans_assign_lds_kernel) reads row perm[p] for position p -- its rows
 // are prefetched a pass ahead and the kernel is bound by the vector ALU, so the scattered 96-byte reads cost nothing measurable
 // (first form: a sorted private copy of the rows, 1.9 GB moved per re-sort; 330 -> 322 ms per 300 iterations without it, and a
-// re-sort fell from 1.0 to 0.45 ms).  A re-sort = keys (label << 22 | the top 22 bits of the float distance^2: non-negative floats
+// re-sort fell from 1.0 to 0.45 ms).  A re-sort = keys (label << 12 | the top 12 bits of the float distance^2: non-negative floats
 // order like their bit patterns), rocPRIM's device radix sort of (key, position) pairs -- a plain library primitive, like a
 // library GEMM --, and a gather of labels and permutation.  Labels and distances live per POSITION; the labels go back to the
 // caller's order at the end.  Nothing here touches the arithmetic of the E / M steps: the labels are those of the unsorted loop
@@ -23,6 +23,12 @@
 
 namespace brov {
 
+#ifndef KM_SORT_DBITS
+#define KM_SORT_DBITS 12      // bits of the float distance^2 (below the sign: exponent + 4 of the mantissa) in the key, under the 10
+                              // label bits: 22-bit keys sort in three radix passes instead of four (300 iterations: 300 -> 289 ms;
+                              // 14 bits: 292 ms; 6 bits -- not even the whole exponent --: 412 ms)
+#endif
+
 __global__ void __launch_bounds__(256) sort_keys_kernel(int64_t N, const int* __restrict__ labels, const float* __restrict__ d2,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -30,7 +36,7 @@ __global__ void __launch_bounds__(256) sort_keys_kernel(int64_t N, const int* __
     const unsigned lab = (unsigned)labels[i] & 0x3FFu;
     const float d = d2[i];
     const unsigned bits = d > 0.0f ? (__float_as_uint(d) & 0x7FFFFFFFu) : 0u;      // NaN / negative: front of its cluster
-    keys[i] = (lab << 22) | (bits >> 9);
+    keys[i] = (lab << KM_SORT_DBITS) | (bits >> (31 - KM_SORT_DBITS));
     vals[i] = (unsigned)i;
 }
 
@@ -54,7 +60,7 @@ __global__ void __launch_bounds__(256) sort_unpermute_kernel(int64_t N, const in
 size_t kmeans_sort_temp_bytes(int64_t N) {
     size_t bytes = 0;
     unsigned* p = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)N, 0, 32, (hipStream_t)nullptr) != hipSuccess) return 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)N, 0, 10 + KM_SORT_DBITS, (hipStream_t)nullptr) != hipSuccess) return 0;
     return bytes;
 }
 
@@ -64,7 +70,7 @@ hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old
     if (N <= 0) return hipSuccess;
     if (N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, labels_old, d2, keys_in, vals_in);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, 32, st);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, 10 + KM_SORT_DBITS, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sort_gather_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, vals_out, labels_old, labels_new, perm_old, perm_new);
     return hipGetLastError();

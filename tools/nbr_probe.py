@@ -48,6 +48,34 @@ for it in its:
         sl = slice(i0, i0 + (1 << 20))
         need[sl] = (Ds_[lab[sl]] < (2 * da[sl] + margin)[:, None]).sum(1).double()
     print(f"                      per-sample candidates mean {need.mean():.1f} (median/p90/p99 {torch.quantile(need[::16], torch.tensor([0.5, 0.9, 0.99], dtype=torch.float64, device=dev)).tolist()})", flush=True)
+    if os.environ.get("NORM") == "1":
+        # would a norm annulus prune further?  c can only win if | |x| - |c| | < d(x, c_a)  (centred coordinates)
+        mu = X.mean(0)
+        xn_all = torch.empty(N, dtype=torch.float64, device=dev)
+        for i0 in range(0, N, 1 << 20):
+            xn_all[i0:i0 + (1 << 20)] = ((X[i0:i0 + (1 << 20)] - mu) ** 2).sum(1).sqrt()
+        xn_ = xn_all[order] if os.environ.get("SORT_BY_LABEL") in ("1", "2") else xn_all
+        cnorm = ((C - mu) ** 2).sum(1).sqrt()
+        need2 = torch.zeros(N, dtype=torch.float64, device=dev)
+        for i0 in range(0, N, 1 << 19):
+            sl = slice(i0, i0 + (1 << 19))
+            tri = Dc_[lab[sl]] < (2 * da[sl] + margin)[:, None]
+            ann = (cnorm[None, :] - xn_[sl][:, None]).abs() < (da[sl] + margin)[:, None]
+            need2[sl] = (tri & ann).sum(1).double()
+        print(f"                      per-sample candidates with the norm annulus: mean {need2.mean():.1f}", flush=True)
+        nwv = N // 64
+        labw = lab[: nwv * 64].view(nwv, 64); daw = da[: nwv * 64].view(nwv, 64); xnw = xn_[: nwv * 64].view(nwv, 64)
+        uni = (labw == labw[:, :1]).all(1)                     # one-label waves
+        uu = daw.max(1).values; lo = xnw.min(1).values - uu - margin; hi = xnw.max(1).values + uu + margin
+        tot_t, tot_b = 0.0, 0.0
+        for w0 in range(0, nwv, 1 << 15):
+            sl = slice(w0, w0 + (1 << 15))
+            tri = Dc_[labw[sl, 0]] < (2 * uu[sl] + margin)[:, None]
+            ann = (cnorm[None, :] > lo[sl][:, None]) & (cnorm[None, :] < hi[sl][:, None])
+            m = uni[sl]
+            tot_t += float(tri[m].sum()); tot_b += float((tri & ann)[m].sum())
+        print(f"                      one-label waves ({float(uni.double().mean()):.3f} of all): candidates/wave {tot_t / float(uni.sum()):.1f} -> "
+              f"{tot_b / float(uni.sum()):.1f} with the annulus", flush=True)
     Dc = torch.cdist(C, C)
     Ds, _ = Dc.sort(1)
     nw = N // 64
