@@ -272,3 +272,37 @@ def test_hand_scheduled_mfma_loops_have_no_copies_or_spills(tmp_path):
     bad.write_text("\n".join(lines[:j + 1] + [f"\tv_mov_b64_e32 v[2:3], {dst}"] + lines[j + 1:]))
     r = subprocess.run([sys.executable, tool, str(bad), "wrows_kernel"], capture_output=True, text=True)
     assert r.returncode == 1 and "PROBLEM" in r.stdout, r.stdout
+
+
+def test_lloyd_lds_kernel_listing(tmp_path):
+    """kmeans_assign_lds_kernel (csrc/kmeans.hip) on the compiler's own listing: 4 waves per SIMD without scratch at n = 12 (the
+    benchmark's instantiation; a few spilled dwords are tolerated in the generic one), every DPP chain seeded behind its
+    `s_nop 1` (a DPP read needs two wait states after a VALU write of its source and the compiler does not look into the asm),
+    and the evaluation loops wait for their LDS reads with an exact count -- never lgkmcnt(0) between two pairs of candidates."""
+    from bluerov2_dynamics_amd import _build
+    asm = tmp_path / "kmeans.s"
+    subprocess.check_call([_build.hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-DBROV2_BUILDING=1", "--offload-device-only", "-S",
+                           "-o", str(asm), os.path.join(_build.CSRC, "kmeans.hip")], stderr=subprocess.DEVNULL)
+    lines = asm.read_text().split("\n")
+    for ns, max_scratch in ((12, 0), (13, 64), (0, 128)):
+        k = next(i for i, l in enumerate(lines) if l.startswith(f"_ZN4brov24kmeans_assign_lds_kernelILi{ns}E"))
+        e = next(i for i in range(k, len(lines)) if lines[i].startswith(".Lfunc_end"))
+        info = {m.group(1): int(m.group(2)) for m in (re.match(r"; (\w+): (\d+)", l) for l in lines[e:e + 40]) if m}
+        assert info["Occupancy"] == 4 and info["ScratchSize"] <= max_scratch and info["NumVgprs"] <= 128, (ns, info)
+        body = [l.strip() for l in lines[k:e]]
+        movs = [i for i, l in enumerate(body) if l.startswith("v_mov_b64_dpp")]
+        assert len(movs) >= 8 + 4                      # eight label groups + two pairs in each of the two evaluation loops
+        for i in movs:
+            prev = next(body[j] for j in range(i - 1, 0, -1) if body[j] and not body[j].startswith(";"))
+            assert prev.startswith("s_nop 1") or prev.startswith("v_mov_b64_dpp"), (ns, body[i - 3:i + 1])
+        # evaluation loops: the innermost loops that hold DPP FMAs
+        heads = [i for i, l in enumerate(body) if "Inner Loop Header" in l]
+        n_eval = 0
+        for h in heads:
+            end = next(i for i in range(h, len(body)) if body[i].startswith("s_cbranch"))
+            loop = body[h:end]
+            if sum(l.startswith("v_fmac_f64_dpp") for l in loop) >= 4 * (12 if ns else 15):
+                n_eval += 1
+                waits = [l for l in loop if l.startswith("s_waitcnt") and "lgkmcnt" in l]
+                assert waits and all("lgkmcnt(0)" not in w for w in waits), (ns, waits)
+        assert n_eval == 2, (ns, n_eval)
