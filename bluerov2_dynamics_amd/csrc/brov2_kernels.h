@@ -124,6 +124,6 @@ size_t kmeanspp_sum_doubles(int64_t N);
 size_t kmeanspp_state_bytes();
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                            long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
-                           void* state, double* C, long long* indices);
+                           void* state, double* C, long long* indices, float* Xf);
 
 }  // namespace brov

@@ -1069,8 +1069,8 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 6 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4");
+    if (!c || variant < 0 || variant > 14 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4 and / or + 8");
     c->kmeans_variant = variant;
     return BROV_OK;
 }
@@ -1490,8 +1490,11 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     const size_t nsum = kmeanspp_sum_doubles(N);
     const size_t nu = (size_t)(k > 1 ? k : 1) * n_trials;        // one spare row: the last round's (unused) draw pointer stays in bounds
     Arena a(c);
+    // a float copy of the coordinates screens out the rows a round cannot affect (kmeans.hip, pp_round_kernel); + 8 in the k-means
+    // variant: every row goes through the fp64 path
+    const bool screening = (c->kmeans_variant & 8) == 0;
     int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) +
-                       Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + 8192);
+                       Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + (screening ? Arena::al((size_t)N * n * 4) : 0) + 8192);
     if (rc) return rc;
     double* Xt = a.take<double>((size_t)N * n);
     double* xsq = a.take<double>(N);
@@ -1501,13 +1504,14 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     long long* dind = a.take<long long>(k);
     char* state = a.take<char>(kmeanspp_state_bytes());
     double* dmean = a.take<double>(16);
+    float* Xf = screening ? a.take<float>((size_t)N * n) : nullptr;
     if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
     if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
         HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
-                                 closest, dsum, state, d_C, dind));
+                                 closest, dsum, state, d_C, dind, Xf));
     }
     if (indices_host) {
         static_assert(sizeof(long long) == sizeof(int64_t), "index width");

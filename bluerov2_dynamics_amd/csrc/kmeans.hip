@@ -813,12 +813,13 @@ constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
 constexpr int PP_THREADS = 256;
 constexpr int PD_THREADS = 1024;      // pp_decide: 4 samples of the chunk per thread
 constexpr int PP_SROWS = PP_LMAX + 1; // rows of S: one per trial + the chunk sums of closest itself (used for the first draw)
+constexpr int PP_SCREEN_FROM = 8;     // rounds before this one evaluate every row in fp64: with so few centres most rows are in reach of a candidate
 
 struct PPState {                      // device-resident scalars of the seeding loop
     double pot;                       // current potential
     long long cand[2][PP_LMAX];       // candidate sample indices: round c reads [(c - 1) & 1], draws the next round's into [c & 1]
     long long last;                   // sample index of the centre chosen last
-    int pad[2];
+    unsigned long long xmax_bits;     // max |x_i|^2 (finite rows) as the bit pattern of a non-negative double: the scale of the screening margin
 };
 
 // |x|^2 accumulated in coordinate order with FMAs: pp_transpose stores it, pp_round recomputes it from the coordinates it has
@@ -837,19 +838,30 @@ __device__ __forceinline__ double pp_norm2(const double x[KM_NMAX]) {
 // (sklearn: row_norms(X, squared=True)).
 template <int NS>
 __global__ void __launch_bounds__(PP_THREADS) pp_transpose_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
-                                                                 const double* __restrict__ mean, double* __restrict__ Xt, double* __restrict__ xsq) {
+                                                                 const double* __restrict__ mean, double* __restrict__ Xt, double* __restrict__ xsq,
+                                                                 float* __restrict__ Xf /* float copy for the screening of pp_round, or nullptr */,
+                                                                 PPState* __restrict__ st) {
     const int64_t i = (int64_t)blockIdx.x * PP_THREADS + threadIdx.x;
-    if (i >= N) return;
-    double x[KM_NMAX];
+    double xx = 0.0;
+    if (i < N) {
+        double x[KM_NMAX];
 #pragma unroll
-    for (int j = 0; j < KM_NMAX; ++j) {
-        x[j] = 0.0;
-        if (NS > 0 ? (j < NS) : (j < n)) {
-            x[j] = X[i * xstride + j] - (mean ? mean[j] : 0.0);
-            Xt[(int64_t)j * N + i] = x[j];
+        for (int j = 0; j < KM_NMAX; ++j) {
+            x[j] = 0.0;
+            if (NS > 0 ? (j < NS) : (j < n)) {
+                x[j] = X[i * xstride + j] - (mean ? mean[j] : 0.0);
+                Xt[(int64_t)j * N + i] = x[j];
+                if (Xf) Xf[(int64_t)j * N + i] = (float)x[j];
+            }
         }
+        xx = pp_norm2<NS>(x);
+        xsq[i] = xx;
     }
-    xsq[i] = pp_norm2<NS>(x);
+    if (Xf) {
+        xx = (xx - xx == 0.0) ? xx : 0.0;                 // a NaN / inf row is never screened out (its comparisons fail)
+        for (int off = 32; off > 0; off >>= 1) xx = fmax(xx, __shfl_down(xx, off));
+        if ((threadIdx.x & 63) == 0) atomicMax(&st->xmax_bits, (unsigned long long)__double_as_longlong(xx));
+    }
 }
 
 template <int NS>
@@ -880,31 +892,72 @@ __device__ __forceinline__ double pp_dist(const double x[KM_NMAX], Row&& crow, d
 template <int NS, int BT>
 __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
                                                              const double* __restrict__ xsq, const PPState* __restrict__ st, int par, int upd,
-                                                             double* __restrict__ closest, double* __restrict__ S) {
+                                                             double* __restrict__ closest, double* __restrict__ S,
+                                                             const float* __restrict__ Xf /* [n][N] float copy of Xt, or nullptr: no screening */) {
     // candidate rows in LDS: [trial][16 coordinates | norm | pad]; row L = the centre chosen last.  A compiler-level memory
     // barrier in front of every trial keeps their reads where they are used: as plain loop invariants the compiler hoisted
     // all 16 x 17 of them into registers (256 VGPRs + scratch, one wave per SIMD).
     constexpr int CSW = KM_NMAX + 2;
     __shared__ double cs[(PP_LMAX + 1) * CSW];
     __shared__ double red[BT / 64][PP_LMAX + 1];
+    __shared__ float csf[(PP_LMAX + 1) * KM_NMAX];    // the same rows as floats (screening)
     for (int e = threadIdx.x; e < (L + 1) * CSW; e += BT) {
         const int t = e / CSW, j = e % CSW;
         const int64_t ci = t < L ? st->cand[par][t] : st->last;
         cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
+        if (j < KM_NMAX) csf[t * KM_NMAX + j] = (float)cs[e];
     }
+    // Screening (rounds with candidates, once closest[] exists): most samples are far from all of the round's points -- its L
+    // candidates and the centre chosen last --, and then the owed update changes nothing and every min(closest, d) is closest.  A
+    // float copy of the coordinates (48 instead of 96 bytes per sample) certifies that: in float, difference form,
+    //   sqrt(d_float) >= sqrt(closest) (1 + 5e-6) + 2.5e-6 R     (R^2 = 2 max |x|^2)
+    // implies true d >= closest by more than (1e-6 R)^2, ten orders above the rounding of the fp64 formula (float inputs err by
+    // 6e-8 R per coordinate, the float arithmetic by 1e-6 relative).  Decided per row of 16 lanes (one 128-byte line of every
+    // fp64 coordinate array); a row that is not certified goes through the fp64 path below unchanged.
+    const bool screening = Xf != nullptr && upd != 1 && L > 0;
+    const int npts = upd == 2 ? L + 1 : L;            // row L (the last centre) only when its update is owed
+    float rmarg = 0.0f;
+    if (screening) rmarg = 2.5e-6f * (float)sqrt(2.0 * __longlong_as_double((long long)st->xmax_bits)) * 1.000001f + 1.0e-37f;
     __syncthreads();
+
     double acc[PP_LMAX], acc0 = 0.0;
 #pragma unroll
     for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
     const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
+    constexpr int NF = NS > 0 ? NS : KM_NMAX;
 #pragma unroll 1
     for (int q = 0; q < PP_CHUNK / BT; ++q) {
         const int64_t i = base + q * BT + threadIdx.x;
-        if (i < N) {
+        bool need = i < N;
+        double old = (upd == 1 || i >= N) ? 0.0 : closest[i];
+        if (screening) {
+            bool certified = true;                    // lanes beyond N do not ask for anything
+            if (i < N) {
+                float xf[NF];
+#pragma unroll
+                for (int j = 0; j < NF; ++j) xf[j] = (NS > 0 || j < n) ? Xf[(int64_t)j * N + i] : 0.0f;
+                const float so = sqrtf((float)old * 1.0000003f + 1.0e-37f) * 1.000005f + rmarg;
+                const float thr = so * so * 1.0000003f;
+                float dmin = 3.0e38f;
+#pragma unroll 1
+                for (int t = 0; t < npts; ++t) {
+                    const float* row = csf + t * KM_NMAX;
+                    float d = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NF; ++j) { const float e = xf[j] - row[j]; d = fmaf(e, e, d); }
+                    dmin = fminf(dmin, d);            // a NaN distance is ignored by fminf: guard below
+                    if (!(d == d)) dmin = 0.0f;
+                }
+                certified = dmin >= thr;              // false for a NaN threshold
+            }
+            unsigned long long b = __ballot(!certified);
+            b |= b >> 8; b |= b >> 4; b |= b >> 2; b |= b >> 1;            // bit 16 r = some lane of row r is not certified
+            need = need && ((b >> (threadIdx.x & 48)) & 1ull);
+        }
+        if (need) {
             double x[KM_NMAX];
             pp_load_col<NS>(Xt, N, n, i, x);
             const double xx = pp_norm2<NS>(x);
-            double old = upd == 1 ? 0.0 : closest[i];
             if (upd) {
                 asm volatile("" ::: "memory");
                 const double* row = cs + L * CSW;
@@ -921,6 +974,12 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
                     acc[t] += old < d ? old : d;
                 }
             }
+        } else if (i < N) {
+            // certified: every min(old, d) is old -- the same value enters the same sum at the same place
+            acc0 += old;
+#pragma unroll
+            for (int t = 0; t < PP_LMAX; ++t)
+                if (t < L) acc[t] += old;
         }
     }
 #pragma unroll
@@ -1095,28 +1154,30 @@ size_t kmeanspp_state_bytes() { return sizeof(PPState); }
 // [kmeanspp_sum_doubles(N)]; C: device [k][n]; indices: device [k] (int64)
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                            long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
-                           void* state, double* C, long long* indices) {
+                           void* state, double* C, long long* indices, float* Xf) {
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;      // prefix table + the chunk's values: N <= 3e7
     if (lds > 100 * 1024) return hipErrorInvalidValue;
     PPState* ps = reinterpret_cast<PPState*>(state);
+    hipError_t e0 = hipMemsetAsync(ps, 0, sizeof(PPState), st);
+    if (e0 != hipSuccess) return e0;
     const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
     const bool small = nchunks <= 256 && N > 2048;     // fewer chunks than CUs (and more than a few waves of samples): latency, not bandwidth
 #define PP_DISPATCH(NS_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq); \
+        hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq, Xf, ps); \
         hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
         if (k > 1) { \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(L), dim3(PD_THREADS), lds, st, N, n, nchunks, L, 0, 1, u, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } \
         for (int c = 1; c < k; ++c) { \
             const int draw = c + 1 < k ? 1 : 0; \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, L, c, draw, u + (size_t)c * L, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);

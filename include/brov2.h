@@ -280,7 +280,9 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * 1 = full scan over all k centres in the caller's order (the independent second implementation; BROV2_KMEANS_PLAIN=1 at brov_create);
  * 2 = candidate filter in the caller's order (no sorting).
  * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
- * still the one for k > 512 or n = 15) instead of the LDS-resident table read through DPP: same arithmetic, same labels. */
+ * still the one for k > 512 or n = 15) instead of the LDS-resident table read through DPP: same arithmetic, same labels.
+ * Adding 8 makes the k-means++ seeding (edmdc_kmeanspp_dev) take every sample through its fp64 distance evaluation in every round
+ * instead of screening rows out with a float copy of the coordinates first: same indices, same centres. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------

@@ -627,6 +627,23 @@ def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
             C, idx = eng.kmeanspp_dev(torch.from_numpy(X).cuda(), k, mean=mean, random_state=seed)
             assert np.array_equal(idx, idx_ref), (N, n, k, seed, int(np.sum(idx != idx_ref)))
             assert np.array_equal(C.cpu().numpy(), C_ref)
+    # rows that a float copy of the coordinates certifies to be out of reach of a round's points never load their fp64
+    # coordinates (pp_round_kernel): the same indices and centres with the screening switched off (variant + 8), on trajectory-
+    # like data where most rows are screened out, on tiny-scale data, and with a NaN row
+    from bluerov2_dynamics_amd import _lib
+    plain = _lib.Context(0)
+    plain.set_kmeans_variant(8)
+    for N, n, k, scale in ((300000, 12, 512, 1.0), (50000, 13, 100, 1e-4), (20000, 3, 40, 30.0)):
+        X = (np.cumsum(rng.normal(0, 0.05, (N, n)), 0) + 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))) * scale
+        if n == 3:
+            X[777, 1] = np.nan
+        Xd = torch.from_numpy(X).cuda()
+        mean = np.nanmean(X, 0)
+        C, idx = eng.kmeanspp_dev(Xd, k, mean=mean, random_state=1)
+        Cp, idxp = eng.kmeanspp_dev(Xd, k, mean=mean, random_state=1, ctx=plain)
+        assert np.array_equal(idx, idxp), (N, n, k, int(np.sum(idx != idxp)))
+        assert np.array_equal(C.cpu().numpy(), Cp.cpu().numpy(), equal_nan=True)
+    plain.close()
     # the random numbers are consumed exactly as scikit-learn consumes them
     first, U, L = eng.kmeanspp_draws(1000, 16, 5)
     rs = np.random.RandomState(5)
