@@ -807,7 +807,8 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
 //                                     are recomputed on the fly -- so the updated closest[] is never needed before the next
 //                                     pp_round writes it.
 // (The first version made two passes per centre: update + chunk sums, then the candidates' potentials; 535 us per centre at
-// N = 1e7 against 270 us now.)  Nothing returns to the host until all k centres are chosen.
+// N = 1e7 against 270 us now.)  Round 3: pp_round screens rows of 16 samples with a float copy of the coordinates before it
+// loads their fp64 ones (see the kernel).  Nothing returns to the host until all k centres are chosen.
 constexpr int PP_CHUNK = 4096;
 constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
 constexpr int PP_THREADS = 256;
