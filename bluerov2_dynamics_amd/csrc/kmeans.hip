@@ -347,8 +347,9 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 //     scanning -- a wave issues one instruction every four cycles, and with four waves per SIMD that rate is the budget;
 //   * the rows of the NEXT pass are loaded before the evaluation loop of this one (16-byte loads when the rows allow) -- through
 //     the loop's sample permutation when there is one (sortperm.hip: row perm[p] for position p, the index loaded a pass earlier
-//     still; labels and distances are per position) --, the distance-table rows of all label groups are requested together;
-//   * the first / unfiltered E-step is the same loop with every mask bit set.
+//     still; labels and distances are per position) --, the distance-table rows of up to four label groups are requested together;
+//   * the records are evaluated in pairs, two interleaved FMA chains (a dependent fp64 FMA does not issue back to back);
+//   * the first / unfiltered E-step is the same schedule over all k centres.
 // Same arithmetic as above, instruction for instruction (seed -|c|^2/2, then fma(x_j, c_j, .) in index order; candidates in
 // increasing index order, first maximum wins): labels and scores are bit-identical to the scalar-record kernel.
 constexpr int KM2_BLOCKS = 256;
