@@ -667,7 +667,8 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
         ctxs.append(c)
     cases = []
     for (N, n, k, shuffle) in ((60000, 12, 512, False), (60000, 12, 512, True), (20011, 13, 100, False), (5000, 12, 70, False), (3000, 5, 64, False),
-                               (300000, 12, 256, False), (270001, 13, 128, True),        # >= 2^18 samples: the loop sorts its private copy
+                               (300000, 12, 256, False), (270001, 13, 128, True),        # >= 2^18 samples: the loop keeps a sorted order
+                               (280000, 12, 512, False), (262144, 5, 70, False),         # ... two blocks of mask words; generic n at exactly 2^18
                                (30000, 12, 600, False), (9000, 15, 130, False), (9000, 14, 130, False), (7001, 3, 200, False)):
         X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0)                   # a random walk: consecutive samples are neighbours
         X += 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))
