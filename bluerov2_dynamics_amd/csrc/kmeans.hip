@@ -714,8 +714,18 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
     const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;       // slot (0..n: coordinates, n: count), sub-range of the blocks
     __shared__ double part[16][17];
     double a = 0.0;
-    if (j <= n)
-        for (int b = sr; b < nblocks; b += 16) a += partial[((int64_t)b * k + c) * np1 + j];
+    if (j <= n) {
+        // the same order of additions as `a += partial[b], b = sr, sr + 16, ...`, eight loads in flight at a time (one at a time,
+        // each addition waited for an L2 round trip of its own)
+        for (int b0 = sr; b0 < nblocks; b0 += 16 * 8) {
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nblocks ? partial[((int64_t)b * k + c) * np1 + j] : 0.0; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+                if (b0 + 16 * q < nblocks) a += v[q];
+        }
+    }
     part[sr][j] = a;
     __syncthreads();
     __shared__ double tot[16];
@@ -1025,8 +1035,19 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
         // one wave per trial: lane l adds every 64th chunk sum, then a fixed shuffle tree
         const int t = tid >> 6, l = tid & 63;
         if (t < L) {
+            // same order of additions as the plain loop `a += S[t][b], b = l, l + 64, ...`, but eight loads are in flight at a time:
+            // as written first, every addition waited for its own load (38 L2 round trips one after the other at N = 1e7 -- most
+            // of this kernel's 26 us)
             double a = 0.0;
-            for (int b = l; b < nchunks; b += 64) a += S[(int64_t)t * nchunks + b];
+            const double* Sr = S + (int64_t)t * nchunks;
+            for (int b0 = l; b0 < nchunks; b0 += 64 * 8) {
+                double v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int b = b0 + 64 * q; v[q] = b < nchunks ? Sr[b] : 0.0; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (b0 + 64 * q < nchunks) a += v[q];
+            }
             for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
             if (l == 0) pots[t] = a;
         }
@@ -1051,8 +1072,15 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
         // scanned in thread order (shuffle scan inside a wave, the 16 wave totals chained) -- fixed grouping, same result every run
         const int per = (nchunks + PD_THREADS - 1) / PD_THREADS;
         const int b0 = tid * per < nchunks ? tid * per : nchunks, b1 = b0 + per < nchunks ? b0 + per : nchunks;
+        // the thread's segment of chunk sums: loaded together (at most 9: the LDS bound on nchunks / 1024 threads), added in order
+        constexpr int PERMAX = 9;
+        double seg[PERMAX];
+#pragma unroll
+        for (int q = 0; q < PERMAX; ++q) seg[q] = b0 + q < b1 ? cs[b0 + q] : 0.0;
         double a = 0.0;
-        for (int b = b0; b < b1; ++b) a += cs[b];
+#pragma unroll
+        for (int q = 0; q < PERMAX; ++q)
+            if (b0 + q < b1) a += seg[q];
         const int lane = tid & 63, w = tid >> 6;
         double incl = a;
         for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
@@ -1061,7 +1089,9 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
         double woff = 0.0;
         for (int q = 0; q < w; ++q) woff += wtot[q];
         double run = woff + (incl - a);
-        for (int b = b0; b < b1; ++b) { prefix[b] = run; run += cs[b]; }
+#pragma unroll
+        for (int q = 0; q < PERMAX; ++q)
+            if (b0 + q < b1) { prefix[b0 + q] = run; run += seg[q]; }
         if (tid == PD_THREADS - 1) {
             prefix[nchunks] = run;
             if (c == 0) { s_pot = run; if (blockIdx.x == 0) st->pot = run; }
@@ -1160,7 +1190,7 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;      // prefix table + the chunk's values: N <= 3e7
-    if (lds > 100 * 1024) return hipErrorInvalidValue;
+    if (lds > 100 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > 9) return hipErrorInvalidValue;     // (9: pp_decide's register segment)
     PPState* ps = reinterpret_cast<PPState*>(state);
     hipError_t e0 = hipMemsetAsync(ps, 0, sizeof(PPState), st);
     if (e0 != hipSuccess) return e0;
