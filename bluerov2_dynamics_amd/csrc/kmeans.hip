@@ -753,10 +753,17 @@ __global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, 
         if (jj == 0) atomicAdd(&stats[0], shift2);
         if (jj == 0 && !(q - q == 0.0)) prm[2] = 1.0;         // a non-finite centre (NaN / inf data): the candidate filter stands down
     }
-    if (blockIdx.x == 0 && threadIdx.x == 64) {
+    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {     // the second wave of block 0: lane l takes blocks l, l + 64, ...; fixed tree
+        const int l = threadIdx.x & 63;
         double in = 0.0, xm = 0.0;
         long long ch = 0;
-        for (int b = 0; b < nblocks; ++b) { in += block_inertia[b]; ch += block_changed[b]; xm = fmax(xm, block_xmax[b]); }
+        for (int b = l; b < nblocks; b += 64) { in += block_inertia[b]; ch += block_changed[b]; xm = fmax(xm, block_xmax[b]); }
+        for (int off = 32; off > 0; off >>= 1) {
+            in += __shfl_down(in, off);
+            ch += __shfl_down(ch, off);
+            xm = fmax(xm, __shfl_down(xm, off));
+        }
+        if (l != 0) return;
         stats[1] = in;
         stats[2] = (double)ch;
         const double R2 = 2.0 * xm;                       // centres are means of samples: |c| <= max |x|
