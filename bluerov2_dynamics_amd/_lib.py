@@ -43,6 +43,28 @@ class BrovError(RuntimeError):
     pass
 
 
+# callback types of include/brov2.h
+FAR_SELECT_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_double_p, i64, ctypes.c_int, ctypes.POINTER(i64))
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, c_void_p, c_void_p, i64, ctypes.c_int)
+
+
+def _numpy_far_select(_user, dist_p, N, n_empty, out_p):
+    """The rows scikit-learn relocates its empty clusters to: `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`
+    (sklearn/cluster/_k_means_common.pyx, `_relocate_empty_clusters_dense`) -- NumPy's own introselect on this host, so that
+    ties and the order of the n_empty farthest rows fall exactly as they do inside scikit-learn."""
+    try:
+        d = np.ctypeslib.as_array(dist_p, shape=(int(N),))
+        far = np.argpartition(d, -int(n_empty))[:-int(n_empty) - 1:-1]
+        out = np.ctypeslib.as_array(out_p, shape=(int(n_empty),))
+        out[:] = far
+        return 0
+    except Exception:                      # never let an exception cross the C boundary
+        return 1
+
+
+_NUMPY_FAR_SELECT = FAR_SELECT_FN(_numpy_far_select)      # one process-wide trampoline (must outlive every ctx that holds it)
+
+
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -111,6 +133,9 @@ SIGNATURES = {
     "edmdc_set_apply_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "edmdc_lift_cache": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "edmdc_set_kmeans_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "edmdc_set_kmeans_far_select": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    "edmdc_kmeans_relocations": (ctypes.c_int, [c_void_p]),
+    "edmdc_set_kmeans_allreduce": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "brov_comm_available": (ctypes.c_int, []),
     "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
     "brov_comm_init_rank": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void_p)]),
@@ -213,6 +238,9 @@ class Context:
         self.h = h
         self.device = int(device)
         self._stream = 0          # handle the ctx currently launches on (0 = the null stream)
+        self._allreduce_cb = None
+        # empty clusters of the Lloyd loop are relocated to the rows NumPy's argpartition picks, as in scikit-learn
+        self.check(self.lib.edmdc_set_kmeans_far_select(self.h, ctypes.cast(_NUMPY_FAR_SELECT, c_void_p), None), "edmdc_set_kmeans_far_select")
 
     @property
     def arch(self) -> str:
@@ -287,6 +315,36 @@ class Context:
     def set_kmeans_variant(self, variant: int):
         """Lloyd's loop: 0 = candidate filter on sorted samples (default), 1 = full scan, 2 = filter without sorting (include/brov2.h)."""
         self.check(self.lib.edmdc_set_kmeans_variant(self.h, int(variant)), "edmdc_set_kmeans_variant")
+
+    def set_kmeans_far_select(self, numpy_rule: bool):
+        """True (default): the empty-cluster relocation picks its rows with np.argpartition, like scikit-learn; False: the
+        library's own descending selection (ties by ascending row), which does not depend on NumPy's introselect."""
+        fn = ctypes.cast(_NUMPY_FAR_SELECT, c_void_p) if numpy_rule else None
+        self.check(self.lib.edmdc_set_kmeans_far_select(self.h, fn, None), "edmdc_set_kmeans_far_select")
+
+    def kmeans_relocations(self) -> int:
+        """Iterations of the last Lloyd call in which empty clusters were relocated."""
+        return int(self.lib.edmdc_kmeans_relocations(self.h))
+
+    def set_kmeans_allreduce(self, fn):
+        """Sharded Lloyd (include/brov2.h: edmdc_set_kmeans_allreduce).  fn(device_ptr: int, count: int, op: int) combines the
+        device buffer over all ranks in place (op 0: sum of int64, op 1: max of uint64), ordered with respect to the ctx stream;
+        None switches back to a single rank."""
+        if fn is None:
+            self._allreduce_cb = None
+            self.check(self.lib.edmdc_set_kmeans_allreduce(self.h, None, None), "edmdc_set_kmeans_allreduce")
+            return
+
+        def tramp(_user, ptr, count, op):
+            try:
+                fn(int(ptr), int(count), int(op))
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._allreduce_cb = ALLREDUCE_FN(tramp)
+        self.check(self.lib.edmdc_set_kmeans_allreduce(self.h, ctypes.cast(self._allreduce_cb, c_void_p), None), "edmdc_set_kmeans_allreduce")
 
     def set_apply_variant(self, variant: int):
         """edmdc_pinv_apply: 0 = tuned W-rows kernel, 1 = the plain second implementation (see include/brov2.h)."""

@@ -100,17 +100,27 @@ int window_scan_chunk();
 hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 
 // ---- k-means (kmeans.hip) ------------------------------------------------------------------
-size_t kmeans_workspace_doubles(int n, int k);
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records);
+int kmeans_epochs(int64_t N, int n, int k, bool scalar_records);
+size_t kmeans_partial_words(int64_t N, int n, int k, bool scalar_records);      // u64 words of the E-step's partial tables
+size_t kmeans_red_words(int n, int k);                                          // int64 words of the totals (+ 2 tail words)
 bool kmeans_reads_through_perm(int n, int k, bool scalar_records);
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2);
-// E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist, prm [3] from launch_kmeans_update)
+hipError_t launch_kmeans_range(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, unsigned long long* rng);
+hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* rng, double* fix, double* prm);
+// E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist); prm [4], fix [32] from launch_kmeans_scale
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
-                                const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records, const int* perm = nullptr);
+                                const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
+                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr);
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc);
-hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
-                                const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm);
+hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
+                                const int* block_changed, long long* red, double* stats);
+hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
+                                 double* c2, double* stats, double* prm, int mode);
+hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
+                                    const int* labels, const int* perm, double* dist_row, int* lab_row);
+hipError_t launch_kmeans_relocate(hipStream_t st, int n, int n_empty, const int* new_ids, const long long* far_rows, const int* old_ids,
+                                  const double* X, int64_t xstride, const double* mean, const double* fix, long long* red);
 
 // sample order of the Lloyd loop (sortperm.hip): sort by (label, distance to the centre), gather rows / labels / permutation
 size_t kmeans_sort_temp_bytes(int64_t N);

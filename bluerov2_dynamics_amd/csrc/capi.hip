@@ -66,6 +66,11 @@ struct brov_ctx {
     unsigned long long io_seq = 0;    // sequence number of the last per-call launch (completion flags at the end of the staging block)
     double* h_stats = nullptr;        // pinned: per-iteration statistics of the Lloyd loop come back while the next E-step runs
     hipEvent_t ev_stats = nullptr;
+    brov_far_select_fn far_select = nullptr;      // rows an empty cluster is relocated to (edmdc_set_kmeans_far_select); nullptr = descending selection
+    void* far_select_user = nullptr;
+    brov_allreduce_fn km_allreduce = nullptr;     // sharded Lloyd (edmdc_set_kmeans_allreduce): sums / maxima over ranks, stream-ordered
+    void* km_allreduce_user = nullptr;
+    int kmeans_relocations = 0;       // relocations of empty clusters in the last edmdc_kmeans_lloyd(_dev) call
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
     char arch[64] = {0};
@@ -1075,6 +1080,20 @@ int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
     return BROV_OK;
 }
 
+int edmdc_set_kmeans_far_select(brov_ctx* c, brov_far_select_fn fn, void* user) {
+    if (!c) return BROV_ERR_ARG;
+    c->far_select = fn;
+    c->far_select_user = user;
+    return BROV_OK;
+}
+int edmdc_kmeans_relocations(brov_ctx* c) { return c ? c->kmeans_relocations : 0; }
+int edmdc_set_kmeans_allreduce(brov_ctx* c, brov_allreduce_fn fn, void* user) {
+    if (!c) return BROV_ERR_ARG;
+    c->km_allreduce = fn;
+    c->km_allreduce_user = user;
+    return BROV_OK;
+}
+
 int edmdc_set_apply_variant(brov_ctx* c, int variant) {
     if (!c || variant < 0 || variant > 1) return fail(c, BROV_ERR_ARG, "edmdc_set_apply_variant: variant must be 0 or 1");
     c->apply_variant = variant;
@@ -1372,6 +1391,95 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 #ifndef KM_SORT_RATE
 #define KM_SORT_RATE 0.01
 #endif
+// `_relocate_empty_clusters_dense`'s choice of rows, `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`, is NumPy's introselect:
+// which of several equal distances it returns, and in which order the n_empty largest come out, is a property of that
+// implementation (and of the SIMD path the host CPU selects).  The Python layer therefore installs a callback that calls
+// np.argpartition itself (engine.py); without one the rows are the n_empty largest distances in descending order, equal
+// distances by ascending row -- identical whenever n_empty = 1 and the maximum is unique.
+static void far_select_default(const double* dist, int64_t N, int n_empty, int64_t* out) {
+    std::vector<int64_t> idx;
+    idx.reserve((size_t)n_empty + 1);
+    auto before = [&](int64_t a, int64_t b) {            // a is "farther" than b (NaN = farthest, like NumPy's sort order)
+        const double da = dist[a], db = dist[b];
+        const bool na = da != da, nb = db != db;
+        if (na != nb) return na;
+        if (!na && da != db) return da > db;
+        return a < b;
+    };
+    for (int64_t i = 0; i < N; ++i) {
+        if ((int)idx.size() == n_empty && !before(i, idx.back())) continue;
+        size_t pos = idx.size();
+        idx.push_back(i);
+        while (pos > 0 && before(i, idx[pos - 1])) { idx[pos] = idx[pos - 1]; --pos; }
+        idx[pos] = i;
+        if ((int)idx.size() > n_empty) idx.pop_back();
+    }
+    for (int q = 0; q < n_empty; ++q) out[q] = q < (int)idx.size() ? idx[q] : 0;
+}
+
+// The rare path of the M-step: stats[3] = n_empty > 0.  The E-step that was queued behind the M-step has returned at once (hold), so
+// the labels and the centres `Cold` are still those the member sums were formed with.  Restates `_relocate_empty_clusters_dense`
+// (sklearn/cluster/_k_means_common.pyx) followed by `_average_centers`; see kmeans.hip.
+static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mp, const double* fix,
+                           const double* Cold, double* Cnew, double* c2, double* stats, double* prm, long long* red,
+                           const int* Lc, const int* Pc, int n_empty) {
+    double* d_dist = nullptr;
+    int* d_lab = nullptr;
+    char* d_list = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_dist); (void)hipFree(d_lab); (void)hipFree(d_list); };
+#define HIPCK_R(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(c, e__, #call); } } while (0)
+    HIPCK_R(hipMalloc((void**)&d_dist, (size_t)N * 8));
+    HIPCK_R(hipMalloc((void**)&d_lab, (size_t)N * 4));
+    HIPCK_R(launch_kmeans_reloc_dist(c->stream, N, n, d_X, xstride, mp, Cold, Lc, Pc, d_dist, d_lab));
+    std::vector<double> dist((size_t)N);
+    std::vector<int> lab((size_t)N);
+    std::vector<long long> hred(kmeans_red_words(n, k));
+    HIPCK_R(hipMemcpyAsync(dist.data(), d_dist, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_R(hipMemcpyAsync(lab.data(), d_lab, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_R(hipMemcpyAsync(hred.data(), red, hred.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_R(hipStreamSynchronize(c->stream));
+    // empty_clusters = np.where(weight_in_clusters == 0)[0], ascending
+    std::vector<int> new_ids;
+    const int np1 = n + 1;
+    for (int q = 0; q < k; ++q) {
+        const __int128 cw = ((__int128)hred[((size_t)q * np1 + n) * 2] << 42) + (__int128)hred[((size_t)q * np1 + n) * 2 + 1];
+        if (cw == 0) new_ids.push_back(q);
+    }
+    n_empty = (int)new_ids.size();
+    double dmax = 0.0;
+    bool any_nan = false;
+    for (int64_t i = 0; i < N; ++i) { if (dist[i] != dist[i]) any_nan = true; else if (dist[i] > dmax) dmax = dist[i]; }
+    // `if np.max(distances) == 0: return` -- more clusters than distinct samples: nothing to relocate to
+    if (n_empty > 0 && (dmax != 0.0 || any_nan) && n_empty <= N) {
+        std::vector<int64_t> far((size_t)n_empty);
+        if (c->far_select) {
+            if (c->far_select(c->far_select_user, dist.data(), N, n_empty, far.data()) != 0) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback failed"); }
+            for (int64_t r : far) if (r < 0 || r >= N) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback returned a row out of range"); }
+        } else {
+            far_select_default(dist.data(), N, n_empty, far.data());
+        }
+        std::vector<int> old_ids((size_t)n_empty);
+        std::vector<long long> far_ll((size_t)n_empty);
+        for (int q = 0; q < n_empty; ++q) { old_ids[q] = lab[(size_t)far[q]]; far_ll[q] = (long long)far[q]; }
+        const size_t lbytes = (size_t)n_empty * (4 + 8 + 4);
+        HIPCK_R(hipMalloc((void**)&d_list, lbytes + 64));
+        long long* d_far = reinterpret_cast<long long*>(d_list);
+        int* d_new = reinterpret_cast<int*>(d_list + (size_t)n_empty * 8);
+        int* d_old = d_new + n_empty;
+        HIPCK_R(hipMemcpyAsync(d_far, far_ll.data(), (size_t)n_empty * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK_R(hipMemcpyAsync(d_new, new_ids.data(), (size_t)n_empty * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK_R(hipMemcpyAsync(d_old, old_ids.data(), (size_t)n_empty * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCK_R(launch_kmeans_relocate(c->stream, n, n_empty, d_new, d_far, d_old, d_X, xstride, mp, fix, red));
+        HIPCK_R(hipStreamSynchronize(c->stream));       // the host vectors are read by the copies above
+        ++c->kmeans_relocations;
+    }
+    HIPCK_R(launch_kmeans_average(c->stream, n, k, red, fix, Cold, Cnew, c2, stats, prm, 1));
+    HIPCK_R(hipStreamSynchronize(c->stream));
+#undef HIPCK_R
+    cleanup();
+    return BROV_OK;
+}
+
 int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host,
                            double* d_C, int max_iter, double tol_abs, int32_t* d_labels, double* inertia, int* n_iter) {
     if (!c || N < 1 || n < 1 || n > 15 || k < 1 || !d_X || !d_C || !d_labels || max_iter < 1 || xstride < n || (size_t)k * (n + 1) * 8 > 150 * 1024)
@@ -1380,6 +1488,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     const int variant = c->kmeans_variant & 3;
     const bool scalar_records = (c->kmeans_variant & 4) != 0;     // the E-step kernel with scalar centre records (kmeans.hip)
     const int nb = kmeans_blocks(N, n, k, scalar_records);
+    const int nparts = nb * kmeans_epochs(N, n, k, scalar_records);
+    const size_t pwords = kmeans_partial_words(N, n, k, scalar_records), rwords = kmeans_red_words(n, k);
     Arena a(c);
     const bool filter = variant != 1 && k >= 64;       // below one mask word there is nothing to skip
     // sample order (sortperm.hip): the filter decides per wave of 64 consecutive samples, so the loop keeps a permutation that orders the
@@ -1387,17 +1497,20 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // through it.  Worth it only at size.
     const bool sorting = filter && variant == 0 && kmeans_reads_through_perm(n, k, scalar_records) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
     const size_t sort_tmp = sorting ? kmeans_sort_temp_bytes(N) : 0;
-    int rc = a.reserve(Arena::al((size_t)nb * k * (n + 1) * 8) + 2 * Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
-                       Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
+    int rc = a.reserve(Arena::al(pwords * 8) + Arena::al(rwords * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
+                       2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
     if (rc) return rc;
-    double* partial = a.take<double>((size_t)nb * k * (n + 1));
+    unsigned long long* partial = a.take<unsigned long long>(pwords);
+    long long* red = a.take<long long>(rwords);
     double* binert = a.take<double>(nb);
-    double* bxmax = a.take<double>(nb);
     float* Dc = a.take<float>(filter ? (size_t)k * ((k + 255) & ~255) : 1);
     int* bchg = a.take<int>(nb);
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
-    double* stats = a.take<double>(8);
+    double* Cb[2] = {a.take<double>((size_t)k * n), a.take<double>((size_t)k * n)};     // centres of this / the next iteration
+    double* stats = a.take<double>(8);                 // [0] squared shift, [1] inertia, [2] changed labels, [3] empty clusters; [4..7] = prm
+    double* fix = a.take<double>(32);                  // fixed-point scales of the member sums
+    unsigned long long* rng = a.take<unsigned long long>(16);
     double* dmean = a.take<double>(16);
     int *Ls[2] = {nullptr, nullptr}, *Ps[2] = {nullptr, nullptr};
     float* d2 = nullptr;
@@ -1414,29 +1527,39 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     HIPCK(c, hipMemsetAsync(d_labels, 0xFF, N * sizeof(int32_t), c->stream));
-    HIPCK(c, launch_kmeans_c2(c->stream, n, k, d_C, c2));
     if (!c->h_stats) HIPCK(c, hipHostMalloc((void**)&c->h_stats, 8 * sizeof(double), hipHostMallocDefault));
     if (!c->ev_stats) HIPCK(c, hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
     CallTimer t(c);
+    double* prm = stats + 4;
+    const double* mp = mean_host ? dmean : nullptr;
+    // one pass over the samples before the loop: the range of every coordinate (scales of the integer member sums) and max |x|^2
+    // (margins of the candidate filter); a sharded run takes the maximum over its ranks here
+    HIPCK(c, launch_kmeans_range(c->stream, N, n, d_X, xstride, mp, rng));
+    if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, rng, 16, 1) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (max) failed");
+    HIPCK(c, launch_kmeans_scale(c->stream, n, rng, fix, prm));
+    HIPCK(c, hipMemcpyAsync(Cb[0], d_C, (size_t)k * n * 8, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(c, launch_kmeans_c2(c->stream, n, k, Cb[0], c2));
     // The E-step of iteration it+1 is queued before the host looks at the statistics of iteration it: if the loop goes on it
     // is the next E-step; if the shift criterion or max_iter ends it, it is the final E-step scikit-learn runs to make the
     // labels consistent with the last centres; under strict convergence the centres did not move and it rewrites the same
-    // labels.  The read-back and the host's round trip hide behind it.
+    // labels.  The read-back and the host's round trip hide behind it.  (With an empty cluster the queued E-step returns at
+    // once -- hold -- and is queued again after the relocation.)
     bool strict = false;
     int it = 0;
-    double hs[3] = {0, 0, 0};
+    double hs[4] = {0, 0, 0, 0};
     // current sample order: labels per position (the caller's label array until the first sort)
     int* Lc = d_labels;
     const int* Pc = nullptr;                            // position -> row of the caller's X (nullptr = identity)
-    int cur = 0;
+    int cur = 0, cc = 0;                                // cc: Cb[cc] = the centres the last E-step used
     bool want_sort = false;
     double moved = 0.0;                                 // labels changed since the last sort
+    c->kmeans_relocations = 0;
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
-    double* prm = stats + 4;
-    const double* mp = mean_host ? dmean : nullptr;
-    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, nullptr, nullptr, d2, scalar_records, nullptr));
+    HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, nullptr, prm, fix, d2, scalar_records, nullptr));
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_update(c->stream, nb, n, k, partial, binert, bchg, bxmax, d_C, c2, stats, prm));
+        HIPCK(c, launch_kmeans_reduce(c->stream, nparts, nb, n, k, partial, binert, bchg, red, stats));
+        if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
+        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
         if (want_sort) {
@@ -1448,9 +1571,21 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             moved = 0.0;
         }
         if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, d_C, c2, Lc, partial, binert, bchg, bxmax, filter ? Dc : nullptr, prm, d2, scalar_records, Pc));
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
-        hs[0] = c->h_stats[0]; hs[1] = c->h_stats[1]; hs[2] = c->h_stats[2];
+        for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];
+        if (hs[3] > 0.0) {
+            // empty clusters: relocate (the queued E-step did nothing), average again, and queue the E-step again
+            if (c->km_allreduce) return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: an empty cluster in a sharded run (relocation needs all samples on one rank)");
+            rc = kmeans_relocate(c, N, n, k, d_X, xstride, mp, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, red, Lc, Pc, (int)hs[3]);
+            if (rc) return rc;
+            HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, hipStreamSynchronize(c->stream));
+            hs[0] = c->h_stats[0];
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
+            HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc));
+        }
+        cc ^= 1;
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
         if (hs[0] <= tol_abs) break;
         if (sorting) {
@@ -1465,6 +1600,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     }
     if (it > max_iter) it = max_iter;
     double in = hs[1];
+    HIPCK(c, hipMemcpyAsync(d_C, Cb[cc], (size_t)k * n * 8, hipMemcpyDeviceToDevice, c->stream));
     if (Pc) HIPCK(c, launch_kmeans_unpermute(c->stream, N, Pc, Lc, d_labels));      // labels back in the caller's order
     if (!strict) {   // labels / inertia consistent with the final centres: the E-step already queued
         std::vector<double> hb(nb);

@@ -5,15 +5,29 @@
 // and this file restates what scikit-learn 1.7.2's `_kmeans_single_lloyd` iterates:
 //   E-step: label_i = argmin_c (|c|^2 - 2 x_i.c)          (first minimum; |x_i|^2 is common to all c;
 //           evaluated as argmax_c (x_i.c - |c|^2 / 2))
-//   M-step: c <- mean of its members (an empty cluster keeps its centre: sklearn relocates it instead)
+//   M-step: c <- mean of its members; an empty cluster is relocated to the sample farthest from its centre
+//           (`_relocate_empty_clusters_dense`), one that stays empty takes the centre of the biggest cluster (`_average_centers`)
 //   stop  : labels unchanged ("strict convergence") or sum |c_new - c_old|^2 <= tol, or max_iter
 // on the mean-centred data (the host passes the column means), so that centres agree with
 // scikit-learn's to rounding whenever no assignment is decided by the last bit.
 //
 // E-step kernel: lane = sample (its n coordinates in VGPRs), loop over centres whose coordinates arrive
 // as wave-uniform scalar loads: 12 FMA + compare/select per (64 samples, centre).  Persistent 1024-thread blocks
-// accumulate member sums and counts with LDS fp64 atomics and write one partial per block; a second
-// kernel reduces the partials in block order and forms the new centres.
+// accumulate member sums and counts in an LDS table and write one partial per block and epoch; a second
+// kernel reduces the partials and a third forms the new centres.
+//
+// Round 4: the member sums are INTEGERS.  Every coordinate of every sample is turned into a 64-bit fixed-point number,
+// q = round(x_j * s_j), s_j = 2^(48 - e_j) with 2^e_j > max_i |x_ij| (one pass over the data before the loop:
+// kmeans_range_kernel), and all additions -- DPP partial sums inside a wave, LDS atomics, block partials, the 128-bit totals,
+// an all-reduce over ranks -- are integer additions: associative, so the centres are the same bits whatever the arrival
+// order of the atomics, the sample order (sorted or the caller's), the kernel (LDS / DPP or scalar records), the number of
+// blocks or the number of GPUs the samples are sharded over.  (Rounds 2-3: fp64 LDS atomics in arrival order; two runs
+// differed in the last bits of their centres.)  The quantum is 2^-48 of a coordinate's range (3.6e-15..7.1e-15 relative to
+// max |x_j|; a sample errs by at most half of it, a mean of m samples by ~1/sqrt(12 m) of it) -- below what the order of
+// scikit-learn's own fp64 additions leaves open.  x -> q is one FMA with the constant 1.5 * 2^52 (the integer sits in
+// the mantissa; the constant's bit pattern is taken off once per flushed table, times the count).  A table is flushed every
+// KM_EPOCH_PASSES passes (2^14 samples x 2^48 < 2^63).  A non-finite sample adds zeros and a poison flag above the count:
+// its centre becomes NaN, as a floating-point sum would have made it.
 //
 // Round 3: the E-step with a candidate filter (kmeans_assign_kernel<NS, true>).  With scikit-learn's stopping rule the config-3
 // centres need all 300 iterations (tol 1e-4 is not reached at N = 1e7, k = 512), so Lloyd is two thirds of a fit().  Exact
@@ -61,19 +75,53 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
     return max(max(r0, r1), max(r2, r3));
 }
 
-// sum over the 8 lanes of half a DPP row, in every lane of it (all lanes active).  Three steps of two 32-bit DPP moves and one
-// add: __builtin_amdgcn_mov_dpp leaves the "old" operand undefined (every source lane is valid), where update_dpp(0, ...) cost
-// two more moves per step.
-__device__ __forceinline__ double half_row_sum_f64(double v) {
-    auto dpp = [](double x, auto ctrl) {
-        const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), decltype(ctrl)::value, 0xF, 0xF, true);
-        const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), decltype(ctrl)::value, 0xF, 0xF, true);
-        return __hiloint2double(hi, lo);
+// ---- member sums in fixed point (header comment): x -> round(x s) as the mantissa of x s + 1.5 * 2^52 ---------------------------
+constexpr int KM_FIX_BITS = 48;                        // |x_j s_j| < 2^48
+constexpr int KM_EPOCH_PASSES = 16;                    // passes of KM_THREADS samples between two flushes of a block's table
+constexpr double KM_MAGIC = 6755399441055744.0;        // 1.5 * 2^52: ulp 1 on [2^52, 2^53)
+constexpr unsigned long long KM_MAGIC_BITS = 0x4338000000000000ull;
+constexpr unsigned long long KM_POISON = 1ull << 40;   // added to the count by a non-finite sample (counts stay below 2^40)
+static_assert((long long)KM_THREADS * KM_EPOCH_PASSES <= (1ll << (62 - KM_FIX_BITS)), "a block's table must not overflow 63 bits between flushes");
+typedef unsigned long long u64;
+typedef const double __attribute__((address_space(4)))* cdp_;
+__device__ __forceinline__ u64 km_fix(double x, double s) { return (u64)__double_as_longlong(fma(x, s, KM_MAGIC)); }
+// sum over the 8 lanes of half a DPP row, in every lane of it: integer additions (any order gives the same bits)
+__device__ __forceinline__ u64 half_row_sum_u64(u64 v) {
+    auto dpp = [](u64 x, auto ctrl) {
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)x, decltype(ctrl)::value, 0xF, 0xF, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(x >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
+        return ((u64)hi << 32) | lo;
     };
     v += dpp(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
     v += dpp(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
     v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
     return v;
+}
+// A block's table [k][n+1] goes out as partial[epoch][block]: the bit pattern of 1.5 * 2^52 is taken off the coordinate sums
+// (count times, poisoned samples included: they added the pattern of a zero), so that a partial is a signed sum of integers.
+__device__ __forceinline__ void km_flush(u64* sums, u64* __restrict__ partial, int ep, int k, int n, bool rezero) {
+    const int np1 = n + 1;
+    __syncthreads();
+    u64* out = partial + ((int64_t)ep * gridDim.x + blockIdx.x) * k * np1;
+    for (int c = threadIdx.x >> 4; c < k; c += KM_THREADS / 16) {
+        const int j = threadIdx.x & 15;
+        if (j <= n) {
+            const u64 cnt = sums[c * np1 + n];
+            const u64 v = sums[c * np1 + j];
+            out[c * np1 + j] = j < n ? v - (cnt & (KM_POISON - 1)) * KM_MAGIC_BITS : v;
+        }
+    }
+    if (rezero) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0ull;
+        __syncthreads();
+    }
+}
+__device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep0, int nep, int k, int n) {
+    for (int ep = ep0; ep < nep; ++ep) {
+        u64* out = partial + ((int64_t)ep * gridDim.x + blockIdx.x) * k * (n + 1);
+        for (int i = threadIdx.x; i < k * (n + 1); i += KM_THREADS) out[i] = 0ull;
+    }
 }
 
 #ifndef KM_PROFILE
@@ -86,29 +134,33 @@ __device__ unsigned long long km_prof[8];
 #define KM_STAMP(slot) do { } while (0)
 #endif
 
-// prm (device, written by kmeans_update_kernel): [0] = margin, [1] = eps2 (see the header comment); Dc: [k][k] centre distances
+// prm (device): [0] = margin, [1] = eps2 (see the header comment; kmeans_scale_kernel), [2] != 0: a centre is not finite, [3] != 0: hold --
+// the M-step found an empty cluster and the host has to relocate it before this E-step may run (it returns at once; kmeans_average_kernel);
+// Dc: [k][k] centre distances; fix [32]: the fixed-point scales s_j of the member sums (and their reciprocals)
 template <int NS, bool PRUNE>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) kmeans_assign_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride,
                                                             const double* __restrict__ mean,
                                                             const double* __restrict__ Ct /* [k][16]: coordinates, |c|^2/2 at [n] */, int* __restrict__ labels,
-                                                            double* __restrict__ partial /* [blocks][k][n+1] */,
+                                                            u64* __restrict__ partial /* [epochs][blocks][k][n+1] */, int nepochs,
                                                             double* __restrict__ block_inertia, int* __restrict__ block_changed,
-                                                            double* __restrict__ block_xmax, const float* __restrict__ Dc,
-                                                            const double* __restrict__ prm, float* __restrict__ d2out) {
-    extern __shared__ double sums[];                  // [k][n+1]: member sums and count
+                                                            const float* __restrict__ Dc,
+                                                            const double* __restrict__ prm, float* __restrict__ d2out, const double* __restrict__ fix) {
+    extern __shared__ u64 sums[];                     // [k][n+1]: member sums (fixed point) and count
+    if (prm[3] != 0.0) return;                        // hold (block-uniform)
     const int np1 = n + 1;
-    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0.0;
+    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0ull;
     __shared__ double sh_inertia[KM_THREADS / 64];
     __shared__ int sh_changed[KM_THREADS / 64];
-    __shared__ double sh_xmax[KM_THREADS / 64];
     __syncthreads();
     const ccp T = (ccp)(unsigned long long)Ct;
-    double inertia = 0.0, xmax = 0.0;
+    const cdp_ FS = (cdp_)(unsigned long long)fix;
+    double inertia = 0.0;
     int changed = 0;
     double margin = 0.0, eps2 = 0.0;
     bool centres_finite = true;
     if constexpr (PRUNE) { margin = prm[0]; eps2 = prm[1]; centres_finite = prm[2] == 0.0; }
     const int lane = threadIdx.x & 63;
+    int pass = 0, ep = 0;
     for (int64_t base = (int64_t)blockIdx.x * KM_THREADS; base < N; base += (int64_t)gridDim.x * KM_THREADS) {
         const int64_t i = base + threadIdx.x;
         const bool live = i < N;
@@ -282,52 +334,59 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
         if (live) {
             if (ol != bi) ++changed;
             labels[i] = bi;
-            xmax = fmax(xmax, x2);
             const double dmin2 = fma(-2.0, best, x2);     // squared distance to the chosen centre (up to rounding)
             if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
             inertia += dmin2;
         }
-        // member sums.  A wave whose 64 samples all went to ONE centre (the rule once the loop keeps its samples sorted) would send
-        // 64 same-address fp64 atomics per coordinate through the LDS, one after the other: 13 x 64 LDS cycles per wave, more than
-        // the filtered evaluation itself.  Such a wave adds its rows up inside groups of 8 lanes first (DPP, three steps) and
-        // sends eight atomics per coordinate (the vector ALU is the scarcer unit: a fourth step costs more than it saves).
+        // member sums, fixed point (header comment).  A wave whose 64 samples all went to ONE centre (the rule once the loop keeps
+        // its samples sorted) would send 64 same-address atomics per coordinate through the LDS, one after the other: 13 x 64 LDS
+        // cycles per wave, more than the filtered evaluation itself.  Such a wave adds its rows up inside groups of 8 lanes first
+        // (DPP, three steps) and sends eight atomics per coordinate (the vector ALU is the scarcer unit: a fourth step costs more
+        // than it saves).  A non-finite sample adds zeros and the poison flag.
+        const bool bad = !(x2 - x2 == 0.0);
+        if (__ballot(bad) != 0ull) {
+#pragma unroll
+            for (int j = 0; j < KM_NMAX; ++j) x[j] = bad ? 0.0 : x[j];
+        }
         const int bi0 = __builtin_amdgcn_readfirstlane(bi);
-        if (__ballot(!live || bi != bi0) == 0ull) {
-            double* s = sums + bi0 * np1;
+        if (__ballot(!live || bi != bi0 || bad) == 0ull) {
+            u64* s = sums + bi0 * np1;
             const bool leader = (lane & 7) == 0;
+            u64 q[KM_NMAX];
 #pragma unroll
             for (int j = 0; j < KM_NMAX; ++j)
-                if (NS > 0 ? (j < NS) : (j < n)) x[j] = half_row_sum_f64(x[j]);       // (x is dead after this pass)
+                if (NS > 0 ? (j < NS) : (j < n)) q[j] = half_row_sum_u64(km_fix(x[j], FS[j]));
             if (leader) {
 #pragma unroll
                 for (int j = 0; j < KM_NMAX; ++j)
-                    if (NS > 0 ? (j < NS) : (j < n)) atomicAdd(&s[j], x[j]);
-                atomicAdd(&s[n], 8.0);
+                    if (NS > 0 ? (j < NS) : (j < n)) atomicAdd(&s[j], q[j]);
+                atomicAdd(&s[n], 8ull);
             }
         } else if (live) {
-            double* s = sums + bi * np1;
-            for (int j = 0; j < n; ++j) atomicAdd(&s[j], x[j]);
-            atomicAdd(&s[n], 1.0);
+            u64* s = sums + bi * np1;
+#pragma unroll
+            for (int j = 0; j < KM_NMAX; ++j)
+                if (NS > 0 ? (j < NS) : (j < n)) atomicAdd(&s[j], km_fix(x[j], FS[j]));
+            atomicAdd(&s[n], bad ? 1ull + KM_POISON : 1ull);
         }
+        if (++pass == KM_EPOCH_PASSES && base + (int64_t)gridDim.x * KM_THREADS < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
     }
     // block reductions of inertia / changed
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
         changed += __shfl_down(changed, off);
-        xmax = fmax(xmax, __shfl_down(xmax, off));
     }
-    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; sh_xmax[threadIdx.x >> 6] = xmax; }
+    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double in = 0.0, xm = 0.0;
+        double in = 0.0;
         int ch = 0;
-        for (int w = 0; w < KM_THREADS / 64; ++w) { in += sh_inertia[w]; ch += sh_changed[w]; xm = fmax(xm, sh_xmax[w]); }
+        for (int w = 0; w < KM_THREADS / 64; ++w) { in += sh_inertia[w]; ch += sh_changed[w]; }
         block_inertia[blockIdx.x] = in;
         block_changed[blockIdx.x] = ch;
-        block_xmax[blockIdx.x] = xm;
     }
-    double* out = partial + (int64_t)blockIdx.x * k * np1;
-    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) out[i] = sums[i];
+    km_flush(sums, partial, ep, k, n, false);
+    km_zero_epochs(partial, ep + 1, nepochs, k, n);
 }
 
 // ---- E-step, second form: centre records from the LDS through DPP ---------------------------------------------------------------
@@ -412,24 +471,27 @@ __device__ __forceinline__ void score2_bcast(double ra, double rb, const double 
 template <int NS>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
-                         const double* __restrict__ Ct, int* __restrict__ labels, double* __restrict__ partial,
-                         double* __restrict__ block_inertia, int* __restrict__ block_changed, double* __restrict__ block_xmax,
+                         const double* __restrict__ Ct, int* __restrict__ labels, u64* __restrict__ partial, int nepochs,
+                         double* __restrict__ block_inertia, int* __restrict__ block_changed,
                          const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
-                         const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */) {
-    extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums and count | candidate lists
+                         const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */,
+                         const double* __restrict__ fix) {
+    extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
+    if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
     double* tab = lds2;
-    double* sums = lds2 + k * 16;
+    u64* sums = reinterpret_cast<u64*>(lds2 + k * 16);
     unsigned short* cand = reinterpret_cast<unsigned short*>(sums + k * (n + 1));      // [16 waves][KM2_LIST]
     const int np1 = n + 1;
     for (int i = threadIdx.x; i < k * 16; i += KM_THREADS) tab[i] = Ct[i];
-    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0.0;
+    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0ull;
     __shared__ double sh_inertia[KM_THREADS / 64];
     __shared__ int sh_changed[KM_THREADS / 64];
-    __shared__ double sh_xmax[KM_THREADS / 64];
     __syncthreads();
     constexpr int NX = NS > 0 ? NS : KM_CMAX;         // coordinates in registers (generic n: slots beyond n hold zeros)
-    double inertia = 0.0, xmax = 0.0;
+    const cdp_ FS = (cdp_)(unsigned long long)fix;
+    double inertia = 0.0;
     int changed = 0;
+    int pass = 0, ep = 0;
     double margin = 0.0, eps2 = 0.0;
     bool centres_finite = true;
     if (Dc) { margin = prm[0]; eps2 = prm[1]; centres_finite = prm[2] == 0.0; }
@@ -638,35 +700,42 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (live) {
             if (ol != bi) ++changed;
             labels[i] = bi;
-            xmax = fmax(xmax, x2);
             const double dmin2 = fma(-2.0, best, x2);     // squared distance to the chosen centre (up to rounding)
             if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
             inertia += dmin2;
         }
-        // member sums (see the kernel above)
-        const int bi0 = __builtin_amdgcn_readfirstlane(bi);
-        if (__ballot(!live || bi != bi0) == 0ull) {
-            double* s = sums + bi0 * np1;
-            const bool leader = (lane & 7) == 0;
+        // member sums, fixed point (see the kernel above)
+        const bool bad = !(x2 - x2 == 0.0);
+        if (__ballot(bad) != 0ull) {
 #pragma unroll
-            for (int j = 0; j < NX; ++j) x[j] = half_row_sum_f64(x[j]);       // (x is dead after this pass)
+            for (int j = 0; j < NX; ++j) x[j] = bad ? 0.0 : x[j];
+        }
+        const int bi0 = __builtin_amdgcn_readfirstlane(bi);
+        if (__ballot(!live || bi != bi0 || bad) == 0ull) {
+            u64* s = sums + bi0 * np1;
+            const bool leader = (lane & 7) == 0;
+            u64 q[NX];
+#pragma unroll
+            for (int j = 0; j < NX; ++j)
+                if (NS > 0 || j < n) q[j] = half_row_sum_u64(km_fix(x[j], FS[j]));       // (x is dead after this pass)
             if (leader) {
 #pragma unroll
                 for (int j = 0; j < NX; ++j)
-                    if (NS > 0 || j < n) atomicAdd(&s[j], x[j]);
-                atomicAdd(&s[n], 8.0);
+                    if (NS > 0 || j < n) atomicAdd(&s[j], q[j]);
+                atomicAdd(&s[n], 8ull);
             }
         } else if (live) {
-            double* s = sums + bi * np1;
+            u64* s = sums + bi * np1;
 #pragma unroll
             for (int j = 0; j < NX; ++j)
-                if (NS > 0 || j < n) atomicAdd(&s[j], x[j]);
-            atomicAdd(&s[n], 1.0);
+                if (NS > 0 || j < n) atomicAdd(&s[j], km_fix(x[j], FS[j]));
+            atomicAdd(&s[n], bad ? 1ull + KM_POISON : 1ull);
         }
 #if KM_PROFILE
         KM_STAMP(4);
         t_acc[7] += 1ull;
 #endif
+        if (++pass == KM_EPOCH_PASSES && base + stride < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
     }
 #if KM_PROFILE
     if (threadIdx.x % 64 == 0) for (int q = 0; q < 8; ++q) atomicAdd(&km_prof[q], t_acc[q]);
@@ -674,20 +743,18 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
         changed += __shfl_down(changed, off);
-        xmax = fmax(xmax, __shfl_down(xmax, off));
     }
-    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; sh_xmax[threadIdx.x >> 6] = xmax; }
+    if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double in = 0.0, xm = 0.0;
+        double in = 0.0;
         int ch = 0;
-        for (int q = 0; q < KM_THREADS / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; xm = fmax(xm, sh_xmax[q]); }
+        for (int q = 0; q < KM_THREADS / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; }
         block_inertia[blockIdx.x] = in;
         block_changed[blockIdx.x] = ch;
-        block_xmax[blockIdx.x] = xm;
     }
-    double* out = partial + (int64_t)blockIdx.x * k * np1;
-    for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) out[i] = sums[i];
+    km_flush(sums, partial, ep, k, n, false);
+    km_zero_epochs(partial, ep + 1, nepochs, k, n);
 }
 
 #if KM_PROFILE
@@ -699,76 +766,275 @@ extern "C" __attribute__((visibility("default"))) int brov_debug_kmprof(unsigned
 }
 namespace brov {
 #endif
-// One 256-thread block per centre: sums the block partials (thread = (coordinate slot j, sub-range s of the blocks); the 16
-// sub-range sums are added in index order: a fixed grouping, the same result for the same partials), forms the new centre and
-// the squared shift.  (Round 2: one wave per centre walked the 512 partials one dependent load after the other, 0.2 ms.)
-// stats[0] = sum of squared centre shifts, stats[1] = inertia, stats[2] = changed labels;
-// prm[0] = margin, prm[1] = eps2 of the candidate filter, from R^2 = 2 max |x|^2 (block_xmax); prm[2] != 0: some centre is not finite.
-__global__ void __launch_bounds__(256) kmeans_update_kernel(int nblocks, int n, int k, const double* __restrict__ partial,
+// ---- M-step --------------------------------------------------------------------------------------------------------------------
+// Totals of the member sums: 128-bit integers kept as two int64 limbs (hi, lo), value = hi * 2^42 + lo with 0 <= lo < 2^42 --
+// limbs that an int64 SUM all-reduce over ranks adds without overflow (|total| < 2^(48 + 40)), after which the pair still
+// stands for the exact total (lo may then exceed 2^42; km_load128 does not care).
+constexpr int KM_LIMB = 42;
+__device__ __forceinline__ __int128 km_load128(const long long* p) { return ((__int128)p[0] << KM_LIMB) + (__int128)p[1]; }
+__device__ __forceinline__ void km_store128(long long* p, __int128 v) {
+    p[0] = (long long)(v >> KM_LIMB);
+    p[1] = (long long)(v & (((__int128)1 << KM_LIMB) - 1));
+}
+__device__ __forceinline__ double km_to_double(__int128 v) {
+    const long long hi = (long long)(v >> 64);
+    const u64 lo = (u64)v;
+    return (double)hi * 18446744073709551616.0 + (double)lo;      // exact below 2^53, one or two roundings above: the same bits every time
+}
+// packed table row of a centre: [coordinates | |c|^2 / 2 at slot n | zeros | -|c|^2 / 2 at slot 15 when n <= 14]; the norm in
+// coordinate order with FMAs -- the one formula of kmeans_c2_kernel and kmeans_average_kernel
+__device__ __forceinline__ double km_pack_centre(int n, const double* __restrict__ c, double* __restrict__ row) {
+    double q = 0.0;
+    for (int j = 0; j < n; ++j) q = fma(c[j], c[j], q);
+    for (int j = 0; j < 16; ++j) row[j] = j < n ? c[j] : (j == n ? 0.5 * q : ((j == 15 && n <= KM2_NMAX) ? -0.5 * q : 0.0));
+    return q;
+}
+
+// One 256-thread block per centre: adds up the partials of all blocks and epochs (thread = (slot j, sub-range of the partials),
+// eight loads in flight) as 128-bit integers -- any grouping gives the same total -- and leaves them in red [k][n+1][2].
+// The second wave of block 0 sums the E-step's per-block statistics: inertia (fp64, lane l takes blocks l, l + 64, ...; fixed
+// tree: the same bits for the same launch geometry) into stats[1], changed labels into the tail of red (an integer, so that it
+// takes part in the all-reduce of a sharded run).
+__global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblocks, int n, int k, const u64* __restrict__ partial,
                                                             const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
-                                                            const double* __restrict__ block_xmax,
-                                                            double* __restrict__ C, double* __restrict__ Ct, double* __restrict__ stats,
-                                                            double* __restrict__ prm) {
+                                                            long long* __restrict__ red, double* __restrict__ stats) {
     const int np1 = n + 1;
     const int c = blockIdx.x;
-    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;       // slot (0..n: coordinates, n: count), sub-range of the blocks
-    __shared__ double part[16][17];
-    double a = 0.0;
+    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
+    __shared__ long long part[16][17][2];
+    __int128 a = 0;
     if (j <= n) {
-        // the same order of additions as `a += partial[b], b = sr, sr + 16, ...`, eight loads in flight at a time (one at a time,
-        // each addition waited for an L2 round trip of its own)
-        for (int b0 = sr; b0 < nblocks; b0 += 16 * 8) {
-            double v[8];
+        for (int b0 = sr; b0 < nparts; b0 += 16 * 8) {
+            long long v[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nblocks ? partial[((int64_t)b * k + c) * np1 + j] : 0.0; }
+            for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nparts ? (long long)partial[((int64_t)b * k + c) * np1 + j] : 0ll; }
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
-                if (b0 + 16 * q < nblocks) a += v[q];
+            for (int q = 0; q < 8; ++q) a += (__int128)v[q];
         }
     }
-    part[sr][j] = a;
+    part[sr][j][0] = (long long)(a >> 64);
+    part[sr][j][1] = (long long)(u64)a;
     __syncthreads();
-    __shared__ double tot[16];
-    if (threadIdx.x < 16) {
-        double t = 0.0;
-        for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
-        tot[threadIdx.x] = t;
+    if (threadIdx.x <= n) {
+        __int128 t = 0;
+        for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
+        km_store128(red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
     }
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int jj = threadIdx.x;
-        const double cnt = tot[n];
-        double nv = 0.0, shift2 = 0.0;
-        if (jj < n) {
-            const double old = C[c * n + jj];
-            nv = cnt > 0.0 ? tot[jj] / cnt : old;
-            C[c * n + jj] = nv;
-            const double dd = nv - old;
-            shift2 = dd * dd;
-        }
-        double q = nv * nv;
-        for (int off = 32; off > 0; off >>= 1) { q += __shfl_down(q, off); shift2 += __shfl_down(shift2, off); }
-        q = __shfl(q, 0);
-        if (jj < 16) Ct[c * 16 + jj] = jj < n ? nv : (jj == n ? 0.5 * q : ((jj == 15 && n <= KM2_NMAX) ? -0.5 * q : 0.0));
-        if (jj == 0) atomicAdd(&stats[0], shift2);
-        if (jj == 0 && !(q - q == 0.0)) prm[2] = 1.0;         // a non-finite centre (NaN / inf data): the candidate filter stands down
-    }
-    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {     // the second wave of block 0: lane l takes blocks l, l + 64, ...; fixed tree
+    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
         const int l = threadIdx.x & 63;
-        double in = 0.0, xm = 0.0;
+        double in = 0.0;
         long long ch = 0;
-        for (int b = l; b < nblocks; b += 64) { in += block_inertia[b]; ch += block_changed[b]; xm = fmax(xm, block_xmax[b]); }
+        for (int b = l; b < nblocks; b += 64) { in += block_inertia[b]; ch += block_changed[b]; }
         for (int off = 32; off > 0; off >>= 1) {
             in += __shfl_down(in, off);
             ch += __shfl_down(ch, off);
-            xm = fmax(xm, __shfl_down(xm, off));
         }
-        if (l != 0) return;
-        stats[1] = in;
-        stats[2] = (double)ch;
-        const double R2 = 2.0 * xm;                       // centres are means of samples: |c| <= max |x|
+        if (l == 0) { stats[1] = in; red[(int64_t)k * np1 * 2] = ch; red[(int64_t)k * np1 * 2 + 1] = 0; }
+    }
+}
+
+// New centres from the totals, one block of 1024 threads (thread = centre): mean = total / s_j / count (scikit-learn multiplies by
+// 1 / count: `_average_centers`), NaN for a poisoned cluster; stats[0] = sum of squared centre shifts (fixed tree), stats[2] =
+// changed labels, stats[3] = empty clusters; the packed table Ct; prm[2] != 0 when a centre is not finite.
+//   mode 0 (every iteration): an empty cluster keeps its old centre for now, and if there is one, prm[3] = 1 puts the E-step that
+//           is already queued on hold -- the host relocates (kmeans_relocate_kernel) and calls mode 1;
+//   mode 1 (after the relocation, or when there was nothing to relocate to): a cluster that is (still) empty takes the new centre
+//           of the cluster with the largest count (the first of them: np.argmax), as `_average_centers` does; the hold is lifted.
+__global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, const long long* __restrict__ red, const double* __restrict__ fix,
+                                                              const double* __restrict__ Cold, double* __restrict__ Cnew, double* __restrict__ Ct,
+                                                              double* __restrict__ stats, double* __restrict__ prm, int mode) {
+    const int np1 = n + 1;
+    __shared__ double sh_d[16];
+    __shared__ long long sh_cnt[16];
+    __shared__ int sh_idx[16], sh_emp[16], sh_bad[16];
+    __shared__ int s_arg;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // pass 1: the non-empty clusters; count of the empty ones; the biggest cluster
+    long long bestc = -1;
+    int besti = 0x7fffffff, empties = 0;
+    for (int c = threadIdx.x; c < k; c += 1024) {
+        const __int128 cw = km_load128(red + ((int64_t)c * np1 + n) * 2);
+        const long long cnt = (long long)(cw & (KM_POISON - 1));
+        const bool poisoned = (cw >> 40) != 0;
+        if (cnt > 0 || poisoned) {
+            for (int j = 0; j < n; ++j) {
+                const double tot = km_to_double(km_load128(red + ((int64_t)c * np1 + j) * 2));
+                Cnew[(int64_t)c * n + j] = poisoned ? __builtin_nan("") : (tot * fix[16 + j]) / (double)cnt;
+            }
+        } else {
+            ++empties;
+            for (int j = 0; j < n; ++j) Cnew[(int64_t)c * n + j] = Cold[(int64_t)c * n + j];
+        }
+        if (cnt > bestc) { bestc = cnt; besti = c; }       // c ascends within a thread: the first maximum stays
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const long long oc = __shfl_down(bestc, off);
+        const int oi = __shfl_down(besti, off);
+        if (oc > bestc || (oc == bestc && oi < besti)) { bestc = oc; besti = oi; }
+        empties += __shfl_down(empties, off);
+    }
+    if (lane == 0) { sh_cnt[w] = bestc; sh_idx[w] = besti; sh_emp[w] = empties; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long bc = -1;
+        int bi = 0x7fffffff, em = 0;
+        for (int q = 0; q < 16; ++q) {
+            if (sh_cnt[q] > bc || (sh_cnt[q] == bc && sh_idx[q] < bi)) { bc = sh_cnt[q]; bi = sh_idx[q]; }
+            em += sh_emp[q];
+        }
+        s_arg = bi;
+        stats[3] = (double)em;
+        stats[2] = (double)red[(int64_t)k * np1 * 2];
+        prm[3] = (mode == 0 && em > 0) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    // pass 2 (mode 1): clusters that are still empty move to the biggest cluster's new centre
+    if (mode == 1) {
+        const int arg = s_arg;
+        for (int c = threadIdx.x; c < k; c += 1024) {
+            const __int128 cw = km_load128(red + ((int64_t)c * np1 + n) * 2);
+            if ((long long)(cw & (KM_POISON - 1)) <= 0 && (cw >> 40) == 0)
+                // `_average_centers` walks the clusters in index order IN PLACE: an empty cluster behind the biggest one copies its
+                // mean, one in front of it copies the row before it was scaled -- the SUM of the biggest cluster's members
+                // (scikit-learn 1.7.2, _k_means_common.pyx: `centers[j, k] = centers[argmax_weight, k]` inside the averaging loop)
+                for (int j = 0; j < n; ++j)
+                    Cnew[(int64_t)c * n + j] = c > arg ? Cnew[(int64_t)arg * n + j]     // (arg is not empty: nobody writes its row here)
+                                                       : km_to_double(km_load128(red + ((int64_t)arg * np1 + j) * 2)) * fix[16 + j];
+        }
+    }
+    // pass 3: shifts, packed table, finiteness
+    double shift2 = 0.0;
+    int bad = 0;
+    for (int c = threadIdx.x; c < k; c += 1024) {
+        double cc[KM_NMAX];
+        for (int j = 0; j < KM_NMAX; ++j) cc[j] = j < n ? Cnew[(int64_t)c * n + j] : 0.0;
+        double sh = 0.0;
+        for (int j = 0; j < n; ++j) { const double dd = cc[j] - Cold[(int64_t)c * n + j]; sh = fma(dd, dd, sh); }
+        shift2 += sh;
+        const double q = km_pack_centre(n, cc, Ct + (int64_t)c * 16);
+        if (!(q - q == 0.0)) bad = 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) { shift2 += __shfl_down(shift2, off); bad |= __shfl_down(bad, off); }
+    if (lane == 0) { sh_d[w] = shift2; sh_bad[w] = bad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        int b = 0;
+        for (int q = 0; q < 16; ++q) { t += sh_d[q]; b |= sh_bad[q]; }
+        stats[0] = t;
+        prm[2] = b ? 1.0 : 0.0;      // a non-finite centre (NaN / inf data): the candidate filter stands down
+    }
+}
+
+// ---- before the loop: the range of every (centred) coordinate -> fixed-point scales; max |x|^2 -> margins of the candidate filter ----
+// rng [16] (zeroed by the caller): bit patterns of non-negative doubles, atomicMax'd -- slots 0..n-1: max_i |x_ij - mean_j| over the finite
+// values, slot 15: max_i |x_i - mean|^2 over the finite rows.  (u64 maxima: an all-reduce(MAX) over ranks of a sharded run keeps the meaning.)
+__global__ void __launch_bounds__(256) kmeans_range_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                                                           u64* __restrict__ rng) {
+    double m[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) m[j] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        double x2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < KM_CMAX; ++j) {
+            if (j < n) {
+                const double x = X[i * xstride + j] - (mean ? mean[j] : 0.0);
+                x2 = fma(x, x, x2);
+                const double ax = fabs(x);
+                if (ax - ax == 0.0) m[j] = fmax(m[j], ax);
+            }
+        }
+        if (x2 - x2 == 0.0) m[15] = fmax(m[15], x2);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        double v = m[j];
+        for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off));
+        if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax(&rng[j], (u64)__double_as_longlong(v));
+    }
+}
+// fix[j] = s_j = 2^(48 - e_j), 2^e_j > max |x_j| (frexp), fix[16 + j] = 1 / s_j;  prm = {margin, eps2, 0, 0} from R^2 = 2 max |x|^2
+// (centres are means of samples: |c| <= max |x|)
+__global__ void kmeans_scale_kernel(int n, const u64* __restrict__ rng, double* __restrict__ fix, double* __restrict__ prm) {
+    const int j = threadIdx.x;
+    if (j < 16) {
+        const double m = __longlong_as_double((long long)rng[j]);
+        int e = 0;
+        if (j < n && m > 0.0) (void)frexp(m, &e);
+        int sh = KM_FIX_BITS - e;
+        sh = sh > 1000 ? 1000 : (sh < -1000 ? -1000 : sh);
+        fix[j] = ldexp(1.0, sh);
+        fix[16 + j] = ldexp(1.0, -sh);
+    }
+    if (j == 0) {
+        const double R2 = 2.0 * __longlong_as_double((long long)rng[15]);
         prm[0] = 1.0e-6 * sqrt(R2);                       // margin
         prm[1] = 1.0e-13 * R2;                            // eps2: 30 x the rounding of a computed squared distance
+        prm[2] = 0.0;
+        prm[3] = 0.0;
+    }
+}
+
+// ---- empty clusters: scikit-learn's `_relocate_empty_clusters_dense` (sklearn/cluster/_k_means_common.pyx) -------------------------
+// distances = ((X - centers_old[labels])**2).sum(axis=1) in NumPy's arithmetic: every square rounded, then the pairwise sum of
+// np.add.reduce over a contiguous axis (n < 8: left to right; else eight running sums over the blocks of 8, combined as
+// ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the remainder left to right) -- no FMA contraction.  Written per ROW of the caller's X
+// (through the loop's permutation), with the label beside it: the host picks the n_empty farthest rows with NumPy's own argpartition
+// (engine.py; the C library's fallback is a plain descending selection) and hands them to kmeans_relocate_kernel.
+__global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
+                                                                const double* __restrict__ mean, const double* __restrict__ Cold,
+                                                                const int* __restrict__ labels, const int* __restrict__ perm,
+                                                                double* __restrict__ dist_row, int* __restrict__ lab_row) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= N) return;
+    const int64_t row = perm ? (int64_t)perm[p] : p;
+    const int lab = labels[p];
+    double sq[KM_NMAX];
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) {
+        sq[j] = 0.0;
+        if (j < n) {
+            const double xc = __dsub_rn(X[row * xstride + j], mean ? mean[j] : 0.0);
+            const double d = __dsub_rn(xc, Cold[(int64_t)lab * n + j]);
+            sq[j] = __dmul_rn(d, d);
+        }
+    }
+    double res;
+    if (n < 8) {
+        res = 0.0;
+#pragma unroll
+        for (int j = 0; j < 7; ++j)
+            if (j < n) res = __dadd_rn(res, sq[j]);
+    } else {
+        res = __dadd_rn(__dadd_rn(__dadd_rn(sq[0], sq[1]), __dadd_rn(sq[2], sq[3])), __dadd_rn(__dadd_rn(sq[4], sq[5]), __dadd_rn(sq[6], sq[7])));
+#pragma unroll
+        for (int j = 8; j < KM_NMAX; ++j)
+            if (j < n) res = __dadd_rn(res, sq[j]);
+    }
+    dist_row[row] = res;
+    lab_row[row] = lab;
+}
+// for idx in range(n_empty): the far row leaves its cluster's totals and becomes the only member of the empty one -- in the order
+// of the list, on the integer totals (exactly what the row had added is taken off).  One thread: n_empty <= k small steps.
+__global__ void kmeans_relocate_kernel(int n, int n_empty, const int* __restrict__ new_ids, const long long* __restrict__ far_rows,
+                                       const int* __restrict__ old_ids, const double* __restrict__ X, int64_t xstride,
+                                       const double* __restrict__ mean, const double* __restrict__ fix, long long* __restrict__ red) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int np1 = n + 1;
+    for (int idx = 0; idx < n_empty; ++idx) {
+        const int nc = new_ids[idx], oc = old_ids[idx];
+        const long long row = far_rows[idx];
+        for (int j = 0; j < n; ++j) {
+            const double x = X[row * xstride + j] - (mean ? mean[j] : 0.0);
+            const __int128 q = (x - x == 0.0) ? (__int128)(long long)(km_fix(x, fix[j]) - KM_MAGIC_BITS) : (__int128)0;
+            long long* po = red + ((int64_t)oc * np1 + j) * 2;
+            km_store128(po, km_load128(po) - q);
+            km_store128(red + ((int64_t)nc * np1 + j) * 2, q);
+        }
+        long long* pc = red + ((int64_t)oc * np1 + n) * 2;
+        km_store128(pc, km_load128(pc) - 1);
+        km_store128(red + ((int64_t)nc * np1 + n) * 2, (__int128)1);
     }
 }
 
@@ -790,13 +1056,13 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
     }
 }
 
-// packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros]
+// packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
 __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const double* __restrict__ C, double* __restrict__ Ct) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= k) return;
-    double s = 0.0;
-    for (int j = 0; j < n; ++j) s = fma(C[c * n + j], C[c * n + j], s);
-    for (int j = 0; j < 16; ++j) Ct[c * 16 + j] = j < n ? C[c * n + j] : (j == n ? 0.5 * s : ((j == 15 && n <= KM2_NMAX) ? -0.5 * s : 0.0));
+    double cc[KM_NMAX];
+    for (int j = 0; j < KM_NMAX; ++j) cc[j] = j < n ? C[(int64_t)c * n + j] : 0.0;
+    (void)km_pack_centre(n, cc, Ct + (int64_t)c * 16);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1224,33 +1490,59 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     return hipGetLastError();
 }
 
-size_t kmeans_workspace_doubles(int n, int k) { return (size_t)KM_BLOCKS * k * (n + 1) + KM_BLOCKS + (size_t)k * 16 + 8; }
+int kmeans_blocks(int64_t N, int n, int k, bool scalar_records);
+// epochs of a block's table: a flush every KM_EPOCH_PASSES passes
+int kmeans_epochs(int64_t N, int n, int k, bool scalar_records) {
+    const int blocks = kmeans_blocks(N, n, k, scalar_records);
+    const int64_t passes = (N + (int64_t)blocks * KM_THREADS - 1) / ((int64_t)blocks * KM_THREADS);
+    const int64_t ep = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
+    return (int)(ep > 0 ? ep : 1);
+}
+size_t kmeans_partial_words(int64_t N, int n, int k, bool scalar_records) {
+    return (size_t)kmeans_blocks(N, n, k, scalar_records) * kmeans_epochs(N, n, k, scalar_records) * k * (n + 1);
+}
+size_t kmeans_red_words(int n, int k) { return (size_t)k * (n + 1) * 2 + 2; }
 
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2) {
     hipLaunchKernelGGL(kmeans_c2_kernel, dim3((k + 255) / 256), dim3(256), 0, st, n, k, C, c2);
     return hipGetLastError();
 }
 
-// one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_update maintain.
-// Dc != nullptr: the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist, prm from launch_kmeans_update).
+// range of the coordinates: rng [16] u64 (maxima as bit patterns; zeroed here).  A sharded run all-reduces rng with MAX before
+// launch_kmeans_scale turns it into fix [32] (scales of the fixed-point member sums) and prm [4] (margins of the candidate filter, flags).
+hipError_t launch_kmeans_range(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, unsigned long long* rng) {
+    if (n > KM_CMAX) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(rng, 0, 16 * sizeof(unsigned long long), st);
+    if (e != hipSuccess) return e;
+    const int64_t need = (N + 255) / 256;
+    hipLaunchKernelGGL(kmeans_range_kernel, dim3((unsigned)(need < 2048 ? need : 2048)), dim3(256), 0, st, N, n, X, xstride, mean, rng);
+    return hipGetLastError();
+}
+hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* rng, double* fix, double* prm) {
+    hipLaunchKernelGGL(kmeans_scale_kernel, dim3(1), dim3(64), 0, st, n, rng, fix, prm);
+    return hipGetLastError();
+}
+
+// one E-step (+ accumulation); c2 = the packed centre table [k][16] that launch_kmeans_c2 / launch_kmeans_average maintain.
+// Dc != nullptr: the candidate-filtered form (Dc [k][k] from launch_kmeans_cdist).  prm [4] and fix [32] from launch_kmeans_scale.
 // `scalar_records`: the kernel with the centre records in scalar registers (the only one for k > 512 or n = 15); otherwise the
 // LDS / DPP kernel.  The block count -- the number of partial sums -- follows the kernel: kmeans_blocks(N, n, k, scalar_records).
 static bool kmeans_lds_form(int n, int k, bool scalar_records) { return !scalar_records && n <= KM2_NMAX && k <= KM2_KMAX; }
 bool kmeans_reads_through_perm(int n, int k, bool scalar_records) { return kmeans_lds_form(n, k, scalar_records); }
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
-                                const double* C, const double* c2, int* labels, double* partial, double* block_inertia, int* block_changed,
-                                double* block_xmax, const float* Dc, const double* prm, float* d2out, bool scalar_records, const int* perm) {
-    (void)C;
+                                const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
+                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm) {
     if (perm && !kmeans_lds_form(n, k, scalar_records)) return hipErrorInvalidValue;      // only the LDS / DPP kernel reads through a permutation
-    if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
+    if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127) || !prm || !fix) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N, n, k, scalar_records);
+    const int nep = kmeans_epochs(N, n, k, scalar_records);
     if (kmeans_lds_form(n, k, scalar_records)) {
         const size_t lds2 = (size_t)k * (16 + n + 1) * sizeof(double) + (KM_THREADS / 64) * KM2_LIST * sizeof(unsigned short);   // 133 KB at k = 512, n = 12
 #define KM2_LAUNCH(NS_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, \
-                           block_inertia, block_changed, block_xmax, Dc, prm, d2out, perm); } while (0)
+        hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
+                           block_inertia, block_changed, Dc, prm, d2out, perm, fix); } while (0)
         if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
 #undef KM2_LAUNCH
         return hipGetLastError();
@@ -1260,8 +1552,8 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 #define KM_LAUNCH(NS_, PR_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_kernel<NS_, PR_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL((kmeans_assign_kernel<NS_, PR_>), dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, \
-                           block_inertia, block_changed, block_xmax, Dc, prm, d2out); } while (0)
+        hipLaunchKernelGGL((kmeans_assign_kernel<NS_, PR_>), dim3(blocks), dim3(KM_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
+                           block_inertia, block_changed, Dc, prm, d2out, fix); } while (0)
     if (Dc) { if (n == 12) KM_LAUNCH(12, true); else if (n == 13) KM_LAUNCH(13, true); else KM_LAUNCH(0, true); }
     else { if (n == 12) KM_LAUNCH(12, false); else if (n == 13) KM_LAUNCH(13, false); else KM_LAUNCH(0, false); }
 #undef KM_LAUNCH
@@ -1276,14 +1568,29 @@ int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
     const int cap = kmeans_lds_form(n, k, scalar_records) ? KM2_BLOCKS : KM_BLOCKS;
     return need < cap ? (int)(need > 0 ? need : 1) : cap;
 }
-hipError_t launch_kmeans_update(hipStream_t st, int nblocks, int n, int k, const double* partial, const double* block_inertia,
-                                const int* block_changed, const double* block_xmax, double* C, double* c2, double* stats, double* prm) {
-    hipError_t e = hipMemsetAsync(stats, 0, 3 * sizeof(double), st);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(prm + 2, 0, sizeof(double), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(kmeans_update_kernel, dim3(k), dim3(256), 0, st, nblocks, n, k, partial, block_inertia, block_changed, block_xmax, C, c2,
-                       stats, prm);
+// M-step, first half: partials (nparts = blocks x epochs tables) -> red [kmeans_red_words] (128-bit totals as int64 limb pairs; tail: changed
+// labels) and stats[1] = inertia.  A sharded run all-reduces red with SUM (int64) before the second half.
+hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
+                                const int* block_changed, long long* red, double* stats) {
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats);
+    return hipGetLastError();
+}
+// M-step, second half: red -> Cnew [k][n], c2 (packed table), stats[0] = squared shift against Cold, [2] = changed labels, [3] = empty clusters,
+// prm[2] (non-finite centre), prm[3] (hold); mode: see kmeans_average_kernel
+hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
+                                 double* c2, double* stats, double* prm, int mode) {
+    hipLaunchKernelGGL(kmeans_average_kernel, dim3(1), dim3(1024), 0, st, n, k, red, fix, Cold, Cnew, c2, stats, prm, mode);
+    return hipGetLastError();
+}
+hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
+                                    const int* labels, const int* perm, double* dist_row, int* lab_row) {
+    hipLaunchKernelGGL(kmeans_reloc_dist_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, n, X, xstride, mean, Cold, labels, perm,
+                       dist_row, lab_row);
+    return hipGetLastError();
+}
+hipError_t launch_kmeans_relocate(hipStream_t st, int n, int n_empty, const int* new_ids, const long long* far_rows, const int* old_ids,
+                                  const double* X, int64_t xstride, const double* mean, const double* fix, long long* red) {
+    hipLaunchKernelGGL(kmeans_relocate_kernel, dim3(1), dim3(64), 0, st, n, n_empty, new_ids, far_rows, old_ids, X, xstride, mean, fix, red);
     return hipGetLastError();
 }
 

@@ -220,7 +220,13 @@ BROV_API int edmdc_simulate(brov_ctx* ctx, int n, int r, int k, double gamma, co
  * in C_io.  X [N][n] (row stride x_stride doubles), mean [n] = column means to subtract (NULL = none; centres
  * are then in the centred frame), stop when no label changes, when the summed squared centre shift is
  * <= tol_abs, or after max_iter iterations.  labels [N] int32 (host version: optional), inertia = sum of
- * squared distances to the final centres, n_iter = iterations run.  Empty clusters keep their centre. */
+ * squared distances to the final centres, n_iter = iterations run.
+ * Empty clusters follow scikit-learn 1.7.2 (sklearn/cluster/_k_means_common.pyx): `_relocate_empty_clusters_dense` moves
+ * each of them to one of the n_empty samples farthest from their own centre (that sample leaves its cluster's sum), unless
+ * all those distances are zero; `_average_centers` then gives a cluster that is still empty the row of the biggest cluster
+ * (its mean, or -- in front of it in index order -- its member SUM, as the in-place loop of that function leaves it).
+ * The member sums are exact integer sums of the samples in 2^-48 fixed point per coordinate range, so the centres are the
+ * same bits from run to run, for every edmdc_set_kmeans_variant, and for any sharding over ranks. */
 BROV_API int edmdc_kmeans_lloyd(brov_ctx* ctx, int64_t N, int n, int k, const double* X, const double* mean,
                                 double* C_io, int max_iter, double tol_abs, int32_t* labels, double* inertia, int* n_iter);
 BROV_API int edmdc_kmeans_lloyd_dev(brov_ctx* ctx, int64_t N, int n, int k, const double* d_X, int64_t x_stride,
@@ -284,6 +290,23 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * Adding 8 makes the k-means++ seeding (edmdc_kmeanspp_dev) take every sample through its fp64 distance evaluation in every round
  * instead of screening rows out with a float copy of the coordinates first: same indices, same centres. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
+/* Which samples `_relocate_empty_clusters_dense` moves its empty clusters to is
+ * `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]` (sklearn/cluster/_k_means_common.pyx): NumPy's introselect decides the
+ * order of the n_empty largest and the winner among equal distances.  The Python layer installs a callback that calls
+ * np.argpartition itself; without one (fn = NULL) the library takes the n_empty largest distances in descending order, equal
+ * ones by ascending row -- the same rows whenever n_empty = 1 and the maximum is unique.  distances [N] (host), rows of the
+ * caller's X; far_rows_out [n_empty]; return 0 on success. */
+typedef int (*brov_far_select_fn)(void* user, const double* distances, int64_t N, int n_empty, int64_t* far_rows_out);
+BROV_API int edmdc_set_kmeans_far_select(brov_ctx* ctx, brov_far_select_fn fn, void* user);
+/* relocations of empty clusters during the last edmdc_kmeans_lloyd(_dev) call (iterations in which at least one took place) */
+BROV_API int edmdc_kmeans_relocations(brov_ctx* ctx);
+/* Sharded Lloyd: every rank calls edmdc_kmeans_lloyd_dev on its own rows with the same initial centres; `fn` is called on the
+ * ctx stream's behalf with a DEVICE buffer that has to be combined over all ranks in place before work queued later on the ctx
+ * stream reads it: op 0 = sum of `count` int64, op 1 = maximum of `count` uint64.  One call with op 1 (16 words) before the loop,
+ * one with op 0 (2 k (n + 1) + 2 words, 53 KB at k = 512) per iteration.  Integer sums: every rank gets the same centres, and
+ * they are the centres of the unsharded run bit for bit.  fn = NULL: single rank.  Return 0 on success. */
+typedef int (*brov_allreduce_fn)(void* user, void* d_buf, int64_t count, int op);
+BROV_API int edmdc_set_kmeans_allreduce(brov_ctx* ctx, brov_allreduce_fn fn, void* user);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over

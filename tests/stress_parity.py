@@ -259,22 +259,17 @@ def lloyds():
             X = np.round(X, 1)                        # many exact duplicates / ties
         C0 = X[rng.choice(N, k, replace=False)].copy()
         mean = X.mean(0)
-        # tie-prone data: one M-step only (after a tie has fallen differently in the two runs their later iterations differ for real)
-        it = 1 if rounded else int(rng.choice([1, 3, 12]) if N < 200000 else rng.choice([12, 50]))
+        it = int(rng.choice([1, 3, 12]) if N < 200000 else rng.choice([12, 50]))
         (Ca, la, ia, na), (Cb, lb, ib, nbb) = [engine.kmeans_lloyd(X, C0 - mean, max_iter=it, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
         assert na == nbb, ("lloyd iterations", N, n_, k, it)
-        assert np.max(np.abs(Ca - Cb)) <= 1e-11 * max(1.0, np.abs(Cb).max()), ("lloyd centres", N, n_, k)
-        # the member sums are fp64 atomics (order not fixed): two RUNS differ by rounding in their centres, so a sample exactly
-        # between two centres (rounded data) may fall either way -- in either variant.  A differing label must be such a tie.
-        for i in np.nonzero(la != lb)[0]:
-            x = (X[i] - mean).astype(np.longdouble)
-            da, db = [float(((x - Cb[j].astype(np.longdouble)) ** 2).sum()) for j in (la[i], lb[i])]
-            assert abs(da - db) <= 1e-12 * max(da, db, float((x * x).sum())), ("lloyd label differs without a tie", N, n_, k, it, int(i), da, db)
-            ties += 1
+        # round 4: integer member sums -- both variants form the same centres bit for bit, so their labels have nothing to differ by
+        # (round 3 had to excuse "exact-distance ties" here: fp64 atomics in arrival order moved the centres between two runs)
+        assert np.array_equal(Ca, Cb), ("lloyd centres", N, n_, k, it, float(np.max(np.abs(Ca - Cb))))
+        assert np.array_equal(la, lb), ("lloyd labels", N, n_, k, it, int(np.sum(la != lb)))
         n += 1
     for c in ctxs:
         c.close()
-    print(f"Lloyd      : {n} cases, candidate filter == full scan (labels, iterations) except {ties} exact-distance ties", flush=True)
+    print(f"Lloyd      : {n} cases, candidate filter == full scan (labels, iterations, centres bit for bit), {ties} excused", flush=True)
 
 
 if __name__ == "__main__":
