@@ -90,22 +90,32 @@ def pmc_traffic(parts, files=("r03_pmc_summary.json", "r02_pmc_summary.json", "r
     return None
 
 
-def lloyd_roofline(rows, kk, ms_per_step):
+def lloyd_roofline(rows, kk, ms_per_step, iterations):
     """fp64 issue-slot roofline of the Lloyd E-step (csrc/kmeans.hip, candidate filter): VALU instructions one E-step executes
-    (SQ_INSTS_VALU of a recorded counter run over the same data, profiles/r03_lloyd_pmc_summary.json) x 64 lanes x 2 flop over
-    the measured time per E + M step, against the fp64 vector peak -- the share of the chip's issue slots the kernel fills."""
+    (SQ_INSTS_VALU of a recorded counter run over the same data, profiles/r0N_lloyd_pmc_summary.json) x 64 lanes x 2 flop over
+    the measured time per E + M step, against the fp64 vector peak -- the share of the chip's issue slots the kernel fills.
+    The counters are a RECORDED run's (mean over its iterations): the summary's kernel-source hash and iteration count are printed
+    beside the current ones, and `stale` says whether the kernels changed since (as pmc_traffic does)."""
     if rows != 10_020_000 or kk != 512 or not ms_per_step:
         return None
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r03_lloyd_pmc_summary.json")))["kmeans_assign_lds_kernel<12>"]
-    except Exception:
-        return None
-    tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
-    return {"kernel": "kmeans_assign_lds_kernel<12> (+ update, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf, "peak": PEAK_FP64_VALU_TFLOPS,
-            "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
-            "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
-            "note": "every VALU slot priced as an FMA; mean over the 300 E-steps of a recorded run of the shipped loop (sorted sample order)",
-            "traffic": None}
+    cur = kernel_source_sha()
+    for name in ("r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
+        try:
+            full = json.load(open(os.path.join(REPO, "profiles", name)))
+            d = full["kmeans_assign_lds_kernel<12>"]
+        except Exception:
+            continue
+        rec = full.get("_kernel_source_sha")
+        tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
+        return {"kernel": "kmeans_assign_lds_kernel<12> (+ reduce / average, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf,
+                "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
+                "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
+                "source": f"profiles/{name} (rocprofv3 --pmc, recorded run)", "recorded_kernel_source_sha": rec, "current_kernel_source_sha": cur,
+                "stale": (rec != cur) if rec else None, "recorded_launches": d.get("launches"), "timed_iterations": iterations,
+                "note": "every VALU slot priced as an FMA; instruction count = mean over the E-steps of the recorded run of the shipped loop "
+                        "(sorted sample order), time = this run's",
+                "traffic": None}
+    return None
 
 
 def parse():
@@ -621,7 +631,8 @@ def main():
             "kmeans": kmeans_info,
         }
         # ---- the call the reference's scripts make: KoopmanEDMDc.fit() (Koopman/koopmanEDMDc.py:72-103; caller
-        # training/train_tank_brov2_full_comparison.py:921-930) end to end on the same device-resident data -- centres with
+        # training/train_tank_brov2_full_comparison.py:921-930): (a) the public call on host arrays, (b) its stages end to end on the
+        # same data device-resident (engine.fit_dev) -- centres with
         # scikit-learn's stopping rule, G^T[G|Y], host pinv, then fit()'s own product order (P G^T) Y as two MFMA passes
         # (edmdc_pinv_apply_dev: rows of W = G P^T, then W^T Y); and fit_multi() (:113-152: P (G^T Y), no apply pass)
         if not a.no_fit and world == 1:
@@ -630,8 +641,28 @@ def main():
             W_ = (k + 15) // 16 * 16 + (n + r + 15) // 16 * 16
             wrows_flop = dec["wrows_items_per_192_rows"] * 24 * 512.0 * W_ / 192.0          # executed MFMA flop per row of W
             wty_flop = dec["wty_tasks"] * 12288.0                                           # executed MFMA flop per pair of W^T Y
-            # warm-up (untimed, like the warm-up launches of the headline): the 45.7 GB block that holds the lifted rows between the
-            # Gram pass and the apply pass comes from torch's caching allocator, whose first allocation of that size takes ~0.5 s
+            # (a) What a user of the drop-in gets: KoopmanEDMDc(...).fit(X_host, U_host) itself -- host arrays in, upload included, the
+            # default lift_cache=False -- as the FIRST fit of this process (cold: scratch arenas, task tables and torch's allocator have
+            # not seen a fit yet) and once more (warm).  One trajectory of nb (L + 1) states (the class's fit() takes one; timing only).
+            from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+            Xh_ = Xe.view(-1, n).cpu().numpy()
+            Uh_ = np.zeros((Xh_.shape[0], r))
+            Uh_[: nb * L] = Ue.view(-1, r).cpu().numpy()
+            host_call = {}
+            for tag in ("first_call_cold_s", "second_call_s"):
+                mk = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge)
+                torch.cuda.synchronize(dev)
+                t0 = time.perf_counter()
+                mk.fit(Xh_, Uh_)
+                host_call[tag] = time.perf_counter() - t0
+            host_call.update(samples=int(Xh_.shape[0] - 1), samples_per_s_second_call=(Xh_.shape[0] - 1) / host_call["second_call_s"],
+                             finite=bool(np.isfinite(mk.A_).all() and np.isfinite(mk.B_).all()),
+                             note="KoopmanEDMDc.fit(X, U) with NumPy arrays: H2D upload of 1.6 GB, k-means with scikit-learn's stopping rule, "
+                                  "G^T G, host pinv, (P G^T) Y with a second lift (lift_cache off), download of A, B")
+            del Xh_, Uh_, mk
+            # (b) the same work on device-resident tensors (fit_dev), lifted rows kept in HBM between the two passes.  Warm-up (untimed,
+            # like the warm-up launches of the headline): the 45.7 GB block that holds the lifted rows comes from torch's caching
+            # allocator, whose first allocation of that size takes ~0.5 s
             engine.fit_dev(Xe.view(-1, n), Ue.view(-1, r), nb, L, k, gamma, ridge, order="fit", centers=Cc, ctx=ctx, lift_cache=True)
             for order in ("fit", "fit_multi"):
                 tmf = {}
@@ -646,7 +677,7 @@ def main():
                                      ("apply_lift_wrows_wty_plus_download" if order == "fit" else "host_P_times_GtY"): tmf["apply_s"] * 1e3},
                        "lloyd_iterations": tmf["lloyd_iterations"], "lloyd_max_iter": a.kmeans_iters, "lloyd_converged": tmf["lloyd_converged"],
                        "kmeanspp_ms_device": tmf.get("kmeanspp_ms"), "lloyd_ms_device": tmf.get("lloyd_ms"),
-                       "lloyd_roofline": lloyd_roofline(nb * (L + 1), k, (tmf.get("lloyd_ms") or 0.0) / (tmf["lloyd_iterations"] + 1)),
+                       "lloyd_roofline": lloyd_roofline(nb * (L + 1), k, (tmf.get("lloyd_ms") or 0.0) / (tmf["lloyd_iterations"] + 1), tmf["lloyd_iterations"]),
                        "finite": bool(np.isfinite(A_f).all() and np.isfinite(B_f).all()),
                        "samples_per_s_excluding_centres": pairs / (tmf["total_s"] - tmf["centres_s"])}
                 if order == "fit" and tmf.get("gram_kernel_ms"):
@@ -671,8 +702,11 @@ def main():
                                                        "achieved": pairs * (2.0 * p * p + 2.0 * p * d) / (apply_kernel_ms * 1e-3) / 1e12}}
                     leg["ratio_to_full_gram_ms"] = (tmf["total_s"] - tmf["centres_s"]) * 1e3 / (ewall / a.edmdc_steps * 1e3)
                 fit_legs[order] = leg
-            fit_legs["config"] = {"workload": f"BASELINE config 3 data ({pairs} pairs in {nb} bags, n=12 r=8 k=512 gamma={gamma} ridge={ridge}), device "
-                                              f"resident; KMeans stopping rule max_iter={a.kmeans_iters} tol=1e-4; wall clock incl. host pinv and downloads"}
+            fit_legs["host_call"] = host_call
+            fit_legs["config"] = {"workload": f"BASELINE config 3 data ({pairs} pairs in {nb} bags, n=12 r=8 k=512 gamma={gamma} ridge={ridge}); "
+                                              f"'fit' / 'fit_multi' = engine.fit_dev on DEVICE-RESIDENT tensors with a warmed lift cache, 'host_call' = "
+                                              f"KoopmanEDMDc.fit() on host arrays, cold and warm; KMeans stopping rule max_iter={a.kmeans_iters} "
+                                              f"tol=1e-4; wall clock incl. host pinv and downloads"}
             out["edmdc_fit"] = fit_legs
         # ---- the same fit() sharded over the ranks (N > 1; weak scaling, 1e7 pairs per GPU): centres from rank 0's shard (already
         # broadcast above), local G^T G, all-reduce, the same host pinv on every rank, local (P G^T) Y, a second all-reduce of the
@@ -820,7 +854,9 @@ def main():
         del U4, X4, GG4, G4, Y4, Xa, Xb, chk
         torch.cuda.empty_cache()
 
-    if rank == 0 and not a.no_cpu and world == 1:
+    if rank == 0 and not a.no_cpu:
+        # (N > 1: rank 0 times the same bounded host samples after every timed region; the other ranks have nothing left to do
+        # but wait at the final barrier)
         out["cpu_baseline"] = cpu_baseline_rollout(a.cpu_seconds, a.integrator)
         out["cpu_baseline_reference_shape"] = cpu_baseline_reference_shape(a.cpu_seconds, a.integrator)
     if world > 1:

@@ -136,6 +136,7 @@ SIGNATURES = {
     "edmdc_set_kmeans_far_select": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "edmdc_kmeans_relocations": (ctypes.c_int, [c_void_p]),
     "edmdc_set_kmeans_allreduce": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
+    "edmdc_set_kmeans_shard": (ctypes.c_int, [c_void_p, i64]),
     "brov_comm_available": (ctypes.c_int, []),
     "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
     "brov_comm_init_rank": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void_p)]),
@@ -144,6 +145,8 @@ SIGNATURES = {
     "brov_comm_rank": (ctypes.c_int, [c_void_p]),
     "brov_comm_last_error": (ctypes.c_char_p, [c_void_p]),
     "edmdc_gram_allreduce_dev": (ctypes.c_int, [c_void_p, c_void_p, i64, c_void_p, i64, c_void_p]),
+    "brov_comm_allreduce_words": (ctypes.c_int, [c_void_p, c_void_p, i64, ctypes.c_int, c_void_p]),
+    "edmdc_kmeans_use_comm": (ctypes.c_int, [c_void_p, c_void_p]),
 }
 
 
@@ -345,6 +348,14 @@ class Context:
                 return 1
         self._allreduce_cb = ALLREDUCE_FN(tramp)
         self.check(self.lib.edmdc_set_kmeans_allreduce(self.h, ctypes.cast(self._allreduce_cb, c_void_p), None), "edmdc_set_kmeans_allreduce")
+
+    def set_kmeans_shard(self, row_offset: int):
+        """Global index of this rank's first row (sharded Lloyd; include/brov2.h: edmdc_set_kmeans_shard)."""
+        self.check(self.lib.edmdc_set_kmeans_shard(self.h, int(row_offset)), "edmdc_set_kmeans_shard")
+
+    def kmeans_use_comm(self, comm):
+        """Sharded Lloyd through the torch-free communicator (a _lib.Comm, or None for a single rank again)."""
+        self.check(self.lib.edmdc_kmeans_use_comm(self.h, comm.h if comm is not None else None), "edmdc_kmeans_use_comm")
 
     def set_apply_variant(self, variant: int):
         """edmdc_pinv_apply: 0 = tuned W-rows kernel, 1 = the plain second implementation (see include/brov2.h)."""

@@ -119,9 +119,11 @@ hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* 
                                  double* c2, double* stats, double* prm, int mode);
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
                                     const int* labels, const int* perm, double* dist_row, int* lab_row);
-hipError_t launch_kmeans_relocate(hipStream_t st, int n, int n_empty, const int* new_ids, const long long* far_rows, const int* old_ids,
-                                  const double* X, int64_t xstride, const double* mean, const double* fix, long long* red);
 
+
+// width of the label field in the sort keys of the Lloyd loop's sample order (sortperm.hip); kmeans.hip checks its own limit against it
+constexpr int KM_SORT_LABEL_BITS = 10;
+constexpr int KM_SORT_LABEL_MAX = 1 << KM_SORT_LABEL_BITS;
 // sample order of the Lloyd loop (sortperm.hip): sort by (label, distance to the centre), gather rows / labels / permutation
 size_t kmeans_sort_temp_bytes(int64_t N);
 hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old, int* labels_new, const int* perm_old, int* perm_new,

@@ -70,6 +70,8 @@ struct brov_ctx {
     void* far_select_user = nullptr;
     brov_allreduce_fn km_allreduce = nullptr;     // sharded Lloyd (edmdc_set_kmeans_allreduce): sums / maxima over ranks, stream-ordered
     void* km_allreduce_user = nullptr;
+    brov_comm* km_comm = nullptr;                 // edmdc_kmeans_use_comm: the exchanges go to this communicator
+    long long km_row_offset = 0;                  // global index of this rank's first row (edmdc_set_kmeans_shard)
     int kmeans_relocations = 0;       // relocations of empty clusters in the last edmdc_kmeans_lloyd(_dev) call
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
@@ -137,6 +139,17 @@ struct Arena {
         off += al(count * sizeof(T));
         return p;
     }
+};
+
+// The lifted-row cache (edmdc_lift_cache) is keyed by the DEVICE addresses of X / U / C.  The host entry points edmdc_gram and
+// edmdc_pinv_apply stage their arrays in allocations of their own and free them on return: a cache armed with those addresses
+// would be found valid by the next host call of the same shape -- hipMalloc hands the same addresses out again -- and that call
+// would read the lifted rows of the PREVIOUS data.  Only a direct _dev call (whose buffers the caller owns and promises to leave
+// alone) may leave the cache armed: the host wrappers disarm it on entry and on every way out.
+struct LiftCacheDisarm {
+    brov_ctx* c;
+    explicit LiftCacheDisarm(brov_ctx* ctx) : c(ctx) { c->lift_cache_valid = false; }
+    ~LiftCacheDisarm() { c->lift_cache_valid = false; }
 };
 
 // ---- small dense helpers (host, fp64) -------------------------------------------------------
@@ -925,10 +938,15 @@ int edmdc_set_chunk_rows(brov_ctx* c, int64_t rows) {
     c->chunk_rows = (rows + 3) / 4 * 4;
     return BROV_OK;
 }
+// the one shape predicate of the EDMDc entry points (the decomposition queries included: the sanitizer sweep of round 4 found them
+// walking shapes -- r = 65 -- that the compute entry points refuse)
+static bool edmdc_shape_supported(int n, int r, int k) {
+    return !(n < 1 || n > 16 || r < 0 || r > 64 || k < 1 || k > 65535 * 16 || ((n + r + 15) / 16 * 16) > 256);
+}
 
 static int edmdc_shape_ok(brov_ctx* c, int n, int r, int k) {
     if (!c) return BROV_ERR_ARG;
-    if (n < 1 || n > 16 || r < 0 || r > 64 || k < 1 || k > 65535 * 16 || ((n + r + 15) / 16 * 16) > 256)
+    if (!edmdc_shape_supported(n, r, k))
         return fail(c, BROV_ERR_ARG, "edmdc: unsupported shape (need 1<=n<=16, 0<=r<=64, k>=1)");
     return BROV_OK;
 }
@@ -1046,19 +1064,19 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
 }
 
 int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
-    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    if (!edmdc_shape_supported(n, r, k)) return BROV_ERR_ARG;
     (void)gram_partial_doubles(edmdc_shape(n, r, k), 0, ntasks, nslabs);
     return BROV_OK;
 }
 
 int edmdc_gtg_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
-    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    if (!edmdc_shape_supported(n, r, k)) return BROV_ERR_ARG;
     (void)gram_partial_doubles(edmdc_shape(n, r, k), 2, ntasks, nslabs);
     return BROV_OK;
 }
 
 int edmdc_apply_decomposition(int n, int r, int k, int* wrows_items_per_192_rows, int* wrows_tiles_wanted, int* wty_tasks, int* wty_slabs) {
-    if (n < 1 || n > 16 || r < 0 || k < 1 || n + r > 256) return BROV_ERR_ARG;
+    if (!edmdc_shape_supported(n, r, k)) return BROV_ERR_ARG;
     const EdmdcShape s = edmdc_shape(n, r, k);
     wrows_decomposition(s, wrows_items_per_192_rows, wrows_tiles_wanted);
     (void)gram_partial_doubles(s, 1, wty_tasks, wty_slabs);
@@ -1091,6 +1109,24 @@ int edmdc_set_kmeans_allreduce(brov_ctx* c, brov_allreduce_fn fn, void* user) {
     if (!c) return BROV_ERR_ARG;
     c->km_allreduce = fn;
     c->km_allreduce_user = user;
+    return BROV_OK;
+}
+
+// the torch-free transport of the sharded Lloyd loop: the exchanges go straight to RCCL on the ctx stream (comm.hip)
+static int km_allreduce_through_comm(void* user, void* d_buf, int64_t count, int op) {
+    brov_ctx* c = static_cast<brov_ctx*>(user);
+    return brov_comm_allreduce_words(c->km_comm, d_buf, count, op, c->stream);
+}
+int edmdc_set_kmeans_shard(brov_ctx* c, int64_t row_offset) {
+    if (!c || row_offset < 0 || row_offset >= (1ll << 61)) return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_shard: bad row offset");
+    c->km_row_offset = row_offset;
+    return BROV_OK;
+}
+int edmdc_kmeans_use_comm(brov_ctx* c, brov_comm* comm) {
+    if (!c) return BROV_ERR_ARG;
+    c->km_comm = comm;
+    c->km_allreduce = comm ? km_allreduce_through_comm : nullptr;
+    c->km_allreduce_user = comm ? c : nullptr;
     return BROV_OK;
 }
 
@@ -1173,6 +1209,7 @@ int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const doubl
     if (rc) return rc;
     if (nbags < 0 || L < 0 || !C || !P || !M || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply: bad argument");
     DeviceGuard g(c);
+    LiftCacheDisarm disarm(c);
     if (nbags <= 1) { xs = L + 1; us = L; }
     const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
     const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
@@ -1202,6 +1239,7 @@ int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, 
     if (rc) return rc;
     if (nbags < 0 || L < 0 || !C || !GtG || !GtY || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_gram: bad argument");
     DeviceGuard g(c);
+    LiftCacheDisarm disarm(c);
     if (nbags <= 1) { xs = L + 1; us = L; }
     const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
     const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
@@ -1419,62 +1457,136 @@ static void far_select_default(const double* dist, int64_t N, int n_empty, int64
 
 // The rare path of the M-step: stats[3] = n_empty > 0.  The E-step that was queued behind the M-step has returned at once (hold), so
 // the labels and the centres `Cold` are still those the member sums were formed with.  Restates `_relocate_empty_clusters_dense`
-// (sklearn/cluster/_k_means_common.pyx) followed by `_average_centers`; see kmeans.hip.
-static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mp, const double* fix,
-                           const double* Cold, double* Cnew, double* c2, double* stats, double* prm, long long* red,
-                           const int* Lc, const int* Pc, int n_empty) {
+// (sklearn/cluster/_k_means_common.pyx) followed by `_average_centers`; see kmeans.hip.  The relocation itself is integer
+// arithmetic on the totals (host side, on a copy every rank holds identically): the far row's fixed-point coordinates leave its
+// old cluster's sums -- exactly what the row had added -- and become the sums of the empty one.
+// Sharded run: distances and labels stay on their ranks; the n_empty farthest rows of the WHOLE set are found one at a time with
+// three small all-reduces each (largest distance; among its holders the lowest global row; the owner's label and coordinates) --
+// the library's descending rule with rows counted globally (edmdc_set_kmeans_shard), so that every rank applies the same
+// changes and the result is that of the unsharded run under the same rule.
+static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host, const double* mp,
+                           const double* fix, const double* Cold, double* Cnew, double* c2, double* stats, double* prm, long long* red,
+                           const int* Lc, const int* Pc) {
     double* d_dist = nullptr;
     int* d_lab = nullptr;
-    char* d_list = nullptr;
-    auto cleanup = [&]() { (void)hipFree(d_dist); (void)hipFree(d_lab); (void)hipFree(d_list); };
+    long long* d_words = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_dist); (void)hipFree(d_lab); (void)hipFree(d_words); };
 #define HIPCK_R(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { cleanup(); return hip_fail(c, e__, #call); } } while (0)
     HIPCK_R(hipMalloc((void**)&d_dist, (size_t)N * 8));
     HIPCK_R(hipMalloc((void**)&d_lab, (size_t)N * 4));
+    HIPCK_R(hipMalloc((void**)&d_words, 64 * 8));
     HIPCK_R(launch_kmeans_reloc_dist(c->stream, N, n, d_X, xstride, mp, Cold, Lc, Pc, d_dist, d_lab));
     std::vector<double> dist((size_t)N);
     std::vector<int> lab((size_t)N);
     std::vector<long long> hred(kmeans_red_words(n, k));
+    double hfix[32];
     HIPCK_R(hipMemcpyAsync(dist.data(), d_dist, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK_R(hipMemcpyAsync(lab.data(), d_lab, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
     HIPCK_R(hipMemcpyAsync(hred.data(), red, hred.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_R(hipMemcpyAsync(hfix, fix, sizeof hfix, hipMemcpyDeviceToHost, c->stream));
     HIPCK_R(hipStreamSynchronize(c->stream));
+    const int np1 = n + 1;
+    auto load = [&](int q, int j) { return ((__int128)hred[((size_t)q * np1 + j) * 2] << 42) + (__int128)hred[((size_t)q * np1 + j) * 2 + 1]; };
+    auto store = [&](int q, int j, __int128 v) {
+        hred[((size_t)q * np1 + j) * 2] = (long long)(v >> 42);
+        hred[((size_t)q * np1 + j) * 2 + 1] = (long long)(v & (((__int128)1 << 42) - 1));
+    };
+    // words through the ranks (device buffer in, device buffer out: the callback's contract), synchronous: this path is rare
+    auto exchange = [&](long long* w, int count, int op) -> int {
+        if (!c->km_allreduce) return BROV_OK;
+        if (hipMemcpyAsync(d_words, w, (size_t)count * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return BROV_ERR_HIP;
+        if (c->km_allreduce(c->km_allreduce_user, d_words, count, op) != 0) return BROV_ERR_COMM;
+        if (hipMemcpyAsync(w, d_words, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return BROV_ERR_HIP;
+        return hipStreamSynchronize(c->stream) == hipSuccess ? BROV_OK : BROV_ERR_HIP;
+    };
+#define EXCH(w, count, op) do { int rc__ = exchange((w), (count), (op)); if (rc__) { cleanup(); return fail(c, rc__, "edmdc_kmeans_lloyd: exchange of the relocation failed"); } } while (0)
     // empty_clusters = np.where(weight_in_clusters == 0)[0], ascending
     std::vector<int> new_ids;
-    const int np1 = n + 1;
-    for (int q = 0; q < k; ++q) {
-        const __int128 cw = ((__int128)hred[((size_t)q * np1 + n) * 2] << 42) + (__int128)hred[((size_t)q * np1 + n) * 2 + 1];
-        if (cw == 0) new_ids.push_back(q);
-    }
-    n_empty = (int)new_ids.size();
+    for (int q = 0; q < k; ++q)
+        if (load(q, n) == 0) new_ids.push_back(q);
+    const int n_empty = (int)new_ids.size();
     double dmax = 0.0;
-    bool any_nan = false;
-    for (int64_t i = 0; i < N; ++i) { if (dist[i] != dist[i]) any_nan = true; else if (dist[i] > dmax) dmax = dist[i]; }
-    // `if np.max(distances) == 0: return` -- more clusters than distinct samples: nothing to relocate to
-    if (n_empty > 0 && (dmax != 0.0 || any_nan) && n_empty <= N) {
-        std::vector<int64_t> far((size_t)n_empty);
-        if (c->far_select) {
-            if (c->far_select(c->far_select_user, dist.data(), N, n_empty, far.data()) != 0) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback failed"); }
-            for (int64_t r : far) if (r < 0 || r >= N) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback returned a row out of range"); }
-        } else {
-            far_select_default(dist.data(), N, n_empty, far.data());
+    long long any_nan = 0;
+    for (int64_t i = 0; i < N; ++i) { if (dist[i] != dist[i]) any_nan = 1; else if (dist[i] > dmax) dmax = dist[i]; }
+    {
+        long long w[2];
+        std::memcpy(&w[0], &dmax, 8);                    // non-negative doubles order like their bit patterns
+        w[1] = any_nan;
+        EXCH(w, 2, 1);
+        std::memcpy(&dmax, &w[0], 8);
+        any_nan = w[1];
+    }
+    // one row: its quantised coordinates leave `oc` and become cluster `nc`
+    auto apply = [&](int nc, int oc, const long long* q) {
+        for (int j = 0; j < n; ++j) { store(oc, j, load(oc, j) - (__int128)q[j]); store(nc, j, (__int128)q[j]); }
+        store(oc, n, load(oc, n) - 1);
+        store(nc, n, (__int128)1);
+    };
+    auto quantise_row = [&](int64_t row, long long* q) -> int {
+        double x[16];
+        if (hipMemcpy(x, d_X + row * xstride, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) return 1;
+        for (int j = 0; j < n; ++j) {
+            const double xc = x[j] - (mean_host ? mean_host[j] : 0.0);
+            q[j] = (xc - xc == 0.0) ? (long long)std::nearbyint(xc * hfix[j]) : 0ll;      // x s is exact (s = 2^m): the device's FMA rounds the same way
         }
-        std::vector<int> old_ids((size_t)n_empty);
-        std::vector<long long> far_ll((size_t)n_empty);
-        for (int q = 0; q < n_empty; ++q) { old_ids[q] = lab[(size_t)far[q]]; far_ll[q] = (long long)far[q]; }
-        const size_t lbytes = (size_t)n_empty * (4 + 8 + 4);
-        HIPCK_R(hipMalloc((void**)&d_list, lbytes + 64));
-        long long* d_far = reinterpret_cast<long long*>(d_list);
-        int* d_new = reinterpret_cast<int*>(d_list + (size_t)n_empty * 8);
-        int* d_old = d_new + n_empty;
-        HIPCK_R(hipMemcpyAsync(d_far, far_ll.data(), (size_t)n_empty * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCK_R(hipMemcpyAsync(d_new, new_ids.data(), (size_t)n_empty * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCK_R(hipMemcpyAsync(d_old, old_ids.data(), (size_t)n_empty * 4, hipMemcpyHostToDevice, c->stream));
-        HIPCK_R(launch_kmeans_relocate(c->stream, n, n_empty, d_new, d_far, d_old, d_X, xstride, mp, fix, red));
-        HIPCK_R(hipStreamSynchronize(c->stream));       // the host vectors are read by the copies above
+        return 0;
+    };
+    // `if np.max(distances) == 0: return` -- more clusters than distinct samples: nothing to relocate to
+    if (n_empty > 0 && (dmax != 0.0 || any_nan)) {
+        if (!c->km_allreduce) {
+            if (n_empty > N) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: more empty clusters than samples"); }
+            std::vector<int64_t> far((size_t)n_empty);
+            if (c->far_select) {
+                if (c->far_select(c->far_select_user, dist.data(), N, n_empty, far.data()) != 0) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback failed"); }
+                for (int64_t r : far) if (r < 0 || r >= N) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback returned a row out of range"); }
+            } else {
+                far_select_default(dist.data(), N, n_empty, far.data());
+            }
+            for (int q = 0; q < n_empty; ++q) {
+                long long qv[16];
+                if (quantise_row(far[q], qv)) { cleanup(); return fail(c, BROV_ERR_HIP, "edmdc_kmeans_lloyd: reading a far row failed"); }
+                apply(new_ids[q], lab[(size_t)far[q]], qv);
+            }
+        } else {
+            std::vector<char> taken((size_t)N, 0);
+            for (int q = 0; q < n_empty; ++q) {
+                // this rank's farthest remaining row (NaN = farthest; equal distances: the lowest row)
+                int64_t best = -1;
+                for (int64_t i = 0; i < N; ++i) {
+                    if (taken[i]) continue;
+                    if (best < 0) { best = i; continue; }
+                    const double a = dist[i], bb = dist[best];
+                    const bool na = a != a, nb = bb != bb;
+                    if ((na && !nb) || (!na && !nb && a > bb)) best = i;
+                }
+                long long w[2] = {0, 0};
+                if (best >= 0) { const double dv = dist[best] != dist[best] ? __builtin_inf() : dist[best]; std::memcpy(&w[0], &dv, 8); }
+                const long long mine = w[0];
+                EXCH(w, 1, 1);
+                const bool holder = best >= 0 && mine == w[0];
+                long long key[1] = {holder ? ((1ll << 62) - (c->km_row_offset + best)) : 0ll};
+                EXCH(key, 1, 1);
+                const bool owner = holder && key[0] == (1ll << 62) - (c->km_row_offset + best);
+                long long msg[18];
+                for (long long& v : msg) v = 0;
+                if (owner) {
+                    if (quantise_row(best, msg)) { cleanup(); return fail(c, BROV_ERR_HIP, "edmdc_kmeans_lloyd: reading a far row failed"); }
+                    msg[16] = lab[(size_t)best];
+                    msg[17] = 1;
+                    taken[best] = 1;
+                }
+                EXCH(msg, 18, 0);
+                if (msg[17] != 1) { cleanup(); return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: the ranks disagree about a relocated row"); }
+                apply(new_ids[q], (int)msg[16], msg);
+            }
+        }
+        HIPCK_R(hipMemcpyAsync(red, hred.data(), hred.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK_R(hipStreamSynchronize(c->stream));
         ++c->kmeans_relocations;
     }
     HIPCK_R(launch_kmeans_average(c->stream, n, k, red, fix, Cold, Cnew, c2, stats, prm, 1));
     HIPCK_R(hipStreamSynchronize(c->stream));
+#undef EXCH
 #undef HIPCK_R
     cleanup();
     return BROV_OK;
@@ -1576,8 +1688,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];
         if (hs[3] > 0.0) {
             // empty clusters: relocate (the queued E-step did nothing), average again, and queue the E-step again
-            if (c->km_allreduce) return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: an empty cluster in a sharded run (relocation needs all samples on one rank)");
-            rc = kmeans_relocate(c, N, n, k, d_X, xstride, mp, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, red, Lc, Pc, (int)hs[3]);
+            rc = kmeans_relocate(c, N, n, k, d_X, xstride, mean_host, mp, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, red, Lc, Pc);
             if (rc) return rc;
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));

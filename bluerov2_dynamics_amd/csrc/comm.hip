@@ -21,7 +21,7 @@ namespace {
 // the slice of rccl.h this file needs (ABI-stable NCCL 2 API: /opt/rocm/include/rccl/rccl.h:40-43,187,448,467)
 struct NcclUniqueId { char internal[128]; };
 typedef void* NcclComm;
-constexpr int kNcclSuccess = 0, kNcclSum = 0, kNcclFloat64 = 8;
+constexpr int kNcclSuccess = 0, kNcclSum = 0, kNcclMax = 2, kNcclInt64 = 4, kNcclUint64 = 5, kNcclFloat64 = 8;
 static_assert(sizeof(NcclUniqueId) == BROV_COMM_ID_BYTES, "ncclUniqueId size");
 
 struct Rccl {
@@ -160,6 +160,20 @@ int edmdc_gram_allreduce_dev(brov_comm* c, double* d_GtG, int64_t n_gtg, double*
     if (rc1 != kNcclSuccess) return nccl_fail(c, rc1, "ncclAllReduce(GtG)");
     if (rc2 != kNcclSuccess) return nccl_fail(c, rc2, "ncclAllReduce(GtY)");
     if (rc != kNcclSuccess) return nccl_fail(c, rc, "ncclGroupEnd");
+    return BROV_OK;
+}
+
+// In-place all-reduce of `count` 64-bit words on `hip_stream` (asynchronous): op 0 = sum of int64, op 1 = maximum of uint64 -- the
+// two exchanges of the sharded Lloyd loop (edmdc_set_kmeans_allreduce / edmdc_kmeans_use_comm): integer member sums, coordinate ranges.
+int brov_comm_allreduce_words(brov_comm* c, void* d_buf, int64_t count, int op, void* hip_stream) {
+    if (!c || count < 0 || (count && !d_buf) || (op != 0 && op != 1)) return cfail(c, BROV_ERR_ARG, "brov_comm_allreduce_words: bad argument");
+    const Rccl* r = rccl();
+    if (!r) return cfail(c, BROV_ERR_COMM, g_rccl.err);
+    if (count == 0) return BROV_OK;
+    DevGuard g(c->device);
+    const int rc = r->AllReduce(d_buf, d_buf, (size_t)count, op == 0 ? kNcclInt64 : kNcclUint64, op == 0 ? kNcclSum : kNcclMax, c->comm,
+                                reinterpret_cast<hipStream_t>(hip_stream));
+    if (rc != kNcclSuccess) return nccl_fail(c, rc, "ncclAllReduce(words)");
     return BROV_OK;
 }
 

@@ -416,6 +416,8 @@ constexpr int KM2_DEPTH = 4;         // records in flight round the evaluation l
 static_assert(KM2_DEPTH == 4, "the evaluation loop of kmeans_assign_lds_kernel is written for two pairs");
 constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
 constexpr int KM2_KMAX = 512;        // 8 mask words
+static_assert(KM2_KMAX * 128 <= 65536, "the candidate lists of kmeans_assign_lds_kernel hold record offsets (c << 7) in 16 bits");
+static_assert(KM2_KMAX <= KM_SORT_LABEL_MAX, "the sort keys of the loop's sample order (sortperm.hip) hold the label in KM_SORT_LABEL_BITS bits");
 constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
 typedef double v2d __attribute__((ext_vector_type(2)));
 
@@ -714,15 +716,25 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (__ballot(!live || bi != bi0 || bad) == 0ull) {
             u64* s = sums + bi0 * np1;
             const bool leader = (lane & 7) == 0;
-            u64 q[NX];
+            if constexpr (NS > 0) {
+                u64 q[NX];
 #pragma unroll
-            for (int j = 0; j < NX; ++j)
-                if (NS > 0 || j < n) q[j] = half_row_sum_u64(km_fix(x[j], FS[j]));       // (x is dead after this pass)
-            if (leader) {
+                for (int j = 0; j < NX; ++j) q[j] = half_row_sum_u64(km_fix(x[j], FS[j]));       // (x is dead after this pass)
+                if (leader) {
 #pragma unroll
-                for (int j = 0; j < NX; ++j)
-                    if (NS > 0 || j < n) atomicAdd(&s[j], q[j]);
-                atomicAdd(&s[n], 8ull);
+                    for (int j = 0; j < NX; ++j) atomicAdd(&s[j], q[j]);
+                    atomicAdd(&s[n], 8ull);
+                }
+            } else {
+                // generic n: one coordinate at a time (fifteen 64-bit sums held at once do not fit beside the two row sets)
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    if (j < n) {
+                        const u64 q = half_row_sum_u64(km_fix(x[j], FS[j]));
+                        if (leader) atomicAdd(&s[j], q);
+                    }
+                }
+                if (leader) atomicAdd(&s[n], 8ull);
             }
         } else if (live) {
             u64* s = sums + bi * np1;
@@ -777,9 +789,11 @@ __device__ __forceinline__ void km_store128(long long* p, __int128 v) {
     p[1] = (long long)(v & (((__int128)1 << KM_LIMB) - 1));
 }
 __device__ __forceinline__ double km_to_double(__int128 v) {
-    const long long hi = (long long)(v >> 64);
-    const u64 lo = (u64)v;
-    return (double)hi * 18446744073709551616.0 + (double)lo;      // exact below 2^53, one or two roundings above: the same bits every time
+    // sign and magnitude (two's-complement halves would cancel: -5 = -2^64 + (2^64 - 5), and the second term rounds to 2^64)
+    const bool neg = v < 0;
+    const unsigned __int128 m = neg ? (unsigned __int128)(-v) : (unsigned __int128)v;
+    const double d = (double)(u64)(m >> 64) * 18446744073709551616.0 + (double)(u64)m;      // one rounding below 2^64, two above: the same bits every time
+    return neg ? -d : d;
 }
 // packed table row of a centre: [coordinates | |c|^2 / 2 at slot n | zeros | -|c|^2 / 2 at slot 15 when n <= 14]; the norm in
 // coordinate order with FMAs -- the one formula of kmeans_c2_kernel and kmeans_average_kernel
@@ -981,7 +995,7 @@ __global__ void kmeans_scale_kernel(int n, const u64* __restrict__ rng, double* 
 // np.add.reduce over a contiguous axis (n < 8: left to right; else eight running sums over the blocks of 8, combined as
 // ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), then the remainder left to right) -- no FMA contraction.  Written per ROW of the caller's X
 // (through the loop's permutation), with the label beside it: the host picks the n_empty farthest rows with NumPy's own argpartition
-// (engine.py; the C library's fallback is a plain descending selection) and hands them to kmeans_relocate_kernel.
+// (engine.py; the C library's fallback is a plain descending selection) and moves their fixed-point coordinates between the totals (capi.hip).
 __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n, const double* __restrict__ X, int64_t xstride,
                                                                 const double* __restrict__ mean, const double* __restrict__ Cold,
                                                                 const int* __restrict__ labels, const int* __restrict__ perm,
@@ -1015,29 +1029,6 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
     dist_row[row] = res;
     lab_row[row] = lab;
 }
-// for idx in range(n_empty): the far row leaves its cluster's totals and becomes the only member of the empty one -- in the order
-// of the list, on the integer totals (exactly what the row had added is taken off).  One thread: n_empty <= k small steps.
-__global__ void kmeans_relocate_kernel(int n, int n_empty, const int* __restrict__ new_ids, const long long* __restrict__ far_rows,
-                                       const int* __restrict__ old_ids, const double* __restrict__ X, int64_t xstride,
-                                       const double* __restrict__ mean, const double* __restrict__ fix, long long* __restrict__ red) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const int np1 = n + 1;
-    for (int idx = 0; idx < n_empty; ++idx) {
-        const int nc = new_ids[idx], oc = old_ids[idx];
-        const long long row = far_rows[idx];
-        for (int j = 0; j < n; ++j) {
-            const double x = X[row * xstride + j] - (mean ? mean[j] : 0.0);
-            const __int128 q = (x - x == 0.0) ? (__int128)(long long)(km_fix(x, fix[j]) - KM_MAGIC_BITS) : (__int128)0;
-            long long* po = red + ((int64_t)oc * np1 + j) * 2;
-            km_store128(po, km_load128(po) - q);
-            km_store128(red + ((int64_t)nc * np1 + j) * 2, q);
-        }
-        long long* pc = red + ((int64_t)oc * np1 + n) * 2;
-        km_store128(pc, km_load128(pc) - 1);
-        km_store128(red + ((int64_t)nc * np1 + n) * 2, (__int128)1);
-    }
-}
-
 // squared centre-centre distances (difference form) for the candidate filter, one block per row, rebuilt after every M-step:
 // floats rounded DOWN (a candidate test that errs, errs towards evaluating), row length kp = k rounded up to 256, permuted inside
 // every block of 256 so that position 4 lane + q holds centre 64 q + lane (see block_masks); padding = +inf (never a candidate)
@@ -1588,10 +1579,4 @@ hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const doub
                        dist_row, lab_row);
     return hipGetLastError();
 }
-hipError_t launch_kmeans_relocate(hipStream_t st, int n, int n_empty, const int* new_ids, const long long* far_rows, const int* old_ids,
-                                  const double* X, int64_t xstride, const double* mean, const double* fix, long long* red) {
-    hipLaunchKernelGGL(kmeans_relocate_kernel, dim3(1), dim3(64), 0, st, n, n_empty, new_ids, far_rows, old_ids, X, xstride, mean, fix, red);
-    return hipGetLastError();
-}
-
 }  // namespace brov

@@ -28,12 +28,13 @@ namespace brov {
                               // label bits: 22-bit keys sort in three radix passes instead of four (300 iterations: 300 -> 289 ms;
                               // 14 bits: 292 ms; 6 bits -- not even the whole exponent --: 412 ms)
 #endif
+static_assert(KM_SORT_LABEL_BITS + KM_SORT_DBITS <= 32, "sort keys are 32-bit");
 
 __global__ void __launch_bounds__(256) sort_keys_kernel(int64_t N, const int* __restrict__ labels, const float* __restrict__ d2,
                                                         unsigned* __restrict__ keys, unsigned* __restrict__ vals) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const unsigned lab = (unsigned)labels[i] & 0x3FFu;
+    const unsigned lab = (unsigned)labels[i] & (unsigned)(KM_SORT_LABEL_MAX - 1);
     const float d = d2[i];
     const unsigned bits = d > 0.0f ? (__float_as_uint(d) & 0x7FFFFFFFu) : 0u;      // NaN / negative: front of its cluster
     keys[i] = (lab << KM_SORT_DBITS) | (bits >> (31 - KM_SORT_DBITS));
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(256) sort_unpermute_kernel(int64_t N, const in
 size_t kmeans_sort_temp_bytes(int64_t N) {
     size_t bytes = 0;
     unsigned* p = nullptr;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)N, 0, 10 + KM_SORT_DBITS, (hipStream_t)nullptr) != hipSuccess) return 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, p, p, p, p, (size_t)N, 0, KM_SORT_LABEL_BITS + KM_SORT_DBITS, (hipStream_t)nullptr) != hipSuccess) return 0;
     return bytes;
 }
 
@@ -70,7 +71,7 @@ hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old
     if (N <= 0) return hipSuccess;
     if (N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, labels_old, d2, keys_in, vals_in);
-    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, 10 + KM_SORT_DBITS, st);
+    hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, KM_SORT_LABEL_BITS + KM_SORT_DBITS, st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(sort_gather_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, vals_out, labels_old, labels_new, perm_old, perm_new);
     return hipGetLastError();

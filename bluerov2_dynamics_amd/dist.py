@@ -156,3 +156,113 @@ def rollout_sharded(model, integrator, B_total, T, dt, seed=0x5EED, layout="tub"
     xT = torch.empty((B, nx), dtype=torch.float64, device=dev)
     engine.rollout_dev(model, integrator, x0, U, dt, traj=traj, xT=xT, layout=layout, stride=stride or 1)
     return b0, b1, xT, traj
+
+
+# ---- sharded k-means (round 4): the centres of KoopmanEDMDc.fit over ALL ranks' samples (Koopman/koopmanEDMDc.py:85 runs KMeans on all of X) ----
+class _DeviceWords:
+    """Zero-copy view of `count` int64 words at a raw device address for torch.as_tensor (__cuda_array_interface__)."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i8", "data": (int(ptr), False), "version": 3}
+
+
+def allreduce_words_(t, op, group=None):
+    """In-place all-reduce of an int64 tensor: op 0 = SUM, op 1 = MAX (bit patterns of non-negative doubles order like integers).
+    nccl (= RCCL) reduces the device tensor where it lies, ordered behind torch's current stream; any other backend (gloo) goes
+    through the host."""
+    import torch.distributed as dist
+    rop = dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX
+    if t.is_cuda and dist.get_backend(group) != "nccl":
+        h = t.cpu()
+        dist.all_reduce(h, op=rop, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=rop, group=group)
+    return t
+
+
+def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, group=None, lloyd_fn=None, ctx=None):
+    """Lloyd's loop over rows sharded across ranks: every rank passes its own rows X_local [N_local, n] and the SAME initial
+    centres C0 [k, n] (centred frame: C0 and the returned centres are relative to `mean`).  Per iteration one all-reduce (SUM,
+    int64) of the member sums -- 2 k (n + 1) + 2 words, 53 KB at k = 512 -- and one all-reduce (MAX) of 16 words before the loop.
+    The member sums are integers (csrc/kmeans.hip), so every rank ends with the same centres and they are the centres of the
+    unsharded run bit for bit.  Returns (centres [k, n], labels of the local rows, local inertia, n_iter); the inertia of the
+    whole set is the sum over ranks.  An empty cluster is relocated to the farthest rows of the WHOLE set by the library's
+    descending rule (distance, then global row; include/brov2.h: edmdc_set_kmeans_shard) -- the rows an unsharded run picks when
+    its NumPy callback is switched off (Context.set_kmeans_far_select(False)), and NumPy's own whenever the maximum is unique.
+    lloyd_fn(X_local, C0, mean, max_iter, tol_abs, allreduce): the loop itself -- default the HIP path
+    (edmdc_kmeans_lloyd_dev with edmdc_set_kmeans_allreduce); the CPU tests inject the oracle's stand-in under gloo."""
+    import torch
+    import torch.distributed as dist
+    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if lloyd_fn is not None:
+        ar = (lambda buf, op: allreduce_words_(buf, op, group)) if sharded else None
+        return lloyd_fn(X_local, C0, mean, max_iter, tol_abs, ar)
+    import ctypes
+    from . import engine
+    from ._lib import _hptr, as_f64
+    ctx = ctx or engine.default_context(X_local.device.index)
+    ctx.use_torch_stream()
+    N, n = X_local.shape
+    k = C0.shape[0]
+    C = C0.to(device=X_local.device, dtype=torch.float64).contiguous().clone()
+    labels = torch.empty(N, dtype=torch.int32, device=X_local.device)
+    inertia, n_iter = ctypes.c_double(0.0), ctypes.c_int(0)
+    m = None if mean is None else as_f64(mean).reshape(n)
+
+    def cb(ptr, count, op):
+        allreduce_words_(torch.as_tensor(_DeviceWords(ptr, count), device=X_local.device), op, group)
+
+    if sharded:
+        # global index of this rank's first row (ranks hold contiguous shards in rank order): the tie-break of an empty cluster's relocation
+        counts = torch.zeros(dist.get_world_size(group), dtype=torch.int64, device=X_local.device)
+        counts[dist.get_rank(group)] = N
+        allreduce_words_(counts, 0, group)
+        ctx.set_kmeans_shard(int(counts[: dist.get_rank(group)].sum().item()))
+        ctx.set_kmeans_allreduce(cb)
+    try:
+        torch.cuda.current_stream(X_local.device).synchronize()
+        ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, X_local.data_ptr(), X_local.stride(0), _hptr(m), C.data_ptr(), int(max_iter),
+                                                 float(tol_abs), labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)),
+                  "edmdc_kmeans_lloyd_dev (sharded)")
+    finally:
+        if sharded:
+            ctx.set_kmeans_allreduce(None)
+            ctx.set_kmeans_shard(0)
+    return C, labels, inertia.value, n_iter.value
+
+
+def column_stats_sharded(X_local, group=None):
+    """(mean [n], mean of the column variances, total rows) over all ranks' rows: per-rank sums all-gathered and added in rank order
+    on every rank (the same bits on every rank).  KMeans centres the data with the column means and scales its tolerance with
+    the mean variance (sklearn/cluster/_kmeans.py: `_tolerance`)."""
+    import torch
+    import torch.distributed as dist
+    n = X_local.shape[1]
+    part = torch.zeros(2 * n + 1, dtype=torch.float64, device=X_local.device)
+    part[:n] = X_local.sum(dim=0)
+    part[2 * n] = X_local.shape[0]
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+    def gather(v):
+        if world == 1:
+            return v
+        parts = [torch.empty_like(v) for _ in range(world)]
+        if v.is_cuda and dist.get_backend(group) != "nccl":
+            hp = [p.cpu() for p in parts]
+            dist.all_gather(hp, v.cpu(), group=group)
+            parts = [p.to(v.device) for p in hp]
+        else:
+            dist.all_gather(parts, v, group=group)
+        out = parts[0].clone()
+        for p in parts[1:]:
+            out += p
+        return out
+
+    tot = gather(part)
+    Nt = tot[2 * n]
+    mean = tot[:n] / Nt
+    part2 = torch.zeros_like(part)
+    part2[:n] = ((X_local - mean) ** 2).sum(dim=0)
+    var = gather(part2)[:n] / Nt
+    return mean, float(var.mean().item()), int(Nt.item())

@@ -343,6 +343,10 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
     Xi = X
     if init_rows is None and N > KMEANSPP_MAX_ROWS:
         init_rows = KMEANSPP_MAX_ROWS // 2          # the device seeding holds its running-sum table in LDS: N <= 3e7 rows
+        import warnings
+        warnings.warn(f"kmeans_centers_dev: {N} rows exceed the {KMEANSPP_MAX_ROWS} the device k-means++ seeding accepts; seeding on a seeded "
+                      f"subsample of {init_rows} rows (scikit-learn would seed on all rows: the centres differ from its); the Lloyd "
+                      "iterations run over all rows", RuntimeWarning, stacklevel=2)
     if init_rows is not None and N > init_rows:
         idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, init_rows, replace=False)).to(X.device)
         Xi = X[idx].contiguous()

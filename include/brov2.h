@@ -307,6 +307,11 @@ BROV_API int edmdc_kmeans_relocations(brov_ctx* ctx);
  * they are the centres of the unsharded run bit for bit.  fn = NULL: single rank.  Return 0 on success. */
 typedef int (*brov_allreduce_fn)(void* user, void* d_buf, int64_t count, int op);
 BROV_API int edmdc_set_kmeans_allreduce(brov_ctx* ctx, brov_allreduce_fn fn, void* user);
+/* Global index of this rank's first row (ranks hold contiguous shards in rank order; default 0).  Only the relocation of an empty
+ * cluster looks at it: in a sharded run the n_empty farthest rows of the whole set are chosen in descending distance, equal
+ * distances by ascending GLOBAL row (three small all-reduces per relocated cluster) -- the library's own rule, also for one rank
+ * when no far-select callback is installed, so sharded and unsharded runs relocate the same rows. */
+BROV_API int edmdc_set_kmeans_shard(brov_ctx* ctx, int64_t row_offset);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over
@@ -328,6 +333,11 @@ BROV_API const char* brov_comm_last_error(const brov_comm* comm);
 /* In-place sum over all ranks of d_GtG (n_gtg doubles) and d_GtY (n_gty doubles), issued as ONE grouped RCCL all-reduce on
  * `hip_stream` (hipStream_t, NULL = null stream; asynchronous: order later work on the same stream or synchronise it). */
 BROV_API int edmdc_gram_allreduce_dev(brov_comm* comm, double* d_GtG, int64_t n_gtg, double* d_GtY, int64_t n_gty, void* hip_stream);
+/* In-place all-reduce of `count` 64-bit words on `hip_stream` (asynchronous): op 0 = sum of int64, op 1 = maximum of uint64. */
+BROV_API int brov_comm_allreduce_words(brov_comm* comm, void* d_buf, int64_t count, int op, void* hip_stream);
+/* Sharded Lloyd without torch: edmdc_kmeans_lloyd_dev on this ctx exchanges its member sums through `comm` (RCCL on the ctx stream);
+ * the same as edmdc_set_kmeans_allreduce with a callback that calls brov_comm_allreduce_words.  comm = NULL: single rank again. */
+BROV_API int edmdc_kmeans_use_comm(brov_ctx* ctx, brov_comm* comm);
 
 #ifdef __cplusplus
 }

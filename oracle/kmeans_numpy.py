@@ -96,3 +96,118 @@ def lloyd(X, C0, max_iter=300, tol_abs=0.0, far_rows=far_rows_numpy):
         labels = e_step(X, C)
     inertia = float(((X - C[labels]) ** 2).sum())
     return C, labels, inertia, n_iter, nreloc
+
+
+# ---- the device loop's own arithmetic (csrc/kmeans.hip, round 4): member sums in 2^-48 fixed point ------------------------------
+# A stand-in for the HIP loop where there is no GPU (the world-size-2 gloo test of the sharded Lloyd) and a bit-for-bit checker
+# of its centres where there is one: the same quantisation (x -> round-half-even(x * 2^(48 - e_j)), 2^e_j > max |x_j|), integer
+# sums, the same conversion back, the same empty-cluster rules.  Only the E-step differs in rounding (a GEMM here, an FMA chain
+# there): labels can differ for a sample within ~1e-16 of a tie, nothing else can.
+FIX_BITS = 48
+LIMB = 42
+
+
+def fix_scales(colmax):
+    """s_j = 2^(48 - e_j) with frexp's e_j (2^e_j > max_j); max_j = 0 -> e_j = 0.  Returns (s, 1/s)."""
+    e = np.where(colmax > 0, np.frexp(np.where(colmax > 0, colmax, 1.0))[1], 0)
+    sh = np.clip(FIX_BITS - e, -1000, 1000)
+    return np.ldexp(1.0, sh), np.ldexp(1.0, -sh)
+
+
+def _to_double(t):
+    """kmeans.hip: km_to_double (sign and magnitude; one rounding below 2^64, two above)."""
+    m = abs(int(t))
+    d = float(m >> 64) * 18446744073709551616.0 + float(m & ((1 << 64) - 1))
+    return -d if t < 0 else d
+
+
+def _int_sums(Q, labels, k):
+    """exact per-cluster sums of the int64 rows Q as Python integers [k][n] (two 24-bit-split passes keep np.add.at inside int64)"""
+    hi, lo = Q >> 24, Q & ((1 << 24) - 1)
+    sh = np.zeros((k, Q.shape[1]), dtype=np.int64)
+    sl = np.zeros((k, Q.shape[1]), dtype=np.int64)
+    np.add.at(sh, labels, hi)
+    np.add.at(sl, labels, lo)
+    return [[(int(sh[c, j]) << 24) + int(sl[c, j]) for j in range(Q.shape[1])] for c in range(k)]
+
+
+def to_limbs(tot, cnt, changed):
+    """[k][n+1][2] int64 limbs (hi * 2^42 + lo, 0 <= lo < 2^42) + the 2-word tail, the layout the ranks all-reduce (kmeans.hip: red)"""
+    k, n = len(tot), len(tot[0])
+    out = np.zeros(k * (n + 1) * 2 + 2, dtype=np.int64)
+    for c in range(k):
+        for j in range(n + 1):
+            v = tot[c][j] if j < n else int(cnt[c])
+            out[(c * (n + 1) + j) * 2] = v >> LIMB
+            out[(c * (n + 1) + j) * 2 + 1] = v & ((1 << LIMB) - 1)
+    out[-2] = changed
+    return out
+
+
+def from_limbs(buf, k, n):
+    tot = [[(int(buf[(c * (n + 1) + j) * 2]) << LIMB) + int(buf[(c * (n + 1) + j) * 2 + 1]) for j in range(n)] for c in range(k)]
+    cnt = [(int(buf[(c * (n + 1) + n) * 2]) << LIMB) + int(buf[(c * (n + 1) + n) * 2 + 1]) for c in range(k)]
+    return tot, cnt, int(buf[-2])
+
+
+def lloyd_fixed_point(X, C0, max_iter=300, tol_abs=0.0, allreduce=None, far_rows=far_rows_sorted):
+    """The device loop (edmdc_kmeans_lloyd_dev) restated: X = this rank's centred rows, C0 the common initial centres.
+    allreduce(int64 array, op) combines a buffer over the ranks in place (op 0: sum, op 1: max) -- None: one rank.
+    Returns (centres, labels, n_iter, relocations).  Empty clusters are relocated on one rank only (as in the library)."""
+    X = np.ascontiguousarray(X, dtype=float)
+    N, n = X.shape
+    k = len(C0)
+    finite = np.isfinite(X)
+    colmax = np.where(finite, np.abs(X), 0.0).max(axis=0) if N else np.zeros(n)
+    rng = np.zeros(16, dtype=np.int64)
+    rng[:n] = colmax.view(np.int64)                     # bit patterns of non-negative doubles order like integers
+    if allreduce is not None:
+        allreduce(rng, 1)
+    s, inv_s = fix_scales(rng[:n].view(np.float64))
+    Q = np.rint(X * s).astype(np.int64)
+    C = np.array(C0, dtype=float)
+    labels_old = np.full(N, -1, dtype=np.int32)
+    n_iter, nreloc = 0, 0
+    for it in range(max_iter):
+        labels = e_step(X, C)
+        tot = _int_sums(Q, labels, k)
+        cnt = np.bincount(labels, minlength=k)
+        buf = to_limbs(tot, cnt, int(np.sum(labels != labels_old)))
+        if allreduce is not None:
+            allreduce(buf, 0)
+        tot, cnt, changed = from_limbs(buf, k, n)
+        empty = [c for c in range(k) if cnt[c] == 0]
+        if empty:
+            if allreduce is not None:
+                raise RuntimeError("an empty cluster in a sharded run")
+            distances = ((X - C[labels]) ** 2).sum(axis=1)
+            if np.max(distances) != 0:
+                far = far_rows(distances, len(empty))
+                for idx, new_c in enumerate(empty):
+                    fi = int(far[idx])
+                    old_c = int(labels[fi])
+                    for j in range(n):
+                        tot[old_c][j] -= int(Q[fi, j])
+                        tot[new_c][j] = int(Q[fi, j])
+                    cnt[new_c] = 1
+                    cnt[old_c] -= 1
+                nreloc += 1
+        arg = int(np.argmax(cnt))
+        C_new = np.empty_like(C)
+        for c in range(k):
+            for j in range(n):
+                if cnt[c] > 0:
+                    C_new[c, j] = (_to_double(tot[c][j]) * inv_s[j]) / float(cnt[c])
+                elif c > arg:
+                    C_new[c, j] = (_to_double(tot[arg][j]) * inv_s[j]) / float(cnt[arg])
+                else:
+                    C_new[c, j] = _to_double(tot[arg][j]) * inv_s[j]
+        shift = ((C_new - C) ** 2).sum()
+        C = C_new
+        n_iter = it + 1
+        if changed == 0:
+            break
+        if shift <= tol_abs:
+            break
+        labels_old = labels
+    return C, e_step(X, C), n_iter, nreloc

@@ -3,6 +3,7 @@
     python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON]
 
 MODE "torch": torch.distributed (backend nccl = RCCL), RENDEZVOUS = TCP port on 127.0.0.1.
+MODE "gloo" : torch.distributed over gloo, every rank on the SAME GPU (cuda:RANK mod the device count) -- the rehearsal a one-GPU box allows.
 MODE "brov" : the torch-free communicator of the C ABI (brov_comm_unique_id / brov_comm_init_rank /
               edmdc_gram_allreduce_dev); RENDEZVOUS = a file path: rank 0 writes the 128-byte id there, the others wait for it.
 BASELINE config 4 at small size: TOTAL_ROLLOUTS x HORIZON RK4 steps in total, contiguous shards (dist.shard_range), commands
@@ -45,17 +46,30 @@ def main():
 
     Xc, _ = rollouts(0, 64)
     idx = torch.from_numpy(np.random.RandomState(0).choice(64 * (T + 1), k, replace=False)).to(dev)
-    C = Xc.view(-1, n)[idx].contiguous()
+    Cdup = Xc.view(-1, n)[idx].contiguous()             # any rows: several are the common initial state -- duplicate centres (k-means leg)
+    idx1 = torch.from_numpy(np.random.RandomState(0).choice(64 * T, k, replace=False)).to(dev)
+    C = Xc[:, 1:, :].reshape(-1, n)[idx1].contiguous()  # rows after the first step: distinct centres, a well-conditioned Gram (fit legs)
     b0, b1 = bd.shard_range(Bt, rank, world)
     X, U = rollouts(b0, b1 - b0)
 
     comm = None
-    if mode == "torch":
+    if mode in ("torch", "gloo"):
         import torch.distributed as dist
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=rdv, RANK=str(rank), WORLD_SIZE=str(world))
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        allreduce = None
+        if mode == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            allreduce = None
+        else:
+            # several ranks on ONE GPU (RCCL refuses that; the one-GPU development box): gloo, the blocks staged through the host
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+            def allreduce(a_, b_):
+                for t_ in (a_, b_):
+                    h_ = t_.cpu()
+                    dist.all_reduce(h_)
+                    t_.copy_(h_)
+                return a_, b_
     else:
         if rank == 0:
             ident = _lib.Comm.unique_id()
@@ -80,9 +94,22 @@ def main():
         allreduce(GtG, GtY)
     A, B = bd.fit_sharded(X, U, C, gamma, ridge, allreduce=allreduce)
     Af, Bf = bd.fit_sharded(X, U, C, gamma, ridge, order="fit", allreduce=allreduce)
+    # round 4: the centres over ALL ranks' states (Koopman/koopmanEDMDc.py:85 runs KMeans over all of X): Lloyd's loop with one integer
+    # all-reduce per iteration, from common initial centres (the seeded rows above, centred with the column means of the first 64
+    # trajectories, which every rank holds) -- the same bits on every rank and for every world size
+    mean_h = Xc.view(-1, n).mean(dim=0).cpu().numpy()
+    C0 = Cdup - torch.from_numpy(mean_h).to(dev)       # duplicate centres: empty clusters in the first iteration -> the sharded relocation
+    ctx.set_kmeans_far_select(False)                   # the library's own relocation rule: the one a sharded run applies
+    if comm is not None:
+        ctx.kmeans_use_comm(comm)
+        ctx.set_kmeans_shard(b0 * (T + 1))
+    Ck, labels_k, inertia_k, iters_k = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx)
+    if comm is not None:
+        ctx.kmeans_use_comm(None)
     torch.cuda.synchronize()
-    np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id)
-    if mode == "torch":
+    np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id,
+             Ck=Ck.cpu().numpy(), iters_k=iters_k, inertia_k=inertia_k, labels_k=labels_k.cpu().numpy(), reloc_k=ctx.kmeans_relocations())
+    if mode in ("torch", "gloo"):
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -107,3 +107,62 @@ def test_two_rank_fit_equals_single_process():
     M = _oracle_apply(torch.from_numpy(np.stack(Xl)), torch.from_numpy(np.stack([u[:-1] for u in Ul])), torch.from_numpy(g["centers"]), 1.0, 8, 199, 200, 199, P).numpy().T
     d = 12 + g["centers"].shape[0]
     assert np.max(np.abs(M[:, :d] - Af0)) < 1e-9 and np.max(np.abs(M[:, d:] - Bf0)) < 1e-9
+
+
+# ---- sharded Lloyd (round 4): one integer all-reduce per iteration; the oracle's fixed-point stand-in runs the loop on the CPU ----
+def _standin_lloyd(X_local, C0, mean, max_iter, tol_abs, allreduce):
+    from oracle import kmeans_numpy as kn
+    ar = None if allreduce is None else (lambda buf, op: allreduce(torch.from_numpy(buf), op))      # shares the buffer's memory
+    Xc = X_local.numpy() - (0.0 if mean is None else mean)
+    C, labels, n_iter, _ = kn.lloyd_fixed_point(Xc, C0.numpy(), max_iter, tol_abs, allreduce=ar)
+    return torch.from_numpy(C), torch.from_numpy(labels), 0.0, n_iter
+
+
+def _km_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from bluerov2_dynamics_amd import dist as bd
+        g = load_golden("edmdc.npz")
+        X = g["X"][:1600]
+        r0, r1 = bd.shard_range(len(X), rank, world)
+        Xl = torch.from_numpy(X[r0:r1].copy())
+        mean, var, Nt = bd.column_stats_sharded(Xl)
+        assert Nt == len(X) and np.max(np.abs(mean.numpy() - X.mean(0))) < 1e-14 and abs(var - np.mean(np.var(X, axis=0))) < 1e-14
+        C0 = torch.from_numpy(X[np.random.RandomState(1).choice(len(X), 24, replace=False)] - X.mean(0))
+        C, labels, _, n_iter = bd.kmeans_lloyd_sharded(Xl, C0, mean=X.mean(0), max_iter=40, tol_abs=0.0, lloyd_fn=_standin_lloyd)
+        q.put((rank, C.numpy(), labels.numpy(), n_iter))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+        raise
+
+
+def test_two_rank_lloyd_equals_single_process_bit_for_bit():
+    """Sharded Lloyd under gloo, world size 2: every rank ends with the same centres, and they are the centres of the one-process
+    run BIT FOR BIT (integer member sums: no order of additions to differ by); labels of the shards = labels of the whole."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_km_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), r[2]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import kmeans_numpy as kn
+    g = load_golden("edmdc.npz")
+    X = g["X"][:1600]
+    C0 = X[np.random.RandomState(1).choice(len(X), 24, replace=False)] - X.mean(0)
+    C1, lab1, it1, _ = kn.lloyd_fixed_point(X - X.mean(0), C0, 40, 0.0)
+    assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][1], C1) and res[0][3] == it1 == res[1][3]
+    assert np.array_equal(np.concatenate([res[0][2], res[1][2]]), lab1)
+    # ... and the fixed-point loop agrees with the floating-point restatement of scikit-learn's loop to rounding
+    Cs, labs, _, its, _ = kn.lloyd(X - X.mean(0), C0, 40, 0.0)
+    assert its == it1 and np.array_equal(labs, lab1) and np.max(np.abs(Cs - C1)) < 1e-13

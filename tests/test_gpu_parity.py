@@ -1415,6 +1415,35 @@ def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):
     assert rel_err(Ck.cpu().numpy(), m.centers_) < 1e-12 and rel_err(A, m.A_) < 1e-9
 
 
+def test_host_entry_points_never_leave_the_lift_cache_armed(eng):
+    """The lifted-row cache (edmdc_lift_cache) is keyed by device addresses.  The host entry points stage their arrays in
+    allocations they free on return, and the next host call of the same shape gets the same addresses back: host gram(X1) followed
+    by host pinv_apply(X2) must lift X2, not read the cached rows of X1 (round-3 advisor finding)."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(77)
+    ctx = _lib.Context(0)
+    buf = torch.empty(96 << 20, dtype=torch.uint8, device="cuda")
+    ctx.lift_cache(buf.data_ptr(), buf.numel())
+    n, r, k, g, N = 12, 8, 96, 1.0, 4000
+    C = rng.normal(0, 0.4, (k, n))
+    p = n + k + r
+    P = rng.normal(0, 1, (p, p)) / np.sqrt(p)
+    X1, X2 = (np.cumsum(rng.normal(0, 0.05, (N, n)), 0) for _ in range(2))
+    U1, U2 = (rng.uniform(-1, 1, (N, r)) for _ in range(2))
+    for _ in range(3):                                    # the allocator recycles addresses from the second round on at the latest
+        G1, _, _ = eng.gram([X1], [U1], C, g, ctx=ctx)
+        M2 = eng.pinv_apply([X2], [U2], C, g, P, ctx=ctx)
+        Mo = (P @ np.hstack([ek.lift(X2[:-1], C, g), U2[:-1]]).T) @ ek.lift(X2[1:], C, g)
+        assert np.max(np.abs(M2 - Mo)) / np.abs(Mo).max() < 1e-11
+        G2, _, _ = eng.gram([X2], [U2], C, g, ctx=ctx)
+        Go, _, _ = ek.gram([X2], [U2], C, g)
+        assert np.linalg.norm(G2 - Go) / np.linalg.norm(Go) < 1e-11
+    ctx.lift_cache(None)
+    ctx.close()
+
+
 def test_rccl_entry_points_single_rank():
     """brov_comm_* / edmdc_gram_allreduce_dev on a one-rank communicator (all this box has): init, in-place all-reduce = identity,
     destroy.  N > 1 runs at the driver's scaling bench; the two-rank logic is covered with gloo on CPU (test_dist_gloo_cpu.py)."""

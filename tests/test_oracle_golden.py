@@ -254,3 +254,36 @@ def test_edmdc_fit_order_fixture_defaults_and_tank_settings():
     assert np.max(np.abs(ms - g["small_ms_rmse"])) < 1e-7, ms - g["small_ms_rmse"]
     # the reference's own two orders, as recorded: 1.06e-6 apart at H = 100 -- above north_star's 1e-6
     assert abs(g["small_multi_order_ms_rmse"][2] - g["small_ms_rmse"][2]) > 5e-7
+
+
+def test_kmeans_oracle_restates_sklearns_empty_cluster_rules():
+    """oracle/kmeans_numpy.py against the fixture scikit-learn 1.7.2 produced (tools/gen_golden.py: gen_kmeans_empty) and against
+    scikit-learn itself: relocation of an empty cluster to the farthest sample, no relocation when all distances are zero, the
+    in-place averaging loop; and the fixed-point stand-in of the device loop (integer member sums) against the floating-point one."""
+    import warnings
+    from oracle import kmeans_numpy as kn
+    g = load_golden("kmeans_empty.npz")
+    X, C0 = g["a_X"], g["a_C0"]
+    mean = X.mean(0)
+    tol_abs = 1e-4 * np.mean(np.var(X, axis=0))
+    C, lab, inertia, n_iter, nrel = kn.lloyd(X - mean, C0 - mean, 300, tol_abs)
+    assert n_iter == int(g["a_n_iter"]) and nrel == 1 and np.max(np.abs(C + mean - g["a_centers"])) < 1e-12
+    assert abs(inertia - float(g["a_inertia"])) <= 1e-10 * float(g["a_inertia"])
+    Cf, labf, itf, nrf = kn.lloyd_fixed_point(X - mean, C0 - mean, 300, tol_abs)
+    assert itf == n_iter and nrf == 1 and np.array_equal(labf, lab) and np.max(np.abs(Cf - C)) < 1e-13
+    Xq, C0q = g["c_X"], g["c_C0"]
+    Cq, _, _, itq, nrq = kn.lloyd(Xq, C0q, 300, 0.0)
+    assert itq == int(g["c_n_iter"]) and nrq == 0 and np.array_equal(Cq, g["c_centers"]) and np.array_equal(Cq[1], [0.0, 0.0, 16.0, 0.0])
+    assert np.array_equal(kn.lloyd_fixed_point(Xq, C0q, 300, 0.0)[0], g["c_centers"])
+    # live against the installed scikit-learn (the pinned 1.7.2): several empties at once (np.argpartition's order)
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(4)
+    X = np.cumsum(rng.normal(0, 0.05, (2500, 12)), 0)
+    C0 = X[rng.choice(len(X), 48, replace=False)].copy()
+    C0[3] += 60.0; C0[20] -= 45.0; C0[47] += 80.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        km = KMeans(n_clusters=48, init=C0, n_init=1).fit(X)
+    mean = X.mean(0)
+    C, lab, _, n_iter, nrel = kn.lloyd(X - mean, C0 - mean, 300, 1e-4 * np.mean(np.var(X, axis=0)))
+    assert n_iter == km.n_iter_ and nrel >= 1 and np.array_equal(lab, km.labels_) and np.max(np.abs(C + mean - km.cluster_centers_)) < 1e-12

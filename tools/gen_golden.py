@@ -545,7 +545,38 @@ def gen_simscript():
              pred200=m.simulate(Xte[0], Ute[:200]), versions=versions())
 
 
-GENS = dict(cfg5_pinc=gen_cfg5_pinc, torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
+def gen_kmeans_empty():
+    """scikit-learn 1.7.2's handling of empty clusters (sklearn/cluster/_k_means_common.pyx), which the reference inherits through
+    KMeans(...).fit (Koopman/koopmanEDMDc.py:85,126): expected centres / iteration counts of KMeans(init=C0, n_init=1) for
+    (a) one initial centre far from all data (empty in the first iteration -> relocated to the farthest sample), (b) more clusters
+    than distinct points, the reference's own call with n_init="auto", random_state=0 (exact arithmetic: all distances zero, no
+    relocation), (c) `_average_centers`' in-place loop (an empty cluster in front of the biggest one takes its member SUM)."""
+    import warnings
+    from sklearn.cluster import KMeans
+    rng = np.random.default_rng(33)
+    out = {}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        X = np.cumsum(rng.normal(0, 0.05, (3000, 12)), 0)
+        C0 = X[rng.choice(len(X), 40, replace=False)].copy()
+        C0[9] += 100.0
+        km = KMeans(n_clusters=40, init=C0, n_init=1).fit(X)
+        out.update(a_X=X, a_C0=C0, a_centers=km.cluster_centers_, a_n_iter=np.int64(km.n_iter_), a_inertia=np.float64(km.inertia_))
+        P = rng.integers(-9, 10, (14, 12)).astype(float)
+        m = rng.choice((2, 4, 8), len(P))
+        Xd = np.concatenate([np.repeat(P, m, axis=0), np.repeat(-P, m, axis=0)])
+        Xd = Xd[rng.permutation(len(Xd))]
+        km = KMeans(n_clusters=40, n_init="auto", random_state=0).fit(Xd)
+        out.update(b_X=Xd, b_centers=km.cluster_centers_, b_n_iter=np.int64(km.n_iter_))
+        pA, pB, pC = np.array([1., 2, 0, 0]), np.array([-1., -2, 0, 0]), np.array([0., 0, 4, 0])
+        Xq = np.concatenate([np.tile(pA, (2, 1)), np.tile(pB, (2, 1)), np.tile(pC, (4, 1)), np.tile(-pC, (4, 1))])
+        C0q = np.array([pA, pA, pB, pC, -pC, pC])
+        km = KMeans(n_clusters=6, init=C0q, n_init=1).fit(Xq)
+        out.update(c_X=Xq, c_C0=C0q, c_centers=km.cluster_centers_, c_n_iter=np.int64(km.n_iter_))
+    np.savez_compressed(os.path.join(OUT, "kmeans_empty.npz"), versions=versions(), **out)
+
+
+GENS = dict(kmeans_empty=gen_kmeans_empty, cfg5_pinc=gen_cfg5_pinc, torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

@@ -1,0 +1,40 @@
+#!/bin/bash
+# Host-side sanitizer leg (CPU only -- never run this on a GPU box: GPU AddressSanitizer is not available on the pool).
+#
+# Builds a copy of libbrov2.so whose HOST code (the C ABI of capi.hip: argument validation, the Gram / apply task tables and their
+# dynamic programmes, derive_fast, the Pade discretisation; comm.hip's dlopen binding) is compiled with AddressSanitizer and
+# UndefinedBehaviourSanitizer (-Xarch_host: the gfx950 device code is compiled as always), then runs, with the sanitizer runtime
+# preloaded into the interpreter:
+#   1. tests/test_cabi_cpu.py and tests/test_host_logic_cpu.py (every symbol bound, struct layout, no-GPU failure paths, ...);
+#   2. tools/sanitize_sweep.py: the decomposition / DP entry points and the host-only numerics over a sweep of (n, r, k), dt and
+#      parameter sets, and every entry point's argument validation with a NULL context.
+# Usage: tools/sanitize_host.sh [logfile]      (default profiles/r04_host_sanitizer.txt)
+set -u -o pipefail
+cd "$(dirname "$0")/.."
+LOG=${1:-profiles/r04_host_sanitizer.txt}
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
+RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
+LIB=$(python - <<PY
+from bluerov2_dynamics_amd import _build
+import os
+flags = [f for s in "$SAN".split() for f in ("-Xarch_host", s)]
+_build.LDFLAGS += ["-fsanitize=address,undefined", "-shared-libsan"]
+print(_build.variant("host_sanitizer", {s: flags for s in _build.SOURCES}))
+PY
+) || { echo "sanitizer build failed"; exit 1; }
+{
+  echo "# host sanitizer leg: $(date -u +%Y-%m-%dT%H:%MZ), $(/opt/rocm/bin/hipcc --version | head -1)"
+  echo "# library: $LIB (host code: $SAN)"
+  echo "# runtime: $RT"
+  export BROV2_LIBRARY="$LIB" LD_PRELOAD="$RT" ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97" UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98"
+  echo "## pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py"
+  # (not test_header_is_plain_c_and_links_from_c: it links a gcc-built C program against the library, and a gcc link line has no
+  #  sanitizer runtime to resolve the instrumented library's __asan_* / __ubsan_* symbols -- an artefact of this build, not a finding)
+  python -m pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py -q -m "not gpu" -p no:cacheprovider -k "not links_from_c" 2>&1 | tail -15
+  echo "rc=$?"
+  echo "## tools/sanitize_sweep.py"
+  python tools/sanitize_sweep.py 2>&1 | tail -25
+  echo "rc=$?"
+} 2>&1 | tee "$LOG"
+if grep -q "ERROR: AddressSanitizer\|runtime error:\|rc=[1-9]" "$LOG"; then echo "SANITIZER FINDINGS (see $LOG)"; exit 1; fi
+echo "clean" | tee -a "$LOG"
