@@ -111,8 +111,10 @@ hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* 
 // E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist); prm [4], fix [32] from launch_kmeans_scale
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
-                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr);
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc);
+                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr,
+                                const unsigned long long* Nk = nullptr);
+// Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr);
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
                                 const int* block_changed, long long* red, double* stats);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,

@@ -1092,8 +1092,8 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 14 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4 and / or + 8");
+    if (!c || variant < 0 || variant > 30 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8 and / or + 16");
     c->kmeans_variant = variant;
     return BROV_OK;
 }
@@ -1424,10 +1424,10 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 
 // ---- k-means (Lloyd) --------------------------------------------------------------------------------------
 #ifndef KM_SORT_MOVED
-#define KM_SORT_MOVED 0.01       // re-sort thresholds of the loop's private sample order, see below
+#define KM_SORT_MOVED 0.03       // re-sort thresholds of the loop's private sample order, see below
 #endif
 #ifndef KM_SORT_RATE
-#define KM_SORT_RATE 0.01
+#define KM_SORT_RATE 0.05
 #endif
 // `_relocate_empty_clusters_dense`'s choice of rows, `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`, is NumPy's introselect:
 // which of several equal distances it returns, and in which order the n_empty largest come out, is a property of that
@@ -1609,14 +1609,20 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // through it.  Worth it only at size.
     const bool sorting = filter && variant == 0 && kmeans_reads_through_perm(n, k, scalar_records) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
     const size_t sort_tmp = sorting ? kmeans_sort_temp_bytes(N) : 0;
+    // single-reference form of the filter (kmeans.hip, round 4): sorted rows of the centre distances for the LDS / DPP kernel; + 16 in the
+    // k-means variant keeps the mask form of round 3 alone (the independent second implementation of the filter)
+    const bool nbr = filter && kmeans_reads_through_perm(n, k, scalar_records) && (c->kmeans_variant & 16) == 0;
+    const size_t kp_ = (size_t)((k + 255) & ~255);
     int rc = a.reserve(Arena::al(pwords * 8) + Arena::al(rwords * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
+                       (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
     if (rc) return rc;
     unsigned long long* partial = a.take<unsigned long long>(pwords);
     long long* red = a.take<long long>(rwords);
     double* binert = a.take<double>(nb);
     float* Dc = a.take<float>(filter ? (size_t)k * ((k + 255) & ~255) : 1);
+    unsigned long long* Nk = nbr ? a.take<unsigned long long>(k * kp_) : nullptr;      // sorted rows of the centre distances (keys)
     int* bchg = a.take<int>(nb);
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* Cb[2] = {a.take<double>((size_t)k * n), a.take<double>((size_t)k * n)};     // centres of this / the next iteration
@@ -1665,6 +1671,9 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     int cur = 0, cc = 0;                                // cc: Cb[cc] = the centres the last E-step used
     bool want_sort = false;
     double moved = 0.0;                                 // labels changed since the last sort
+    double sort_moved = KM_SORT_MOVED, sort_rate = KM_SORT_RATE;
+    if (const char* e = std::getenv("BROV2_KM_SORT_MOVED")) sort_moved = std::atof(e);      // experiments (tools/time_lloyd_ab.py)
+    if (const char* e = std::getenv("BROV2_KM_SORT_RATE")) sort_rate = std::atof(e);
     c->kmeans_relocations = 0;
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
     HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, nullptr, prm, fix, d2, scalar_records, nullptr));
@@ -1682,8 +1691,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             want_sort = false;
             moved = 0.0;
         }
-        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc));
+        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk));
+        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc, Nk));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];
         if (hs[3] > 0.0) {
@@ -1693,8 +1702,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
-            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc));
-            HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc));
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk));
+            HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc, Nk));
         }
         cc ^= 1;
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
@@ -1704,9 +1713,13 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             // the last sort (a fresh order costs ~55 candidates per wave, the caller's ~130; a sort costs less than half an E-step),
             // but not while more than 1 % still change per iteration -- such an order is stale at once.  Thresholds from scans at
             // 10^7 x 12, k = 512 (tools/run_lloyd_variants.sh): 314 ms per 300 iterations; 0.02 / 0.01: 322 ms; 0.005 / 0.005: 331 ms;
-            // every iteration: 384 ms; the caller's order: 423 ms.
+            // every iteration: 384 ms; the caller's order: 423 ms.  Round 4, single-reference filter (a moved label widens the wave's
+            // radius a little instead of opening a second candidate set: the order decays more slowly): moved / rate 0.01 / 0.01: 305 ms;
+            // 0.02 / 0.2: 290; 0.03 / 0.01: 294; 0.05 / 0.05: 288; 0.08 / 0.01: 299; 0.15 / 0.01: 314; 0.005 / 0.2: 326; never: 484
+            // (mask form alone: 313 / - / 313 / 326 / 331 / 355 / - / 557).  An order made while a fifth of the labels still move
+            // per iteration buys nothing (rate 0.2 or 1.0 at moved 0.01: 303-304 ms).
             moved += hs[2];
-            if (moved >= KM_SORT_MOVED * (double)N && hs[2] <= KM_SORT_RATE * (double)N) want_sort = true;
+            if (moved >= sort_moved * (double)N && hs[2] <= sort_rate * (double)N) want_sort = true;
         }
     }
     if (it > max_iter) it = max_iter;

@@ -97,6 +97,28 @@ __device__ __forceinline__ u64 half_row_sum_u64(u64 v) {
     v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
     return v;
 }
+// The same reduction for all NC coordinates of a sample at once, carries through VCC, the DPP operand fused into the additions
+// (the compiler's form: two v_mov_b32_dpp + add + addc per step and coordinate, 144 instructions for 12 coordinates; here 72 + one
+// s_nop).  lo / hi: the halves of the NC fixed-point numbers; every lane ends with the sum over its group of 8 lanes.  A DPP read
+// needs two wait states after a VALU write of its source: the leading s_nop covers the values computed just before, inside the
+// block every register is re-read 2 NC - 1 instructions after it was written.
+#define KM_DPPADD(ctrl, L, H) "v_add_co_u32_dpp %" #L ", vcc, %" #L ", %" #L " " ctrl " row_mask:0xf bank_mask:0xf\n\tv_addc_co_u32_dpp %" #H ", vcc, %" #H ", %" #H ", vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"
+#define KM_DPPSTEP12(ctrl) KM_DPPADD(ctrl, 0, 1) KM_DPPADD(ctrl, 2, 3) KM_DPPADD(ctrl, 4, 5) KM_DPPADD(ctrl, 6, 7) KM_DPPADD(ctrl, 8, 9) KM_DPPADD(ctrl, 10, 11) \
+    KM_DPPADD(ctrl, 12, 13) KM_DPPADD(ctrl, 14, 15) KM_DPPADD(ctrl, 16, 17) KM_DPPADD(ctrl, 18, 19) KM_DPPADD(ctrl, 20, 21) KM_DPPADD(ctrl, 22, 23)
+#define KM_DPPSTEP13(ctrl) KM_DPPSTEP12(ctrl) KM_DPPADD(ctrl, 24, 25)
+#define KM_Q2(a) "+v"(lo[a]), "+v"(hi[a])
+__device__ __forceinline__ void half_row_sum_u64x(unsigned (&lo)[12], unsigned (&hi)[12]) {
+    asm volatile("s_nop 1\n\t" KM_DPPSTEP12("quad_perm:[1,0,3,2]") KM_DPPSTEP12("quad_perm:[2,3,0,1]") KM_DPPSTEP12("row_half_mirror")
+                 : KM_Q2(0), KM_Q2(1), KM_Q2(2), KM_Q2(3), KM_Q2(4), KM_Q2(5), KM_Q2(6), KM_Q2(7), KM_Q2(8), KM_Q2(9), KM_Q2(10), KM_Q2(11) : : "vcc");
+}
+__device__ __forceinline__ void half_row_sum_u64x(unsigned (&lo)[13], unsigned (&hi)[13]) {
+    asm volatile("s_nop 1\n\t" KM_DPPSTEP13("quad_perm:[1,0,3,2]") KM_DPPSTEP13("quad_perm:[2,3,0,1]") KM_DPPSTEP13("row_half_mirror")
+                 : KM_Q2(0), KM_Q2(1), KM_Q2(2), KM_Q2(3), KM_Q2(4), KM_Q2(5), KM_Q2(6), KM_Q2(7), KM_Q2(8), KM_Q2(9), KM_Q2(10), KM_Q2(11), KM_Q2(12) : : "vcc");
+}
+#undef KM_Q2
+#undef KM_DPPSTEP13
+#undef KM_DPPSTEP12
+#undef KM_DPPADD
 // A block's table [k][n+1] goes out as partial[epoch][block]: the bit pattern of 1.5 * 2^52 is taken off the coordinate sums
 // (count times, poisoned samples included: they added the pattern of a zero), so that a partial is a signed sum of integers.
 __device__ __forceinline__ void km_flush(u64* sums, u64* __restrict__ partial, int ep, int k, int n, bool rezero) {
@@ -128,7 +150,7 @@ __device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep
 #define KM_PROFILE 0
 #endif
 #if KM_PROFILE
-__device__ unsigned long long km_prof[8];
+__device__ unsigned long long km_prof[16];     // [0..4] phase ticks, [7] wave passes, [8] single-reference passes, [9] their candidates, [10] tie repeats, [11] mask-form passes, [12] their candidates, [13] full scans
 #define KM_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[slot] += now_ - t_prev; t_prev = now_; } while (0)
 #else
 #define KM_STAMP(slot) do { } while (0)
@@ -416,6 +438,7 @@ constexpr int KM2_DEPTH = 4;         // records in flight round the evaluation l
 static_assert(KM2_DEPTH == 4, "the evaluation loop of kmeans_assign_lds_kernel is written for two pairs");
 constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
 constexpr int KM2_KMAX = 512;        // 8 mask words
+constexpr int KM2_NBR_MAX = 128;     // candidates the single-reference form of the filter takes from a sorted row (two loads per lane)
 static_assert(KM2_KMAX * 128 <= 65536, "the candidate lists of kmeans_assign_lds_kernel hold record offsets (c << 7) in 16 bits");
 static_assert(KM2_KMAX <= KM_SORT_LABEL_MAX, "the sort keys of the loop's sample order (sortperm.hip) hold the label in KM_SORT_LABEL_BITS bits");
 constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
@@ -477,7 +500,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                          double* __restrict__ block_inertia, int* __restrict__ block_changed,
                          const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
                          const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */,
-                         const double* __restrict__ fix) {
+                         const double* __restrict__ fix, const unsigned long long* __restrict__ Nk) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
     double* tab = lds2;
@@ -529,8 +552,25 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         load_rows(base, perm ? perm[position(base)] : 0, xn, oln);
         if (perm && base + stride < N) pnext = perm[position(base + stride)];
     }
+    // reference centre of the single-reference filter for the pass whose rows are in flight, and the head of its sorted row:
+    // the label most lanes carry (lane 0's, or the next one when fewer than half the lanes share it)
+    int a_nx = -1;
+    unsigned long long nk0 = 0ull, nk1 = 0ull;
+    auto reference_ahead = [&]() {
+        a_nx = -1;
+        if (!Nk) return;
+        int a = __builtin_amdgcn_readfirstlane(oln);
+        const unsigned long long same = __ballot(oln == a);
+        if (__builtin_popcountll(same) < 32) a = __builtin_amdgcn_readlane(oln, __builtin_ctzll(~same));
+        if ((unsigned)a >= (unsigned)k) return;
+        a_nx = a;
+        const unsigned long long* row = Nk + (int64_t)a * kp;
+        nk0 = row[lane];
+        nk1 = row[64 + lane];
+    };
+    if (base < N) reference_ahead();
 #if KM_PROFILE
-    unsigned long long t_acc[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long t_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #endif
     for (; base < N; base += stride) {
 #if KM_PROFILE
@@ -542,14 +582,48 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #pragma unroll
         for (int j = 0; j < NX; ++j) { x[j] = xn[j] - mm[j]; x2 = fma(x[j], x[j], x2); }
         const int ol = oln;                           // label of the previous iteration (-1 before the first)
+        const int a_ref = a_nx;
+        const unsigned long long key0 = nk0, key1 = nk1;
 #if KM_PROFILE
         asm volatile("; rows have arrived" :: "v"(x2), "v"(ol));
         KM_STAMP(0);
 #endif
         unsigned long long mws[8] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
-        bool filtered = false;
-        if (Dc) {
-            // ---- candidate filter (header comment of this file); every branch below is wave-uniform
+        unsigned short* lst = cand + (threadIdx.x >> 6) * KM2_LIST;
+        // ---- candidate filter, first form (round 4): ONE reference centre per wave.  For any centre a, a centre c with
+        // d(c_a, c) >= 2 u + margin, u = max over the wave's lanes of d(x, c_a), is farther from every lane than c_a is by at least
+        // `margin` -- whatever labels the lanes carry: the old labels only pick a good reference (the label most lanes share; in the
+        // loop's sorted order a wave is one cluster's samples at one radius, give or take the few whose label has moved since the
+        // sort -- as a second label GROUP those cost a second candidate set, as lanes of this one a slightly larger u).  The candidates
+        // are a PREFIX of row a of the sorted centre distances (kmeans_cdist_kernel: Nk): no masks, no compaction; the 128 keys at the
+        // head of the row are requested a pass ahead, as soon as the next pass's labels have arrived.  They are
+        // evaluated in the order of that row, not by index, so an exact tie between two candidates' scores could fall to the other
+        // one than in the full scan (first of equal maxima by INDEX): every evaluation that equals the running best raises a flag,
+        // and a flagged wave repeats the pass through the mask form below (index order).  Exact duplicates of a centre are neighbours
+        // in the row in index order, but they do tie: such waves always take the second form.
+        auto select_by_nbr = [&](int& ncand) -> bool {
+            if (a_ref < 0 || __ballot(!((x2 - x2 == 0.0) && centres_finite)) != 0ull) return false;
+            const int a = a_ref;
+            const double sc = score_bcast(record(((unsigned)a << 7) + laneoff), x);
+            const double d2 = fma(-2.0, sc, x2);                           // |x - c_a|^2 up to rounding
+            float rf = (float)fmax(d2, 0.0);                               // squared radius as a float rounded UP
+            rf = rf * 1.0000005f + 1.0e-37f;
+            const unsigned rb = wave_max_u32(__float_as_uint(rf));
+            const double u2 = (double)__uint_as_float(rb) + eps2;          // >= the true squared radius u^2 of the wave about c_a
+            const double t2 = fma(4.004, u2, 1001.0 * margin * margin);    // >= (2 u + margin)^2
+            const unsigned tb = __float_as_uint(fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f));     // non-negative floats order like their bits
+            const int cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
+            if (cnt >= KM2_NBR_MAX) return false;                          // a wide wave (a cluster boundary of the order, unsorted data): second form
+            lst[lane] = (unsigned short)(((unsigned)key0 & 0xFFFFu) << 7);
+            lst[64 + lane] = (unsigned short)(((unsigned)key1 & 0xFFFFu) << 7);
+            const unsigned short last = lst[cnt - 1];                      // (cnt >= 1: c_a itself is at distance 0)
+            if (lane < 2 * KM2_DEPTH + 2) lst[cnt + lane] = last;          // the tail repeats the last candidate
+            ncand = cnt;
+            return true;
+        };
+        // ---- second form (round 3): label groups, masks over all k centres, candidates in index order
+        auto select_by_masks = [&]() -> bool {
+            bool filtered = false;
             const bool usable = (unsigned)ol < (unsigned)k && (x2 - x2 == 0.0) && centres_finite;
             if (__ballot(!usable) == 0ull) {
                 int ga[KM_GMAX] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -619,7 +693,12 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                     }
                 }
             }
-        }
+                    return filtered;
+        };
+        bool filtered = false, by_nbr = false;
+        int ncand_nbr = 0;
+        if (Nk) by_nbr = select_by_nbr(ncand_nbr);
+        if (!by_nbr && Dc) filtered = select_by_masks();
         KM_STAMP(2);
         // rows of the next pass: in flight during the evaluation (which waits on the LDS only)
         if (base + stride < N) {
@@ -631,19 +710,22 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         unsigned baddr = laneoff;                     // LDS address of the best record so far: the index is baddr >> 7
         unsigned addr[KM2_DEPTH];
         double rec[KM2_DEPTH];
-        auto eval2 = [&](int d) {                    // candidates d and d + 1 of the ring, in this order
+        unsigned long long tiem = 0ull;               // lanes that saw a score EQUAL to their running best (first form only)
+        unsigned long long tq[KM2_DEPTH] = {0ull, 0ull, 0ull, 0ull};      // ... per position of the trip (the padded tail of a list must not count)
+        auto eval2 = [&](int d, auto TIE) {          // candidates d and d + 1 of the ring, in this order
             double sa, sb;
             score2_bcast(rec[d], rec[d + 1], x, sa, sb);
             // strict '>' to replace: the first maximum wins, like np.argmin on the distances
+            if constexpr (decltype(TIE)::value) tq[d] = __ballot(sa == best);
             baddr = (sa <= best) ? baddr : addr[d];
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sa));
+            if constexpr (decltype(TIE)::value) tq[d + 1] = __ballot(sb == best);
             baddr = (sb <= best) ? baddr : addr[d + 1];
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sb));
         };
-        if (filtered) {
+        auto compact = [&]() -> int {
             // the candidates of the eight mask words as one list of LDS record offsets (128 c as 16 bits: k <= 512), written by
             // the lanes that hold the bits; the tail repeats the last candidate (an equal score never replaces the best)
-            unsigned short* lst = cand + (threadIdx.x >> 6) * KM2_LIST;
             int ncand = 0, lastc = 0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -656,6 +738,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                 }
             }
             if (lane < 2 * KM2_DEPTH + 2) lst[ncand + lane] = (unsigned short)(lastc << 7);
+            return ncand;
+        };
+        auto run_list = [&](int ncand, auto TIE) {
             // The trip evaluates pair A = candidates (4t, 4t + 1), then pair B = (4t + 2, 4t + 3), and ENDS with an evaluation: the
             // compiler waits for every LDS read at the loop head, so the reads issued last before it must be an evaluation old.
             //   head: records of B (offsets cn[2..3], read a trip ago) | evaluate A | records of the next A | evaluate B
@@ -669,15 +754,21 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #pragma unroll
                 for (int e = 2; e < 4; ++e) { addr[e] = cn[e] + laneoff; rec[e] = record(addr[e]); cn[e] = lp[e - 2]; }
                 __builtin_amdgcn_sched_barrier(0);
-                eval2(0);
+                eval2(0, TIE);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { addr[e] = cn[e] + laneoff; rec[e] = record(addr[e]); cn[e] = lp[e + 2]; }
                 __builtin_amdgcn_sched_barrier(0);
-                eval2(2);
+                eval2(2, TIE);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (decltype(TIE)::value) {
+                    // positions of the last trip beyond the list repeat its last candidate: their equality with the best is no tie
+                    const int rem = ncand - t * KM2_DEPTH;
+                    tiem |= tq[0] | (rem > 1 ? tq[1] : 0ull) | (rem > 2 ? tq[2] : 0ull) | (rem > 3 ? tq[3] : 0ull);
+                }
             }
-        } else {
+        };
+        auto run_all = [&]() {
             // all k centres, same schedule
             auto off = [&](int c) { return ((unsigned)min(c, k - 1) << 7) + laneoff; };
 #pragma unroll
@@ -688,16 +779,39 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #pragma unroll
                 for (int e = 2; e < 4; ++e) { addr[e] = off(t * KM2_DEPTH + e); rec[e] = record(addr[e]); }
                 __builtin_amdgcn_sched_barrier(0);
-                eval2(0);
+                eval2(0, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int e = 0; e < 2; ++e) { addr[e] = off((t + 1) * KM2_DEPTH + e); rec[e] = record(addr[e]); }
                 __builtin_amdgcn_sched_barrier(0);
-                eval2(2);
+                eval2(2, std::false_type{});
                 __builtin_amdgcn_sched_barrier(0);
             }
+                };
+        if (by_nbr) {
+            run_list(ncand_nbr, std::true_type{});
+#if KM_PROFILE
+            t_acc[8] += 1ull; t_acc[9] += (unsigned long long)ncand_nbr; t_acc[10] += tiem != 0ull ? 1ull : 0ull;
+#endif
+            if (tiem != 0ull) {                       // an exact tie somewhere: once more in index order
+                best = -1.0e300;
+                baddr = laneoff;
+                if (select_by_masks()) run_list(compact(), std::false_type{}); else run_all();
+            }
+        } else if (filtered) {
+            const int nc_ = compact();
+#if KM_PROFILE
+            t_acc[11] += 1ull; t_acc[12] += (unsigned long long)nc_;
+#endif
+            run_list(nc_, std::false_type{});
+        } else {
+#if KM_PROFILE
+            t_acc[13] += 1ull;
+#endif
+            run_all();
         }
         const int bi = (int)(baddr >> 7);
+        if (base + stride < N) reference_ahead();     // the next pass's labels have arrived during the evaluation
         KM_STAMP(3);
         if (live) {
             if (ol != bi) ++changed;
@@ -716,13 +830,14 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (__ballot(!live || bi != bi0 || bad) == 0ull) {
             u64* s = sums + bi0 * np1;
             const bool leader = (lane & 7) == 0;
-            if constexpr (NS > 0) {
-                u64 q[NX];
+            if constexpr (NS == 12 || NS == 13) {
+                unsigned qlo[NX], qhi[NX];
 #pragma unroll
-                for (int j = 0; j < NX; ++j) q[j] = half_row_sum_u64(km_fix(x[j], FS[j]));       // (x is dead after this pass)
+                for (int j = 0; j < NX; ++j) { const u64 q = km_fix(x[j], FS[j]); qlo[j] = (unsigned)q; qhi[j] = (unsigned)(q >> 32); }       // (x is dead after this pass)
+                half_row_sum_u64x(qlo, qhi);
                 if (leader) {
 #pragma unroll
-                    for (int j = 0; j < NX; ++j) atomicAdd(&s[j], q[j]);
+                    for (int j = 0; j < NX; ++j) atomicAdd(&s[j], ((u64)qhi[j] << 32) | qlo[j]);
                     atomicAdd(&s[n], 8ull);
                 }
             } else {
@@ -750,7 +865,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (++pass == KM_EPOCH_PASSES && base + stride < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
     }
 #if KM_PROFILE
-    if (threadIdx.x % 64 == 0) for (int q = 0; q < 8; ++q) atomicAdd(&km_prof[q], t_acc[q]);
+    if (threadIdx.x % 64 == 0) for (int q = 0; q < 16; ++q) atomicAdd(&km_prof[q], t_acc[q]);
 #endif
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
@@ -772,8 +887,8 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #if KM_PROFILE
 }  // namespace brov
 extern "C" __attribute__((visibility("default"))) int brov_debug_kmprof(unsigned long long* out8, int reset) {
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(brov::km_prof), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(brov::km_prof), z, 64) != hipSuccess) return -1; }
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(brov::km_prof), 128) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(brov::km_prof), z, 128) != hipSuccess) return -1; }
     return 0;
 }
 namespace brov {
@@ -1031,10 +1146,17 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 }
 // squared centre-centre distances (difference form) for the candidate filter, one block per row, rebuilt after every M-step:
 // floats rounded DOWN (a candidate test that errs, errs towards evaluating), row length kp = k rounded up to 256, permuted inside
-// every block of 256 so that position 4 lane + q holds centre 64 q + lane (see block_masks); padding = +inf (never a candidate)
-__global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc) {
+// every block of 256 so that position 4 lane + q holds centre 64 q + lane (see block_masks); padding = +inf (never a candidate).
+// Round 4: the same row once more SORTED, as 64-bit keys (bits of the distance << 16 | centre index: distances ascending, equal ones
+// by index) -- the candidates of a wave whose reference centre is a are a PREFIX of row a of Nk (kmeans_assign_lds_kernel, single-
+// reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 512 (the LDS /
+// DPP kernel's range).  Bitonic sort in the LDS.
+__global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
+                                                           unsigned long long* __restrict__ Nk) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
+    __shared__ unsigned long long keys[512];
+    const bool sorting = Nk != nullptr && kp <= 512;
     for (int c = threadIdx.x; c < kp; c += 256) {
         float v = __builtin_inff();
         if (c < k) {
@@ -1044,7 +1166,21 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
         }
         const int r = c & 255;
         Dc[(int64_t)a * kp + (c & ~255) + (r & 63) * 4 + (r >> 6)] = v;
+        if (sorting) keys[c] = ((unsigned long long)__float_as_uint(v) << 16) | (unsigned)c;      // non-negative floats (NaN included: last) order like their bits
     }
+    if (!sorting) return;
+    __syncthreads();
+    for (int size = 2; size <= kp; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = threadIdx.x; i < (kp >> 1); i += 256) {
+                const int lo = ((i / stride) * 2 * stride) + (i % stride), hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const unsigned long long x = keys[lo], y = keys[hi];
+                if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < kp; i += 256) Nk[(int64_t)a * kp + i] = keys[i];
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -1522,8 +1658,10 @@ static bool kmeans_lds_form(int n, int k, bool scalar_records) { return !scalar_
 bool kmeans_reads_through_perm(int n, int k, bool scalar_records) { return kmeans_lds_form(n, k, scalar_records); }
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
-                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm) {
+                                const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm,
+                                const unsigned long long* Nk) {
     if (perm && !kmeans_lds_form(n, k, scalar_records)) return hipErrorInvalidValue;      // only the LDS / DPP kernel reads through a permutation
+    if (Nk && (!Dc || !kmeans_lds_form(n, k, scalar_records))) return hipErrorInvalidValue;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127) || !prm || !fix) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N, n, k, scalar_records);
     const int nep = kmeans_epochs(N, n, k, scalar_records);
@@ -1533,7 +1671,7 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
-                           block_inertia, block_changed, Dc, prm, d2out, perm, fix); } while (0)
+                           block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk); } while (0)
         if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
 #undef KM2_LAUNCH
         return hipGetLastError();
@@ -1550,8 +1688,8 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 #undef KM_LAUNCH
     return hipGetLastError();
 }
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc) {
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc);
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk) {
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk);
     return hipGetLastError();
 }
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {

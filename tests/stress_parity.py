@@ -241,7 +241,7 @@ def lloyds():
     scan in the scalar-record kernel: identical labels and iteration counts."""
     n, ties, t0 = 0, 0, time.time()
     ctxs = []
-    for v in (0, 5):
+    for v in (0, 5, 16):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
@@ -260,7 +260,8 @@ def lloyds():
         C0 = X[rng.choice(N, k, replace=False)].copy()
         mean = X.mean(0)
         it = int(rng.choice([1, 3, 12]) if N < 200000 else rng.choice([12, 50]))
-        (Ca, la, ia, na), (Cb, lb, ib, nbb) = [engine.kmeans_lloyd(X, C0 - mean, max_iter=it, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
+        (Ca, la, ia, na), (Cb, lb, ib, nbb), (Cc, lc, ic, ncc) = [engine.kmeans_lloyd(X, C0 - mean, max_iter=it, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
+        assert ncc == nbb and np.array_equal(Cc, Cb) and np.array_equal(lc, lb), ("lloyd mask form", N, n_, k, it)
         assert na == nbb, ("lloyd iterations", N, n_, k, it)
         # round 4: integer member sums -- both variants form the same centres bit for bit, so their labels have nothing to differ by
         # (round 3 had to excuse "exact-distance ties" here: fp64 atomics in arrival order moved the centres between two runs)
