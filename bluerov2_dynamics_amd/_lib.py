@@ -136,7 +136,7 @@ SIGNATURES = {
     "edmdc_set_kmeans_far_select": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "edmdc_kmeans_relocations": (ctypes.c_int, [c_void_p]),
     "edmdc_set_kmeans_allreduce": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
-    "edmdc_set_kmeans_shard": (ctypes.c_int, [c_void_p, i64]),
+    "edmdc_set_kmeans_shard": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64]),
     "brov_comm_available": (ctypes.c_int, []),
     "brov_comm_unique_id": (ctypes.c_int, [c_void_p]),
     "brov_comm_init_rank": (ctypes.c_int, [ctypes.c_int, c_void_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(c_void_p)]),
@@ -349,9 +349,9 @@ class Context:
         self._allreduce_cb = ALLREDUCE_FN(tramp)
         self.check(self.lib.edmdc_set_kmeans_allreduce(self.h, ctypes.cast(self._allreduce_cb, c_void_p), None), "edmdc_set_kmeans_allreduce")
 
-    def set_kmeans_shard(self, row_offset: int):
-        """Global index of this rank's first row (sharded Lloyd; include/brov2.h: edmdc_set_kmeans_shard)."""
-        self.check(self.lib.edmdc_set_kmeans_shard(self.h, int(row_offset)), "edmdc_set_kmeans_shard")
+    def set_kmeans_shard(self, rank: int = 0, world: int = 1, row_offset: int = 0, n_global: int = 0):
+        """This rank's place in a sharded k-means (include/brov2.h: edmdc_set_kmeans_shard); the defaults are a single rank."""
+        self.check(self.lib.edmdc_set_kmeans_shard(self.h, int(rank), int(world), int(row_offset), int(n_global)), "edmdc_set_kmeans_shard")
 
     def kmeans_use_comm(self, comm):
         """Sharded Lloyd through the torch-free communicator (a _lib.Comm, or None for a single rank again)."""

@@ -140,4 +140,10 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
                            long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
                            void* state, double* C, long long* indices, float* Xf);
 
+size_t kmeanspp_shard_doubles(int world);
+hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
+                                   long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
+                                   void* state, double* C, long long* indices, float* Xf, int world, int rank, long long row0,
+                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed);
+
 }  // namespace brov

@@ -72,6 +72,8 @@ struct brov_ctx {
     void* km_allreduce_user = nullptr;
     brov_comm* km_comm = nullptr;                 // edmdc_kmeans_use_comm: the exchanges go to this communicator
     long long km_row_offset = 0;                  // global index of this rank's first row (edmdc_set_kmeans_shard)
+    int km_rank = 0, km_world = 1;                // this rank's place in a sharded k-means
+    long long km_n_global = 0;                    // rows over all ranks
     int kmeans_relocations = 0;       // relocations of empty clusters in the last edmdc_kmeans_lloyd(_dev) call
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
@@ -1092,8 +1094,8 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 30 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8 and / or + 16");
+    if (!c || variant < 0 || variant > 62 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16 and / or + 32");
     c->kmeans_variant = variant;
     return BROV_OK;
 }
@@ -1117,9 +1119,13 @@ static int km_allreduce_through_comm(void* user, void* d_buf, int64_t count, int
     brov_ctx* c = static_cast<brov_ctx*>(user);
     return brov_comm_allreduce_words(c->km_comm, d_buf, count, op, c->stream);
 }
-int edmdc_set_kmeans_shard(brov_ctx* c, int64_t row_offset) {
-    if (!c || row_offset < 0 || row_offset >= (1ll << 61)) return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_shard: bad row offset");
+int edmdc_set_kmeans_shard(brov_ctx* c, int rank, int world, int64_t row_offset, int64_t n_global) {
+    if (!c || world < 1 || rank < 0 || rank >= world || row_offset < 0 || row_offset >= (1ll << 61) || n_global < 0)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_shard: bad argument");
+    c->km_rank = rank;
+    c->km_world = world;
     c->km_row_offset = row_offset;
+    c->km_n_global = n_global;
     return BROV_OK;
 }
 int edmdc_kmeans_use_comm(brov_ctx* c, brov_comm* comm) {
@@ -1743,7 +1749,9 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
 // ---- k-means++ seeding (scikit-learn's algorithm, scikit-learn's random numbers) ----------------------------
 int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, int64_t xstride, const double* mean_host,
                        int64_t first_index, int n_trials, const double* uniforms_host, double* d_C, int64_t* indices_host) {
-    if (!c || N < 1 || n < 1 || n > 16 || k < 1 || k > N || !d_X || !d_C || xstride < n || first_index < 0 || first_index >= N ||
+    const bool sharded = c && c->km_allreduce && c->km_world > 1;
+    const int64_t Ng = sharded ? (int64_t)c->km_n_global : N;         // the first index and k refer to the rows of all ranks
+    if (!c || N < 1 || n < 1 || n > 16 || k < 1 || k > Ng || !d_X || !d_C || xstride < n || first_index < 0 || first_index >= Ng ||
         n_trials < 1 || n_trials > 16 || (k > 1 && !uniforms_host) || N > 30000000)
         return fail(c, BROV_ERR_ARG, "edmdc_kmeanspp_dev: bad argument (need 1<=n<=16, 1<=n_trials<=16, k<=N<=3e7)");
     DeviceGuard g(c);
@@ -1753,7 +1761,8 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     // a float copy of the coordinates screens out the rows a round cannot affect (kmeans.hip, pp_round_kernel); + 8 in the k-means
     // variant: every row goes through the fp64 path
     const bool screening = (c->kmeans_variant & 8) == 0;
-    int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) +
+    const size_t nshard = kmeanspp_shard_doubles(sharded ? c->km_world : 1);
+    int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) + Arena::al(nshard * 8) +
                        Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + (screening ? Arena::al((size_t)N * n * 4) : 0) + 8192);
     if (rc) return rc;
     double* Xt = a.take<double>((size_t)N * n);
@@ -1765,13 +1774,24 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     char* state = a.take<char>(kmeanspp_state_bytes());
     double* dmean = a.take<double>(16);
     float* Xf = screening ? a.take<float>((size_t)N * n) : nullptr;
+    double* dshard = a.take<double>(nshard);
     if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
     if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
-        HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
-                                 closest, dsum, state, d_C, dind, Xf));
+        if (sharded || (c->kmeans_variant & 32)) {
+            // rows sharded over ranks (edmdc_set_kmeans_allreduce / edmdc_set_kmeans_shard): two small exchanges per centre; + 32 in the
+            // k-means variant sends a single rank through the same kernels (the tests' check of that path against the one above)
+            int comm_failed = 0;
+            HIPCK(c, launch_kmeanspp_sharded(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
+                                             closest, dsum, state, d_C, dind, Xf, sharded ? c->km_world : 1, sharded ? c->km_rank : 0,
+                                             sharded ? c->km_row_offset : 0, dshard, c->km_allreduce, c->km_allreduce_user, &comm_failed));
+            if (comm_failed) return fail(c, BROV_ERR_COMM, "edmdc_kmeanspp_dev: an exchange between the ranks failed");
+        } else {
+            HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
+                                     closest, dsum, state, d_C, dind, Xf));
+        }
     }
     if (indices_host) {
         static_assert(sizeof(long long) == sizeof(int64_t), "index width");

@@ -1225,6 +1225,7 @@ constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
 constexpr int PP_THREADS = 256;
 constexpr int PD_THREADS = 1024;      // pp_decide: 4 samples of the chunk per thread
 constexpr int PP_SROWS = PP_LMAX + 1; // rows of S: one per trial + the chunk sums of closest itself (used for the first draw)
+constexpr int PP_CW = KM_NMAX + 2;      // a row of the sharded run's candidate table: 16 coordinates, |x|^2, the GLOBAL sample index (as a double)
 constexpr int PP_SCREEN_FROM = 8;     // rounds before this one evaluate every row in fp64: with so few centres most rows are in reach of a candidate
 
 struct PPState {                      // device-resident scalars of the seeding loop
@@ -1305,7 +1306,8 @@ template <int NS, int BT>
 __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
                                                              const double* __restrict__ xsq, const PPState* __restrict__ st, int par, int upd,
                                                              double* __restrict__ closest, double* __restrict__ S,
-                                                             const float* __restrict__ Xf /* [n][N] float copy of Xt, or nullptr: no screening */) {
+                                                             const float* __restrict__ Xf /* [n][N] float copy of Xt, or nullptr: no screening */,
+                                                             const double* __restrict__ crow /* sharded run: the round's rows [PP_LMAX + 1][PP_CW] (nullptr: from Xt through st) */) {
     // candidate rows in LDS: [trial][16 coordinates | norm | pad]; row L = the centre chosen last.  A compiler-level memory
     // barrier in front of every trial keeps their reads where they are used: as plain loop invariants the compiler hoisted
     // all 16 x 17 of them into registers (256 VGPRs + scratch, one wave per SIMD).
@@ -1315,8 +1317,13 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
     __shared__ float csf[(PP_LMAX + 1) * KM_NMAX];    // the same rows as floats (screening)
     for (int e = threadIdx.x; e < (L + 1) * CSW; e += BT) {
         const int t = e / CSW, j = e % CSW;
-        const int64_t ci = t < L ? st->cand[par][t] : st->last;
-        cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
+        if (crow) {
+            // sharded run: a candidate lives on ONE rank; its row was exchanged (pp_decide_sh_kernel) -- slot KM_NMAX holds |x|^2
+            cs[e] = j <= KM_NMAX ? crow[(t < L ? t : PP_LMAX) * PP_CW + j] : 0.0;
+        } else {
+            const int64_t ci = t < L ? st->cand[par][t] : st->last;
+            cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
+        }
         if (j < KM_NMAX) csf[t * KM_NMAX + j] = (float)cs[e];
     }
     // Screening (rounds with candidates, once closest[] exists): most samples are far from all of the round's points -- its L
@@ -1408,111 +1415,53 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
     }
 }
 
-// One block per trial of the NEXT round (one block when nothing is drawn); every block repeats the cheap global part.
-//   c > 0: winner = first trial with the smallest potential (np.argmin) among the candidates cand[(c-1)&1]; block 0 records it
-//          as centre c.  Potentials: one wave per trial, a lane takes every 64th chunk sum, then a fixed tree.
-//   draw : value = u[trial] * pot (pot = the winner's potential; before round 1 the sum of the chunk sums of closest);
-//          chunk = first chunk whose running sum reaches it (running sums of S[winner][.]); inside the chunk thread th
-//          owns 4 consecutive samples, whose values min(closest_i, d(x_i, centre c)) are recomputed here.
-//          cand = first index with running sum >= value, clipped to N - 1 (np.searchsorted + np.clip).
-template <int NS>
-__global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n, int nchunks, int L, int c, int draw, const double* __restrict__ u,
-                                                              const double* __restrict__ Xt, const double* __restrict__ xsq,
-                                                              const double* __restrict__ closest, const double* __restrict__ S,
-                                                              const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
-                                                              PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
-    extern __shared__ double dyn[];               // prefix[nchunks + 1] | vals[PP_CHUNK]
-    double* prefix = dyn;
-    double* vals = dyn + (nchunks + 1);
-    __shared__ double pots[PP_LMAX];
-    __shared__ double wtot[PD_THREADS / 64];
-    __shared__ int wfirst[PD_THREADS / 64];
-    __shared__ long long s_last, s_found;
-    __shared__ double s_pot;
-    __shared__ int s_row;
+// running sums of a row of chunk sums, in chunk order, into prefix[0 .. nchunks] (prefix[nchunks] = the total): every thread adds up a
+// contiguous segment; the segment totals are scanned in thread order (shuffle scan inside a wave, the 16 wave totals chained) --
+// fixed grouping, same result every run.  All PD_THREADS threads of the block; ends with a barrier.
+__device__ __forceinline__ void pp_chunk_prefix(int nchunks, const double* __restrict__ cs, double* prefix, double* wtot) {
     const int tid = threadIdx.x;
-    if (c > 0) {
-        // one wave per trial: lane l adds every 64th chunk sum, then a fixed shuffle tree
-        const int t = tid >> 6, l = tid & 63;
-        if (t < L) {
-            // same order of additions as the plain loop `a += S[t][b], b = l, l + 64, ...`, but eight loads are in flight at a time:
-            // as written first, every addition waited for its own load (38 L2 round trips one after the other at N = 1e7 -- most
-            // of this kernel's 26 us)
-            double a = 0.0;
-            const double* Sr = S + (int64_t)t * nchunks;
-            for (int b0 = l; b0 < nchunks; b0 += 64 * 8) {
-                double v[8];
+    const int per = (nchunks + PD_THREADS - 1) / PD_THREADS;
+    const int b0 = tid * per < nchunks ? tid * per : nchunks, b1 = b0 + per < nchunks ? b0 + per : nchunks;
+    // the thread's segment of chunk sums: loaded together (at most 9: the LDS bound on nchunks / 1024 threads), added in order
+    constexpr int PERMAX = 9;
+    double seg[PERMAX];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { const int b = b0 + 64 * q; v[q] = b < nchunks ? Sr[b] : 0.0; }
+    for (int q = 0; q < PERMAX; ++q) seg[q] = b0 + q < b1 ? cs[b0 + q] : 0.0;
+    double a = 0.0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q)
-                    if (b0 + 64 * q < nchunks) a += v[q];
-            }
-            for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-            if (l == 0) pots[t] = a;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int best = 0;
-            for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
-            const long long win = st->cand[(c - 1) & 1][best];
-            s_row = best; s_last = win; s_pot = pots[best];
-            if (blockIdx.x == 0) { st->pot = pots[best]; st->last = win; indices[c] = win; }
-        }
-        __syncthreads();
-        if (blockIdx.x == 0 && tid < n) C[(int64_t)c * n + tid] = X[s_last * xstride + tid] - (mean ? mean[tid] : 0.0);
-    } else {
-        if (tid == 0) { s_row = PP_LMAX; s_last = -1; s_pot = 0.0; }
-        __syncthreads();
-    }
-    if (!draw) return;
-    const double* cs = S + (int64_t)s_row * nchunks;
-    {
-        // running sums of the chunk sums, in chunk order: every thread adds up a contiguous segment; the segment totals are
-        // scanned in thread order (shuffle scan inside a wave, the 16 wave totals chained) -- fixed grouping, same result every run
-        const int per = (nchunks + PD_THREADS - 1) / PD_THREADS;
-        const int b0 = tid * per < nchunks ? tid * per : nchunks, b1 = b0 + per < nchunks ? b0 + per : nchunks;
-        // the thread's segment of chunk sums: loaded together (at most 9: the LDS bound on nchunks / 1024 threads), added in order
-        constexpr int PERMAX = 9;
-        double seg[PERMAX];
-#pragma unroll
-        for (int q = 0; q < PERMAX; ++q) seg[q] = b0 + q < b1 ? cs[b0 + q] : 0.0;
-        double a = 0.0;
-#pragma unroll
-        for (int q = 0; q < PERMAX; ++q)
-            if (b0 + q < b1) a += seg[q];
-        const int lane = tid & 63, w = tid >> 6;
-        double incl = a;
-        for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
-        if (lane == 63) wtot[w] = incl;
-        __syncthreads();
-        double woff = 0.0;
-        for (int q = 0; q < w; ++q) woff += wtot[q];
-        double run = woff + (incl - a);
-#pragma unroll
-        for (int q = 0; q < PERMAX; ++q)
-            if (b0 + q < b1) { prefix[b0 + q] = run; run += seg[q]; }
-        if (tid == PD_THREADS - 1) {
-            prefix[nchunks] = run;
-            if (c == 0) { s_pot = run; if (blockIdx.x == 0) st->pot = run; }
-        }
-        __syncthreads();                          // wtot is reused below
-    }
+    for (int q = 0; q < PERMAX; ++q)
+        if (b0 + q < b1) a += seg[q];
+    const int lane = tid & 63, w = tid >> 6;
+    double incl = a;
+    for (int off = 1; off < 64; off <<= 1) { const double t = __shfl_up(incl, off); if (lane >= off) incl += t; }
+    if (lane == 63) wtot[w] = incl;
     __syncthreads();
-    const int trial = blockIdx.x;
-    const double v = u[trial] * s_pot;
-    // first chunk b with prefix[b + 1] >= v (binary search, block-uniform)
+    double woff = 0.0;
+    for (int q = 0; q < w; ++q) woff += wtot[q];
+    double run = woff + (incl - a);
+#pragma unroll
+    for (int q = 0; q < PERMAX; ++q)
+        if (b0 + q < b1) { prefix[b0 + q] = run; run += seg[q]; }
+    if (tid == PD_THREADS - 1) prefix[nchunks] = run;
+    __syncthreads();                              // (wtot is reused by pp_find_sample)
+}
+
+// The sample a drawn value v falls on: first chunk b with prefix[b + 1] >= v (binary search, block-uniform); inside it thread th owns
+// 4 consecutive samples whose values min(closest_i, d(x_i, last centre)) are recomputed here; *found = first index whose running sum
+// reaches v, clipped to N - 1 (np.searchsorted + np.clip).  cl / cn: the centre chosen last (coordinates, |c|^2) when have_last.
+template <int NS>
+__device__ __forceinline__ void pp_find_sample(int64_t N, int n, int nchunks, double v, const double* prefix, bool have_last, const double (&cl)[KM_NMAX],
+                                               double cn, const double* __restrict__ Xt, const double* __restrict__ xsq,
+                                               const double* __restrict__ closest, double* vals, double* wtot, int* wfirst, long long* found) {
+    const int tid = threadIdx.x;
     int lo = 0, hi = nchunks;                     // answer in [lo, hi]; hi = nchunks means "beyond the end"
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         if (prefix[mid + 1] >= v) hi = mid; else lo = mid + 1;
     }
-    if (tid == 0) s_found = N - 1;
+    if (tid == 0) *found = N - 1;
     if (lo < nchunks) {
         const int64_t base = (int64_t)lo * PP_CHUNK;
-        const long long last = s_last;
-        double cl[KM_NMAX], cn = 0.0;
-        if (last >= 0) { pp_load_col<NS>(Xt, N, n, last, cl); cn = xsq[last]; }
 #pragma unroll
         for (int q = 0; q < PP_CHUNK / PD_THREADS; ++q) {
             const int sidx = q * PD_THREADS + tid;
@@ -1520,7 +1469,7 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
             double val = 0.0;
             if (i < N) {
                 val = closest[i];
-                if (last >= 0) {
+                if (have_last) {
                     double x[KM_NMAX];
                     pp_load_col<NS>(Xt, N, n, i, x);
                     const double d = pp_dist<NS>(x, [&](int j) { return cl[j]; }, cn, xsq[i]);
@@ -1559,14 +1508,90 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
                     run += mine[q];
                     if (run >= v) { idx = i; break; }
                 }
-                s_found = idx;
+                *found = idx;
             }
         } else if (tid == 0) {
             // rounding between the chunk's tree sum and its sequential sum: the value lies just past this chunk
             const long long nxt = (long long)(lo + 1) * PP_CHUNK;
-            s_found = nxt < N ? nxt : N - 1;
+            *found = nxt < N ? nxt : N - 1;
         }
     }
+}
+
+// potential of one trial: lane l adds every 64th chunk sum (eight loads in flight, additions in the order of the plain loop), then a
+// fixed shuffle tree -- the one summation pp_decide_kernel and pp_tot_kernel share
+__device__ __forceinline__ double pp_row_total(const double* __restrict__ Sr, int nchunks, int l) {
+    double a = 0.0;
+    for (int b0 = l; b0 < nchunks; b0 += 64 * 8) {
+        double v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const int b = b0 + 64 * q; v[q] = b < nchunks ? Sr[b] : 0.0; }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (b0 + 64 * q < nchunks) a += v[q];
+    }
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+    return a;
+}
+
+// One block per trial of the NEXT round (one block when nothing is drawn); every block repeats the cheap global part.
+//   c > 0: winner = first trial with the smallest potential (np.argmin) among the candidates cand[(c-1)&1]; block 0 records it
+//          as centre c.  Potentials: one wave per trial, a lane takes every 64th chunk sum, then a fixed tree.
+//   draw : value = u[trial] * pot (pot = the winner's potential; before round 1 the sum of the chunk sums of closest);
+//          chunk = first chunk whose running sum reaches it (running sums of S[winner][.]); inside the chunk thread th
+//          owns 4 consecutive samples, whose values min(closest_i, d(x_i, centre c)) are recomputed here.
+//          cand = first index with running sum >= value, clipped to N - 1 (np.searchsorted + np.clip).
+template <int NS>
+__global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n, int nchunks, int L, int c, int draw, const double* __restrict__ u,
+                                                              const double* __restrict__ Xt, const double* __restrict__ xsq,
+                                                              const double* __restrict__ closest, const double* __restrict__ S,
+                                                              const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                                                              PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+    extern __shared__ double dyn[];               // prefix[nchunks + 1] | vals[PP_CHUNK]
+    double* prefix = dyn;
+    double* vals = dyn + (nchunks + 1);
+    __shared__ double pots[PP_LMAX];
+    __shared__ double wtot[PD_THREADS / 64];
+    __shared__ int wfirst[PD_THREADS / 64];
+    __shared__ long long s_last, s_found;
+    __shared__ double s_pot;
+    __shared__ int s_row;
+    const int tid = threadIdx.x;
+    if (c > 0) {
+        // one wave per trial: lane l adds every 64th chunk sum, then a fixed shuffle tree
+        const int t = tid >> 6, l = tid & 63;
+        if (t < L) {
+            // (eight loads in flight at a time: as written first, every addition waited for its own load -- 38 L2 round trips one after
+            // the other at N = 1e7, most of this kernel's 26 us)
+            const double a = pp_row_total(S + (int64_t)t * nchunks, nchunks, l);
+            if (l == 0) pots[t] = a;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int best = 0;
+            for (int q = 1; q < L; ++q) if (pots[q] < pots[best]) best = q;
+            const long long win = st->cand[(c - 1) & 1][best];
+            s_row = best; s_last = win; s_pot = pots[best];
+            if (blockIdx.x == 0) { st->pot = pots[best]; st->last = win; indices[c] = win; }
+        }
+        __syncthreads();
+        if (blockIdx.x == 0 && tid < n) C[(int64_t)c * n + tid] = X[s_last * xstride + tid] - (mean ? mean[tid] : 0.0);
+    } else {
+        if (tid == 0) { s_row = PP_LMAX; s_last = -1; s_pot = 0.0; }
+        __syncthreads();
+    }
+    if (!draw) return;
+    pp_chunk_prefix(nchunks, S + (int64_t)s_row * nchunks, prefix, wtot);
+    if (c == 0 && tid == 0) { s_pot = prefix[nchunks]; if (blockIdx.x == 0) st->pot = prefix[nchunks]; }
+    __syncthreads();
+    const int trial = blockIdx.x;
+    const double v = u[trial] * s_pot;
+    const long long last = s_last;
+    double cl[KM_NMAX], cn = 0.0;
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) cl[j] = 0.0;
+    if (last >= 0) { pp_load_col<NS>(Xt, N, n, last, cl); cn = xsq[last]; }
+    pp_find_sample<NS>(N, n, nchunks, v, prefix, last >= 0, cl, cn, Xt, xsq, closest, vals, wtot, wfirst, &s_found);
     __syncthreads();
     if (tid == 0) st->cand[c & 1][trial] = s_found;
 }
@@ -1602,18 +1627,187 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
         hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq, Xf, ps); \
         hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
         if (k > 1) { \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(L), dim3(PD_THREADS), lds, st, N, n, nchunks, L, 0, 1, u, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } \
         for (int c = 1; c < k; ++c) { \
             const int draw = c + 1 < k ? 1 : 0; \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, L, c, draw, u + (size_t)c * L, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
 #undef PP_DISPATCH
+    return hipGetLastError();
+}
+
+// ---- the seeding over rows sharded across ranks (round 4) -----------------------------------------------------------------------
+// `_kmeans_plusplus` walks ALL samples: the running sum the candidates are drawn from runs over the ranks' rows in rank order, and a
+// candidate's potential is a sum over all of them.  Every rank keeps the passes over its own rows (pp_round_kernel); what crosses
+// the ranks per round are two small tables, both as SUMs of 64-bit words in which one rank writes and the others hold zeros (the
+// exchange of the sharded Lloyd loop: edmdc_set_kmeans_allreduce):
+//   tot  [world][PP_SROWS]  rank r's sum over its chunks of S[t][.] for every trial t (and of closest itself);
+//   crow [PP_LMAX + 1][PP_CW]  the rows of the next round's candidates -- coordinates, |x|^2, GLOBAL index -- each written by the rank
+//                           that owns the sample the drawn value falls on; row PP_LMAX = the centre chosen last (rank 0 writes it).
+// Every rank then takes the same decisions from the same numbers: potentials = sums of tot over the ranks in rank order, the first
+// smallest wins; a drawn value u * pot is located first among the ranks (running sum of tot[.][winner]), then -- by the owner,
+// with the value reduced by the ranks before it -- among its chunks and inside the chunk exactly as on one rank.  The running
+// sum is thereby grouped by rank and chunk instead of by chunk alone: a candidate can differ from the one-rank run's (and from
+// scikit-learn's) only where a drawn value falls within rounding of a running-sum boundary, the caveat the chunked sum carries anyway.
+__global__ void __launch_bounds__(PD_THREADS) pp_tot_kernel(int nchunks, int L, const double* __restrict__ S, double* __restrict__ tot_mine) {
+    const int l = threadIdx.x & 63;
+    for (int t = threadIdx.x >> 6; t <= L; t += PD_THREADS / 64) {      // a wave per row: the trials t < L, then the row of closest itself
+        const int row = t < L ? t : PP_LMAX;
+        const double a = pp_row_total(S + (int64_t)row * nchunks, nchunks, l);
+        if (l == 0) tot_mine[row] = a;
+    }
+}
+
+// the first centre: its owner writes the row (others: zeros; the table is summed over the ranks afterwards)
+template <int NS>
+__global__ void pp_first_sh_kernel(int64_t N, int n, long long first_global, long long row0, const double* __restrict__ Xt,
+                                   const double* __restrict__ xsq, double* __restrict__ crow) {
+    const int j = threadIdx.x;
+    if (j >= PP_CW) return;
+    const long long li = first_global - row0;
+    double v = 0.0;
+    if (li >= 0 && li < N) v = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + li] : 0.0) : (j == KM_NMAX ? xsq[li] : (double)first_global);
+    crow[PP_LMAX * PP_CW + j] = v;
+}
+__global__ void pp_record_kernel(int n, int c, const double* __restrict__ row, double* __restrict__ C, long long* __restrict__ indices) {
+    const int j = threadIdx.x;
+    if (j < n) C[(int64_t)c * n + j] = row[j];
+    if (j == 0) indices[c] = (long long)row[KM_NMAX + 1];
+}
+
+// pp_decide_kernel for a sharded run; one block per trial of the next round (one block when nothing is drawn).
+//   crow_cur: the rows of this round (candidates 0..L-1, the previous centre at PP_LMAX) -- identical on every rank
+//   crow_nxt: zeroed by the caller; receives this rank's contributions to the next round's rows
+template <int NS>
+__global__ void __launch_bounds__(PD_THREADS) pp_decide_sh_kernel(int64_t N, int n, int nchunks, int L, int c, int draw, const double* __restrict__ u,
+                                                                 const double* __restrict__ Xt, const double* __restrict__ xsq,
+                                                                 const double* __restrict__ closest, const double* __restrict__ S,
+                                                                 int world, int rank, long long row0, const double* __restrict__ tot,
+                                                                 const double* __restrict__ crow_cur, double* __restrict__ crow_nxt,
+                                                                 double* __restrict__ C, long long* __restrict__ indices) {
+    extern __shared__ double dyn[];               // prefix[nchunks + 1] | vals[PP_CHUNK]
+    double* prefix = dyn;
+    double* vals = dyn + (nchunks + 1);
+    __shared__ double wtot[PD_THREADS / 64];
+    __shared__ int wfirst[PD_THREADS / 64];
+    __shared__ long long s_found;
+    __shared__ double s_pot, s_before;
+    __shared__ int s_row, s_owner;
+    const int tid = threadIdx.x, trial = blockIdx.x;
+    if (tid == 0) {
+        int row = PP_LMAX;
+        if (c > 0) {
+            double bestp = 0.0;
+            for (int t = 0; t < L; ++t) {
+                double p = 0.0;
+                for (int r = 0; r < world; ++r) p += tot[r * PP_SROWS + t];
+                if (t == 0 || p < bestp) { bestp = p; row = t; }         // np.argmin: the first smallest
+            }
+        }
+        double pot = 0.0;
+        for (int r = 0; r < world; ++r) pot += tot[r * PP_SROWS + row];
+        s_row = row;
+        s_pot = pot;
+        // the rank a drawn value falls on: first rank whose running sum reaches it (the last one when rounding puts it past the end)
+        const double v = draw ? u[trial] * pot : 0.0;
+        double run = 0.0;
+        int owner = world - 1;
+        double before = 0.0;
+        for (int r = 0; r < world; ++r) {
+            const double nxt = run + tot[r * PP_SROWS + row];
+            if (nxt >= v) { owner = r; before = run; break; }
+            if (r == world - 1) before = run;
+            run = nxt;
+        }
+        s_owner = owner;
+        s_before = before;
+    }
+    __syncthreads();
+    const int row = s_row;
+    // the centre this round has chosen: the winner's row (c > 0; centre 0 was recorded by pp_record_kernel); it is the next round's
+    // "last" row, which rank 0 alone contributes
+    const double* win = crow_cur + (c > 0 ? row : PP_LMAX) * PP_CW;
+    if (blockIdx.x == 0) {
+        if (c > 0) {
+            if (tid < n) C[(int64_t)c * n + tid] = win[tid];
+            if (tid == 0) indices[c] = (long long)win[KM_NMAX + 1];
+        }
+        if (draw && rank == 0 && tid < PP_CW) crow_nxt[PP_LMAX * PP_CW + tid] = win[tid];
+    }
+    if (!draw) return;
+    if (rank != s_owner) return;                  // (block-uniform) the table keeps this rank's zeros for the trial
+    pp_chunk_prefix(nchunks, S + (int64_t)row * nchunks, prefix, wtot);
+    const double v = u[trial] * s_pot - s_before;
+    double cl[KM_NMAX];
+#pragma unroll
+    for (int j = 0; j < KM_NMAX; ++j) cl[j] = win[j];
+    pp_find_sample<NS>(N, n, nchunks, v, prefix, c > 0, cl, win[KM_NMAX], Xt, xsq, closest, vals, wtot, wfirst, &s_found);
+    __syncthreads();
+    const long long li = s_found;
+    if (tid < PP_CW)
+        crow_nxt[trial * PP_CW + tid] = tid < KM_NMAX ? ((NS > 0 ? tid < NS : tid < n) ? Xt[(int64_t)tid * N + li] : 0.0)
+                                                      : (tid == KM_NMAX ? xsq[li] : (double)(row0 + li));
+}
+
+size_t kmeanspp_shard_doubles(int world) { return (size_t)world * PP_SROWS + 2 * (size_t)(PP_LMAX + 1) * PP_CW + 16; }
+
+// The sharded seeding loop, stream ordered.  exch(user, device words, count, op): the ranks' exchange (op 0: sum of int64 words,
+// op 1: maximum of uint64 words); first: GLOBAL index of the first centre; u: the uniforms every rank draws identically; shard:
+// device scratch [kmeanspp_shard_doubles(world)]; indices come back GLOBAL.
+hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
+                                   long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
+                                   void* state, double* C, long long* indices, float* Xf, int world, int rank, long long row0,
+                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed) {
+    if (n > KM_NMAX || L > PP_LMAX || L < 1 || world < 1 || rank < 0 || rank >= world || N < 1) return hipErrorInvalidValue;
+    *comm_failed = 0;
+    const int nchunks = kmeanspp_chunks(N);
+    const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;
+    if (lds > 100 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > 9) return hipErrorInvalidValue;
+    PPState* ps = reinterpret_cast<PPState*>(state);
+    double* tot = shard;
+    double* crow[2] = {shard + (size_t)world * PP_SROWS, shard + (size_t)world * PP_SROWS + (size_t)(PP_LMAX + 1) * PP_CW};
+    const size_t tot_bytes = (size_t)world * PP_SROWS * 8, crow_bytes = (size_t)(PP_LMAX + 1) * PP_CW * 8;
+    auto exchange = [&](void* p, int64_t words, int op) -> bool {
+        if (world == 1 || !exch) return true;
+        if (exch(user, p, words, op) != 0) { *comm_failed = 1; return false; }
+        return true;
+    };
+    hipError_t e0 = hipMemsetAsync(ps, 0, sizeof(PPState), st);
+    if (e0 != hipSuccess) return e0;
+    const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
+#define PPS_DISPATCH(NS_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_sh_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e_ != hipSuccess) return e_; \
+        hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq, Xf, ps); \
+        if (Xf && !exchange(&ps->xmax_bits, 1, 1)) return hipSuccess;        /* the scale of the screening margin: over all ranks */ \
+        if ((e_ = hipMemsetAsync(crow[1], 0, crow_bytes, st)) != hipSuccess) return e_; \
+        hipLaunchKernelGGL(pp_first_sh_kernel<NS_>, dim3(1), dim3(64), 0, st, N, n, first, row0, Xt, xsq, crow[1]); \
+        if (!exchange(crow[1], (int64_t)(PP_LMAX + 1) * PP_CW, 0)) return hipSuccess; \
+        hipLaunchKernelGGL(pp_record_kernel, dim3(1), dim3(64), 0, st, n, 0, crow[1] + PP_LMAX * PP_CW, C, indices); \
+        for (int c = 0; c < k; ++c) { \
+            if (k == 1) break; \
+            const int draw = c + 1 < k ? 1 : 0; \
+            const int Lc = c == 0 ? 0 : L; \
+            const double* cur = crow[(c + 1) & 1];                       /* round c reads T[(c - 1) & 1], written by decide(c - 1) (c = 0: pp_first) */ \
+            hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, Lc, nchunks, Xt, xsq, ps, 0, \
+                               c == 0 ? 1 : (c == 1 ? 0 : 2), closest, S, (c >= PP_SCREEN_FROM) ? Xf : nullptr, cur); \
+            if ((e_ = hipMemsetAsync(tot, 0, tot_bytes, st)) != hipSuccess) return e_; \
+            hipLaunchKernelGGL(pp_tot_kernel, dim3(1), dim3(PD_THREADS), 0, st, nchunks, Lc, S, tot + (size_t)rank * PP_SROWS); \
+            if (!exchange(tot, (int64_t)world * PP_SROWS, 0)) return hipSuccess; \
+            double* nxt = crow[c & 1]; \
+            if ((e_ = hipMemsetAsync(nxt, 0, crow_bytes, st)) != hipSuccess) return e_; \
+            hipLaunchKernelGGL(pp_decide_sh_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, Lc, c, draw, u + (size_t)c * L, Xt, xsq, \
+                               closest, S, world, rank, row0, tot, cur, nxt, C, indices); \
+            if (draw && !exchange(nxt, (int64_t)(PP_LMAX + 1) * PP_CW, 0)) return hipSuccess; \
+        } } while (0)
+    if (n == 12) PPS_DISPATCH(12); else if (n == 13) PPS_DISPATCH(13); else PPS_DISPATCH(0);
+#undef PPS_DISPATCH
     return hipGetLastError();
 }
 

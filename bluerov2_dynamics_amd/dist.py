@@ -181,6 +181,78 @@ def allreduce_words_(t, op, group=None):
     return t
 
 
+def _shard_place(n_local, device, group=None):
+    """(rank, world, global index of this rank's first row, rows over all ranks) for contiguous shards in rank order."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    counts = torch.zeros(world, dtype=torch.int64, device=device)
+    counts[rank] = n_local
+    allreduce_words_(counts, 0, group)
+    counts = counts.cpu()
+    return rank, world, int(counts[:rank].sum().item()), int(counts.sum().item())
+
+
+def kmeanspp_sharded(X_local, k, mean=None, random_state=0, group=None, ctx=None):
+    """k-means++ seeding (scikit-learn's `_kmeans_plusplus`, scikit-learn's random stream) over rows sharded across ranks in rank
+    order: every rank passes its rows and ends with the same k centres (centred frame) and the same GLOBAL sample indices -- those
+    of the unsharded seeding unless a drawn value falls within rounding of a running-sum boundary.  Two small exchanges per centre
+    (csrc/kmeans.hip: launch_kmeanspp_sharded).  One rank (or no process group): the plain device seeding."""
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    ctx = ctx or engine.default_context(X_local.device.index)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+        return engine.kmeanspp_dev(X_local, k, mean=mean, random_state=random_state, ctx=ctx)
+    N, n = X_local.shape
+    rank, world, row0, Ng = _shard_place(N, X_local.device, group)
+
+    def cb(ptr, count, op):
+        allreduce_words_(torch.as_tensor(_DeviceWords(ptr, count), device=X_local.device), op, group)
+
+    ctx.set_kmeans_shard(rank, world, row0, Ng)
+    ctx.set_kmeans_allreduce(cb)
+    try:
+        return engine.kmeanspp_dev(X_local, k, mean=mean, random_state=random_state, ctx=ctx, n_global=Ng)
+    finally:
+        ctx.set_kmeans_allreduce(None)
+        ctx.set_kmeans_shard()
+
+
+def kmeans_centers_sharded(X_local, k, random_state=0, max_iter=300, tol=1e-4, group=None, ctx=None, timings=None):
+    """The RBF centres of KoopmanEDMDc.fit over ALL ranks' rows (Koopman/koopmanEDMDc.py:85: KMeans(k, n_init="auto",
+    random_state=0).fit(X) sees every sample): column means and the tolerance's variance over all rows, the k-means++ seeding
+    over all rows, Lloyd's loop with one integer all-reduce per iteration.  Every rank returns the same (centres CUDA [k, n],
+    inertia over all rows, n_iter); they are the one-rank centres up to the rounding of the column means (the Lloyd loop itself is
+    bit-identical for identical means and seeds)."""
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import engine
+    ctx = ctx or engine.default_context(X_local.device.index)
+    mean, var, _ = column_stats_sharded(X_local, group)
+    mean_h = mean.cpu().numpy()
+    t0 = time.perf_counter()
+    C0, _ = kmeanspp_sharded(X_local, k, mean=mean_h, random_state=random_state, group=group, ctx=ctx)
+    torch.cuda.synchronize(X_local.device)
+    t1 = time.perf_counter()
+    C, _, inertia, n_iter = kmeans_lloyd_sharded(X_local, C0, mean=mean_h, max_iter=max_iter, tol_abs=var * tol, group=group, ctx=ctx)
+    torch.cuda.synchronize(X_local.device)
+    t2 = time.perf_counter()
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        it = torch.tensor([inertia], dtype=torch.float64, device=X_local.device)
+        if dist.get_backend(group) != "nccl":
+            h = it.cpu()
+            dist.all_reduce(h, group=group)
+            it = h
+        else:
+            dist.all_reduce(it, group=group)
+        inertia = float(it.item())
+    if timings is not None:
+        timings.update(kmeanspp_s=t1 - t0, lloyd_s=t2 - t1, lloyd_iterations=n_iter)
+    return C + mean, inertia, n_iter
+
+
 def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, group=None, lloyd_fn=None, ctx=None):
     """Lloyd's loop over rows sharded across ranks: every rank passes its own rows X_local [N_local, n] and the SAME initial
     centres C0 [k, n] (centred frame: C0 and the returned centres are relative to `mean`).  Per iteration one all-reduce (SUM,
@@ -215,10 +287,8 @@ def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, grou
 
     if sharded:
         # global index of this rank's first row (ranks hold contiguous shards in rank order): the tie-break of an empty cluster's relocation
-        counts = torch.zeros(dist.get_world_size(group), dtype=torch.int64, device=X_local.device)
-        counts[dist.get_rank(group)] = N
-        allreduce_words_(counts, 0, group)
-        ctx.set_kmeans_shard(int(counts[: dist.get_rank(group)].sum().item()))
+        rank, world, row0, Ng = _shard_place(N, X_local.device, group)
+        ctx.set_kmeans_shard(rank, world, row0, Ng)
         ctx.set_kmeans_allreduce(cb)
     try:
         torch.cuda.current_stream(X_local.device).synchronize()
@@ -228,7 +298,7 @@ def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, grou
     finally:
         if sharded:
             ctx.set_kmeans_allreduce(None)
-            ctx.set_kmeans_shard(0)
+            ctx.set_kmeans_shard()
     return C, labels, inertia.value, n_iter.value
 
 

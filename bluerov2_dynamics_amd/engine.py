@@ -295,15 +295,17 @@ def kmeanspp_draws(N, k, random_state=0):
     return first, U, L
 
 
-def kmeanspp_dev(X, k, mean=None, random_state=0, ctx=None):
+def kmeanspp_dev(X, k, mean=None, random_state=0, ctx=None, n_global=None):
     """k-means++ seeding of a device-resident X (torch CUDA [N,n]) with scikit-learn's algorithm and random stream
-    (edmdc_kmeanspp_dev).  Returns (C0 CUDA [k,n] in the frame of X - mean, indices [k] int64 numpy)."""
+    (edmdc_kmeanspp_dev).  Returns (C0 CUDA [k,n] in the frame of X - mean, indices [k] int64 numpy).
+    n_global: rows over all ranks when X is this rank's shard of a sharded seeding (dist.kmeanspp_sharded installs the exchange):
+    the random numbers are drawn for that many rows, indices come back global."""
     import torch
     ctx = ctx or default_context(X.device.index)
     ctx.use_torch_stream()
     N, n = X.shape
     assert X.stride(1) == 1
-    first, U, L = kmeanspp_draws(N, k, random_state)
+    first, U, L = kmeanspp_draws(N if n_global is None else int(n_global), k, random_state)
     C = torch.empty((k, n), dtype=torch.float64, device=X.device)
     ind = np.empty(k, dtype=np.int64)
     m = None if mean is None else as_f64(mean).reshape(n)

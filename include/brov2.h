@@ -288,7 +288,11 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
  * still the one for k > 512 or n = 15) instead of the LDS-resident table read through DPP: same arithmetic, same labels.
  * Adding 8 makes the k-means++ seeding (edmdc_kmeanspp_dev) take every sample through its fp64 distance evaluation in every round
- * instead of screening rows out with a float copy of the coordinates first: same indices, same centres. */
+ * instead of screening rows out with a float copy of the coordinates first: same indices, same centres.
+ * Adding 16 keeps the round-3 form of the candidate filter alone (label groups and masks over all centres) instead of trying the
+ * single-reference form first (candidates = a prefix of the reference centre's sorted distance row): same labels, same centres.
+ * Adding 32 sends the seeding of a single rank through the kernels of the sharded run (candidate rows from a table, potentials
+ * through the per-rank totals): same indices. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
 /* Which samples `_relocate_empty_clusters_dense` moves its empty clusters to is
  * `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]` (sklearn/cluster/_k_means_common.pyx): NumPy's introselect decides the
@@ -307,11 +311,16 @@ BROV_API int edmdc_kmeans_relocations(brov_ctx* ctx);
  * they are the centres of the unsharded run bit for bit.  fn = NULL: single rank.  Return 0 on success. */
 typedef int (*brov_allreduce_fn)(void* user, void* d_buf, int64_t count, int op);
 BROV_API int edmdc_set_kmeans_allreduce(brov_ctx* ctx, brov_allreduce_fn fn, void* user);
-/* Global index of this rank's first row (ranks hold contiguous shards in rank order; default 0).  Only the relocation of an empty
- * cluster looks at it: in a sharded run the n_empty farthest rows of the whole set are chosen in descending distance, equal
- * distances by ascending GLOBAL row (three small all-reduces per relocated cluster) -- the library's own rule, also for one rank
- * when no far-select callback is installed, so sharded and unsharded runs relocate the same rows. */
-BROV_API int edmdc_set_kmeans_shard(brov_ctx* ctx, int64_t row_offset);
+/* This rank's place in a sharded k-means: ranks hold contiguous shards of the rows in rank order, row_offset = global index of this
+ * rank's first row, n_global = rows over all ranks (defaults: rank 0 of 1).  With an exchange installed (edmdc_set_kmeans_allreduce
+ * or edmdc_kmeans_use_comm):
+ *   edmdc_kmeanspp_dev seeds over ALL rows -- first_index and the returned indices are global, k <= n_global, every rank passes the
+ *     same first_index and uniforms (drawn for n_global rows) and ends with the same centres; two small exchanges per centre (the
+ *     ranks' partial potentials, the rows of the next candidates);
+ *   edmdc_kmeans_lloyd_dev relocates an empty cluster to the farthest rows of the whole set: descending distance, equal distances by
+ *     ascending GLOBAL row (three small exchanges per relocated cluster) -- the library's own rule, also for one rank when no
+ *     far-select callback is installed, so sharded and unsharded runs relocate the same rows. */
+BROV_API int edmdc_set_kmeans_shard(brov_ctx* ctx, int rank, int world, int64_t row_offset, int64_t n_global);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------
  * Rollouts shard over trajectories with no communication; the sharded EDMDc fit has exactly one exchange: the sum over

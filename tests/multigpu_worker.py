@@ -102,13 +102,20 @@ def main():
     ctx.set_kmeans_far_select(False)                   # the library's own relocation rule: the one a sharded run applies
     if comm is not None:
         ctx.kmeans_use_comm(comm)
-        ctx.set_kmeans_shard(b0 * (T + 1))
+        ctx.set_kmeans_shard(rank, world, b0 * (T + 1), Bt * (T + 1))
     Ck, labels_k, inertia_k, iters_k = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx)
+    # ... and the k-means++ seeding over all ranks' rows: scikit-learn's random stream for Bt (T + 1) rows, two small exchanges per centre
+    if comm is not None:
+        Cs, idx_s = engine.kmeanspp_dev(X.view(-1, n), k, mean=mean_h, random_state=3, ctx=ctx, n_global=Bt * (T + 1))
+    else:
+        Cs, idx_s = bd.kmeanspp_sharded(X.view(-1, n), k, mean=mean_h, random_state=3, ctx=ctx)
     if comm is not None:
         ctx.kmeans_use_comm(None)
+        ctx.set_kmeans_shard()
     torch.cuda.synchronize()
     np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id,
-             Ck=Ck.cpu().numpy(), iters_k=iters_k, inertia_k=inertia_k, labels_k=labels_k.cpu().numpy(), reloc_k=ctx.kmeans_relocations())
+             Ck=Ck.cpu().numpy(), iters_k=iters_k, inertia_k=inertia_k, labels_k=labels_k.cpu().numpy(), reloc_k=ctx.kmeans_relocations(),
+             Cs=Cs.cpu().numpy(), idx_s=idx_s)
     if mode in ("torch", "gloo"):
         import torch.distributed as dist
         dist.barrier()

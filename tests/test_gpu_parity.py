@@ -644,6 +644,16 @@ def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
         assert np.array_equal(idx, idxp), (N, n, k, int(np.sum(idx != idxp)))
         assert np.array_equal(C.cpu().numpy(), Cp.cpu().numpy(), equal_nan=True)
     plain.close()
+    # the kernels of the sharded seeding (candidate rows from a table, potentials through per-rank totals) on one rank: variant + 32
+    sh = _lib.Context(0)
+    sh.set_kmeans_variant(32)
+    for N, n, k in ((30011, 12, 512), (8193, 13, 40), (70000, 5, 100), (60, 12, 20)):
+        X = np.concatenate([rng.normal(m, 0.4, (N // 5 + 1, n)) for m in rng.uniform(-2, 2, (5, n))])[:N]
+        mean = X.mean(0)
+        C_ref, idx_ref = kmeans_plusplus(X - mean, k, random_state=np.random.RandomState(2))
+        C, idx = eng.kmeanspp_dev(torch.from_numpy(X).cuda(), k, mean=mean, random_state=2, ctx=sh)
+        assert np.array_equal(idx, idx_ref) and np.array_equal(C.cpu().numpy(), C_ref), (N, n, k, int(np.sum(idx != idx_ref)))
+    sh.close()
     # the random numbers are consumed exactly as scikit-learn consumes them
     first, U, L = eng.kmeanspp_draws(1000, 16, 5)
     rs = np.random.RandomState(5)

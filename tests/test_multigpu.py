@@ -59,6 +59,8 @@ def _check(res, one, shared_gpu=False):
         # sharded Lloyd (integer member sums): the 1-rank centres BIT FOR BIT on every rank, the same iteration count
         assert np.array_equal(z["Ck"], one["Ck"]) and int(z["iters_k"]) == int(one["iters_k"])
         assert int(z["reloc_k"]) == int(one["reloc_k"]) > 0          # duplicate initial centres: the (sharded) relocation has run
+        # sharded k-means++ seeding: the same global sample indices and centres on every rank as the one-rank seeding
+        assert np.array_equal(z["idx_s"], one["idx_s"]) and np.array_equal(z["Cs"], one["Cs"])
     assert abs(sum(float(z["inertia_k"]) for z in res) - float(one["inertia_k"])) <= 1e-10 * float(one["inertia_k"])
     assert np.array_equal(np.concatenate([z["labels_k"] for z in sorted(res, key=lambda z: int(z["b0"]))]), one["labels_k"])
     assert sorted(int(z["b0"]) for z in res)[0] == 0 and (shared_gpu or len({int(z["device"]) for z in res}) == len(res))
@@ -68,7 +70,7 @@ def test_worker_single_rank_both_transports(tmp_path):
     """The worker at world size 1, both transports: runs on any GPU box; the N-rank tests compare against this."""
     a = _run("torch", 1, str(tmp_path))[0]
     b = _run("brov", 1, str(tmp_path))[0]
-    for key in ("GtG", "GtY", "A", "B", "Af", "Bf", "Ck", "labels_k"):
+    for key in ("GtG", "GtY", "A", "B", "Af", "Bf", "Ck", "labels_k", "idx_s", "Cs"):
         assert np.array_equal(a[key], b[key]), key
     assert np.isfinite(a["A"]).all() and np.isfinite(a["Af"]).all()
     assert np.max(np.abs(a["A"] - a["Af"])) < 1e-6            # the two product orders agree to the conditioning of the Gram
