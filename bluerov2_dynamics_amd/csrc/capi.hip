@@ -1433,7 +1433,7 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 #define KM_SORT_MOVED 0.03       // re-sort thresholds of the loop's private sample order, see below
 #endif
 #ifndef KM_SORT_RATE
-#define KM_SORT_RATE 0.05
+#define KM_SORT_RATE 0.2
 #endif
 // `_relocate_empty_clusters_dense`'s choice of rows, `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`, is NumPy's introselect:
 // which of several equal distances it returns, and in which order the n_empty largest come out, is a property of that
@@ -1723,7 +1723,9 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             // radius a little instead of opening a second candidate set: the order decays more slowly): moved / rate 0.01 / 0.01: 305 ms;
             // 0.02 / 0.2: 290; 0.03 / 0.01: 294; 0.05 / 0.05: 288; 0.08 / 0.01: 299; 0.15 / 0.01: 314; 0.005 / 0.2: 326; never: 484
             // (mask form alone: 313 / - / 313 / 326 / 331 / 355 / - / 557).  An order made while a fifth of the labels still move
-            // per iteration buys nothing (rate 0.2 or 1.0 at moved 0.01: 303-304 ms).
+            // per iteration buys nothing (rate 0.2 or 1.0 at moved 0.01: 303-304 ms).  Once a wave with a few moved labels sums its main
+            // label over the wave (kmeans.hip: KM2_SUM_MIN) an early order pays after all: 0.03 / 0.05: 274 ms; 0.03 / 0.2: 263.5; 0.03 / 1.0: 264;
+            // 0.05 / 0.2: 264; 0.08 / 1.0: 273 (one box).
             moved += hs[2];
             if (moved >= sort_moved * (double)N && hs[2] <= sort_rate * (double)N) want_sort = true;
         }

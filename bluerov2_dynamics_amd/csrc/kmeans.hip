@@ -97,28 +97,36 @@ __device__ __forceinline__ u64 half_row_sum_u64(u64 v) {
     v += dpp(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
     return v;
 }
-// The same reduction for all NC coordinates of a sample at once, carries through VCC, the DPP operand fused into the additions
-// (the compiler's form: two v_mov_b32_dpp + add + addc per step and coordinate, 144 instructions for 12 coordinates; here 72 + one
-// s_nop).  lo / hi: the halves of the NC fixed-point numbers; every lane ends with the sum over its group of 8 lanes.  A DPP read
-// needs two wait states after a VALU write of its source: the leading s_nop covers the values computed just before, inside the
-// block every register is re-read 2 NC - 1 instructions after it was written.
-#define KM_DPPADD(ctrl, L, H) "v_add_co_u32_dpp %" #L ", vcc, %" #L ", %" #L " " ctrl " row_mask:0xf bank_mask:0xf\n\tv_addc_co_u32_dpp %" #H ", vcc, %" #H ", %" #H ", vcc " ctrl " row_mask:0xf bank_mask:0xf\n\t"
-#define KM_DPPSTEP12(ctrl) KM_DPPADD(ctrl, 0, 1) KM_DPPADD(ctrl, 2, 3) KM_DPPADD(ctrl, 4, 5) KM_DPPADD(ctrl, 6, 7) KM_DPPADD(ctrl, 8, 9) KM_DPPADD(ctrl, 10, 11) \
-    KM_DPPADD(ctrl, 12, 13) KM_DPPADD(ctrl, 14, 15) KM_DPPADD(ctrl, 16, 17) KM_DPPADD(ctrl, 18, 19) KM_DPPADD(ctrl, 20, 21) KM_DPPADD(ctrl, 22, 23)
-#define KM_DPPSTEP13(ctrl) KM_DPPSTEP12(ctrl) KM_DPPADD(ctrl, 24, 25)
+// The sum over ALL 64 lanes for all NC coordinates of a sample at once, carries through VCC, the DPP operand fused into the
+// additions: six steps (quad_perm xor 1, xor 2, row_half_mirror, row_mirror: every lane holds its row's sum; row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's), 2 NC instructions each.  lo / hi: the halves of the NC
+// fixed-point numbers.  (First form of round 4: three steps, sums over groups of 8 lanes, eight lanes sending the atomics of a
+// coordinate to ONE LDS address -- SQ_LDS_ADDR_CONFLICT counted more LDS cycles in conflicts than in accesses, and the phase cost
+// 0.13 ms of a 0.87 ms E-step; rows of 16 and four lanes: 288 -> 277 ms per 300 iterations; the whole wave and one lane: 272 ms.
+// The compiler's own form of a step is two v_mov_b32_dpp + add + addc.)  A DPP read needs two wait states after a VALU write of
+// its source: the leading s_nop covers the values computed just before, inside the block every register is re-read 2 NC - 1
+// instructions after it was written.
+#define KM_DPPADDM(ctrl, rm, L, H) "v_add_co_u32_dpp %" #L ", vcc, %" #L ", %" #L " " ctrl " row_mask:" rm " bank_mask:0xf\n\tv_addc_co_u32_dpp %" #H ", vcc, %" #H ", %" #H ", vcc " ctrl " row_mask:" rm " bank_mask:0xf\n\t"
+#define KM_DPPSTEP12(ctrl, rm) KM_DPPADDM(ctrl, rm, 0, 1) KM_DPPADDM(ctrl, rm, 2, 3) KM_DPPADDM(ctrl, rm, 4, 5) KM_DPPADDM(ctrl, rm, 6, 7) KM_DPPADDM(ctrl, rm, 8, 9) \
+    KM_DPPADDM(ctrl, rm, 10, 11) KM_DPPADDM(ctrl, rm, 12, 13) KM_DPPADDM(ctrl, rm, 14, 15) KM_DPPADDM(ctrl, rm, 16, 17) KM_DPPADDM(ctrl, rm, 18, 19) \
+    KM_DPPADDM(ctrl, rm, 20, 21) KM_DPPADDM(ctrl, rm, 22, 23)
+#define KM_DPPSTEP13(ctrl, rm) KM_DPPSTEP12(ctrl, rm) KM_DPPADDM(ctrl, rm, 24, 25)
+#define KM_DPPALL(STEP) STEP("quad_perm:[1,0,3,2]", "0xf") STEP("quad_perm:[2,3,0,1]", "0xf") STEP("row_half_mirror", "0xf") STEP("row_mirror", "0xf") \
+    STEP("row_bcast:15", "0xa") STEP("row_bcast:31", "0xc")
 #define KM_Q2(a) "+v"(lo[a]), "+v"(hi[a])
-__device__ __forceinline__ void half_row_sum_u64x(unsigned (&lo)[12], unsigned (&hi)[12]) {
-    asm volatile("s_nop 1\n\t" KM_DPPSTEP12("quad_perm:[1,0,3,2]") KM_DPPSTEP12("quad_perm:[2,3,0,1]") KM_DPPSTEP12("row_half_mirror")
+__device__ __forceinline__ void wave_sum_u64x(unsigned (&lo)[12], unsigned (&hi)[12]) {
+    asm volatile("s_nop 1\n\t" KM_DPPALL(KM_DPPSTEP12)
                  : KM_Q2(0), KM_Q2(1), KM_Q2(2), KM_Q2(3), KM_Q2(4), KM_Q2(5), KM_Q2(6), KM_Q2(7), KM_Q2(8), KM_Q2(9), KM_Q2(10), KM_Q2(11) : : "vcc");
 }
-__device__ __forceinline__ void half_row_sum_u64x(unsigned (&lo)[13], unsigned (&hi)[13]) {
-    asm volatile("s_nop 1\n\t" KM_DPPSTEP13("quad_perm:[1,0,3,2]") KM_DPPSTEP13("quad_perm:[2,3,0,1]") KM_DPPSTEP13("row_half_mirror")
+__device__ __forceinline__ void wave_sum_u64x(unsigned (&lo)[13], unsigned (&hi)[13]) {
+    asm volatile("s_nop 1\n\t" KM_DPPALL(KM_DPPSTEP13)
                  : KM_Q2(0), KM_Q2(1), KM_Q2(2), KM_Q2(3), KM_Q2(4), KM_Q2(5), KM_Q2(6), KM_Q2(7), KM_Q2(8), KM_Q2(9), KM_Q2(10), KM_Q2(11), KM_Q2(12) : : "vcc");
 }
 #undef KM_Q2
+#undef KM_DPPALL
 #undef KM_DPPSTEP13
 #undef KM_DPPSTEP12
-#undef KM_DPPADD
+#undef KM_DPPADDM
 // A block's table [k][n+1] goes out as partial[epoch][block]: the bit pattern of 1.5 * 2^52 is taken off the coordinate sums
 // (count times, poisoned samples included: they added the pattern of a zero), so that a partial is a signed sum of integers.
 __device__ __forceinline__ void km_flush(u64* sums, u64* __restrict__ partial, int ep, int k, int n, bool rezero) {
@@ -438,7 +446,8 @@ constexpr int KM2_DEPTH = 4;         // records in flight round the evaluation l
 static_assert(KM2_DEPTH == 4, "the evaluation loop of kmeans_assign_lds_kernel is written for two pairs");
 constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
 constexpr int KM2_KMAX = 512;        // 8 mask words
-constexpr int KM2_NBR_MAX = 128;     // candidates the single-reference form of the filter takes from a sorted row (two loads per lane)
+constexpr int KM2_SUM_MIN = 32;       // lanes that must share a label for their member sums to go through a wave sum and one lane's atomics
+constexpr int KM2_NBR_MAX = 256;     // candidates the single-reference form of the filter takes from a sorted row (128 fetched a pass ahead, 128 more on demand)
 static_assert(KM2_KMAX * 128 <= 65536, "the candidate lists of kmeans_assign_lds_kernel hold record offsets (c << 7) in 16 bits");
 static_assert(KM2_KMAX <= KM_SORT_LABEL_MAX, "the sort keys of the loop's sample order (sortperm.hip) hold the label in KM_SORT_LABEL_BITS bits");
 constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
@@ -612,10 +621,19 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             const double u2 = (double)__uint_as_float(rb) + eps2;          // >= the true squared radius u^2 of the wave about c_a
             const double t2 = fma(4.004, u2, 1001.0 * margin * margin);    // >= (2 u + margin)^2
             const unsigned tb = __float_as_uint(fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f));     // non-negative floats order like their bits
-            const int cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
-            if (cnt >= KM2_NBR_MAX) return false;                          // a wide wave (a cluster boundary of the order, unsorted data): second form
+            int cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
             lst[lane] = (unsigned short)(((unsigned)key0 & 0xFFFFu) << 7);
             lst[64 + lane] = (unsigned short)(((unsigned)key1 & 0xFFFFu) << 7);
+            if (cnt == 128) {
+                // a wide wave (the outermost samples of a cluster, a cluster boundary of the order): the next 128 keys of the row, on demand
+                if (kp < 256 + 0) return false;
+                const unsigned long long* row = Nk + (int64_t)a * kp;
+                const unsigned long long key2 = row[128 + lane], key3 = row[192 + lane];
+                cnt += __builtin_popcountll(__ballot((unsigned)(key2 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key3 >> 16) < tb));
+                if (cnt >= KM2_NBR_MAX) return false;                      // wider still (unsorted data): second form
+                lst[128 + lane] = (unsigned short)(((unsigned)key2 & 0xFFFFu) << 7);
+                lst[192 + lane] = (unsigned short)(((unsigned)key3 & 0xFFFFu) << 7);
+            }
             const unsigned short last = lst[cnt - 1];                      // (cnt >= 1: c_a itself is at distance 0)
             if (lane < 2 * KM2_DEPTH + 2) lst[cnt + lane] = last;          // the tail repeats the last candidate
             ncand = cnt;
@@ -820,42 +838,41 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
             inertia += dmin2;
         }
-        // member sums, fixed point (see the kernel above)
+        // member sums, fixed point (see the kernel above).  Same-address atomics are what this phase costs (see wave_sum_u64x), so
+        // when at least half of the wave's lanes went to one centre -- a sorted wave: all of them but the few whose label has moved
+        // since the sort -- their coordinates are summed over the wave first, the other lanes adding zeros, and sent by ONE lane; the
+        // rest -- lanes of other labels, of a non-finite sample (zeros and the poison flag) -- send their own atomics.  (Scans: the
+        // same for up to 2 or 4 labels per pass that 8, 16 or 24 lanes share: 264-268 ms per 300 iterations against 261-264 for
+        // this form; without it, every lane of a wave with a single moved label sent its own: 270 ms.)
         const bool bad = !(x2 - x2 == 0.0);
-        if (__ballot(bad) != 0ull) {
+        const bool ok = live && !bad;
+        bool sent = false;
+        if constexpr (NS == 12 || NS == 13) {
+            const unsigned long long okm = __ballot(ok);
+            if (okm != 0ull) {
+                const int lab = __builtin_amdgcn_readlane(bi, __builtin_ctzll(okm));
+                const bool mine = ok && bi == lab;
+                const int cnt = __builtin_popcountll(__ballot(mine));
+                if (cnt >= KM2_SUM_MIN) {
+                    unsigned qlo[NX], qhi[NX];
 #pragma unroll
-            for (int j = 0; j < NX; ++j) x[j] = bad ? 0.0 : x[j];
-        }
-        const int bi0 = __builtin_amdgcn_readfirstlane(bi);
-        if (__ballot(!live || bi != bi0 || bad) == 0ull) {
-            u64* s = sums + bi0 * np1;
-            const bool leader = (lane & 7) == 0;
-            if constexpr (NS == 12 || NS == 13) {
-                unsigned qlo[NX], qhi[NX];
+                    for (int j = 0; j < NX; ++j) { const u64 q = mine ? km_fix(x[j], FS[j]) : 0ull; qlo[j] = (unsigned)q; qhi[j] = (unsigned)(q >> 32); }
+                    wave_sum_u64x(qlo, qhi);
+                    if (lane == 63) {                 // one lane, one atomic per coordinate: no two lanes on an address
+                        u64* s = sums + lab * np1;
 #pragma unroll
-                for (int j = 0; j < NX; ++j) { const u64 q = km_fix(x[j], FS[j]); qlo[j] = (unsigned)q; qhi[j] = (unsigned)(q >> 32); }       // (x is dead after this pass)
-                half_row_sum_u64x(qlo, qhi);
-                if (leader) {
-#pragma unroll
-                    for (int j = 0; j < NX; ++j) atomicAdd(&s[j], ((u64)qhi[j] << 32) | qlo[j]);
-                    atomicAdd(&s[n], 8ull);
-                }
-            } else {
-                // generic n: one coordinate at a time (fifteen 64-bit sums held at once do not fit beside the two row sets)
-#pragma unroll
-                for (int j = 0; j < NX; ++j) {
-                    if (j < n) {
-                        const u64 q = half_row_sum_u64(km_fix(x[j], FS[j]));
-                        if (leader) atomicAdd(&s[j], q);
+                        for (int j = 0; j < NX; ++j) atomicAdd(&s[j], ((u64)qhi[j] << 32) | qlo[j]);
+                        atomicAdd(&s[n], (u64)cnt);
                     }
+                    sent = mine;
                 }
-                if (leader) atomicAdd(&s[n], 8ull);
             }
-        } else if (live) {
+        }
+        if (live && !sent) {
             u64* s = sums + bi * np1;
 #pragma unroll
             for (int j = 0; j < NX; ++j)
-                if (NS > 0 || j < n) atomicAdd(&s[j], km_fix(x[j], FS[j]));
+                if (NS > 0 || j < n) atomicAdd(&s[j], km_fix(bad ? 0.0 : x[j], FS[j]));
             atomicAdd(&s[n], bad ? 1ull + KM_POISON : 1ull);
         }
 #if KM_PROFILE
