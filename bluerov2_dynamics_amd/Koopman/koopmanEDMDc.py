@@ -59,6 +59,7 @@ class KoopmanEDMDc:
     B_: np.ndarray = None
     lift_dim_: int = None
     kmeans: str = "hip"                 # "hip" (k-means++ seeding and Lloyd on the GPU) or "sklearn"
+    pinv: str = "host"                  # "host": numpy.linalg.pinv like the reference (:97); "device": symmetric eigendecomposition on the GPU (opt-in)
 
     # ------------------------------------------------------------------ fitting
     def fit(self, X, U, centers=None) -> None:
@@ -80,7 +81,7 @@ class KoopmanEDMDc:
         Ud = torch.from_numpy(np.ascontiguousarray(U[:N - 1])).to(dev)
         Cd = None if centers is None else torch.from_numpy(np.ascontiguousarray(np.asarray(centers, dtype=float))).to(dev)
         k = self.n_rbfs if centers is None else Cd.shape[0]
-        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=engine.default_context())
+        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=engine.default_context(), pinv=self.pinv)
         self.centers_ = C.cpu().numpy() if centers is None else np.asarray(centers, dtype=float)
         self.lift_dim_ = self.state_dim + self.centers_.shape[0]
 

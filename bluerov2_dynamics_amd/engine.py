@@ -410,8 +410,23 @@ def pinv_apply_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, P, M, c
                                            _dptr(X), _dptr(U), _hptr(P), _dptr(M)), "edmdc_pinv_apply_dev")
 
 
+def pinv_sym_device(G, ridge, rcond=1e-15):
+    """pinv(G + ridge I) of the symmetric p x p Gram ON THE DEVICE: symmetric eigendecomposition (torch.linalg.eigh = the ROCm
+    LAPACK library, a library primitive like a library GEMM) with numpy.linalg.pinv's cut-off -- eigenvalues (= singular values of
+    a symmetric matrix, up to sign) not above rcond * the largest are dropped.  G: CUDA tensor [p, p]; returns a CUDA tensor.
+    Opt-in (fit_dev(pinv="device")): 13 ms against 31-93 ms for the host's LAPACK pinv at p = 532 (tools/time_pinv_device.py;
+    the library's time is not monotone in p -- 87 ms at p = 520), P agrees with numpy's to 5e-12..2e-11 relative on the fixtures."""
+    import torch
+    A = G + ridge * torch.eye(G.shape[0], dtype=G.dtype, device=G.device)
+    A = 0.5 * (A + A.T)
+    w, Q = torch.linalg.eigh(A)
+    cut = rcond * w.abs().max()
+    winv = torch.where(w.abs() > cut, 1.0 / w, torch.zeros_like(w))
+    return (Q * winv) @ Q.T
+
+
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None, lift_cache=False):
+            timings=None, lift_cache=False, pinv="host"):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
@@ -420,7 +435,8 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     the stopping rule fired before max_iter.  lift_cache=True: keep the lifted rows of the Gram pass in HBM for the apply pass
     when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
     45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
-    so it pays for repeated fits in one process, not for a single one; off by default."""
+    so it pays for repeated fits in one process, not for a single one; off by default.  pinv="host": numpy.linalg.pinv like the
+    reference (:97/:147); "device": pinv_sym_device (opt-in)."""
     import time
     import torch
     ctx = ctx or default_context(X.device.index)
@@ -462,12 +478,18 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
         if cache_buf is not None:
             ctx.lift_cache(cache_buf.data_ptr(), need)
         gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
-        Gh = GtG.cpu().numpy()
         if getattr(ctx, "timing", False):
             tm["gram_kernel_ms"] = ctx.last_kernel_ms()
-        t2 = tick()
-        with _blas_threads():
-            P = np.linalg.pinv(Gh + ridge * np.eye(p))
+        if pinv == "device":
+            t2 = tick()
+            P = pinv_sym_device(GtG, ridge).cpu().numpy()
+        elif pinv == "host":
+            Gh = GtG.cpu().numpy()
+            t2 = tick()
+            with _blas_threads():
+                P = np.linalg.pinv(Gh + ridge * np.eye(p))
+        else:
+            raise ValueError("pinv must be 'host' or 'device'")
         t3 = time.perf_counter()
         if order == "fit":
             M = torch.empty((p, d), dtype=torch.float64, device=X.device)

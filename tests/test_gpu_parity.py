@@ -1342,6 +1342,16 @@ def test_fit_keeps_the_references_own_product_order(eng):
     print("fit() order, ill-conditioned case: |dRMSE| H=1/10/100 =", err, " (fit_multi's order would be",
           np.abs(g["small_multi_order_ms_rmse"] - g["small_ms_rmse"]), ")")
     assert np.max(err) < 1e-6, err
+    # (4) the opt-in device pinv (symmetric eigendecomposition with numpy.linalg.pinv's cut-off): the same three cases
+    for tag, Xa, Ua, Xb, Ub, kk, gg, rr, cc, ref in (
+            ("def", X[:ntr], U[:ntr], Xt, Ut, int(g["def_k"]), float(g["def_gamma"]), float(g["def_ridge"]), g["def_centers"], g["def_ms_rmse"]),
+            ("tank", X[:ntr], U[:ntr], Xt, Ut, int(g["tank_k"]), float(g["tank_gamma"]), float(g["tank_ridge"]), g["tank_centers"], g["tank_ms_rmse"]),
+            ("small", Xs[:ns], Us[:ns], Xs[ns:], Us[ns:], 200, 1.0, 1e-8, g["small_centers"], g["small_ms_rmse"])):
+        md = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=kk, gamma=gg, ridge=rr, pinv="device")
+        md.fit(Xa, Ua, centers=cc)
+        errd = np.abs(np.array([md.multistep_rmse(Xb, Ub, H) for H in (1, 10, 100)]) - ref)
+        print(f"device pinv, {tag}: |dRMSE| H=1/10/100 =", errd)
+        assert np.max(errd) < 1e-6, (tag, errd)
 
 
 def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):
