@@ -114,7 +114,15 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
                                 const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr,
                                 const unsigned long long* Nk = nullptr);
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr);
+// Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr);
+// E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
+int kmeans_pk_blocks(int64_t N);
+int kmeans_pk_epochs(int64_t N);
+bool kmeans_pk_supported(int n, int k);
+hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean, const double* c2,
+                                   int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
+                                   const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf);
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
                                 const int* block_changed, long long* red, double* stats);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,

@@ -460,6 +460,7 @@ int brov_create(int device_id, brov_ctx** out) {
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_APPLY_SIMPLE")) c->apply_variant = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_KMEANS_PLAIN")) c->kmeans_variant = (e[0] == '1');
+    if (const char* e = std::getenv("BROV2_KMEANS_VARIANT")) { const int v = std::atoi(e); if (v >= 0 && v <= 126 && (v & 3) != 3) c->kmeans_variant = v; }      // experiments
     if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
@@ -1094,8 +1095,8 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 62 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16 and / or + 32");
+    if (!c || variant < 0 || variant > 126 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16, + 32 and / or + 64");
     c->kmeans_variant = variant;
     return BROV_OK;
 }
@@ -1619,20 +1620,30 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // k-means variant keeps the mask form of round 3 alone (the independent second implementation of the filter)
     const bool nbr = filter && kmeans_reads_through_perm(n, k, scalar_records) && (c->kmeans_variant & 16) == 0;
     const size_t kp_ = (size_t)((k + 255) & ~255);
-    int rc = a.reserve(Arena::al(pwords * 8) + Arena::al(rwords * 8) + Arena::al(nb * 8) + Arena::al(nb * 4) + Arena::al((size_t)k * 16 * 8) +
+    // third form of the E-step (kmeans.hip): candidates screened in packed fp32, exact arithmetic for the winner; for the loop's sorted
+    // order.  + 64 in the k-means variant selects it.
+    const bool pk = nbr && sorting && (c->kmeans_variant & 64) != 0 && kmeans_pk_supported(n, k);
+    const int nb_pk = pk ? kmeans_pk_blocks(N) : 0;
+    const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N) : 0;
+    const size_t pwords_pk = (size_t)nparts_pk * k * (n + 1);
+    const size_t pw_max = pwords > pwords_pk ? pwords : pwords_pk;
+    const int nb_max = nb > nb_pk ? nb : nb_pk;
+    int rc = a.reserve(Arena::al(pw_max * 8) + Arena::al(rwords * 8) + Arena::al(nb_max * 8) + Arena::al(nb_max * 4) + Arena::al((size_t)k * 16 * 8) +
+                       (pk ? Arena::al(k * (kp_ / 2) * 32 * 4) : 0) + 256 +
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
     if (rc) return rc;
-    unsigned long long* partial = a.take<unsigned long long>(pwords);
+    unsigned long long* partial = a.take<unsigned long long>(pw_max);
     long long* red = a.take<long long>(rwords);
-    double* binert = a.take<double>(nb);
+    double* binert = a.take<double>(nb_max);
     float* Dc = a.take<float>(filter ? (size_t)k * ((k + 255) & ~255) : 1);
     unsigned long long* Nk = nbr ? a.take<unsigned long long>(k * kp_) : nullptr;      // sorted rows of the centre distances (keys)
-    int* bchg = a.take<int>(nb);
+    int* bchg = a.take<int>(nb_max);
+    float* Pf = pk ? a.take<float>(k * (kp_ / 2) * 32) : nullptr;         // float pair records of the sorted rows
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* Cb[2] = {a.take<double>((size_t)k * n), a.take<double>((size_t)k * n)};     // centres of this / the next iteration
-    double* stats = a.take<double>(8);                 // [0] squared shift, [1] inertia, [2] changed labels, [3] empty clusters; [4..7] = prm
+    double* stats = a.take<double>(16);                // [0] squared shift, [1] inertia, [2] changed labels, [3] empty clusters; [4..11] = prm
     double* fix = a.take<double>(32);                  // fixed-point scales of the member sums
     unsigned long long* rng = a.take<unsigned long long>(16);
     double* dmean = a.take<double>(16);
@@ -1683,8 +1694,18 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     c->kmeans_relocations = 0;
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
     HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, nullptr, prm, fix, d2, scalar_records, nullptr));
+    int e_nparts = nparts, e_nb = nb;                  // geometry of the E-step whose partials are waiting (the packed-fp32 kernel has its own)
+    auto e_step = [&](bool filtered) -> hipError_t {
+        if (filtered && pk) {
+            e_nparts = nparts_pk; e_nb = nb_pk;
+            return launch_kmeans_assign_pk(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, prm, fix, d2, Pc, Nk, Pf);
+        }
+        e_nparts = nparts; e_nb = nb;
+        return launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filtered && filter ? Dc : nullptr, prm, fix, d2,
+                                    scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr);
+    };
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_reduce(c->stream, nparts, nb, n, k, partial, binert, bchg, red, stats));
+        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats));
         if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
         HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
@@ -1697,8 +1718,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             want_sort = false;
             moved = 0.0;
         }
-        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk));
-        HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc, Nk));
+        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+        HIPCK(c, e_step(true));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];
         if (hs[3] > 0.0) {
@@ -1708,8 +1729,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
-            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk));
-            HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filter ? Dc : nullptr, prm, fix, d2, scalar_records, Pc, Nk));
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+            HIPCK(c, e_step(true));
         }
         cc ^= 1;
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
@@ -1735,8 +1756,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     HIPCK(c, hipMemcpyAsync(d_C, Cb[cc], (size_t)k * n * 8, hipMemcpyDeviceToDevice, c->stream));
     if (Pc) HIPCK(c, launch_kmeans_unpermute(c->stream, N, Pc, Lc, d_labels));      // labels back in the caller's order
     if (!strict) {   // labels / inertia consistent with the final centres: the E-step already queued
-        std::vector<double> hb(nb);
-        HIPCK(c, hipMemcpyAsync(hb.data(), binert, nb * 8, hipMemcpyDeviceToHost, c->stream));
+        std::vector<double> hb(e_nb);
+        HIPCK(c, hipMemcpyAsync(hb.data(), binert, e_nb * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipStreamSynchronize(c->stream));
         in = 0.0;
         for (double v : hb) in += v;

@@ -133,7 +133,7 @@ __device__ __forceinline__ void km_flush(u64* sums, u64* __restrict__ partial, i
     const int np1 = n + 1;
     __syncthreads();
     u64* out = partial + ((int64_t)ep * gridDim.x + blockIdx.x) * k * np1;
-    for (int c = threadIdx.x >> 4; c < k; c += KM_THREADS / 16) {
+    for (int c = threadIdx.x >> 4; c < k; c += (int)blockDim.x / 16) {
         const int j = threadIdx.x & 15;
         if (j <= n) {
             const u64 cnt = sums[c * np1 + n];
@@ -143,14 +143,14 @@ __device__ __forceinline__ void km_flush(u64* sums, u64* __restrict__ partial, i
     }
     if (rezero) {
         __syncthreads();
-        for (int i = threadIdx.x; i < k * np1; i += KM_THREADS) sums[i] = 0ull;
+        for (int i = threadIdx.x; i < k * np1; i += (int)blockDim.x) sums[i] = 0ull;
         __syncthreads();
     }
 }
 __device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep0, int nep, int k, int n) {
     for (int ep = ep0; ep < nep; ++ep) {
         u64* out = partial + ((int64_t)ep * gridDim.x + blockIdx.x) * k * (n + 1);
-        for (int i = threadIdx.x; i < k * (n + 1); i += KM_THREADS) out[i] = 0ull;
+        for (int i = threadIdx.x; i < k * (n + 1); i += (int)blockDim.x) out[i] = 0ull;
     }
 }
 
@@ -446,6 +446,7 @@ constexpr int KM2_DEPTH = 4;         // records in flight round the evaluation l
 static_assert(KM2_DEPTH == 4, "the evaluation loop of kmeans_assign_lds_kernel is written for two pairs");
 constexpr int KM2_LIST = 512 + 2 * KM2_DEPTH + 8;      // candidate list of a wave: 16-bit LDS offsets, padded
 constexpr int KM2_KMAX = 512;        // 8 mask words
+constexpr int KM_PK_NMAX = 13;        // coordinates a record of the packed-fp32 pair table holds (2 x 13 + 2 floats of 32)
 constexpr int KM2_SUM_MIN = 32;       // lanes that must share a label for their member sums to go through a wave sum and one lane's atomics
 constexpr int KM2_NBR_MAX = 256;     // candidates the single-reference form of the filter takes from a sorted row (128 fetched a pass ahead, 128 more on demand)
 static_assert(KM2_KMAX * 128 <= 65536, "the candidate lists of kmeans_assign_lds_kernel hold record offsets (c << 7) in 16 bits");
@@ -901,6 +902,303 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     km_zero_epochs(partial, ep + 1, nepochs, k, n);
 }
 
+// ---- E-step, third form (round 4): candidates screened in PACKED fp32, the exact arithmetic only for the winner ------------------
+// The evaluation is what an E-step costs (two thirds of a wave's pass in the LDS / DPP kernel: 17-19 fp64 issue slots per candidate
+// and 64 samples), and v_pk_fma_f32 does two candidates per slot.  With the single-reference filter the candidates of a wave are a
+// prefix of its reference centre's sorted row, so consecutive candidates can be PAIRED once per iteration: kmeans_cdist_kernel
+// writes every row as float pair records (Pf), a wave streams the prefix through scalar registers -- the (c0_j, c1_j) pair is the
+// scalar operand of the packed FMA, the sample's coordinate the vector one -- and keeps, per lane, the best and second-best float
+// score and the pair the best came from: 20 slots per PAIR.  Then, per lane:
+//   certified  (best - second > mf): the exact fp64 argmax lies in that pair -- every other candidate's float score is lower by more
+//              than twice the screening error.  The screening works in the frame of the reference centre (y = x - c_a against
+//              d = c - c_a: the exact score of c minus that of c_a), where every term is of the size of the wave's radius u: float
+//              inputs 2^-24 relative each, thirteen float FMAs, |error| <= 16 * 2^-24 * (|d|^2 / 2 + |y| |d|) <= 3.8e-6 u^2, mf =
+//              8e-6 u^2.  (In the data's own frame the same bound is 1.4e-6 max |x|^2 -- a hundred times the gap between a
+//              sample's two best centres, and 28 % of the waves held a lane that could not be certified.)  The centres outside
+//              the prefix are out by the triangle inequality as before.  Both members are evaluated in fp64 -- the full scan's own chain,
+//              seed -|c|^2/2, fma(x_j, c_j, .) by index -- and the larger wins (equal: the lower index): label and score are the
+//              full scan's bit for bit;
+//   otherwise  (a near-tie of two centres, 1e-4 of the samples; any lane of the wave): the wave walks the same prefix in fp64,
+//              first maximum by INDEX.
+// A wave without a usable reference (first E-step, non-finite sample or centre) takes the full scan over all k centres.
+// 512-thread blocks, three per CU (the member sums are the only LDS table; the exact records come from L1 / L2), six waves per
+// SIMD: the pair records arrive by SMEM, which can only be waited for as a whole -- other waves fill the gap.
+constexpr int PK_THREADS = 512;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4)))* cfp_;
+typedef const unsigned long long __attribute__((address_space(4)))* cu64p_;
+
+typedef int pk16i __attribute__((ext_vector_type(16)));
+typedef int pk8i __attribute__((ext_vector_type(8)));
+typedef int pk4i __attribute__((ext_vector_type(4)));
+struct PkRec { pk16i a; pk8i b; pk4i c; };           // one pair record in scalar registers: coordinates 0-7 | 8-11 | 12 and the two -|c|^2/2
+__device__ __forceinline__ void pk_issue(PkRec& r, cfp_ p) {
+    // (early-clobber outputs: the three requests read the address one after the other, none of their destinations may share its registers)
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c) : "s"(p));
+}
+__device__ __forceinline__ void pk_wait(PkRec& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c)); }
+__device__ __forceinline__ v2f pk_pr(int lo, int hi) { v2f v; v[0] = __int_as_float(lo); v[1] = __int_as_float(hi); return v; }
+// two candidates through the packed FMAs; fb / fs: the lane's best and second-best float score so far, bp: the pair the best is in
+template <int NS>
+__device__ __forceinline__ void pk_pair(const PkRec& r, const v2f (&xx)[NS], float& fb, float& fs, int& bp, int t) {
+    v2f acc = pk_pr(r.c[2], r.c[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_elementwise_fma(xx[j], pk_pr(r.a[2 * j], r.a[2 * j + 1]), acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_elementwise_fma(xx[8 + j], pk_pr(r.b[2 * j], r.b[2 * j + 1]), acc);
+    if constexpr (NS == 13) acc = __builtin_elementwise_fma(xx[12], pk_pr(r.c[0], r.c[1]), acc);
+    fs = __builtin_amdgcn_fmed3f(fb, acc[0], fs);
+    const float b1 = fmaxf(fb, acc[0]);
+    fs = __builtin_amdgcn_fmed3f(b1, acc[1], fs);
+    const float b2 = fmaxf(b1, acc[1]);
+    bp = b2 > fb ? t : bp;
+    fb = b2;
+}
+
+template <int NS>
+__global__ void __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                        const double* __restrict__ Ct, int* __restrict__ labels, u64* __restrict__ partial, int nepochs,
+                        double* __restrict__ block_inertia, int* __restrict__ block_changed, const double* __restrict__ prm,
+                        float* __restrict__ d2out, const int* __restrict__ perm, const double* __restrict__ fix,
+                        const unsigned long long* __restrict__ Nk, const float* __restrict__ Pf) {
+    static_assert(NS == 12 || NS == 13, "the pair records hold 12 or 13 coordinates");
+    extern __shared__ u64 sums[];                     // [k][n+1]: member sums (fixed point) and count
+    if (prm[3] != 0.0) return;                        // hold (block-uniform)
+    const int np1 = n + 1;
+    for (int i = threadIdx.x; i < k * np1; i += PK_THREADS) sums[i] = 0ull;
+    __shared__ double sh_inertia[PK_THREADS / 64];
+    __shared__ int sh_changed[PK_THREADS / 64];
+    __syncthreads();
+    const ccp T = (ccp)(unsigned long long)Ct;
+    const cdp_ FS = (cdp_)(unsigned long long)fix;
+    const cdp_ MM = (cdp_)(unsigned long long)mean;
+    const cu64p_ NKs = (cu64p_)(unsigned long long)Nk;
+    const cfp_ PFs = (cfp_)(unsigned long long)Pf;
+    const double margin = prm[0], eps2 = prm[1];
+    const bool centres_finite = prm[2] == 0.0;
+    const bool pk_ok = prm[5] != 0.0;
+    const int lane = threadIdx.x & 63;
+    const int kp = (k + 255) & ~255;
+    const int64_t stride = (int64_t)gridDim.x * PK_THREADS;
+    double inertia = 0.0;
+    int changed = 0, pass = 0, ep = 0;
+    auto position = [&](int64_t b) { const int64_t i = b + threadIdx.x; return i < N ? i : N - 1; };
+    // the old labels and the loop's permutation a pass ahead: they give the next pass's reference centre and the head of its sorted
+    // row (as in kmeans_assign_lds_kernel) and the addresses of its rows; the rows themselves are loaded where they are used -- six
+    // waves per SIMD cover that latency, and twelve doubles in flight per lane would not fit beside the float copy of the sample
+    int oln = -1, pnext = 0, a_nx = -1;
+    unsigned long long nk0 = 0ull, nk1 = 0ull;
+    auto labels_ahead = [&](int64_t b) {
+        const int64_t ii = position(b);
+        oln = labels[ii];
+        pnext = perm ? perm[ii] : 0;
+    };
+    auto reference_ahead = [&]() {
+        a_nx = -1;
+        int a = __builtin_amdgcn_readfirstlane(oln);
+        const unsigned long long same = __ballot(oln == a);
+        if (__builtin_popcountll(same) < 32) a = __builtin_amdgcn_readlane(oln, __builtin_ctzll(~same));
+        if ((unsigned)a >= (unsigned)k) return;
+        a_nx = a;
+        const unsigned long long* row = Nk + (int64_t)a * kp;
+        nk0 = row[lane];
+        nk1 = row[64 + lane];
+    };
+    int64_t base = (int64_t)blockIdx.x * PK_THREADS;
+    if (base < N) {
+        labels_ahead(base);
+        reference_ahead();
+    }
+    // the exact score of one centre for this lane's sample: the full scan's chain on a record gathered from the packed table
+    auto score64 = [&](const double (&x)[NS], int c) {
+        const double* r = Ct + (int64_t)c * 16;
+        double sc = fma(x[0], r[0], -r[NS]);
+#pragma unroll
+        for (int j = 1; j < NS; ++j) sc = fma(x[j], r[j], sc);
+        return sc;
+    };
+    for (; base < N; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < N;
+        const double* xrow = X + (perm ? (int64_t)pnext : position(base)) * xstride;
+        double x[NS], x2 = 0.0;
+#pragma unroll
+        for (int j = 0; j < NS; ++j) { x[j] = xrow[j] - (mean ? MM[j] : 0.0); x2 = fma(x[j], x[j], x2); }
+        const int ol = oln, a = a_nx;
+        const unsigned long long key0 = nk0, key1 = nk1;
+        if (base + stride < N) labels_ahead(base + stride);
+        double best = -1.0e300;
+        int bi = 0;
+        bool done = false;
+#if KM_PROFILE
+        bool certified_ = false;
+#endif
+        const bool fast = pk_ok && a >= 0 && centres_finite && __ballot(!(x2 - x2 == 0.0)) == 0ull;
+        int cnt = 0;
+        if (fast) {
+            // ---- the wave's radius about its reference centre -> the prefix of the sorted row (single-reference filter)
+            Cen ca;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) ca.v[j] = T[a].v[j];
+            double sa = fma(x[0], ca.v[0], -ca.v[NS]);
+#pragma unroll
+            for (int j = 1; j < NS; ++j) sa = fma(x[j], ca.v[j], sa);
+            const double d2 = fma(-2.0, sa, x2);
+            float rf = (float)fmax(d2, 0.0);
+            rf = rf * 1.0000005f + 1.0e-37f;
+            const unsigned rb = wave_max_u32(__float_as_uint(rf));
+            const double u2 = (double)__uint_as_float(rb) + eps2;
+            const double t2 = fma(4.004, u2, 1001.0 * margin * margin);
+            const unsigned tb = __float_as_uint(fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f));
+            cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
+            for (int off = 128; cnt == off && off < kp; off += 128) {      // a wide wave: the next 128 keys of the row, on demand
+                const unsigned long long* row = Nk + (int64_t)a * kp + off;
+                cnt += __builtin_popcountll(__ballot((unsigned)(row[lane] >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(row[64 + lane] >> 16) < tb));
+            }
+            // ---- packed fp32 screening: pairs of the prefix through scalar registers
+            // the sample in the frame of the reference centre; two float scores further apart than mf are ordered like the exact
+            // ones: a float score errs by <= 16 * 2^-24 * (|d|^2 / 2 + |y| |d|) <= 16 * 2^-24 * 4.01 u^2 (|y| <= u, |d| < 2 u + margin)
+            v2f xx[NS];
+#pragma unroll
+            for (int j = 0; j < NS; ++j) { const float f = (float)(x[j] - ca.v[j]); xx[j][0] = f; xx[j][1] = f; }
+            const float mf = (float)(8.0e-6 * u2) * 1.001f + 1.0e-37f;
+            float fb = -3.0e38f, fs = -3.0e38f;
+            int bp = 0;
+            const int npairs = (cnt + 1) >> 1;
+            const cfp_ rows = PFs + (int64_t)a * (kp >> 1) * 32;
+            // The record of the NEXT pair is requested before this one is worked on: scalar loads come back in any order and can only
+            // be waited for all together, so a record asked for where it is used stalls the wave for the whole round trip.  The
+            // compiler cannot be told that a load is in flight, so requests and waits are asm statements tied to the record's
+            // registers (the wait "rewrites" them: nothing may read them before it), with scheduling barriers between the four phases.
+            PkRec recA, recB;
+            pk_issue(recA, rows);
+            pk_wait(recA);
+            const int npairs2 = (npairs + 1) & ~1;             // (a pair past the prefix is a real candidate or the row's padding: harmless)
+#pragma unroll 1
+            for (int t = 0; t < npairs2; t += 2) {
+                pk_issue(recB, rows + (t + 1) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+                pk_pair<NS>(recA, xx, fb, fs, bp, t);
+                __builtin_amdgcn_sched_barrier(0);
+                pk_wait(recB);
+                pk_issue(recA, rows + (t + 2 < (kp >> 1) ? t + 2 : t) * 32);
+                __builtin_amdgcn_sched_barrier(0);
+                pk_pair<NS>(recB, xx, fb, fs, bp, t + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                pk_wait(recA);
+            }
+            if (__ballot(!(fb - fs > mf)) == 0ull) {
+                // ---- certified: the exact argmax is one of the two members of pair bp
+                const unsigned long long* kr = Nk + (int64_t)a * kp + 2 * bp;
+                const int i0 = (int)(kr[0] & 0xFFFFull), i1 = (int)(kr[1] & 0xFFFFull);
+                const double s0 = i0 < k ? score64(x, i0) : -1.0e300;          // (an index >= k is the row's padding)
+                const double s1 = i1 < k ? score64(x, i1) : -1.0e300;
+                const bool second = s1 > s0 || (s1 == s0 && i1 < i0);
+                best = second ? s1 : s0;
+                bi = second ? i1 : i0;
+                done = true;
+#if KM_PROFILE
+                certified_ = true;
+#endif
+            }
+        }
+        if (!done) {
+            if (fast) {
+                // ---- a near-tie somewhere in the wave: the same prefix in fp64, first maximum by index
+#pragma unroll 1
+                for (int t = 0; t < cnt; ++t) {
+                    const int c = (int)(NKs[(int64_t)a * kp + t] & 0xFFFFull);
+                    Cen r;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) r.v[j] = T[c].v[j];
+                    double sc = fma(x[0], r.v[0], -r.v[NS]);
+#pragma unroll
+                    for (int j = 1; j < NS; ++j) sc = fma(x[j], r.v[j], sc);
+                    const bool take = sc > best || (sc == best && c < bi);
+                    best = take ? sc : best;
+                    bi = take ? c : bi;
+                }
+            } else {
+                // ---- no reference (first E-step), a non-finite sample or centre: the full scan
+#pragma unroll 1
+                for (int c = 0; c < k; ++c) {
+                    Cen r;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) r.v[j] = T[c].v[j];
+                    double sc = fma(x[0], r.v[0], -r.v[NS]);
+#pragma unroll
+                    for (int j = 1; j < NS; ++j) sc = fma(x[j], r.v[j], sc);
+                    bi = (sc <= best) ? bi : c;
+                    asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sc));
+                }
+            }
+        }
+#if KM_PROFILE
+        if (lane == 0) {
+            atomicAdd(&km_prof[7], 1ull);
+            if (fast) { atomicAdd(&km_prof[8], 1ull); atomicAdd(&km_prof[9], (unsigned long long)cnt); if (!certified_) atomicAdd(&km_prof[10], 1ull); }
+            else atomicAdd(&km_prof[13], 1ull);
+        }
+#endif
+        if (base + stride < N) reference_ahead();
+        if (live) {
+            if (ol != bi) ++changed;
+            labels[i] = bi;
+            const double dmin2 = fma(-2.0, best, x2);
+            if (d2out) d2out[i] = (float)dmin2;
+            inertia += dmin2;
+        }
+        // member sums (see kmeans_assign_lds_kernel)
+        const bool bad = !(x2 - x2 == 0.0);
+        const bool ok = live && !bad;
+        bool sent = false;
+        {
+            const unsigned long long okm = __ballot(ok);
+            if (okm != 0ull) {
+                const int lab = __builtin_amdgcn_readlane(bi, __builtin_ctzll(okm));
+                const bool mine = ok && bi == lab;
+                const int cntm = __builtin_popcountll(__ballot(mine));
+                if (cntm >= KM2_SUM_MIN) {
+                    unsigned qlo[NS], qhi[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; ++j) { const u64 q = mine ? km_fix(x[j], FS[j]) : 0ull; qlo[j] = (unsigned)q; qhi[j] = (unsigned)(q >> 32); }
+                    wave_sum_u64x(qlo, qhi);
+                    if (lane == 63) {
+                        u64* sp = sums + lab * np1;
+#pragma unroll
+                        for (int j = 0; j < NS; ++j) atomicAdd(&sp[j], ((u64)qhi[j] << 32) | qlo[j]);
+                        atomicAdd(&sp[n], (u64)cntm);
+                    }
+                    sent = mine;
+                }
+            }
+        }
+        if (live && !sent) {
+            u64* sp = sums + bi * np1;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) atomicAdd(&sp[j], km_fix(bad ? 0.0 : x[j], FS[j]));
+            atomicAdd(&sp[n], bad ? 1ull + KM_POISON : 1ull);
+        }
+        if (++pass == KM_EPOCH_PASSES && base + stride < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        inertia += __shfl_down(inertia, off);
+        changed += __shfl_down(changed, off);
+    }
+    if (lane == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double in = 0.0;
+        int ch = 0;
+        for (int q = 0; q < PK_THREADS / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; }
+        block_inertia[blockIdx.x] = in;
+        block_changed[blockIdx.x] = ch;
+    }
+    km_flush(sums, partial, ep, k, n, false);
+    km_zero_epochs(partial, ep + 1, nepochs, k, n);
+}
+
 #if KM_PROFILE
 }  // namespace brov
 extern "C" __attribute__((visibility("default"))) int brov_debug_kmprof(unsigned long long* out8, int reset) {
@@ -1119,6 +1417,12 @@ __global__ void kmeans_scale_kernel(int n, const u64* __restrict__ rng, double* 
         prm[1] = 1.0e-13 * R2;                            // eps2: 30 x the rounding of a computed squared distance
         prm[2] = 0.0;
         prm[3] = 0.0;
+        // packed-fp32 screening (kmeans_assign_pk_kernel): a float score errs by <= 16 * 2^-24 * (|c|^2 / 2 + |x| |c|) <= 1.43e-6 M^2,
+        // M^2 = max |x|^2 = R^2 / 2; two scores further apart than marginf = 4e-6 M^2 are ordered like their exact values.  The
+        // screening is used only when M^2 is far from float's range limits.
+        const double M2 = 0.5 * R2;
+        prm[4] = 4.0e-6 * M2 * 1.000001;
+        prm[5] = (M2 > 1.0e-24 && M2 < 1.0e24) ? 1.0 : 0.0;
     }
 }
 
@@ -1169,7 +1473,7 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 // reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 512 (the LDS /
 // DPP kernel's range).  Bitonic sort in the LDS.
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
-                                                           unsigned long long* __restrict__ Nk) {
+                                                           unsigned long long* __restrict__ Nk, float* __restrict__ Pf) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
     __shared__ unsigned long long keys[512];
@@ -1198,6 +1502,27 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
             __syncthreads();
         }
     for (int i = threadIdx.x; i < kp; i += 256) Nk[(int64_t)a * kp + i] = keys[i];
+    if (!Pf) return;
+    // the row once more as FLOAT PAIRS for the packed-fp32 screening (kmeans_assign_pk_kernel), in the frame of the row's own centre:
+    // pair t = the row's candidates 2 t and 2 t + 1, one 128-byte record [d0_0 d1_0 d0_1 d1_1 ... | -h0 -h1 | pad], d = c - c_a (formed
+    // in fp64), h = |c - c_a|^2 / 2 -- what a wave streams through scalar registers as the second operand of v_pk_fma_f32.  With
+    // y = x - c_a the float score y.d - h is the exact score of c minus that of c_a, and its terms are of the size of the wave's
+    // radius, not of the data: the screening's error shrinks with them.  A pair past the end of the row (k odd) carries "minus infinity".
+    for (int e = threadIdx.x; e < (kp >> 1) * 32; e += 256) {
+        const int t = e >> 5, w = e & 31;
+        const int c = (int)(keys[2 * t + (w & 1)] & 0xFFFFull);
+        float v = 0.0f;
+        if (w < 2 * KM_PK_NMAX) { const int j = w >> 1; v = (c < k && j < n) ? (float)(Ct[c * 16 + j] - Ct[a * 16 + j]) : 0.0f; }
+        else if (w < 2 * KM_PK_NMAX + 2) {
+            v = -3.0e38f;
+            if (c < k) {
+                double h2 = 0.0;
+                for (int j = 0; j < n; ++j) { const double d = Ct[c * 16 + j] - Ct[a * 16 + j]; h2 = fma(d, d, h2); }
+                v = -(float)(0.5 * h2);
+            }
+        }
+        Pf[((int64_t)a * (kp >> 1) + t) * 32 + w] = v;
+    }
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -1899,8 +2224,36 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 #undef KM_LAUNCH
     return hipGetLastError();
 }
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk) {
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk);
+// the packed-fp32 form of the E-step (sorted order, single-reference filter): its own block geometry
+int kmeans_pk_blocks(int64_t N) {
+    const int64_t need = (N + PK_THREADS - 1) / PK_THREADS;
+    return need < 768 ? (int)(need > 0 ? need : 1) : 768;          // three 512-thread blocks per CU
+}
+int kmeans_pk_epochs(int64_t N) {
+    const int blocks = kmeans_pk_blocks(N);
+    const int64_t passes = (N + (int64_t)blocks * PK_THREADS - 1) / ((int64_t)blocks * PK_THREADS);
+    const int64_t ep = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
+    return (int)(ep > 0 ? ep : 1);
+}
+bool kmeans_pk_supported(int n, int k) { return (n == 12 || n == 13) && k >= 64 && k <= KM2_KMAX && (size_t)k * (n + 1) * 8 <= 53 * 1024; }
+hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean, const double* c2,
+                                   int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
+                                   const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf) {
+    if (!kmeans_pk_supported(n, k) || !Nk || !Pf || !prm || !fix || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
+    const int blocks = kmeans_pk_blocks(N), nep = kmeans_pk_epochs(N);
+    const size_t lds = (size_t)k * (n + 1) * sizeof(double);
+#define PK_LAUNCH(NS_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_pk_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        if (e_ != hipSuccess) return e_; \
+        hipLaunchKernelGGL((kmeans_assign_pk_kernel<NS_>), dim3(blocks), dim3(PK_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
+                           block_inertia, block_changed, prm, d2out, perm, fix, Nk, Pf); } while (0)
+    if (n == 12) PK_LAUNCH(12); else PK_LAUNCH(13);
+#undef PK_LAUNCH
+    return hipGetLastError();
+}
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf) {
+    if (Pf && (!Nk || n > KM_PK_NMAX)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf);
     return hipGetLastError();
 }
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {

@@ -291,6 +291,9 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * instead of screening rows out with a float copy of the coordinates first: same indices, same centres.
  * Adding 16 keeps the round-3 form of the candidate filter alone (label groups and masks over all centres) instead of trying the
  * single-reference form first (candidates = a prefix of the reference centre's sorted distance row): same labels, same centres.
+ * Adding 64 runs the E-steps of the sorted loop (variant 0, n = 12 or 13, 64 <= k <= 512) through the kernel that screens the
+ * candidates in packed fp32 (two per issue slot) and evaluates in fp64 only the pair the winner is certified to lie in: the same
+ * labels, the same centres.
  * Adding 32 sends the seeding of a single rank through the kernels of the sharded run (candidate rows from a table, potentials
  * through the per-rank totals): same indices. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);

@@ -23,7 +23,7 @@ X = Xe.view(-1, n)
 res = {}
 runs = (("filtered", 0), ("full scan", 1), ("filtered", 0))
 if len(sys.argv) > 3 and sys.argv[3] == "default":        # the shipped loop only (counter runs: every launch of the kernel is a filtered one but the first)
-    runs = (("filtered", 0),)
+    runs = (("filtered", int(os.environ.get("BROV2_KMEANS_VARIANT", "0"))),)
 if len(sys.argv) > 3 and sys.argv[3] == "all":            # + the caller's order, and the scalar-record kernel (variant + 4)
     runs += (("filtered, caller's order", 2), ("scalar records: filtered", 4), ("scalar records: full scan", 5), ("scalar records: caller's order", 6))
 for name, v in runs:
