@@ -70,7 +70,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(parts, files=("r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(parts, files=("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  parts: {kernel name in the summary: launches}; the figure is
     the sum over ALL of them (a fit = lift + tail + Gram per chunk).  PMC counters cannot be read from inside the timed
@@ -697,7 +697,7 @@ def main():
                                        "kernel_ms": apply_kernel_ms, "flop_per_sample": wrows_flop + wty_flop,
                                        "wrows_flop_per_sample": wrows_flop, "wty_flop_per_sample": wty_flop, "decomposition": dec,
                                        "note": "executed MFMA flop of the two passes of (P G^T) Y / time of the whole apply pass (any re-lift included)",
-                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r03_fit_pmc_summary.json",)) if pairs == 10_000_000 else None,
+                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r04_fit_pmc_summary.json", "r03_fit_pmc_summary.json")) if pairs == 10_000_000 else None,
                                        "algorithmic": {"flop_per_sample": 2.0 * p * p + 2.0 * p * d, "unit": "TFLOP/s",
                                                        "achieved": pairs * (2.0 * p * p + 2.0 * p * d) / (apply_kernel_ms * 1e-3) / 1e12}}
                     leg["ratio_to_full_gram_ms"] = (tmf["total_s"] - tmf["centres_s"]) * 1e3 / (ewall / a.edmdc_steps * 1e3)

@@ -5,7 +5,7 @@
 # trace only) and pmc_summary.json, fetch_probe.txt (known-bytes calibration of FETCH_SIZE / WRITE_SIZE).
 # Copy what should be judged into profiles/.
 set -e -o pipefail
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 root=$(pwd)
@@ -13,6 +13,9 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 echo "bench done"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu --no-variants > $root/$out/trace.log 2>&1 )
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
+# per-kernel launch times WITHOUT the first launch of each kernel in the profiled process (code-object load, cold caches): median /
+# min / mean -- the figures comparable with bench.py's own ms_per_step (the --stats average includes that first launch)
+python3 tools/kernel_times.py $(find $out/trace -name "*kernel_trace.csv" | head -1) > $out/kernel_times.json
 echo "trace done"
 short="--steps 1 --warmup 1 --edmdc-steps 1 --no-cpu --no-cfg4 --no-ar1 --no-variants --no-fit --kmeans-iters 10"
 tools/pmc_pass.sh $out/pmc/fetch "FETCH_SIZE" -- python3 $root/bench.py $short
