@@ -1005,7 +1005,10 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
         nk0 = row[lane];
         nk1 = row[64 + lane];
     };
-    int64_t base = (int64_t)blockIdx.x * PK_THREADS;
+    // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8): the blocks of ONE XCD -- and with them the waves that share a
+    // scalar cache -- take neighbouring positions of the sorted order, i.e. the same few clusters' pair records.
+    const int64_t vblock = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+    int64_t base = vblock * PK_THREADS;
     if (base < N) {
         labels_ahead(base);
         reference_ahead();
