@@ -112,7 +112,7 @@ hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* 
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
                                 const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr,
-                                const unsigned long long* Nk = nullptr);
+                                const unsigned long long* Nk = nullptr, const float* Pf = nullptr);
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr);

@@ -460,7 +460,7 @@ int brov_create(int device_id, brov_ctx** out) {
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_APPLY_SIMPLE")) c->apply_variant = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_KMEANS_PLAIN")) c->kmeans_variant = (e[0] == '1');
-    if (const char* e = std::getenv("BROV2_KMEANS_VARIANT")) { const int v = std::atoi(e); if (v >= 0 && v <= 126 && (v & 3) != 3) c->kmeans_variant = v; }      // experiments
+    if (const char* e = std::getenv("BROV2_KMEANS_VARIANT")) { const int v = std::atoi(e); if (v >= 0 && v <= 254 && (v & 3) != 3) c->kmeans_variant = v; }      // experiments
     if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
@@ -1095,7 +1095,7 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 126 || (variant & 3) == 3)
+    if (!c || variant < 0 || variant > 254 || (variant & 3) == 3)
         return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16, + 32 and / or + 64");
     c->kmeans_variant = variant;
     return BROV_OK;
@@ -1623,13 +1623,16 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // third form of the E-step (kmeans.hip): candidates screened in packed fp32, exact arithmetic for the winner; for the loop's sorted
     // order.  + 64 in the k-means variant selects it.
     const bool pk = nbr && sorting && (c->kmeans_variant & 64) != 0 && kmeans_pk_supported(n, k);
+    // ... and the same screening as an evaluation path INSIDE the LDS / DPP kernel (its prefetching, its LDS-resident exact records): the
+    // default for the sorted loop; + 128 switches it off (fp64 evaluation of every candidate, the form of round 3 and early round 4)
+    const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & 128) == 0 && kmeans_pk_supported(n, k);
     const int nb_pk = pk ? kmeans_pk_blocks(N) : 0;
     const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N) : 0;
     const size_t pwords_pk = (size_t)nparts_pk * k * (n + 1);
     const size_t pw_max = pwords > pwords_pk ? pwords : pwords_pk;
     const int nb_max = nb > nb_pk ? nb : nb_pk;
     int rc = a.reserve(Arena::al(pw_max * 8) + Arena::al(rwords * 8) + Arena::al(nb_max * 8) + Arena::al(nb_max * 4) + Arena::al((size_t)k * 16 * 8) +
-                       (pk ? Arena::al(k * (kp_ / 2) * 32 * 4) : 0) + 256 +
+                       ((pk || pk_lds) ? Arena::al(k * (kp_ / 2) * 32 * 4) : 0) + 256 +
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
@@ -1640,7 +1643,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     float* Dc = a.take<float>(filter ? (size_t)k * ((k + 255) & ~255) : 1);
     unsigned long long* Nk = nbr ? a.take<unsigned long long>(k * kp_) : nullptr;      // sorted rows of the centre distances (keys)
     int* bchg = a.take<int>(nb_max);
-    float* Pf = pk ? a.take<float>(k * (kp_ / 2) * 32) : nullptr;         // float pair records of the sorted rows
+    float* Pf = (pk || pk_lds) ? a.take<float>(k * (kp_ / 2) * 32) : nullptr;         // float pair records of the sorted rows
     double* c2 = a.take<double>((size_t)k * 16);       // packed centre table (kmeans.hip)
     double* Cb[2] = {a.take<double>((size_t)k * n), a.take<double>((size_t)k * n)};     // centres of this / the next iteration
     double* stats = a.take<double>(16);                // [0] squared shift, [1] inertia, [2] changed labels, [3] empty clusters; [4..11] = prm
@@ -1702,7 +1705,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         }
         e_nparts = nparts; e_nb = nb;
         return launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filtered && filter ? Dc : nullptr, prm, fix, d2,
-                                    scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr);
+                                    scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr, filtered && pk_lds ? Pf : nullptr);
     };
     for (it = 1; it <= max_iter; ++it) {
         HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats));

@@ -158,7 +158,7 @@ __device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep
 #define KM_PROFILE 0
 #endif
 #if KM_PROFILE
-__device__ unsigned long long km_prof[16];     // [0..4] phase ticks, [7] wave passes, [8] single-reference passes, [9] their candidates, [10] tie repeats, [11] mask-form passes, [12] their candidates, [13] full scans
+__device__ unsigned long long km_prof[16];     // [0..4] phase ticks, [7] wave passes, [8] single-reference passes, [9] their candidates, [10] tie repeats, [11] mask-form passes, [12] their candidates, [13] full scans, [14] passes settled by the packed-fp32 screening, [15] their candidates
 #define KM_STAMP(slot) do { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[slot] += now_ - t_prev; t_prev = now_; } while (0)
 #else
 #define KM_STAMP(slot) do { } while (0)
@@ -503,6 +503,56 @@ __device__ __forceinline__ void score2_bcast(double ra, double rb, const double 
 #undef KM2_F
 #undef KM2_SEED
 
+// y_j = x_j - c_j for the record held by the DPP rows of `rec` (lane l: double l & 15): v_fmac_f64_dpp with the factor -1 -- the
+// product is exact, so the one rounding is that of the subtraction
+#define KM_SUBB(j) "v_fmac_f64_dpp %" #j ", %12, %13 row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void sub_bcast(double rec, double (&y)[12]) {
+    const double m1 = -1.0;
+    asm("s_nop 1\n\t" KM_SUBB(0) KM_SUBB(1) KM_SUBB(2) KM_SUBB(3) KM_SUBB(4) KM_SUBB(5) KM_SUBB(6) KM_SUBB(7) KM_SUBB(8) KM_SUBB(9) KM_SUBB(10) KM_SUBB(11)
+        : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]), "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11])
+        : "v"(rec), "v"(m1));
+}
+#define KM_SUBC(j) "v_fmac_f64_dpp %" #j ", %13, %14 row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void sub_bcast(double rec, double (&y)[13]) {
+    const double m1 = -1.0;
+    asm("s_nop 1\n\t" KM_SUBC(0) KM_SUBC(1) KM_SUBC(2) KM_SUBC(3) KM_SUBC(4) KM_SUBC(5) KM_SUBC(6) KM_SUBC(7) KM_SUBC(8) KM_SUBC(9) KM_SUBC(10) KM_SUBC(11) KM_SUBC(12)
+        : "+v"(y[0]), "+v"(y[1]), "+v"(y[2]), "+v"(y[3]), "+v"(y[4]), "+v"(y[5]), "+v"(y[6]), "+v"(y[7]), "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12])
+        : "v"(rec), "v"(m1));
+}
+#undef KM_SUBB
+#undef KM_SUBC
+constexpr int PK_THREADS = 512;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef const float __attribute__((address_space(4)))* cfp_;
+typedef const unsigned long long __attribute__((address_space(4)))* cu64p_;
+
+typedef int pk16i __attribute__((ext_vector_type(16)));
+typedef int pk8i __attribute__((ext_vector_type(8)));
+typedef int pk4i __attribute__((ext_vector_type(4)));
+struct PkRec { pk16i a; pk8i b; pk4i c; };           // one pair record in scalar registers: coordinates 0-7 | 8-11 | 12 and the two -|c|^2/2
+__device__ __forceinline__ void pk_issue(PkRec& r, cfp_ p) {
+    // (early-clobber outputs: the three requests read the address one after the other, none of their destinations may share its registers)
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c) : "s"(p));
+}
+__device__ __forceinline__ void pk_wait(PkRec& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c)); }
+__device__ __forceinline__ v2f pk_pr(int lo, int hi) { v2f v; v[0] = __int_as_float(lo); v[1] = __int_as_float(hi); return v; }
+// two candidates through the packed FMAs; fb / fs: the lane's best and second-best float score so far, bp: the pair the best is in
+template <int NS>
+__device__ __forceinline__ void pk_pair(const PkRec& r, const v2f (&xx)[NS], float& fb, float& fs, int& bp, int t) {
+    v2f acc = pk_pr(r.c[2], r.c[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc = __builtin_elementwise_fma(xx[j], pk_pr(r.a[2 * j], r.a[2 * j + 1]), acc);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc = __builtin_elementwise_fma(xx[8 + j], pk_pr(r.b[2 * j], r.b[2 * j + 1]), acc);
+    if constexpr (NS == 13) acc = __builtin_elementwise_fma(xx[12], pk_pr(r.c[0], r.c[1]), acc);
+    fs = __builtin_amdgcn_fmed3f(fb, acc[0], fs);
+    const float b1 = fmaxf(fb, acc[0]);
+    fs = __builtin_amdgcn_fmed3f(b1, acc[1], fs);
+    const float b2 = fmaxf(b1, acc[1]);
+    bp = b2 > fb ? t : bp;
+    fb = b2;
+}
+
 template <int NS>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
@@ -510,7 +560,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                          double* __restrict__ block_inertia, int* __restrict__ block_changed,
                          const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
                          const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */,
-                         const double* __restrict__ fix, const unsigned long long* __restrict__ Nk) {
+                         const double* __restrict__ fix, const unsigned long long* __restrict__ Nk, const float* __restrict__ Pf) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
     double* tab = lds2;
@@ -530,6 +580,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     double margin = 0.0, eps2 = 0.0;
     bool centres_finite = true;
     if (Dc) { margin = prm[0]; eps2 = prm[1]; centres_finite = prm[2] == 0.0; }
+    const bool pk_ok = Pf != nullptr && prm[5] != 0.0;      // packed-fp32 screening (its pair table given, the data's scale far from float's limits)
     const int lane = threadIdx.x & 63;
     const unsigned laneoff = (unsigned)(lane & 15) * 8u;
     auto record = [&](unsigned addr) { return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + addr); };
@@ -611,6 +662,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         // one than in the full scan (first of equal maxima by INDEX): every evaluation that equals the running best raises a flag,
         // and a flagged wave repeats the pass through the mask form below (index order).  Exact duplicates of a centre are neighbours
         // in the row in index order, but they do tie: such waves always take the second form.
+        double u2_ref = 0.0;                          // the wave's squared radius about its reference centre (single-reference form)
         auto select_by_nbr = [&](int& ncand) -> bool {
             if (a_ref < 0 || __ballot(!((x2 - x2 == 0.0) && centres_finite)) != 0ull) return false;
             const int a = a_ref;
@@ -620,6 +672,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             rf = rf * 1.0000005f + 1.0e-37f;
             const unsigned rb = wave_max_u32(__float_as_uint(rf));
             const double u2 = (double)__uint_as_float(rb) + eps2;          // >= the true squared radius u^2 of the wave about c_a
+            u2_ref = u2;
             const double t2 = fma(4.004, u2, 1001.0 * margin * margin);    // >= (2 u + margin)^2
             const unsigned tb = __float_as_uint(fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f));     // non-negative floats order like their bits
             int cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
@@ -807,7 +860,63 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                 __builtin_amdgcn_sched_barrier(0);
             }
                 };
-        if (by_nbr) {
+        bool by_pk = false;
+        if constexpr (NS == 12 || NS == 13) {
+            if (by_nbr && pk_ok) {
+                // ---- packed-fp32 screening of the prefix (see kmeans_assign_pk_kernel for the argument): pair records through scalar
+                // registers in the frame of the reference centre; certified waves evaluate in fp64 only the pair the best lies in
+                const double rec_a = record(((unsigned)a_ref << 7) + laneoff);
+                double yd[NX];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) yd[j] = x[j];
+                sub_bcast(rec_a, yd);
+                v2f xx[NX];
+#pragma unroll
+                for (int j = 0; j < NX; ++j) { const float f = (float)yd[j]; xx[j][0] = f; xx[j][1] = f; }
+                const float mf = (float)(8.0e-6 * u2_ref) * 1.001f + 1.0e-37f;
+                float fb = -3.0e38f, fs = -3.0e38f;
+                int bp = 0;
+                const int npairs2 = (((ncand_nbr + 1) >> 1) + 1) & ~1;
+                const cfp_ rows = (cfp_)(unsigned long long)Pf + (int64_t)a_ref * (kp >> 1) * 32;
+                // Two records per round trip, worked on together (two independent FMA chains: no wait states between them).  With
+                // four waves on a SIMD and a record that comes from the L2 (each pass walks another cluster's row: the scalar cache
+                // is cold) a wave spends most of a trip waiting whatever the schedule; twice the work per trip is what counts --
+                // one record ahead of the arithmetic (the form of kmeans_assign_pk_kernel) was 1.6 x slower here.
+                PkRec recA, recB;
+#pragma unroll 1
+                for (int t = 0; t < npairs2; t += 2) {
+                    pk_issue(recA, rows + t * 32);
+                    pk_issue(recB, rows + (t + 1) * 32);
+                    pk_wait(recA);
+                    pk_wait(recB);
+                    pk_pair<NX>(recA, xx, fb, fs, bp, t);
+                    pk_pair<NX>(recB, xx, fb, fs, bp, t + 1);
+                }
+                if (__ballot(!(fb - fs > mf)) == 0ull) {
+                    // the two members of pair bp: entries 2 bp and 2 bp + 1 of the wave's list (a member past the prefix repeats the last
+                    // candidate there: it cannot be the argmax, see DESIGN f2), their records gathered from the LDS table
+                    const unsigned o0 = lst[2 * bp], o1 = lst[2 * bp + 1];
+                    auto gather = [&](unsigned off) {
+                        const double* r = reinterpret_cast<const double*>(reinterpret_cast<const char*>(tab) + off);
+                        double sc = fma(x[0], r[0], -r[NX]);
+#pragma unroll
+                        for (int j = 1; j < NX; ++j) sc = fma(x[j], r[j], sc);
+                        return sc;
+                    };
+                    const double s0 = gather(o0), s1 = gather(o1);
+                    const bool second = s1 > s0 || (s1 == s0 && o1 < o0);
+                    best = second ? s1 : s0;
+                    baddr = (second ? o1 : o0) + laneoff;
+                    by_pk = true;
+                }
+            }
+        }
+        if (by_pk) {
+            // (label and score are the full scan's: nothing more to evaluate)
+#if KM_PROFILE
+            t_acc[14] += 1ull; t_acc[15] += (unsigned long long)ncand_nbr;
+#endif
+        } else if (by_nbr) {
             run_list(ncand_nbr, std::true_type{});
 #if KM_PROFILE
             t_acc[8] += 1ull; t_acc[9] += (unsigned long long)ncand_nbr; t_acc[10] += tiem != 0ull ? 1ull : 0ull;
@@ -923,38 +1032,6 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 // A wave without a usable reference (first E-step, non-finite sample or centre) takes the full scan over all k centres.
 // 512-thread blocks, three per CU (the member sums are the only LDS table; the exact records come from L1 / L2), six waves per
 // SIMD: the pair records arrive by SMEM, which can only be waited for as a whole -- other waves fill the gap.
-constexpr int PK_THREADS = 512;
-typedef float v2f __attribute__((ext_vector_type(2)));
-typedef const float __attribute__((address_space(4)))* cfp_;
-typedef const unsigned long long __attribute__((address_space(4)))* cu64p_;
-
-typedef int pk16i __attribute__((ext_vector_type(16)));
-typedef int pk8i __attribute__((ext_vector_type(8)));
-typedef int pk4i __attribute__((ext_vector_type(4)));
-struct PkRec { pk16i a; pk8i b; pk4i c; };           // one pair record in scalar registers: coordinates 0-7 | 8-11 | 12 and the two -|c|^2/2
-__device__ __forceinline__ void pk_issue(PkRec& r, cfp_ p) {
-    // (early-clobber outputs: the three requests read the address one after the other, none of their destinations may share its registers)
-    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx8 %1, %3, 0x40\n\ts_load_dwordx4 %2, %3, 0x60" : "=&s"(r.a), "=&s"(r.b), "=&s"(r.c) : "s"(p));
-}
-__device__ __forceinline__ void pk_wait(PkRec& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r.a), "+s"(r.b), "+s"(r.c)); }
-__device__ __forceinline__ v2f pk_pr(int lo, int hi) { v2f v; v[0] = __int_as_float(lo); v[1] = __int_as_float(hi); return v; }
-// two candidates through the packed FMAs; fb / fs: the lane's best and second-best float score so far, bp: the pair the best is in
-template <int NS>
-__device__ __forceinline__ void pk_pair(const PkRec& r, const v2f (&xx)[NS], float& fb, float& fs, int& bp, int t) {
-    v2f acc = pk_pr(r.c[2], r.c[3]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc = __builtin_elementwise_fma(xx[j], pk_pr(r.a[2 * j], r.a[2 * j + 1]), acc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc = __builtin_elementwise_fma(xx[8 + j], pk_pr(r.b[2 * j], r.b[2 * j + 1]), acc);
-    if constexpr (NS == 13) acc = __builtin_elementwise_fma(xx[12], pk_pr(r.c[0], r.c[1]), acc);
-    fs = __builtin_amdgcn_fmed3f(fb, acc[0], fs);
-    const float b1 = fmaxf(fb, acc[0]);
-    fs = __builtin_amdgcn_fmed3f(b1, acc[1], fs);
-    const float b2 = fmaxf(b1, acc[1]);
-    bp = b2 > fb ? t : bp;
-    fb = b2;
-}
-
 template <int NS>
 __global__ void __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
 kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
@@ -980,7 +1057,14 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
     const bool pk_ok = prm[5] != 0.0;
     const int lane = threadIdx.x & 63;
     const int kp = (k + 255) & ~255;
+#ifdef KM_PK_CONTIG
+    // experiment: a block walks a CONTIGUOUS range of positions (consecutive passes stay in one cluster: its pair records stay in
+    // the scalar cache) instead of striding through the whole order
+    const int64_t stride = PK_THREADS;
+    const int64_t per_block = ((N + PK_THREADS - 1) / PK_THREADS + gridDim.x - 1) / gridDim.x * PK_THREADS;
+#else
     const int64_t stride = (int64_t)gridDim.x * PK_THREADS;
+#endif
     double inertia = 0.0;
     int changed = 0, pass = 0, ep = 0;
     auto position = [&](int64_t b) { const int64_t i = b + threadIdx.x; return i < N ? i : N - 1; };
@@ -989,6 +1073,7 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
     // waves per SIMD cover that latency, and twelve doubles in flight per lane would not fit beside the float copy of the sample
     int oln = -1, pnext = 0, a_nx = -1;
     unsigned long long nk0 = 0ull, nk1 = 0ull;
+    double carn = 0.0;
     auto labels_ahead = [&](int64_t b) {
         const int64_t ii = position(b);
         oln = labels[ii];
@@ -1004,12 +1089,19 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
         const unsigned long long* row = Nk + (int64_t)a * kp;
         nk0 = row[lane];
         nk1 = row[64 + lane];
+        carn = Ct[(int64_t)a * 16 + (lane & 15)];      // the reference centre's record, one double per lane: every DPP row holds it whole
     };
     // Blocks are dealt round-robin over the 8 XCDs (blockIdx % 8): the blocks of ONE XCD -- and with them the waves that share a
     // scalar cache -- take neighbouring positions of the sorted order, i.e. the same few clusters' pair records.
     const int64_t vblock = (gridDim.x & 7) == 0 ? (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : (int64_t)blockIdx.x;
+#ifdef KM_PK_CONTIG
+    int64_t base = vblock * per_block;
+    const int64_t Nend = base + per_block < N ? base + per_block : N;
+#else
     int64_t base = vblock * PK_THREADS;
-    if (base < N) {
+    const int64_t Nend = N;
+#endif
+    if (base < Nend) {
         labels_ahead(base);
         reference_ahead();
     }
@@ -1021,7 +1113,11 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
         for (int j = 1; j < NS; ++j) sc = fma(x[j], r[j], sc);
         return sc;
     };
-    for (; base < N; base += stride) {
+#if KM_PROFILE
+    unsigned long long t_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
+    unsigned long long tp_ = __builtin_readcyclecounter();
+#endif
+    for (; base < Nend; base += stride) {
         const int64_t i = base + threadIdx.x;
         const bool live = i < N;
         const double* xrow = X + (perm ? (int64_t)pnext : position(base)) * xstride;
@@ -1030,7 +1126,12 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
         for (int j = 0; j < NS; ++j) { x[j] = xrow[j] - (mean ? MM[j] : 0.0); x2 = fma(x[j], x[j], x2); }
         const int ol = oln, a = a_nx;
         const unsigned long long key0 = nk0, key1 = nk1;
-        if (base + stride < N) labels_ahead(base + stride);
+        const double car = carn;
+#if KM_PROFILE
+        asm volatile("; x ready" :: "v"(x2));
+        { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[0] += now_ - tp_; tp_ = now_; }
+#endif
+        if (base + stride < Nend) labels_ahead(base + stride);
         double best = -1.0e300;
         int bi = 0;
         bool done = false;
@@ -1041,12 +1142,25 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
         int cnt = 0;
         if (fast) {
             // ---- the wave's radius about its reference centre -> the prefix of the sorted row (single-reference filter)
-            Cen ca;
+            // (the record came with the labels, a pass ahead, one double per lane; the centre's coordinates reach the arithmetic
+            // through DPP row broadcasts as in kmeans_assign_lds_kernel -- a scalar load here was a round trip on the critical path)
+            double sa;
+            double yd[NS];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) ca.v[j] = T[a].v[j];
-            double sa = fma(x[0], ca.v[0], -ca.v[NS]);
+            for (int j = 0; j < NS; ++j) yd[j] = x[j];
+            if constexpr (NS == 12) {
+                sa = score_bcast(car, x);
+                sub_bcast(car, yd);
+            } else {
+                Cen ca;
 #pragma unroll
-            for (int j = 1; j < NS; ++j) sa = fma(x[j], ca.v[j], sa);
+                for (int j = 0; j < 16; ++j) ca.v[j] = T[a].v[j];
+                sa = fma(x[0], ca.v[0], -ca.v[NS]);
+#pragma unroll
+                for (int j = 1; j < NS; ++j) sa = fma(x[j], ca.v[j], sa);
+#pragma unroll
+                for (int j = 0; j < NS; ++j) yd[j] = x[j] - ca.v[j];
+            }
             const double d2 = fma(-2.0, sa, x2);
             float rf = (float)fmax(d2, 0.0);
             rf = rf * 1.0000005f + 1.0e-37f;
@@ -1064,7 +1178,7 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
             // ones: a float score errs by <= 16 * 2^-24 * (|d|^2 / 2 + |y| |d|) <= 16 * 2^-24 * 4.01 u^2 (|y| <= u, |d| < 2 u + margin)
             v2f xx[NS];
 #pragma unroll
-            for (int j = 0; j < NS; ++j) { const float f = (float)(x[j] - ca.v[j]); xx[j][0] = f; xx[j][1] = f; }
+            for (int j = 0; j < NS; ++j) { const float f = (float)yd[j]; xx[j][0] = f; xx[j][1] = f; }
             const float mf = (float)(8.0e-6 * u2) * 1.001f + 1.0e-37f;
             float fb = -3.0e38f, fs = -3.0e38f;
             int bp = 0;
@@ -1074,6 +1188,10 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
             // be waited for all together, so a record asked for where it is used stalls the wave for the whole round trip.  The
             // compiler cannot be told that a load is in flight, so requests and waits are asm statements tied to the record's
             // registers (the wait "rewrites" them: nothing may read them before it), with scheduling barriers between the four phases.
+#if KM_PROFILE
+            asm volatile("; loop starts" :: "v"(xx[0]), "s"(npairs));
+            { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[1] += now_ - tp_; tp_ = now_; }
+#endif
             PkRec recA, recB;
             pk_issue(recA, rows);
             pk_wait(recA);
@@ -1091,10 +1209,30 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
                 __builtin_amdgcn_sched_barrier(0);
                 pk_wait(recA);
             }
+#if KM_PROFILE
+            asm volatile("; loop done" :: "v"(fb), "v"(fs));
+            { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[2] += now_ - tp_; tp_ = now_; }
+#endif
             if (__ballot(!(fb - fs > mf)) == 0ull) {
                 // ---- certified: the exact argmax is one of the two members of pair bp
-                const unsigned long long* kr = Nk + (int64_t)a * kp + 2 * bp;
-                const int i0 = (int)(kr[0] & 0xFFFFull), i1 = (int)(kr[1] & 0xFFFFull);
+                // the two centres of pair bp: keys 2 bp and 2 bp + 1 of the row -- lane l holds keys l and 64 + l of its head (no trip
+                // to memory for them: a cross-lane read); beyond the head (a wide wave) they are fetched
+                int i0, i1;
+                {
+                    const int q0 = 2 * bp, q1 = 2 * bp + 1;
+                    const int lo0 = (int)((unsigned)key0 & 0xFFFFu), lo1 = (int)((unsigned)key1 & 0xFFFFu);
+                    const int a0 = __builtin_amdgcn_ds_bpermute((q0 & 63) << 2, lo0), b0 = __builtin_amdgcn_ds_bpermute((q0 & 63) << 2, lo1);
+                    const int a1 = __builtin_amdgcn_ds_bpermute((q1 & 63) << 2, lo0), b1 = __builtin_amdgcn_ds_bpermute((q1 & 63) << 2, lo1);
+                    i0 = q0 < 64 ? a0 : b0;
+                    i1 = q1 < 64 ? a1 : b1;
+                    if (__ballot(q1 >= 128) != 0ull) {
+                        if (q1 >= 128) {
+                            const unsigned long long* kr = Nk + (int64_t)a * kp + q0;
+                            i0 = (int)(kr[0] & 0xFFFFull);
+                            i1 = (int)(kr[1] & 0xFFFFull);
+                        }
+                    }
+                }
                 const double s0 = i0 < k ? score64(x, i0) : -1.0e300;          // (an index >= k is the row's padding)
                 const double s1 = i1 < k ? score64(x, i1) : -1.0e300;
                 const bool second = s1 > s0 || (s1 == s0 && i1 < i0);
@@ -1138,13 +1276,13 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
             }
         }
 #if KM_PROFILE
-        if (lane == 0) {
-            atomicAdd(&km_prof[7], 1ull);
-            if (fast) { atomicAdd(&km_prof[8], 1ull); atomicAdd(&km_prof[9], (unsigned long long)cnt); if (!certified_) atomicAdd(&km_prof[10], 1ull); }
-            else atomicAdd(&km_prof[13], 1ull);
-        }
+        asm volatile("; exact done" :: "v"(best), "v"(bi));
+        { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[3] += now_ - tp_; tp_ = now_; }
+        t_acc[7] += 1ull;
+        if (fast) { t_acc[8] += 1ull; t_acc[9] += (unsigned long long)cnt; if (!certified_) t_acc[10] += 1ull; }
+        else t_acc[13] += 1ull;
 #endif
-        if (base + stride < N) reference_ahead();
+        if (base + stride < Nend) reference_ahead();
         if (live) {
             if (ol != bi) ++changed;
             labels[i] = bi;
@@ -1183,8 +1321,14 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
             for (int j = 0; j < NS; ++j) atomicAdd(&sp[j], km_fix(bad ? 0.0 : x[j], FS[j]));
             atomicAdd(&sp[n], bad ? 1ull + KM_POISON : 1ull);
         }
-        if (++pass == KM_EPOCH_PASSES && base + stride < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
+#if KM_PROFILE
+        { const unsigned long long now_ = __builtin_readcyclecounter(); t_acc[4] += now_ - tp_; tp_ = now_; }
+#endif
+        if (++pass == KM_EPOCH_PASSES && base + stride < Nend) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
     }
+#if KM_PROFILE
+    if (lane == 0) for (int q = 0; q < 16; ++q) atomicAdd(&km_prof[q], t_acc[q]);
+#endif
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
         changed += __shfl_down(changed, off);
@@ -1524,21 +1668,30 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
     // in fp64), h = |c - c_a|^2 / 2 -- what a wave streams through scalar registers as the second operand of v_pk_fma_f32.  With
     // y = x - c_a the float score y.d - h is the exact score of c minus that of c_a, and its terms are of the size of the wave's
     // radius, not of the data: the screening's error shrinks with them.  A pair past the end of the row (k odd) carries "minus infinity".
-    for (int e = threadIdx.x; e < (kp >> 1) * 32; e += 256) {
-        const int t = e >> 5, w = e & 31;
-        const int c = (int)(keys[2 * t + (w & 1)] & 0xFFFFull);
-        float v = 0.0f;
-        if (w < 2 * KM_PK_NMAX) { const int j = w >> 1; v = (c < k && j < n) ? (float)(Ct[c * 16 + j] - Ct[a * 16 + j]) : 0.0f; }
-        else if (w < 2 * KM_PK_NMAX + 2) {
-            v = -3.0e38f;
-            if (c < k) {
-                double h2 = 0.0;
-                for (int j = 0; j < n; ++j) { const double d = Ct[c * 16 + j] - Ct[a * 16 + j]; h2 = fma(d, d, h2); }
-                v = -(float)(0.5 * h2);
+    // (one thread per candidate of the row forms its half of a record in the LDS -- twelve differences and their norm --, then the
+    // block writes the records out as 16-byte pieces: entry by entry, with two of 32 threads walking the norm, this took 40 us)
+    __shared__ float recs[256 * 32];
+    for (int e = threadIdx.x; e < (kp >> 1) * 32; e += 256) recs[e] = 0.0f;
+    __syncthreads();
+    for (int tm = threadIdx.x; tm < kp; tm += 256) {
+        const int t = tm >> 1, m = tm & 1;
+        const int c = (int)(keys[tm] & 0xFFFFull);
+        float hneg = -3.0e38f;
+        if (c < k) {
+            double h2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double d = Ct[c * 16 + j] - Ct[a * 16 + j];
+                h2 = fma(d, d, h2);
+                recs[t * 32 + 2 * j + m] = (float)d;
             }
+            hneg = -(float)(0.5 * h2);
         }
-        Pf[((int64_t)a * (kp >> 1) + t) * 32 + w] = v;
+        recs[t * 32 + 2 * KM_PK_NMAX + m] = hneg;
     }
+    __syncthreads();
+    float4* out = reinterpret_cast<float4*>(Pf + (int64_t)a * (kp >> 1) * 32);
+    const float4* src = reinterpret_cast<const float4*>(recs);
+    for (int e = threadIdx.x; e < (kp >> 1) * 8; e += 256) out[e] = src[e];
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -2221,7 +2374,7 @@ bool kmeans_reads_through_perm(int n, int k, bool scalar_records) { return kmean
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
                                 const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm,
-                                const unsigned long long* Nk) {
+                                const unsigned long long* Nk, const float* Pf) {
     if (perm && !kmeans_lds_form(n, k, scalar_records)) return hipErrorInvalidValue;      // only the LDS / DPP kernel reads through a permutation
     if (Nk && (!Dc || !kmeans_lds_form(n, k, scalar_records))) return hipErrorInvalidValue;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127) || !prm || !fix) return hipErrorInvalidValue;
@@ -2233,7 +2386,7 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
-                           block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk); } while (0)
+                           block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk, Nk ? Pf : nullptr); } while (0)
         if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
 #undef KM2_LAUNCH
         return hipGetLastError();

@@ -241,7 +241,7 @@ def lloyds():
     scan in the scalar-record kernel: identical labels and iteration counts."""
     n, ties, t0 = 0, 0, time.time()
     ctxs = []
-    for v in (0, 5, 16):
+    for v in (0, 5, 16 + 128):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)

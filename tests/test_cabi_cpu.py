@@ -286,7 +286,7 @@ def test_lloyd_lds_kernel_listing(tmp_path):
     lines = asm.read_text().split("\n")
     # (round 4: the single-reference filter added state; at n = 12 eleven loop-invariant dwords are parked in scratch at kernel
     # entry and re-read only inside the mask-form fallback -- never in an evaluation loop, which the walk below asserts)
-    for ns, max_scratch in ((12, 64), (13, 128), (0, 160)):
+    for ns, max_scratch in ((12, 96), (13, 128), (0, 160)):
         k = next(i for i, l in enumerate(lines) if l.startswith(f"_ZN4brov24kmeans_assign_lds_kernelILi{ns}E"))
         e = next(i for i in range(k, len(lines)) if lines[i].startswith(".Lfunc_end"))
         info = {m.group(1): int(m.group(2)) for m in (re.match(r"; (\w+): (\d+)", l) for l in lines[e:e + 40]) if m}

@@ -671,7 +671,7 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(21)
     ctxs = []
-    for v in (0, 1, 2, 4, 5, 6, 16, 18, 64):                                 # filter + sorted order, full scan, filter in the caller's order; + 4 scalar records; + 16 mask form only
+    for v in (0, 1, 2, 4, 5, 6, 16, 18, 64, 128):                                 # filter + sorted order, full scan, filter in the caller's order; + 4 scalar records; + 16 mask form only
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)

@@ -29,7 +29,7 @@ prof.restype = ctypes.c_int
 prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 names = ["rows load", "label groups", "candidate masks", "evaluation", "labels + member sums"]
-for variant, label in ((0, "sorted, single reference"), (64, "packed fp32 screening")) + (((2, "caller's order"),) if len(sys.argv) > 3 else ()):
+for variant, label in ((0, "sorted, single reference"), (128, "sorted, packed fp32 screening in the LDS kernel")) + (((2, "caller's order"),) if len(sys.argv) > 3 else ()):
     ctx.set_kmeans_variant(variant)
     tm = {}
     ctx.set_timing(True)
@@ -41,8 +41,11 @@ for variant, label in ((0, "sorted, single reference"), (64, "packed fp32 screen
     tot = v[:5].sum()
     print(f"{label}: {n_iter} iterations, Lloyd {tm['lloyd_ms']:.1f} ms; {int(v[7])} wave passes, {tot / v[7]:.0f} ticks per pass", flush=True)
     if variant == 64:
+        print("    ticks per pass: rows+x %.0f | reference, radius, prefix %.0f | packed loop %.0f | exact pair %.0f | stores + member sums %.0f" % tuple(v[q] / max(v[7], 1) for q in range(5)))
         print(f"    pk kernel: {int(v[7])} passes, {int(v[8])} screened ({v[9] / max(v[8], 1):.1f} candidates), {int(v[10])} not certified, {int(v[13])} full scans")
         continue
+    if v[14]:
+        print(f"    settled by the packed-fp32 screening: {int(v[14])} passes ({v[15] / v[14]:.1f} candidates)")
     print(f"    single-reference passes {int(v[8])} ({v[9] / max(v[8], 1):.1f} candidates, {int(v[10])} repeated for a tie), mask-form passes {int(v[11])} "
           f"({v[12] / max(v[11], 1):.1f} candidates), full scans {int(v[13])}")
     for nm, t in zip(names, v[:5]):
