@@ -117,8 +117,8 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr);
 // E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
-int kmeans_pk_blocks(int64_t N);
-int kmeans_pk_epochs(int64_t N);
+int kmeans_pk_blocks(int64_t N, int n, int k);
+int kmeans_pk_epochs(int64_t N, int n, int k);
 bool kmeans_pk_supported(int n, int k);
 hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean, const double* c2,
                                    int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,

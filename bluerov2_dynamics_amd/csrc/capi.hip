@@ -1614,20 +1614,23 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // sample order (sortperm.hip): the filter decides per wave of 64 consecutive samples, so the loop keeps a permutation that orders the
     // samples by (label, distance to the centre), re-sorted when enough labels have moved; the LDS / DPP kernel reads its rows
     // through it.  Worth it only at size.
-    const bool sorting = filter && variant == 0 && kmeans_reads_through_perm(n, k, scalar_records) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
+    // k = 513 ... 1024 (n = 12 / 13): beyond the LDS / DPP kernel's table; the packed-fp32 kernel (kmeans_assign_pk_kernel) reads the same order
+    // and the same sorted rows with only the member sums in the LDS.  + 128 (screening off) or + 4 keeps the scalar-record kernel there.
+    const bool big = !scalar_records && !kmeans_reads_through_perm(n, k, false) && kmeans_pk_supported(n, k) && (c->kmeans_variant & (16 | 128)) == 0;
+    const bool sorting = filter && variant == 0 && (kmeans_reads_through_perm(n, k, scalar_records) || big) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
     const size_t sort_tmp = sorting ? kmeans_sort_temp_bytes(N) : 0;
     // single-reference form of the filter (kmeans.hip, round 4): sorted rows of the centre distances for the LDS / DPP kernel; + 16 in the
     // k-means variant keeps the mask form of round 3 alone (the independent second implementation of the filter)
-    const bool nbr = filter && kmeans_reads_through_perm(n, k, scalar_records) && (c->kmeans_variant & 16) == 0;
+    const bool nbr = filter && (kmeans_reads_through_perm(n, k, scalar_records) || (big && sorting)) && (c->kmeans_variant & 16) == 0;
     const size_t kp_ = (size_t)((k + 255) & ~255);
     // third form of the E-step (kmeans.hip): candidates screened in packed fp32, exact arithmetic for the winner; for the loop's sorted
     // order.  + 64 in the k-means variant selects it.
-    const bool pk = nbr && sorting && (c->kmeans_variant & 64) != 0 && kmeans_pk_supported(n, k);
+    const bool pk = nbr && sorting && ((c->kmeans_variant & 64) != 0 || big) && kmeans_pk_supported(n, k);
     // ... and the same screening as an evaluation path INSIDE the LDS / DPP kernel (its prefetching, its LDS-resident exact records): the
     // default for the sorted loop; + 128 switches it off (fp64 evaluation of every candidate, the form of round 3 and early round 4)
-    const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & 128) == 0 && kmeans_pk_supported(n, k);
-    const int nb_pk = pk ? kmeans_pk_blocks(N) : 0;
-    const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N) : 0;
+    const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & 128) == 0 && kmeans_pk_supported(n, k) && kmeans_reads_through_perm(n, k, scalar_records);
+    const int nb_pk = pk ? kmeans_pk_blocks(N, n, k) : 0;
+    const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N, n, k) : 0;
     const size_t pwords_pk = (size_t)nparts_pk * k * (n + 1);
     const size_t pw_max = pwords > pwords_pk ? pwords : pwords_pk;
     const int nb_max = nb > nb_pk ? nb : nb_pk;

@@ -1032,8 +1032,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 // A wave without a usable reference (first E-step, non-finite sample or centre) takes the full scan over all k centres.
 // 512-thread blocks, three per CU (the member sums are the only LDS table; the exact records come from L1 / L2), six waves per
 // SIMD: the pair records arrive by SMEM, which can only be waited for as a whole -- other waves fill the gap.
-template <int NS>
-__global__ void __launch_bounds__(PK_THREADS) __attribute__((amdgpu_waves_per_eu(6, 6)))
+// k = 513 ... 1024 (the LDS / DPP kernel's table and offsets end at 512): the member sums take up to 106 KB, one block per CU -- of
+// 1024 threads (TH), four waves per SIMD; the loop's sorted order, the sorted rows and the pair records are the same.
+template <int NS, int TH>
+__global__ void __launch_bounds__(TH) __attribute__((amdgpu_waves_per_eu(6, 6)))
 kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
                         const double* __restrict__ Ct, int* __restrict__ labels, u64* __restrict__ partial, int nepochs,
                         double* __restrict__ block_inertia, int* __restrict__ block_changed, const double* __restrict__ prm,
@@ -1043,9 +1045,9 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
     extern __shared__ u64 sums[];                     // [k][n+1]: member sums (fixed point) and count
     if (prm[3] != 0.0) return;                        // hold (block-uniform)
     const int np1 = n + 1;
-    for (int i = threadIdx.x; i < k * np1; i += PK_THREADS) sums[i] = 0ull;
-    __shared__ double sh_inertia[PK_THREADS / 64];
-    __shared__ int sh_changed[PK_THREADS / 64];
+    for (int i = threadIdx.x; i < k * np1; i += TH) sums[i] = 0ull;
+    __shared__ double sh_inertia[TH / 64];
+    __shared__ int sh_changed[TH / 64];
     __syncthreads();
     const ccp T = (ccp)(unsigned long long)Ct;
     const cdp_ FS = (cdp_)(unsigned long long)fix;
@@ -1060,10 +1062,10 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
 #ifdef KM_PK_CONTIG
     // experiment: a block walks a CONTIGUOUS range of positions (consecutive passes stay in one cluster: its pair records stay in
     // the scalar cache) instead of striding through the whole order
-    const int64_t stride = PK_THREADS;
-    const int64_t per_block = ((N + PK_THREADS - 1) / PK_THREADS + gridDim.x - 1) / gridDim.x * PK_THREADS;
+    const int64_t stride = TH;
+    const int64_t per_block = ((N + TH - 1) / TH + gridDim.x - 1) / gridDim.x * TH;
 #else
-    const int64_t stride = (int64_t)gridDim.x * PK_THREADS;
+    const int64_t stride = (int64_t)gridDim.x * TH;
 #endif
     double inertia = 0.0;
     int changed = 0, pass = 0, ep = 0;
@@ -1098,7 +1100,7 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
     int64_t base = vblock * per_block;
     const int64_t Nend = base + per_block < N ? base + per_block : N;
 #else
-    int64_t base = vblock * PK_THREADS;
+    int64_t base = vblock * TH;
     const int64_t Nend = N;
 #endif
     if (base < Nend) {
@@ -1338,7 +1340,7 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
     if (threadIdx.x == 0) {
         double in = 0.0;
         int ch = 0;
-        for (int q = 0; q < PK_THREADS / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; }
+        for (int q = 0; q < TH / 64; ++q) { in += sh_inertia[q]; ch += sh_changed[q]; }
         block_inertia[blockIdx.x] = in;
         block_changed[blockIdx.x] = ch;
     }
@@ -1630,14 +1632,14 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 // every block of 256 so that position 4 lane + q holds centre 64 q + lane (see block_masks); padding = +inf (never a candidate).
 // Round 4: the same row once more SORTED, as 64-bit keys (bits of the distance << 16 | centre index: distances ascending, equal ones
 // by index) -- the candidates of a wave whose reference centre is a are a PREFIX of row a of Nk (kmeans_assign_lds_kernel, single-
-// reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 512 (the LDS /
-// DPP kernel's range).  Bitonic sort in the LDS.
+// reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 1024 (the
+// range of the kernels that use it).  Bitonic sort in the LDS.
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
-    __shared__ unsigned long long keys[512];
-    const bool sorting = Nk != nullptr && kp <= 512;
+    __shared__ unsigned long long keys[1024];
+    const bool sorting = Nk != nullptr && kp <= 1024;
     for (int c = threadIdx.x; c < kp; c += 256) {
         float v = __builtin_inff();
         if (c < k) {
@@ -1650,10 +1652,12 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
         if (sorting) keys[c] = ((unsigned long long)__float_as_uint(v) << 16) | (unsigned)c;      // non-negative floats (NaN included: last) order like their bits
     }
     if (!sorting) return;
+    const int ks = kp <= 256 ? 256 : (kp <= 512 ? 512 : 1024);      // the bitonic network wants a power of two (kp = 768): keys of all ones behind the row
+    for (int c = kp + threadIdx.x; c < ks; c += 256) keys[c] = ~0ull;
     __syncthreads();
-    for (int size = 2; size <= kp; size <<= 1)
+    for (int size = 2; size <= ks; size <<= 1)
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = threadIdx.x; i < (kp >> 1); i += 256) {
+            for (int i = threadIdx.x; i < (ks >> 1); i += 256) {
                 const int lo = ((i / stride) * 2 * stride) + (i % stride), hi = lo + stride;
                 const bool up = (lo & size) == 0;
                 const unsigned long long x = keys[lo], y = keys[hi];
@@ -1670,28 +1674,32 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
     // radius, not of the data: the screening's error shrinks with them.  A pair past the end of the row (k odd) carries "minus infinity".
     // (one thread per candidate of the row forms its half of a record in the LDS -- twelve differences and their norm --, then the
     // block writes the records out as 16-byte pieces: entry by entry, with two of 32 threads walking the norm, this took 40 us)
-    __shared__ float recs[256 * 32];
-    for (int e = threadIdx.x; e < (kp >> 1) * 32; e += 256) recs[e] = 0.0f;
-    __syncthreads();
-    for (int tm = threadIdx.x; tm < kp; tm += 256) {
-        const int t = tm >> 1, m = tm & 1;
-        const int c = (int)(keys[tm] & 0xFFFFull);
-        float hneg = -3.0e38f;
-        if (c < k) {
-            double h2 = 0.0;
-            for (int j = 0; j < n; ++j) {
-                const double d = Ct[c * 16 + j] - Ct[a * 16 + j];
-                h2 = fma(d, d, h2);
-                recs[t * 32 + 2 * j + m] = (float)d;
+    __shared__ float recs[256 * 32];                  // 256 pairs at a time (kp = 1024: two rounds)
+    for (int p0 = 0; p0 < (kp >> 1); p0 += 256) {
+        const int np = min(256, (kp >> 1) - p0);
+        __syncthreads();
+        for (int e = threadIdx.x; e < np * 32; e += 256) recs[e] = 0.0f;
+        __syncthreads();
+        for (int tm = threadIdx.x; tm < 2 * np; tm += 256) {
+            const int t = tm >> 1, m = tm & 1;
+            const int c = (int)(keys[2 * p0 + tm] & 0xFFFFull);
+            float hneg = -3.0e38f;
+            if (c < k) {
+                double h2 = 0.0;
+                for (int j = 0; j < n; ++j) {
+                    const double d = Ct[c * 16 + j] - Ct[a * 16 + j];
+                    h2 = fma(d, d, h2);
+                    recs[t * 32 + 2 * j + m] = (float)d;
+                }
+                hneg = -(float)(0.5 * h2);
             }
-            hneg = -(float)(0.5 * h2);
+            recs[t * 32 + 2 * KM_PK_NMAX + m] = hneg;
         }
-        recs[t * 32 + 2 * KM_PK_NMAX + m] = hneg;
+        __syncthreads();
+        float4* out = reinterpret_cast<float4*>(Pf + ((int64_t)a * (kp >> 1) + p0) * 32);
+        const float4* src = reinterpret_cast<const float4*>(recs);
+        for (int e = threadIdx.x; e < np * 8; e += 256) out[e] = src[e];
     }
-    __syncthreads();
-    float4* out = reinterpret_cast<float4*>(Pf + (int64_t)a * (kp >> 1) * 32);
-    const float4* src = reinterpret_cast<const float4*>(recs);
-    for (int e = threadIdx.x; e < (kp >> 1) * 8; e += 256) out[e] = src[e];
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -2404,29 +2412,36 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
     return hipGetLastError();
 }
 // the packed-fp32 form of the E-step (sorted order, single-reference filter): its own block geometry
-int kmeans_pk_blocks(int64_t N) {
-    const int64_t need = (N + PK_THREADS - 1) / PK_THREADS;
-    return need < 768 ? (int)(need > 0 ? need : 1) : 768;          // three 512-thread blocks per CU
+constexpr int KM_PK_KMAX = 1024;      // labels in KM_SORT_LABEL_BITS bits, centre indices in the 16 low bits of a key
+static_assert(KM_PK_KMAX <= KM_SORT_LABEL_MAX, "the sort keys of the loop's sample order hold the label in KM_SORT_LABEL_BITS bits");
+// 512-thread blocks, three per CU, while their member sums fit three times (k <= 512 at n = 12 / 13); 1024-thread blocks, one per CU, above
+static bool kmeans_pk_small(int n, int k) { return (size_t)k * (n + 1) * 8 <= 53 * 1024; }
+int kmeans_pk_threads(int n, int k) { return kmeans_pk_small(n, k) ? PK_THREADS : 2 * PK_THREADS; }
+int kmeans_pk_blocks(int64_t N, int n, int k) {
+    const int th = kmeans_pk_threads(n, k), cap = kmeans_pk_small(n, k) ? 768 : 256;
+    const int64_t need = (N + th - 1) / th;
+    return need < cap ? (int)(need > 0 ? need : 1) : cap;
 }
-int kmeans_pk_epochs(int64_t N) {
-    const int blocks = kmeans_pk_blocks(N);
-    const int64_t passes = (N + (int64_t)blocks * PK_THREADS - 1) / ((int64_t)blocks * PK_THREADS);
+int kmeans_pk_epochs(int64_t N, int n, int k) {
+    const int blocks = kmeans_pk_blocks(N, n, k), th = kmeans_pk_threads(n, k);
+    const int64_t passes = (N + (int64_t)blocks * th - 1) / ((int64_t)blocks * th);
     const int64_t ep = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
     return (int)(ep > 0 ? ep : 1);
 }
-bool kmeans_pk_supported(int n, int k) { return (n == 12 || n == 13) && k >= 64 && k <= KM2_KMAX && (size_t)k * (n + 1) * 8 <= 53 * 1024; }
+bool kmeans_pk_supported(int n, int k) { return (n == 12 || n == 13) && k >= 64 && k <= KM_PK_KMAX && (size_t)k * (n + 1) * 8 <= 150 * 1024; }
 hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean, const double* c2,
                                    int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
                                    const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf) {
     if (!kmeans_pk_supported(n, k) || !Nk || !Pf || !prm || !fix || (reinterpret_cast<uintptr_t>(c2) & 127)) return hipErrorInvalidValue;
-    const int blocks = kmeans_pk_blocks(N), nep = kmeans_pk_epochs(N);
+    const int blocks = kmeans_pk_blocks(N, n, k), nep = kmeans_pk_epochs(N, n, k);
     const size_t lds = (size_t)k * (n + 1) * sizeof(double);
-#define PK_LAUNCH(NS_) do { \
-        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_pk_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+#define PK_LAUNCH(NS_, TH_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_pk_kernel<NS_, TH_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL((kmeans_assign_pk_kernel<NS_>), dim3(blocks), dim3(PK_THREADS), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
+        hipLaunchKernelGGL((kmeans_assign_pk_kernel<NS_, TH_>), dim3(blocks), dim3(TH_), lds, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
                            block_inertia, block_changed, prm, d2out, perm, fix, Nk, Pf); } while (0)
-    if (n == 12) PK_LAUNCH(12); else PK_LAUNCH(13);
+    if (kmeans_pk_small(n, k)) { if (n == 12) PK_LAUNCH(12, PK_THREADS); else PK_LAUNCH(13, PK_THREADS); }
+    else { if (n == 12) PK_LAUNCH(12, 2 * PK_THREADS); else PK_LAUNCH(13, 2 * PK_THREADS); }
 #undef PK_LAUNCH
     return hipGetLastError();
 }

@@ -667,7 +667,8 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     (integer member sums).  Trajectory-ordered data (few label groups per wave),
     shuffled data (more than 8 groups: the wave falls back to the full scan), duplicate centres (exact score ties: the lowest
     index must win in both), k not a multiple of 64, n = 13, and a NaN row.  Both E-step kernels: centre records from the LDS
-    through DPP (variants 0-2) and through scalar registers (variants 4-6); k = 600 and n = 15 only exist in the second."""
+    through DPP (variants 0-2) and through scalar registers (variants 4-6); n = 15 only exists in the second; k = 513 ... 1024 at >= 2^18 samples runs the packed-fp32
+    kernel (variants 0, 64) against the scalar-record one (the others)."""
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(21)
     ctxs = []
@@ -679,6 +680,7 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     for (N, n, k, shuffle) in ((60000, 12, 512, False), (60000, 12, 512, True), (20011, 13, 100, False), (5000, 12, 70, False), (3000, 5, 64, False),
                                (300000, 12, 256, False), (270001, 13, 128, True),        # >= 2^18 samples: the loop keeps a sorted order
                                (280000, 12, 512, False), (262144, 5, 70, False),         # ... two blocks of mask words; generic n at exactly 2^18
+                               (265000, 12, 1024, False), (270001, 13, 600, True),       # k = 513 ... 1024 in the sorted order: the packed-fp32 kernel (round 4)
                                (30000, 12, 600, False), (9000, 15, 130, False), (9000, 14, 130, False), (7001, 3, 200, False)):
         X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0)                   # a random walk: consecutive samples are neighbours
         X += 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))

@@ -11,7 +11,7 @@ variants = [int(v) for v in sys.argv[2:]] or [0, 16]
 pairs = 10_000_000
 dev = torch.device("cuda", 0)
 ctx = _lib.default_context(0)
-n, r, k, L = 12, 8, 512, 500
+n, r, k, L = 12, 8, int(os.environ.get("AB_K", "512")), 500
 nb = max(1, pairs // L)
 Ue = torch.empty((nb, L, r), dtype=torch.float64, device=dev)
 engine.fill_controls_dev(Ue, "btu", "ar1", seed=0xED3D, b0=0, T_total=L, ctx=ctx)
