@@ -253,7 +253,7 @@ def kmeans_centers_sharded(X_local, k, random_state=0, max_iter=300, tol=1e-4, g
     return C + mean, inertia, n_iter
 
 
-def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, group=None, lloyd_fn=None, ctx=None):
+def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, group=None, lloyd_fn=None, ctx=None, force_exchange=False):
     """Lloyd's loop over rows sharded across ranks: every rank passes its own rows X_local [N_local, n] and the SAME initial
     centres C0 [k, n] (centred frame: C0 and the returned centres are relative to `mean`).  Per iteration one all-reduce (SUM,
     int64) of the member sums -- 2 k (n + 1) + 2 words, 53 KB at k = 512 -- and one all-reduce (MAX) of 16 words before the loop.
@@ -263,10 +263,12 @@ def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, grou
     descending rule (distance, then global row; include/brov2.h: edmdc_set_kmeans_shard) -- the rows an unsharded run picks when
     its NumPy callback is switched off (Context.set_kmeans_far_select(False)), and NumPy's own whenever the maximum is unique.
     lloyd_fn(X_local, C0, mean, max_iter, tol_abs, allreduce): the loop itself -- default the HIP path
-    (edmdc_kmeans_lloyd_dev with edmdc_set_kmeans_allreduce); the CPU tests inject the oracle's stand-in under gloo."""
+    (edmdc_kmeans_lloyd_dev with edmdc_set_kmeans_allreduce); the CPU tests inject the oracle's stand-in under gloo.
+    force_exchange: install the exchange in a process group of ONE rank too (tests: the all-reduce of the library's own device
+    words through the group's backend, on a box with a single GPU)."""
     import torch
     import torch.distributed as dist
-    sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    sharded = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_exchange)
     if lloyd_fn is not None:
         ar = (lambda buf, op: allreduce_words_(buf, op, group)) if sharded else None
         return lloyd_fn(X_local, C0, mean, max_iter, tol_abs, ar)

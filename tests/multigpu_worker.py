@@ -104,6 +104,13 @@ def main():
         ctx.kmeans_use_comm(comm)
         ctx.set_kmeans_shard(rank, world, b0 * (T + 1), Bt * (T + 1))
     Ck, labels_k, inertia_k, iters_k = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx)
+    forced = False
+    if mode == "torch" and world == 1:
+        # one rank, backend nccl: the same loop once more with the exchange installed -- every all-reduce of the loop goes through RCCL
+        # on the library's own device words (the path the N-rank runs take), and must change nothing
+        Cf, labels_f, inertia_f, iters_f = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx, force_exchange=True)
+        assert torch.equal(Cf, Ck) and torch.equal(labels_f, labels_k) and iters_f == iters_k and inertia_f == inertia_k
+        forced = True
     # ... and the k-means++ seeding over all ranks' rows: scikit-learn's random stream for Bt (T + 1) rows, two small exchanges per centre
     if comm is not None:
         Cs, idx_s = engine.kmeanspp_dev(X.view(-1, n), k, mean=mean_h, random_state=3, ctx=ctx, n_global=Bt * (T + 1))
@@ -115,7 +122,7 @@ def main():
     torch.cuda.synchronize()
     np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id,
              Ck=Ck.cpu().numpy(), iters_k=iters_k, inertia_k=inertia_k, labels_k=labels_k.cpu().numpy(), reloc_k=ctx.kmeans_relocations(),
-             Cs=Cs.cpu().numpy(), idx_s=idx_s)
+             Cs=Cs.cpu().numpy(), idx_s=idx_s, forced_exchange=forced)
     if mode in ("torch", "gloo"):
         import torch.distributed as dist
         dist.barrier()

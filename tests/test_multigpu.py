@@ -72,6 +72,7 @@ def test_worker_single_rank_both_transports(tmp_path):
     b = _run("brov", 1, str(tmp_path))[0]
     for key in ("GtG", "GtY", "A", "B", "Af", "Bf", "Ck", "labels_k", "idx_s", "Cs"):
         assert np.array_equal(a[key], b[key]), key
+    assert bool(a["forced_exchange"])                      # the Lloyd loop's all-reduces went through RCCL (one rank) and changed nothing
     assert np.isfinite(a["A"]).all() and np.isfinite(a["Af"]).all()
     assert np.max(np.abs(a["A"] - a["Af"])) < 1e-6            # the two product orders agree to the conditioning of the Gram
 
