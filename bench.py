@@ -114,7 +114,11 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
                 "stale": (rec != cur) if rec else None, "recorded_launches": d.get("launches"), "timed_iterations": iterations,
                 "note": "every VALU slot priced as an FMA; instruction count = mean over the E-steps of the recorded run of the shipped loop "
                         "(sorted sample order), time = this run's",
-                "traffic": None}
+                "traffic": ({"bytes_per_e_step": d["hbm_total_GB_per_launch"] * 1e9, "read_GB": d.get("hbm_read_GB_per_launch_corrected_x2"),
+                             "write_GB": d.get("hbm_write_GB_per_launch"), "algorithmic_GB": rows * (12 * 8 + 4 + 4 + 4 + 4) / 1e9,
+                             "note": "FETCH_SIZE (x 2: the gfx950 correction, profiles/r04_fetch_probe.txt) + WRITE_SIZE per E-step of the recorded run; "
+                                     "algorithmic = one 96-byte row, its permutation index and old label in, label and sort key out per sample"}
+                            if "hbm_total_GB_per_launch" in d else None)}
     return None
 
 

@@ -50,6 +50,14 @@ def _dptr(t):
     return t.data_ptr()
 
 
+def _drows(t):
+    """device pointer of a 2-D fp64 CUDA tensor whose ROWS are contiguous (any row stride: a column slice of a padded buffer)."""
+    import torch
+    assert t.is_cuda and t.dtype == torch.float64 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1], \
+        "need a 2-D fp64 CUDA tensor with contiguous rows"
+    return t.data_ptr()
+
+
 # ------------------------------------------------------------------------------------------ host path
 def rhs(model, x, u, dt=0.02, lag=None, ctx=None):
     """Batched dynamics().  Returns (xdot [B,nx], lag_after [B,8,3] or None)."""
@@ -311,7 +319,7 @@ def kmeanspp_dev(X, k, mean=None, random_state=0, ctx=None, n_global=None):
     m = None if mean is None else as_f64(mean).reshape(n)
     Uc = np.ascontiguousarray(U)
     torch.cuda.current_stream(X.device).synchronize()
-    ctx.check(ctx.lib.edmdc_kmeanspp_dev(ctx.h, N, n, k, _dptr(X), X.stride(0), _hptr(m), first, L, _hptr(Uc) if k > 1 else None,
+    ctx.check(ctx.lib.edmdc_kmeanspp_dev(ctx.h, N, n, k, _drows(X), X.stride(0), _hptr(m), first, L, _hptr(Uc) if k > 1 else None,
                                          _dptr(C), ind.ctypes.data), "edmdc_kmeanspp_dev")
     return C, ind
 
@@ -366,7 +374,7 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
     inertia = ctypes.c_double(0.0)
     n_iter = ctypes.c_int(0)
     torch.cuda.current_stream(X.device).synchronize()
-    ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _dptr(X), X.stride(0), _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
+    ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _drows(X), X.stride(0), _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
                                              labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
     if timings is not None and getattr(ctx, "timing", False):
         timings["lloyd_ms"] = ctx.last_kernel_ms()

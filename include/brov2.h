@@ -282,18 +282,23 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
 /* Lloyd's loop in edmdc_kmeans_lloyd(_dev):
  * 0 = E-step with the per-wave candidate filter (triangle inequality over the centre-centre distances; the same labels as the
  *     full scan bit for bit), visiting the samples in an order kept sorted by (label, distance to the centre) -- a permutation,
- *     re-sorted as labels move; for >= 2^18 samples, k <= 512 and n <= 14; the labels are returned in the caller's order -- default;
+ *     re-sorted as labels move; for >= 2^18 samples, n <= 14 and k <= 512 (k <= 1024 for n = 12 or 13); in that order the candidates
+ *     of a wave are screened in packed fp32 (two per issue slot, in the frame of the wave's reference centre) and only the pair the
+ *     winner is certified to lie in is evaluated in fp64 (n = 12 or 13); the labels are returned in the caller's order -- default;
  * 1 = full scan over all k centres in the caller's order (the independent second implementation; BROV2_KMEANS_PLAIN=1 at brov_create);
  * 2 = candidate filter in the caller's order (no sorting).
  * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
- * still the one for k > 512 or n = 15) instead of the LDS-resident table read through DPP: same arithmetic, same labels.
+ * still the one for k > 1024, n = 15, and k > 512 below 2^18 samples) instead of the LDS-resident table read through DPP: same
+ * arithmetic, same labels.
  * Adding 8 makes the k-means++ seeding (edmdc_kmeanspp_dev) take every sample through its fp64 distance evaluation in every round
  * instead of screening rows out with a float copy of the coordinates first: same indices, same centres.
  * Adding 16 keeps the round-3 form of the candidate filter alone (label groups and masks over all centres) instead of trying the
  * single-reference form first (candidates = a prefix of the reference centre's sorted distance row): same labels, same centres.
- * Adding 64 runs the E-steps of the sorted loop (variant 0, n = 12 or 13, 64 <= k <= 512) through the kernel that screens the
- * candidates in packed fp32 (two per issue slot) and evaluates in fp64 only the pair the winner is certified to lie in: the same
- * labels, the same centres.
+ * Adding 64 runs the E-steps of the sorted loop (variant 0, n = 12 or 13, 64 <= k <= 1024) through the stand-alone kernel of the
+ * packed-fp32 screening (member sums the only LDS table; the form k = 513 ... 1024 always takes) instead of the screening inside the
+ * LDS / DPP kernel: the same labels, the same centres.
+ * Adding 128 switches the packed-fp32 screening off: every candidate is evaluated in fp64 (the form of round 3 / early round 4; for
+ * k > 512 the scalar-record kernel in the caller's order): the same labels, the same centres.
  * Adding 32 sends the seeding of a single rank through the kernels of the sharded run (candidate rows from a table, potentials
  * through the per-rank totals): same indices. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);

@@ -248,7 +248,7 @@ def lloyds():
     while time.time() - t0 < budget:
         N = int(rng.choice([70, 1000, 4097, 30000, 120000, 270000]))
         n_ = int(rng.choice([3, 5, 12, 13, 14, 15]))
-        k = int(rng.choice([2, 63, 64, 65, 128, 300, 512, 700]))
+        k = int(rng.choice([2, 63, 64, 65, 128, 300, 512, 700, 1024]))
         if k > N:
             continue
         X = np.cumsum(rng.normal(0, 0.05, (N, n_)), 0) * float(rng.choice([1e-3, 1.0, 50.0]))

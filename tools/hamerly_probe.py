@@ -49,6 +49,8 @@ def scan(C):
 
 
 betas = (0.0, 0.1, 0.25, 0.5, 1e9)
+KN = int(os.environ.get("PROBE_KN", "0"))       # > 0: the lower bound decays by the largest shift among the KN nearest centres of the sample's own
+                                                # (the others are held off by the triangle inequality through the own centre) instead of the largest of all
 lab, d1, d2 = scan(C)
 ub = {b: d1.clone() for b in betas}
 lb = {b: torch.minimum(d2, (1.0 + 2.0 * b) * d1) for b in betas}
@@ -62,6 +64,12 @@ for it in range(1, iters + 1):
     top = torch.topk(p, 2).values
     pa = p[lab]
     other = torch.where(pa == top[0], top[1], top[0])            # largest shift among the other centres
+    far = None
+    if KN > 0:
+        Dn, In = torch.sort(torch.cdist(C, C), dim=1)
+        m_near = p[In[:, 1:KN + 1]].max(dim=1).values            # per own centre: the largest shift among its KN nearest
+        other = m_near[lab]
+        far = Dn[:, KN + 1][lab]                                 # distance from the own centre to the first centre outside that set
     lab_n, d1, d2 = scan(C)
     changed = (lab_n != lab).float().mean().item() * 100
     da = (Xc - C[lab]).norm(dim=1)                               # exact distance to the old centre (tightening)
@@ -69,6 +77,8 @@ for it in range(1, iters + 1):
     for b in betas:
         u = ub[b] + pa
         l = lb[b] - other
+        if far is not None:
+            l = torch.minimum(l, far - u)
         f1 = u >= l
         f2 = f1 & (da >= l)
         line += f"  {f1.float().mean().item() * 100:6.2f} / {f2.float().mean().item() * 100:6.2f}"
@@ -78,7 +88,7 @@ for it in range(1, iters + 1):
             line += f" (!{wrong})"
         ub[b] = torch.where(f2, d1, torch.where(f1, da, u))
         lb[b] = torch.where(f2, torch.minimum(d2, (1.0 + 2.0 * b) * d1), l)
-    print(line + f"   max shift {top[0].item():.2e}  median r {d1.median().item():.2e}", flush=True)
+    print(line + f"   max shift {top[0].item():.2e}  median shift {p.median().item():.2e}  median r {d1.median().item():.2e}", flush=True)
     lab = lab_n
 # candidates a scan radius costs: centres within 2 (1 + beta) r of the sample's own centre
 Dcc = torch.cdist(C, C)

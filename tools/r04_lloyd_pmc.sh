@@ -4,6 +4,8 @@ set -e -o pipefail
 out=gpurun_out/${1:-r04_lloyd}; mkdir -p $out
 root=$(pwd)
 cmd="python3 $root/tools/time_lloyd.py 10000000 ${2:-300} default"
+tools/pmc_pass.sh $out/pmc/fetch "FETCH_SIZE" -- $cmd
+tools/pmc_pass.sh $out/pmc/write "WRITE_SIZE" -- $cmd
 tools/pmc_pass.sh $out/pmc/sq1 "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS GRBM_GUI_ACTIVE" -- $cmd
 tools/pmc_pass.sh $out/pmc/sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VMEM SQ_INSTS_VALU_FMA_F64 SQ_ACTIVE_INST_LDS" -- $cmd
 tools/pmc_pass.sh $out/pmc/sq3 "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_FLAT SQ_WAVES_EQ_64" -- $cmd || echo "sq3 failed"

@@ -21,6 +21,10 @@ g = torch.Generator(device=dev); g.manual_seed(1234)
 sig = torch.tensor([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3, dtype=torch.float64, device=dev)
 Xe += torch.randn(Xe.shape, generator=g, dtype=torch.float64, device=dev) * sig
 X = Xe.view(-1, n)
+if os.environ.get("AB_PAD"):          # experiment: rows padded to a stride of 16 doubles (one 128-byte line per gathered row)
+    Xp = torch.zeros((X.shape[0], 16), dtype=torch.float64, device=dev)
+    Xp[:, :n] = X
+    X = Xp[:, :n]
 ref = None
 for rep in range(2):
     for v in variants:
