@@ -108,11 +108,23 @@ bool kmeans_reads_through_perm(int n, int k, bool scalar_records);
 hipError_t launch_kmeans_c2(hipStream_t st, int n, int k, const double* C, double* c2);
 hipError_t launch_kmeans_range(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, unsigned long long* rng);
 hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* rng, double* fix, double* prm);
+// distance bounds of the sorted loop (kmeans.hip: kmeans_bounds_kernel): per-position bounds moved by the centres' shifts; the positions
+// whose bounds fail go to `list` (tiles padded to whole waves with ~position), their number to nlist[0]
+struct KmBounds {
+    float* ub = nullptr;            // [N] >= distance to the own centre
+    float* lb = nullptr;            // [N] <= distance to every other centre
+    const float* shiftc = nullptr;  // [k + 4] from launch_kmeans_average
+    int* list = nullptr;            // [kmeans_bounds_list_words(N)]
+    int* nlist = nullptr;           // [2]
+    bool use_list = false;          // the E-step visits the list only and its partials are CHANGES (launch_kmeans_reduce: delta)
+};
+size_t kmeans_bounds_list_words(int64_t N);
+hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm);
 // E-step; Dc != nullptr selects the candidate-filtered form (Dc [k][k rounded up to 256] floats from launch_kmeans_cdist); prm [4], fix [32] from launch_kmeans_scale
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
                                 const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm = nullptr,
-                                const unsigned long long* Nk = nullptr, const float* Pf = nullptr);
+                                const unsigned long long* Nk = nullptr, const float* Pf = nullptr, const KmBounds* bounds = nullptr);
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr);
@@ -124,9 +136,9 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
                                    int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
                                    const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf);
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats);
+                                const int* block_changed, long long* red, double* stats, long long* tot = nullptr, int delta = 0);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
-                                 double* c2, double* stats, double* prm, int mode);
+                                 double* c2, double* stats, double* prm, int mode, float* shiftc = nullptr);
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
                                     const int* labels, const int* perm, double* dist_row, int* lab_row);
 
@@ -138,7 +150,8 @@ constexpr int KM_SORT_LABEL_MAX = 1 << KM_SORT_LABEL_BITS;
 size_t kmeans_sort_temp_bytes(int64_t N);
 hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old, int* labels_new, const int* perm_old, int* perm_new,
                                 const float* d2, unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, void* temp,
-                                size_t temp_bytes);
+                                size_t temp_bytes, float* d2_new = nullptr, const float* ub_old = nullptr, float* ub_new = nullptr,
+                                const float* lb_old = nullptr, float* lb_new = nullptr);
 hipError_t launch_kmeans_unpermute(hipStream_t st, int64_t N, const int* perm, const int* labels_sorted, int* labels_out);
 
 int kmeanspp_chunks(int64_t N);

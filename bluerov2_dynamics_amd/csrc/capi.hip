@@ -1095,8 +1095,8 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 254 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16, + 32 and / or + 64");
+    if (!c || variant < 0 || variant > 510 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16, + 32, + 64, + 128 and / or + 256");
     c->kmeans_variant = variant;
     return BROV_OK;
 }
@@ -1629,6 +1629,11 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // ... and the same screening as an evaluation path INSIDE the LDS / DPP kernel (its prefetching, its LDS-resident exact records): the
     // default for the sorted loop; + 128 switches it off (fp64 evaluation of every candidate, the form of round 3 and early round 4)
     const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & 128) == 0 && kmeans_pk_supported(n, k) && kmeans_reads_through_perm(n, k, scalar_records);
+    // distance bounds (kmeans.hip: kmeans_bounds_kernel): once few labels change per iteration, an E-step visits only the samples whose
+    // bounds fail and the M-step adds their CHANGES to the totals it keeps; + 256 in the k-means variant (or BROV2_KM_BOUNDS=0) switches it off
+    bool bnd = pk_lds && (c->kmeans_variant & 256) == 0;
+    if (const char* e = std::getenv("BROV2_KM_BOUNDS")) bnd = bnd && std::atoi(e) != 0;
+    const size_t lwords = bnd ? kmeans_bounds_list_words(N) : 0;
     const int nb_pk = pk ? kmeans_pk_blocks(N, n, k) : 0;
     const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N, n, k) : 0;
     const size_t pwords_pk = (size_t)nparts_pk * k * (n + 1);
@@ -1638,7 +1643,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                        ((pk || pk_lds) ? Arena::al(k * (kp_ / 2) * 32 * 4) : 0) + 256 +
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
-                       (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) + 8192);
+                       (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) +
+                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 2 * Arena::al((size_t)k * 8) + 1024 : 0) + 8192);
     if (rc) return rc;
     unsigned long long* partial = a.take<unsigned long long>(pw_max);
     long long* red = a.take<long long>(rwords);
@@ -1655,6 +1661,10 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     double* dmean = a.take<double>(16);
     int *Ls[2] = {nullptr, nullptr}, *Ps[2] = {nullptr, nullptr};
     float* d2 = nullptr;
+    float *d2s[2] = {nullptr, nullptr}, *ubs[2] = {nullptr, nullptr}, *lbs[2] = {nullptr, nullptr};      // per position: two copies each, swapped by a re-sort
+    long long* tot = nullptr;
+    float* shiftc = nullptr;
+    int *blist = nullptr, *nlist = nullptr;
     unsigned *kin = nullptr, *kout = nullptr, *vin = nullptr, *vout = nullptr;
     void* stmp = nullptr;
     if (sorting) {
@@ -1662,6 +1672,14 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         d2 = a.take<float>(N);
         kin = a.take<unsigned>(N); kout = a.take<unsigned>(N); vin = a.take<unsigned>(N); vout = a.take<unsigned>(N);
         stmp = a.take<char>(sort_tmp + 256);
+    }
+    if (bnd) {
+        d2s[0] = d2; d2s[1] = a.take<float>(N);
+        for (int q = 0; q < 2; ++q) { ubs[q] = a.take<float>(N); lbs[q] = a.take<float>(N); }
+        blist = a.take<int>(lwords);
+        tot = a.take<long long>(rwords);
+        shiftc = a.take<float>((size_t)k + 4);
+        nlist = a.take<int>(64);
     }
     if (mean_host) {
         HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -1701,30 +1719,62 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
     HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, nullptr, prm, fix, d2, scalar_records, nullptr));
     int e_nparts = nparts, e_nb = nb;                  // geometry of the E-step whose partials are waiting (the packed-fp32 kernel has its own)
+    // distance bounds: bcur = the copies of d2 / ub / lb in the current order; bounds_valid: a full E-step has left bounds for every position
+    // since the centres were last changed behind the loop's back (relocation); e_list: the E-step whose partials are waiting walked the list
+    int bcur = 0;
+    bool bounds_valid = false, e_list = false, any_list = false, use_list = false;
+    double bounds_rate = 0.03;                          // list form once at most this share of the labels changed in the last summed iteration
+    if (const char* e = std::getenv("BROV2_KM_BOUNDS_RATE")) bounds_rate = std::atof(e);
+    const bool bounds_log = std::getenv("BROV2_KM_BOUNDS_LOG") != nullptr;
+    const double n_all = (c->km_allreduce && c->km_n_global > 0) ? (double)c->km_n_global : (double)N;
     auto e_step = [&](bool filtered) -> hipError_t {
         if (filtered && pk) {
             e_nparts = nparts_pk; e_nb = nb_pk;
             return launch_kmeans_assign_pk(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, prm, fix, d2, Pc, Nk, Pf);
         }
         e_nparts = nparts; e_nb = nb;
-        return launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filtered && filter ? Dc : nullptr, prm, fix, d2,
-                                    scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr, filtered && pk_lds ? Pf : nullptr);
+        KmBounds kb;
+        const bool with_bounds = bnd && filtered && Pc != nullptr;
+        e_list = false;
+        if (with_bounds) {
+            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.shiftc = shiftc; kb.list = blist; kb.nlist = nlist;
+            kb.use_list = use_list && bounds_valid;
+            if (kb.use_list) {
+                hipError_t e = launch_kmeans_bounds(c->stream, N, k, Lc, kb, prm);
+                if (e != hipSuccess) return e;
+                e_list = any_list = true;
+            }
+            bounds_valid = true;                        // (a full pass writes them all; a list pass keeps them)
+        }
+        return launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filtered && filter ? Dc : nullptr, prm, fix,
+                                    bnd ? d2s[bcur] : d2, scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr, filtered && pk_lds ? Pf : nullptr,
+                                    with_bounds ? &kb : nullptr);
     };
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats));
+        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats, tot, e_list ? 1 : 0));
         if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
-        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0));
+        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0, shiftc));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
         if (want_sort) {
             // (label, distance) of the E-step that has just been summed up; labels and permutation move together
-            HIPCK(c, launch_kmeans_resort(c->stream, N, Lc, Ls[cur], Pc, Ps[cur], d2, kin, kout, vin, vout, stmp, sort_tmp));
+            if (bnd) {
+                // (the bounds and the sort key's distance move with their samples; before the first sort there are no bounds yet)
+                const bool have = bounds_valid;
+                HIPCK(c, launch_kmeans_resort(c->stream, N, Lc, Ls[cur], Pc, Ps[cur], d2s[bcur], kin, kout, vin, vout, stmp, sort_tmp, d2s[bcur ^ 1],
+                                              have ? ubs[bcur] : nullptr, have ? ubs[bcur ^ 1] : nullptr, have ? lbs[bcur] : nullptr, have ? lbs[bcur ^ 1] : nullptr));
+                bcur ^= 1;
+            } else {
+                HIPCK(c, launch_kmeans_resort(c->stream, N, Lc, Ls[cur], Pc, Ps[cur], d2, kin, kout, vin, vout, stmp, sort_tmp));
+            }
             Lc = Ls[cur]; Pc = Ps[cur];
             cur ^= 1;
             want_sort = false;
             moved = 0.0;
         }
         if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+        // hs still holds the statistics of the iteration before this one (the host has not waited yet): few changed labels -> list form
+        use_list = bnd && it >= 2 && hs[2] <= bounds_rate * n_all;
         HIPCK(c, e_step(true));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];
@@ -1736,9 +1786,15 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
             if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+            bounds_valid = false;                       // relocated centres jumped: a full E-step, whose sums start the totals afresh
             HIPCK(c, e_step(true));
         }
         cc ^= 1;
+        if (bounds_log && e_list) {
+            int hn[2] = {0, 0};
+            HIPCK(c, hipMemcpy(hn, nlist, sizeof hn, hipMemcpyDeviceToHost));
+            std::fprintf(stderr, "[kmeans bounds] iteration %d: changed %.0f, next E-step walks %d of %lld positions\n", it, hs[2], hn[0], (long long)N);
+        }
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
         if (hs[0] <= tol_abs) break;
         if (sorting) {
@@ -1759,6 +1815,13 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     }
     if (it > max_iter) it = max_iter;
     double in = hs[1];
+    if (any_list) {
+        // inertia over ALL samples: one plain pass with the final centres (the list form sums only what it visits; the labels it
+        // rewrites are the ones already there)
+        use_list = false;
+        HIPCK(c, e_step(true));
+        strict = false;
+    }
     HIPCK(c, hipMemcpyAsync(d_C, Cb[cc], (size_t)k * n * 8, hipMemcpyDeviceToDevice, c->stream));
     if (Pc) HIPCK(c, launch_kmeans_unpermute(c->stream, N, Pc, Lc, d_labels));      // labels back in the caller's order
     if (!strict) {   // labels / inertia consistent with the final centres: the E-step already queued

@@ -553,14 +553,21 @@ __device__ __forceinline__ void pk_pair(const PkRec& r, const v2f (&xx)[NS], flo
     fb = b2;
 }
 
-template <int NS>
+// LIST (round 4, distance bounds): the pass walks the positions kmeans_bounds_kernel has listed (entry p, or ~p: a padding lane that
+// loads p's row and counts for nothing) instead of all N, its member sums are the CHANGES (a sample that moves takes its
+// fixed-point coordinates from the old cluster to the new one; kmeans_reduce_kernel adds them to the kept totals), and labels,
+// sort keys and bounds are written per listed position.  ubo / lbo != nullptr (either form): the packed-fp32 path leaves the sample's
+// bounds there (NaN from every other path: such a sample is evaluated again next time), and the prefix is cut at 2 (1 + beta) u
+// instead of 2 u (tscale = (1 + beta)^2): what lies beyond it is then at least (1 + 2 beta) u from every lane -- a lower bound worth keeping.
+template <int NS, bool LIST>
 __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
                          const double* __restrict__ Ct, int* __restrict__ labels, u64* __restrict__ partial, int nepochs,
                          double* __restrict__ block_inertia, int* __restrict__ block_changed,
                          const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
                          const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */,
-                         const double* __restrict__ fix, const unsigned long long* __restrict__ Nk, const float* __restrict__ Pf) {
+                         const double* __restrict__ fix, const unsigned long long* __restrict__ Nk, const float* __restrict__ Pf,
+                         const int* __restrict__ list, const int* __restrict__ nlist, float* __restrict__ ubo, float* __restrict__ lbo, double tscale) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
     double* tab = lds2;
@@ -588,9 +595,15 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #pragma unroll
     for (int j = 0; j < NX; ++j) mm[j] = (mean && (NS > 0 || j < n)) ? mean[j] : 0.0;
     const bool vec = NS > 0 && (NS & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (xstride & 1) == 0;
-    auto position = [&](int64_t base) { const int64_t i = base + threadIdx.x; return i < N ? i : N - 1; };
-    auto load_rows = [&](int64_t base, int prow, double (&xr)[NX], int& lab) {
-        const int64_t ii = position(base);
+    // M: the positions this launch walks (LIST: the entries of the list, whole waves); a slot beyond the end repeats the last one
+    const int64_t M = LIST ? (int64_t)nlist[0] : N;
+    auto slot = [&](int64_t base) { const int64_t i = base + threadIdx.x; return i < M ? i : M - 1; };
+    // position of a slot (LIST: through the list; ~p marks padding)
+    auto position = [&](int64_t base) -> int64_t {
+        if constexpr (LIST) { const int e = list[slot(base)]; return (int64_t)(e < 0 ? ~e : e); }
+        else return slot(base);
+    };
+    auto load_rows = [&](int64_t ii, int prow, double (&xr)[NX], int& lab) {
         const double* row = X + (perm ? (int64_t)prow : ii) * xstride;
         if (vec) {
 #pragma unroll
@@ -607,11 +620,24 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     double xn[NX];
     int oln = -1;
     int64_t base = (int64_t)blockIdx.x * KM_THREADS;
-    // sample order through `perm`: the row index of a pass is loaded one pass before its rows are
+    // sample order through `perm`: the row index of a pass is loaded one pass before its rows are (LIST: the list entry one pass
+    // before that).  pos_cur / pos_nx / pos_nx2: positions of this pass, the next (rows in flight) and the one after; dead_*: padding
     int pnext = 0;
-    if (base < N) {
-        load_rows(base, perm ? perm[position(base)] : 0, xn, oln);
-        if (perm && base + stride < N) pnext = perm[position(base + stride)];
+    int64_t pos_cur = 0, pos_nx = 0;
+    int ent_nx2 = 0;                                  // LIST: the raw entry of the pass after the next
+    bool dead_cur = false, dead_nx = false;
+    auto entry = [&](int64_t b, int64_t& pos, bool& dead) {
+        if constexpr (LIST) { const int e = list[slot(b)]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0 || b + threadIdx.x >= M; }
+        else { pos = slot(b); dead = b + threadIdx.x >= M; }
+    };
+    if (base < M) {
+        entry(base, pos_cur, dead_cur);
+        load_rows(pos_cur, perm ? perm[pos_cur] : 0, xn, oln);
+        if (base + stride < M) {
+            entry(base + stride, pos_nx, dead_nx);
+            if (perm) pnext = perm[pos_nx];
+        }
+        if constexpr (LIST) { if (base + 2 * stride < M) ent_nx2 = list[slot(base + 2 * stride)]; }
     }
     // reference centre of the single-reference filter for the pass whose rows are in flight, and the head of its sorted row:
     // the label most lanes carry (lane 0's, or the next one when fewer than half the lanes share it)
@@ -629,16 +655,16 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         nk0 = row[lane];
         nk1 = row[64 + lane];
     };
-    if (base < N) reference_ahead();
+    if (base < M) reference_ahead();
 #if KM_PROFILE
     unsigned long long t_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #endif
-    for (; base < N; base += stride) {
+    for (; base < M; base += stride) {
 #if KM_PROFILE
         unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
-        const int64_t i = base + threadIdx.x;
-        const bool live = i < N;
+        const int64_t i = pos_cur;                    // the position this lane works on (labels, sort keys and bounds are per position)
+        const bool live = !dead_cur;
         double x[NX], x2 = 0.0;
 #pragma unroll
         for (int j = 0; j < NX; ++j) { x[j] = xn[j] - mm[j]; x2 = fma(x[j], x[j], x2); }
@@ -663,6 +689,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         // and a flagged wave repeats the pass through the mask form below (index order).  Exact duplicates of a centre are neighbours
         // in the row in index order, but they do tie: such waves always take the second form.
         double u2_ref = 0.0;                          // the wave's squared radius about its reference centre (single-reference form)
+        double d2_ref = 0.0, t2_ref = 0.0;            // this lane's squared distance to that centre; the squared radius the prefix was cut at
         auto select_by_nbr = [&](int& ncand) -> bool {
             if (a_ref < 0 || __ballot(!((x2 - x2 == 0.0) && centres_finite)) != 0ull) return false;
             const int a = a_ref;
@@ -673,7 +700,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             const unsigned rb = wave_max_u32(__float_as_uint(rf));
             const double u2 = (double)__uint_as_float(rb) + eps2;          // >= the true squared radius u^2 of the wave about c_a
             u2_ref = u2;
-            const double t2 = fma(4.004, u2, 1001.0 * margin * margin);    // >= (2 u + margin)^2
+            d2_ref = d2;
+            const double t2 = fma(4.004 * tscale, u2, 1001.0 * margin * margin);    // >= (2 u + margin)^2 (tscale = 1)
+            t2_ref = t2;
             const unsigned tb = __float_as_uint(fminf((float)(t2 * 1.0000001) + 1.0e-37f, 3.4028234e38f));     // non-negative floats order like their bits
             int cnt = __builtin_popcountll(__ballot((unsigned)(key0 >> 16) < tb)) + __builtin_popcountll(__ballot((unsigned)(key1 >> 16) < tb));
             lst[lane] = (unsigned short)(((unsigned)key0 & 0xFFFFu) << 7);
@@ -773,9 +802,13 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (!by_nbr && Dc) filtered = select_by_masks();
         KM_STAMP(2);
         // rows of the next pass: in flight during the evaluation (which waits on the LDS only)
-        if (base + stride < N) {
-            load_rows(base + stride, pnext, xn, oln);
-            if (perm && base + 2 * stride < N) pnext = perm[position(base + 2 * stride)];
+        if (base + stride < M) {
+            load_rows(pos_nx, pnext, xn, oln);
+            if constexpr (LIST) {
+                if (base + 2 * stride < M) pnext = perm[ent_nx2 < 0 ? ~ent_nx2 : ent_nx2];
+            } else {
+                if (perm && base + 2 * stride < M) pnext = perm[slot(base + 2 * stride)];
+            }
         }
         // ---- evaluation in increasing index order, KM2_DEPTH records in flight
         double best = -1.0e300;
@@ -861,6 +894,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             }
                 };
         bool by_pk = false;
+        float ubv = __builtin_nanf(""), lbv = __builtin_nanf("");      // the sample's new bounds (packed-fp32 path only)
         if constexpr (NS == 12 || NS == 13) {
             if (by_nbr && pk_ok) {
                 // ---- packed-fp32 screening of the prefix (see kmeans_assign_pk_kernel for the argument): pair records through scalar
@@ -908,6 +942,22 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                     best = second ? s1 : s0;
                     baddr = (second ? o1 : o0) + laneoff;
                     by_pk = true;
+                    if (ubo) {
+                        // bounds for kmeans_bounds_kernel.  Upper: the exact distance to the winner.  Lower, over every other centre:
+                        //   the pair's other member -- its exact score is at hand (o1 == o0: there is none, the list's padding);
+                        //   any other candidate of the scanned prefix: its float score is at most the runner-up's fs and errs by less
+                        //     than mf, so in the reference centre's frame |x - c|^2 = |y|^2 - 2 S_c >= |y|^2 - 2 (fs + mf);
+                        //   any centre beyond the prefix: at least sqrt(t2) from the reference centre, |y| of which the lane can cover.
+                        const double dbest2 = fma(-2.0, best, x2);
+                        const double dlose2 = o1 != o0 ? fma(-2.0, second ? s0 : s1, x2) : 1.0e300;
+                        const double dscan2 = fma(-2.0, (double)fs + (double)mf, d2_ref);
+                        const double l2 = fmin(dlose2, dscan2) - 4.0 * eps2;
+                        const double lfar = sqrt(t2_ref) * 0.9999999 - sqrt(fmax(d2_ref, 0.0) + eps2) * 1.0000001;
+                        const double lbd = fmin(l2 > 0.0 ? sqrt(l2) : 0.0, lfar);
+                        ubv = (float)sqrt(fmax(dbest2, 0.0) + eps2) * 1.0000003f + 1.0e-37f;
+                        lbv = (float)lbd;
+                        lbv = lbv > 0.0f ? lbv * 0.9999997f : lbv;
+                    }
                 }
             }
         }
@@ -939,7 +989,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             run_all();
         }
         const int bi = (int)(baddr >> 7);
-        if (base + stride < N) reference_ahead();     // the next pass's labels have arrived during the evaluation
+        if (base + stride < M) reference_ahead();     // the next pass's labels have arrived during the evaluation
         KM_STAMP(3);
         if (live) {
             if (ol != bi) ++changed;
@@ -947,6 +997,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             const double dmin2 = fma(-2.0, best, x2);     // squared distance to the chosen centre (up to rounding)
             if (d2out) d2out[i] = (float)dmin2;            // sort key of the loop's sample order (sortperm.hip)
             inertia += dmin2;
+            if (ubo) { ubo[i] = ubv; lbo[i] = lbv; }
         }
         // member sums, fixed point (see the kernel above).  Same-address atomics are what this phase costs (see wave_sum_u64x), so
         // when at least half of the wave's lanes went to one centre -- a sorted wave: all of them but the few whose label has moved
@@ -957,7 +1008,25 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         const bool bad = !(x2 - x2 == 0.0);
         const bool ok = live && !bad;
         bool sent = false;
-        if constexpr (NS == 12 || NS == 13) {
+        if constexpr (LIST) {
+            // CHANGES of the member sums: a sample that moved leaves its old cluster and joins the new one (two's-complement words:
+            // the block's partial table holds signed differences; kmeans_reduce_kernel adds them to the totals it keeps)
+            sent = true;
+            if (live && ol != bi && (unsigned)ol < (unsigned)k) {
+                u64* sn = sums + bi * np1;
+                u64* so = sums + ol * np1;
+#pragma unroll
+                for (int j = 0; j < NX; ++j) {
+                    const u64 q = km_fix(bad ? 0.0 : x[j], FS[j]);
+                    atomicAdd(&sn[j], q);
+                    atomicAdd(&so[j], 0ull - q);
+                }
+                const u64 one = bad ? 1ull + KM_POISON : 1ull;
+                atomicAdd(&sn[n], one);
+                atomicAdd(&so[n], 0ull - one);
+            }
+        }
+        if constexpr (!LIST && (NS == 12 || NS == 13)) {
             const unsigned long long okm = __ballot(ok);
             if (okm != 0ull) {
                 const int lab = __builtin_amdgcn_readlane(bi, __builtin_ctzll(okm));
@@ -989,7 +1058,19 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         KM_STAMP(4);
         t_acc[7] += 1ull;
 #endif
-        if (++pass == KM_EPOCH_PASSES && base + stride < N) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
+        // the positions move up a pass
+        pos_cur = pos_nx;
+        dead_cur = dead_nx;
+        if (base + 2 * stride < M) {
+            if constexpr (LIST) {
+                pos_nx = (int64_t)(ent_nx2 < 0 ? ~ent_nx2 : ent_nx2);
+                dead_nx = ent_nx2 < 0 || base + 2 * stride + threadIdx.x >= M;
+                if (base + 3 * stride < M) ent_nx2 = list[slot(base + 3 * stride)];
+            } else {
+                entry(base + 2 * stride, pos_nx, dead_nx);
+            }
+        }
+        if (++pass == KM_EPOCH_PASSES && base + stride < M) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
     }
 #if KM_PROFILE
     if (threadIdx.x % 64 == 0) for (int q = 0; q < 16; ++q) atomicAdd(&km_prof[q], t_acc[q]);
@@ -1388,9 +1469,14 @@ __device__ __forceinline__ double km_pack_centre(int n, const double* __restrict
 // The second wave of block 0 sums the E-step's per-block statistics: inertia (fp64, lane l takes blocks l, l + 64, ...; fixed
 // tree: the same bits for the same launch geometry) into stats[1], changed labels into the tail of red (an integer, so that it
 // takes part in the all-reduce of a sharded run).
+// `tot` (round 4, distance bounds): this rank's own totals, kept from iteration to iteration.  delta = 0: the partials are the sums
+// over ALL samples (tot = their total); delta = 1: the partials are the CHANGES of an E-step that visited only the samples whose
+// bounds failed -- what a sample that moved took from its old cluster and brought to its new one, integers like the sums themselves
+// -- and tot += their total: the same 128-bit integers as a fresh summation, bit for bit.  red = tot either way.
 __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblocks, int n, int k, const u64* __restrict__ partial,
                                                             const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
-                                                            long long* __restrict__ red, double* __restrict__ stats) {
+                                                            long long* __restrict__ red, double* __restrict__ stats, long long* __restrict__ tot,
+                                                            int delta) {
     const int np1 = n + 1;
     const int c = blockIdx.x;
     const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
@@ -1411,6 +1497,10 @@ __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblo
     if (threadIdx.x <= n) {
         __int128 t = 0;
         for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
+        if (tot) {
+            if (delta) t += km_load128(tot + ((int64_t)c * np1 + threadIdx.x) * 2);
+            km_store128(tot + ((int64_t)c * np1 + threadIdx.x) * 2, t);
+        }
         km_store128(red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
     }
     if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
@@ -1435,7 +1525,9 @@ __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblo
 //           of the cluster with the largest count (the first of them: np.argmax), as `_average_centers` does; the hold is lifted.
 __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, const long long* __restrict__ red, const double* __restrict__ fix,
                                                               const double* __restrict__ Cold, double* __restrict__ Cnew, double* __restrict__ Ct,
-                                                              double* __restrict__ stats, double* __restrict__ prm, int mode) {
+                                                              double* __restrict__ stats, double* __restrict__ prm, int mode,
+                                                              float* __restrict__ shiftc /* [k + 4] or nullptr: |c_new - c_old| of every centre, rounded UP; then the
+                                                                 largest, the second largest (over the OTHER centres) and the index of the largest (distance bounds) */) {
     const int np1 = n + 1;
     __shared__ double sh_d[16];
     __shared__ long long sh_cnt[16];
@@ -1498,12 +1590,23 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
     // pass 3: shifts, packed table, finiteness
     double shift2 = 0.0;
     int bad = 0;
+    float m1 = -1.0f, m2 = -1.0f;                      // this thread's largest and second largest shift, and where the largest is
+    int i1 = -1;
+    bool snan = false;
     for (int c = threadIdx.x; c < k; c += 1024) {
         double cc[KM_NMAX];
         for (int j = 0; j < KM_NMAX; ++j) cc[j] = j < n ? Cnew[(int64_t)c * n + j] : 0.0;
         double sh = 0.0;
         for (int j = 0; j < n; ++j) { const double dd = cc[j] - Cold[(int64_t)c * n + j]; sh = fma(dd, dd, sh); }
         shift2 += sh;
+        if (shiftc) {
+            // >= the true shift: sh carries n roundings of 2^-53; NaN (a poisoned centre) stays NaN and fails every bound test
+            const float f = (float)sqrt(sh) * 1.000001f + 1.0e-37f;
+            shiftc[c] = f;
+            if (!(f == f)) snan = true;
+            else if (f > m1) { m2 = m1; m1 = f; i1 = c; }
+            else if (f > m2) m2 = f;
+        }
         const double q = km_pack_centre(n, cc, Ct + (int64_t)c * 16);
         if (!(q - q == 0.0)) bad = 1;
     }
@@ -1516,6 +1619,33 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
         for (int q = 0; q < 16; ++q) { t += sh_d[q]; b |= sh_bad[q]; }
         stats[0] = t;
         prm[2] = b ? 1.0 : 0.0;      // a non-finite centre (NaN / inf data): the candidate filter stands down
+    }
+    if (shiftc) {
+        // the two largest shifts of all centres (kmeans_bounds_kernel: a sample's lower bound gives way by the largest shift among the
+        // OTHER centres): merged over the wave, then over the 16 waves; a NaN shift poisons both
+        for (int off = 32; off > 0; off >>= 1) {
+            const float o1 = __shfl_down(m1, off), o2 = __shfl_down(m2, off);
+            const int oi = __shfl_down(i1, off);
+            if (o1 > m1) { m2 = fmaxf(m1, o2); m1 = o1; i1 = oi; } else m2 = fmaxf(m2, o1);
+        }
+        __shared__ float sh_m1[16], sh_m2[16];
+        __shared__ int sh_i1[16], sh_nan[16];
+        const unsigned long long nanm = __ballot(snan);
+        if (lane == 0) { sh_m1[w] = m1; sh_m2[w] = m2; sh_i1[w] = i1; sh_nan[w] = nanm != 0ull; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a1 = -1.0f, a2 = -1.0f;
+            int ai = -1, an = 0;
+            for (int q = 0; q < 16; ++q) {
+                if (sh_m1[q] > a1) { a2 = fmaxf(a1, sh_m2[q]); a1 = sh_m1[q]; ai = sh_i1[q]; } else a2 = fmaxf(a2, sh_m1[q]);
+                an |= sh_nan[q];
+            }
+            const float nanf_ = __builtin_nanf("");
+            shiftc[k] = an ? nanf_ : fmaxf(a1, 0.0f);
+            shiftc[k + 1] = an ? nanf_ : fmaxf(a2, 0.0f);
+            shiftc[k + 2] = __int_as_float(ai);
+            shiftc[k + 3] = 0.0f;
+        }
     }
 }
 
@@ -1634,6 +1764,9 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 // by index) -- the candidates of a wave whose reference centre is a are a PREFIX of row a of Nk (kmeans_assign_lds_kernel, single-
 // reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 1024 (the
 // range of the kernels that use it).  Bitonic sort in the LDS.
+#ifndef KM_BND_BETA
+#define KM_BND_BETA 0.1                  // the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u instead of 2 u
+#endif
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf) {
     const int a = blockIdx.x;
@@ -1700,6 +1833,99 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
         const float4* src = reinterpret_cast<const float4*>(recs);
         for (int e = threadIdx.x; e < np * 8; e += 256) out[e] = src[e];
     }
+}
+
+// ---- distance bounds (round 4): which samples of the sorted loop need an E-step at all ------------------------------------------------
+// Per position: ub >= d(x, c_a) for the sample's centre a, lb <= d(x, c) for every other centre c -- both left by the last E-step that
+// evaluated the sample (kmeans_assign_lds_kernel, packed-fp32 path: the exact distance to the winner; the loser of the certified
+// pair, the float runner-up with the screening's error, and for the centres outside the scanned prefix the triangle inequality
+// through the reference centre).  After an M-step every centre has moved by shift_c (kmeans_average_kernel):
+//     ub' = ub + shift_a
+//     lb' = lb - max{shift_c : c != a}
+// (Hamerly's bounds.  The largest shift is a single outlying cluster's on the config-3 data, 1.5 % of a cluster radius per iteration
+// at iteration 70 against a median of 0.2 %; restricting it to the K nearest centres of a -- the others held off by the triangle
+// inequality through c_a -- was probed for K = 8 ... 256, alone and all at once, and buys nothing in 12 dimensions with 512
+// centres: the 65th nearest centre of a cluster is hardly farther than its 2nd; tools/hamerly_probe.py.)  While ub' + margin < lb' the sample's
+// nearest centre is still a, by more than the rounding of the E-step's scores: its label -- the full scan's -- cannot change, it keeps
+// its bounds and is skipped.  Everything else goes to the list the next E-step walks: position p, in position order within a tile of
+// 4096 positions, every tile's piece padded to whole waves with ~p of its last entry (a lane that loads the same row and counts for
+// nothing), tiles in the order their blocks finish -- which no result depends on: labels are per sample, the member sums integers.
+// All float operations round away from "skip".  NaN anywhere (a fresh sample, a poisoned centre) fails the test.
+constexpr int KM_BND_TILE = 4096;
+__global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, const int* __restrict__ labels, float* __restrict__ ub, float* __restrict__ lb,
+                                                            const float* __restrict__ shiftc /* [k + 4]: kmeans_average_kernel */,
+                                                            const double* __restrict__ prm, int* __restrict__ list, int* __restrict__ nlist) {
+    if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation
+    const float smax1 = shiftc[k], smax2 = shiftc[k + 1];
+    const int smaxi = __float_as_int(shiftc[k + 2]);
+    __shared__ int buf[KM_BND_TILE + 64];
+    __shared__ int wcnt[4];
+    __shared__ int s_off;
+    const float margin = (float)prm[0] * 1.0001f + 1.0e-37f;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * KM_BND_TILE;
+    int count = 0;
+    // a thread takes four consecutive positions per round (16-byte loads and stores; the arrays are the arena's: aligned)
+    for (int r = 0; r < KM_BND_TILE / 1024; ++r) {
+        const int64_t p0 = base + r * 1024 + threadIdx.x * 4;
+        int a4[4] = {0, 0, 0, 0};
+        float u4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const bool whole = p0 + 3 < N;
+        if (whole) {
+            const int4 av = *reinterpret_cast<const int4*>(labels + p0);
+            const float4 uv = *reinterpret_cast<const float4*>(ub + p0), lv = *reinterpret_cast<const float4*>(lb + p0);
+            a4[0] = av.x; a4[1] = av.y; a4[2] = av.z; a4[3] = av.w;
+            u4[0] = uv.x; u4[1] = uv.y; u4[2] = uv.z; u4[3] = uv.w;
+            l4[0] = lv.x; l4[1] = lv.y; l4[2] = lv.z; l4[3] = lv.w;
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < N) { a4[j] = labels[p0 + j]; u4[j] = ub[p0 + j]; l4[j] = lb[p0 + j]; }
+        }
+        unsigned act = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (p0 + j >= N) continue;
+            bool active = true;
+            const int a = a4[j];
+            if ((unsigned)a < (unsigned)k) {
+                const float u = (u4[j] + shiftc[a]) * 1.0000003f + 1.0e-37f;
+                float l = l4[j] - (a == smaxi ? smax2 : smax1);
+                l = l > 0.0f ? l * 0.9999997f : l;
+                if (u + margin < l) { active = false; u4[j] = u; l4[j] = l; }     // (false for any NaN)
+            }
+            act |= active ? 1u << j : 0u;
+        }
+        if (whole) {
+            if (act != 15u) {                          // (an active sample's bounds stay as they are: its E-step rewrites them)
+                *reinterpret_cast<float4*>(ub + p0) = make_float4(u4[0], u4[1], u4[2], u4[3]);
+                *reinterpret_cast<float4*>(lb + p0) = make_float4(l4[0], l4[1], l4[2], l4[3]);
+            }
+        } else {
+            for (int j = 0; j < 4; ++j)
+                if (p0 + j < N && !((act >> j) & 1u)) { ub[p0 + j] = u4[j]; lb[p0 + j] = l4[j]; }
+        }
+        // ranks in position order: an inclusive scan of the threads' counts over the wave, the waves' totals through the LDS
+        const int cnt = __builtin_popcount(act);
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+        if (lane == 63) wcnt[w] = incl;
+        __syncthreads();
+        int at = count + incl - cnt;
+        for (int q = 0; q < w; ++q) at += wcnt[q];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if ((act >> j) & 1u) buf[at++] = (int)(p0 + j);
+        count += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    if (count == 0) return;                           // (block-uniform)
+    const int padded = (count + 63) & ~63;
+    if (threadIdx.x < padded - count) buf[count + threadIdx.x] = ~buf[count - 1];
+    if (threadIdx.x == 0) s_off = atomicAdd(nlist, padded);
+    __syncthreads();
+    int* out = list + s_off;
+    for (int e = threadIdx.x; e < padded; e += 256) out[e] = buf[e];
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -2382,20 +2608,29 @@ bool kmeans_reads_through_perm(int n, int k, bool scalar_records) { return kmean
 hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean,
                                 const double* c2, int* labels, unsigned long long* partial, double* block_inertia, int* block_changed,
                                 const float* Dc, const double* prm, const double* fix, float* d2out, bool scalar_records, const int* perm,
-                                const unsigned long long* Nk, const float* Pf) {
+                                const unsigned long long* Nk, const float* Pf, const KmBounds* bounds) {
     if (perm && !kmeans_lds_form(n, k, scalar_records)) return hipErrorInvalidValue;      // only the LDS / DPP kernel reads through a permutation
     if (Nk && (!Dc || !kmeans_lds_form(n, k, scalar_records))) return hipErrorInvalidValue;
     if (n > KM_CMAX || (reinterpret_cast<uintptr_t>(c2) & 127) || !prm || !fix) return hipErrorInvalidValue;
+    // distance bounds: only where the packed-fp32 path can leave them (sorted loop, n = 12 / 13, LDS / DPP kernel)
+    if (bounds && (!Pf || !Nk || !perm || (n != 12 && n != 13) || !bounds->ub || !bounds->lb || N >= ((int64_t)1 << 31))) return hipErrorInvalidValue;
+    if (bounds && bounds->use_list && (!bounds->list || !bounds->nlist)) return hipErrorInvalidValue;
     const int blocks = kmeans_blocks(N, n, k, scalar_records);
     const int nep = kmeans_epochs(N, n, k, scalar_records);
     if (kmeans_lds_form(n, k, scalar_records)) {
         const size_t lds2 = (size_t)k * (16 + n + 1) * sizeof(double) + (KM_THREADS / 64) * KM2_LIST * sizeof(unsigned short);   // 133 KB at k = 512, n = 12
-#define KM2_LAUNCH(NS_) do { \
-        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
+        const bool use_list = bounds && bounds->use_list;
+        float* ubo = bounds ? bounds->ub : nullptr;
+        float* lbo = bounds ? bounds->lb : nullptr;
+        const double tscale = bounds ? (1.0 + KM_BND_BETA) * (1.0 + KM_BND_BETA) : 1.0;
+#define KM2_LAUNCH(NS_, LIST_) do { \
+        hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_, LIST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
-        hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
-                           block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk, Nk ? Pf : nullptr); } while (0)
-        if (n == 12) KM2_LAUNCH(12); else if (n == 13) KM2_LAUNCH(13); else KM2_LAUNCH(0);
+        hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_, LIST_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
+                           block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk, Nk ? Pf : nullptr, \
+                           use_list ? bounds->list : nullptr, use_list ? bounds->nlist : nullptr, ubo, lbo, tscale); } while (0)
+        if (use_list) { if (n == 12) KM2_LAUNCH(12, true); else KM2_LAUNCH(13, true); }
+        else if (n == 12) KM2_LAUNCH(12, false); else if (n == 13) KM2_LAUNCH(13, false); else KM2_LAUNCH(0, false);
 #undef KM2_LAUNCH
         return hipGetLastError();
     }
@@ -2450,6 +2685,15 @@ hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, f
     hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf);
     return hipGetLastError();
 }
+size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
+hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
+    if (!b.ub || !b.lb || !b.shiftc || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    hipError_t e = hipMemsetAsync(b.nlist, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(256), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
+                       prm, b.list, b.nlist);
+    return hipGetLastError();
+}
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
     const int64_t need = (N + KM_THREADS - 1) / KM_THREADS;
     const int cap = kmeans_lds_form(n, k, scalar_records) ? KM2_BLOCKS : KM_BLOCKS;
@@ -2458,15 +2702,15 @@ int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
 // M-step, first half: partials (nparts = blocks x epochs tables) -> red [kmeans_red_words] (128-bit totals as int64 limb pairs; tail: changed
 // labels) and stats[1] = inertia.  A sharded run all-reduces red with SUM (int64) before the second half.
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats) {
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats);
+                                const int* block_changed, long long* red, double* stats, long long* tot, int delta) {
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats, tot, delta);
     return hipGetLastError();
 }
 // M-step, second half: red -> Cnew [k][n], c2 (packed table), stats[0] = squared shift against Cold, [2] = changed labels, [3] = empty clusters,
 // prm[2] (non-finite centre), prm[3] (hold); mode: see kmeans_average_kernel
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
-                                 double* c2, double* stats, double* prm, int mode) {
-    hipLaunchKernelGGL(kmeans_average_kernel, dim3(1), dim3(1024), 0, st, n, k, red, fix, Cold, Cnew, c2, stats, prm, mode);
+                                 double* c2, double* stats, double* prm, int mode, float* shiftc) {
+    hipLaunchKernelGGL(kmeans_average_kernel, dim3(1), dim3(1024), 0, st, n, k, red, fix, Cold, Cnew, c2, stats, prm, mode, shiftc);
     return hipGetLastError();
 }
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,

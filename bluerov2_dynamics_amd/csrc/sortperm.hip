@@ -43,13 +43,21 @@ __global__ void __launch_bounds__(256) sort_keys_kernel(int64_t N, const int* __
 
 // position j of the new order = position src[j] of the old one: labels and the permutation to the caller's rows move, the rows
 // themselves stay where they are (perm_old == nullptr: the old order is the caller's)
+// (round 4, distance bounds: three per-position float arrays -- the sort key's distance and the two bounds -- move with the labels: an
+// E-step that visits only the samples whose bounds failed does not rewrite the others')
 __global__ void __launch_bounds__(256) sort_gather_index_kernel(int64_t N, const unsigned* __restrict__ src, const int* __restrict__ labels_old,
-                                                                int* __restrict__ labels_new, const int* __restrict__ perm_old, int* __restrict__ perm_new) {
+                                                                int* __restrict__ labels_new, const int* __restrict__ perm_old, int* __restrict__ perm_new,
+                                                                const float* __restrict__ f0_old, float* __restrict__ f0_new,
+                                                                const float* __restrict__ f1_old, float* __restrict__ f1_new,
+                                                                const float* __restrict__ f2_old, float* __restrict__ f2_new) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
     const int64_t s = src[j];
     labels_new[j] = labels_old[s];
     perm_new[j] = perm_old ? perm_old[s] : (int)s;
+    if (f0_new) f0_new[j] = f0_old[s];
+    if (f1_new) f1_new[j] = f1_old[s];
+    if (f2_new) f2_new[j] = f2_old[s];
 }
 
 __global__ void __launch_bounds__(256) sort_unpermute_kernel(int64_t N, const int* __restrict__ perm, const int* __restrict__ labels_sorted,
@@ -67,13 +75,14 @@ size_t kmeans_sort_temp_bytes(int64_t N) {
 
 hipError_t launch_kmeans_resort(hipStream_t st, int64_t N, const int* labels_old, int* labels_new, const int* perm_old, int* perm_new,
                                 const float* d2, unsigned* keys_in, unsigned* keys_out, unsigned* vals_in, unsigned* vals_out, void* temp,
-                                size_t temp_bytes) {
+                                size_t temp_bytes, float* d2_new, const float* ub_old, float* ub_new, const float* lb_old, float* lb_new) {
     if (N <= 0) return hipSuccess;
     if (N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(sort_keys_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, labels_old, d2, keys_in, vals_in);
     hipError_t e = rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)N, 0, KM_SORT_LABEL_BITS + KM_SORT_DBITS, st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sort_gather_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, vals_out, labels_old, labels_new, perm_old, perm_new);
+    hipLaunchKernelGGL(sort_gather_index_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, N, vals_out, labels_old, labels_new, perm_old, perm_new,
+                       d2, d2_new, ub_old, ub_new, lb_old, lb_new);
     return hipGetLastError();
 }
 

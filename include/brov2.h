@@ -299,6 +299,11 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * LDS / DPP kernel: the same labels, the same centres.
  * Adding 128 switches the packed-fp32 screening off: every candidate is evaluated in fp64 (the form of round 3 / early round 4; for
  * k > 512 the scalar-record kernel in the caller's order): the same labels, the same centres.
+ * Adding 256 switches the distance bounds of the sorted loop off (default on wherever the packed-fp32 screening runs inside the LDS /
+ * DPP kernel: n = 12 or 13, k <= 512, >= 2^18 samples): with them, once few labels change per iteration, an E-step visits only the
+ * samples whose bounds (Hamerly's: distance to the own centre from above, to every other centre from below, moved by the centres'
+ * shifts) cannot rule a change out, and the M-step adds the CHANGES of the integer member sums to the totals it keeps: the same labels,
+ * the same centres bit for bit.
  * Adding 32 sends the seeding of a single rank through the kernels of the sharded run (candidate rows from a table, potentials
  * through the per-rank totals): same indices. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);

@@ -672,7 +672,7 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(21)
     ctxs = []
-    for v in (0, 1, 2, 4, 5, 6, 16, 18, 64, 128):                                 # filter + sorted order, full scan, filter in the caller's order; + 4 scalar records; + 16 mask form only
+    for v in (0, 1, 2, 4, 5, 6, 16, 18, 64, 128, 256):                                 # filter + sorted order, full scan, filter in the caller's order; + 4 scalar records; + 16 mask form only
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
@@ -809,6 +809,52 @@ def test_kmeans_with_more_clusters_than_distinct_points(eng):
             ref = KMeans(n_clusters=k, n_init="auto", random_state=0).fit(X)
         C = eng.kmeans_centers(X, k)
         assert np.array_equal(C, ref.cluster_centers_), (k, float(np.max(np.abs(C - ref.cluster_centers_))))
+
+
+def test_lloyd_distance_bounds_change_nothing(eng, monkeypatch):
+    """The sorted loop's distance bounds (csrc/kmeans.hip: kmeans_bounds_kernel; round 4): once few labels change per iteration an
+    E-step visits only the samples whose bounds fail and the M-step adds the CHANGES of their integer member sums to the totals it
+    keeps.  Labels, centres (bit for bit), iteration count and inertia must be those of the loop without bounds (variant + 256) and
+    of the full scan (variant 5) -- with the list form switched on as early as it can be (BROV2_KM_BOUNDS_RATE = 1: from the first
+    sorted iteration, when most bounds still fail), at its default threshold, over re-sorts, through an empty cluster's relocation
+    (duplicate initial centres) in mid-run, and to convergence (strict: no label changes)."""
+    from bluerov2_dynamics_amd import _lib
+    rng = np.random.default_rng(77)
+    ctxs = []
+    for v in (0, 256, 5):
+        c = _lib.Context(0)
+        c.set_kmeans_variant(v)
+        c.set_kmeans_far_select(False)
+        ctxs.append(c)
+    cases = []
+    for (N, n, k) in ((300000, 12, 256), (280000, 13, 100), (420000, 12, 512)):
+        X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0) + 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))
+        C0 = X[rng.choice(N, k, replace=False)].copy()
+        cases.append((X, C0))
+    X, C0 = cases[0]
+    Cd = C0.copy()
+    Cd[5] = Cd[200] = Cd[17]                          # duplicates: empty clusters in the first iteration -> relocation
+    cases.append((X, Cd))
+    blobs = np.concatenate([rng.normal(m, 0.02, (70000, 12)) for m in rng.normal(0, 1.0, (4, 12))])      # converges (strict) within a few iterations
+    cases.append((blobs[rng.permutation(len(blobs))], blobs[rng.choice(len(blobs), 64, replace=False)].copy()))
+    for ci, (X, C0) in enumerate(cases):
+        mean = X.mean(0)
+        for rate in ("1.0", None):
+            if rate is None:
+                monkeypatch.delenv("BROV2_KM_BOUNDS_RATE", raising=False)
+            else:
+                monkeypatch.setenv("BROV2_KM_BOUNDS_RATE", rate)
+            for max_iter in (9, 60):
+                (Ca, la, ia, na), (Cb, lb_, ib, nb_), (Cc, lc, ic, nc) = [eng.kmeans_lloyd(X, C0 - mean, max_iter=max_iter, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
+                assert na == nb_ == nc, (ci, rate, max_iter, na, nb_, nc)
+                assert np.array_equal(la, lb_) and np.array_equal(la, lc), (ci, rate, max_iter, int(np.sum(la != lb_)), int(np.sum(la != lc)))
+                assert np.array_equal(Ca, Cb) and np.array_equal(Ca, Cc), (ci, rate, max_iter)
+                assert abs(ia - ib) <= 1e-10 * abs(ib) and abs(ia - ic) <= 1e-10 * abs(ic), (ci, rate, max_iter, ia, ib, ic)
+        if ci == 3:
+            assert ctxs[0].kmeans_relocations() > 0
+    monkeypatch.delenv("BROV2_KM_BOUNDS_RATE", raising=False)
+    for c in ctxs:
+        c.close()
 
 
 def test_fit_twice_gives_the_same_bits(eng):

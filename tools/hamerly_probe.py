@@ -49,6 +49,7 @@ def scan(C):
 
 
 betas = (0.0, 0.1, 0.25, 0.5, 1e9)
+KNS = [int(v) for v in os.environ.get("PROBE_KNS", "").split(",") if v]
 KN = int(os.environ.get("PROBE_KN", "0"))       # > 0: the lower bound decays by the largest shift among the KN nearest centres of the sample's own
                                                 # (the others are held off by the triangle inequality through the own centre) instead of the largest of all
 lab, d1, d2 = scan(C)
@@ -65,11 +66,17 @@ for it in range(1, iters + 1):
     pa = p[lab]
     other = torch.where(pa == top[0], top[1], top[0])            # largest shift among the other centres
     far = None
+    multi = []
     if KN > 0:
         Dn, In = torch.sort(torch.cdist(C, C), dim=1)
         m_near = p[In[:, 1:KN + 1]].max(dim=1).values            # per own centre: the largest shift among its KN nearest
         other = m_near[lab]
         far = Dn[:, KN + 1][lab]                                 # distance from the own centre to the first centre outside that set
+    if KNS:
+        # several near sets at once (each gives a valid bound; the sample takes the best), the set of ALL centres among them
+        Dn, In = torch.sort(torch.cdist(C, C), dim=1)
+        for kn in KNS:
+            multi.append((p[In[:, 1:kn + 1]].max(dim=1).values[lab], Dn[:, kn + 1][lab]))
     lab_n, d1, d2 = scan(C)
     changed = (lab_n != lab).float().mean().item() * 100
     da = (Xc - C[lab]).norm(dim=1)                               # exact distance to the old centre (tightening)
@@ -79,6 +86,8 @@ for it in range(1, iters + 1):
         l = lb[b] - other
         if far is not None:
             l = torch.minimum(l, far - u)
+        for (mk, fk) in multi:
+            l = torch.maximum(l, torch.minimum(lb[b] - mk, fk - u))
         f1 = u >= l
         f2 = f1 & (da >= l)
         line += f"  {f1.float().mean().item() * 100:6.2f} / {f2.float().mean().item() * 100:6.2f}"
