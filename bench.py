@@ -102,18 +102,22 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
     for name in ("r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
         try:
             full = json.load(open(os.path.join(REPO, "profiles", name)))
-            d = full["kmeans_assign_lds_kernel<12>"]
+            d = full.get("kmeans_assign") or full["kmeans_assign_lds_kernel<12>"]      # (all launches of the E-step kernel of the recorded loop)
         except Exception:
             continue
         rec = full.get("_kernel_source_sha")
         tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
-        return {"kernel": "kmeans_assign_lds_kernel<12> (+ reduce / average, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf,
+        lst = full.get("kmeans_assign_lds_kernel<12, true>") or {}
+        return {"kernel": "kmeans_assign_lds_kernel<12, LIST> (+ bounds, reduce / average, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf,
+                "list_form_launches_of_recorded_run": lst.get("launches_SQ_INSTS_VALU"), "list_form_valu_instr_per_e_step": lst.get("SQ_INSTS_VALU"),
                 "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
                 "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
                 "source": f"profiles/{name} (rocprofv3 --pmc, recorded run)", "recorded_kernel_source_sha": rec, "current_kernel_source_sha": cur,
                 "stale": (rec != cur) if rec else None, "recorded_launches": d.get("launches"), "timed_iterations": iterations,
                 "note": "every VALU slot priced as an FMA; instruction count = mean over the E-steps of the recorded run of the shipped loop "
-                        "(sorted sample order), time = this run's",
+                        "(sorted sample order; with the distance bounds most E-steps evaluate only the samples whose bounds fail: fewer "
+                        "instructions AND less time than the plain loop -- the fraction says how full the issue slots are, not how much work was avoided), "
+                        "time = this run's",
                 "traffic": ({"bytes_per_e_step": d["hbm_total_GB_per_launch"] * 1e9, "read_GB": d.get("hbm_read_GB_per_launch_corrected_x2"),
                              "write_GB": d.get("hbm_write_GB_per_launch"), "algorithmic_GB": rows * (12 * 8 + 4 + 4 + 4 + 4) / 1e9,
                              "note": "FETCH_SIZE (x 2: the gfx950 correction, profiles/r04_fetch_probe.txt) + WRITE_SIZE per E-step of the recorded run; "

@@ -116,6 +116,7 @@ struct KmBounds {
     const float* shiftc = nullptr;  // [k + 4] from launch_kmeans_average
     int* list = nullptr;            // [kmeans_bounds_list_words(N)]
     int* nlist = nullptr;           // [2]
+    double beta = -1.0;             // >= 0: the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u (default KM_BND_BETA)
     bool use_list = false;          // the E-step visits the list only and its partials are CHANGES (launch_kmeans_reduce: delta)
 };
 size_t kmeans_bounds_list_words(int64_t N);
@@ -138,7 +139,7 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
                                 const int* block_changed, long long* red, double* stats, long long* tot = nullptr, int delta = 0);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
-                                 double* c2, double* stats, double* prm, int mode, float* shiftc = nullptr);
+                                 double* c2, double* stats, double* prm, int mode, float* shiftc = nullptr, int* nlist = nullptr);
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
                                     const int* labels, const int* perm, double* dist_row, int* lab_row);
 

@@ -1712,7 +1712,9 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     int cur = 0, cc = 0;                                // cc: Cb[cc] = the centres the last E-step used
     bool want_sort = false;
     double moved = 0.0;                                 // labels changed since the last sort
-    double sort_moved = KM_SORT_MOVED, sort_rate = KM_SORT_RATE;
+    // (with the distance bounds an E-step visits a fraction of the samples while a sort still handles them all: later sorts -- 0.03: 169 ms per
+    // 300 iterations at 1e7 x 12, k = 512; 0.06: 165; 0.1: 166.5; 0.2: 177.5)
+    double sort_moved = bnd ? 2.0 * KM_SORT_MOVED : KM_SORT_MOVED, sort_rate = KM_SORT_RATE;
     if (const char* e = std::getenv("BROV2_KM_SORT_MOVED")) sort_moved = std::atof(e);      // experiments (tools/time_lloyd_ab.py)
     if (const char* e = std::getenv("BROV2_KM_SORT_RATE")) sort_rate = std::atof(e);
     c->kmeans_relocations = 0;
@@ -1726,6 +1728,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     double bounds_rate = 0.03;                          // list form once at most this share of the labels changed in the last summed iteration
     if (const char* e = std::getenv("BROV2_KM_BOUNDS_RATE")) bounds_rate = std::atof(e);
     const bool bounds_log = std::getenv("BROV2_KM_BOUNDS_LOG") != nullptr;
+    double bounds_beta = -1.0;
+    if (const char* e = std::getenv("BROV2_KM_BOUNDS_BETA")) bounds_beta = std::atof(e);      // experiments (tools/time_lloyd_ab.py)
     const double n_all = (c->km_allreduce && c->km_n_global > 0) ? (double)c->km_n_global : (double)N;
     auto e_step = [&](bool filtered) -> hipError_t {
         if (filtered && pk) {
@@ -1737,7 +1741,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         const bool with_bounds = bnd && filtered && Pc != nullptr;
         e_list = false;
         if (with_bounds) {
-            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.shiftc = shiftc; kb.list = blist; kb.nlist = nlist;
+            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.beta = bounds_beta; kb.shiftc = shiftc; kb.list = blist; kb.nlist = nlist;
             kb.use_list = use_list && bounds_valid;
             if (kb.use_list) {
                 hipError_t e = launch_kmeans_bounds(c->stream, N, k, Lc, kb, prm);
@@ -1753,7 +1757,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     for (it = 1; it <= max_iter; ++it) {
         HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats, tot, e_list ? 1 : 0));
         if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
-        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0, shiftc));
+        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0, shiftc, nlist));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
         if (want_sort) {

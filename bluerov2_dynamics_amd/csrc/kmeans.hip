@@ -1527,7 +1527,8 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
                                                               const double* __restrict__ Cold, double* __restrict__ Cnew, double* __restrict__ Ct,
                                                               double* __restrict__ stats, double* __restrict__ prm, int mode,
                                                               float* __restrict__ shiftc /* [k + 4] or nullptr: |c_new - c_old| of every centre, rounded UP; then the
-                                                                 largest, the second largest (over the OTHER centres) and the index of the largest (distance bounds) */) {
+                                                                 largest, the second largest (over the OTHER centres) and the index of the largest (distance bounds) */,
+                                                              int* __restrict__ nlist /* or nullptr: the counter of kmeans_bounds_kernel's list, zeroed here for the next one */) {
     const int np1 = n + 1;
     __shared__ double sh_d[16];
     __shared__ long long sh_cnt[16];
@@ -1619,6 +1620,7 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
         for (int q = 0; q < 16; ++q) { t += sh_d[q]; b |= sh_bad[q]; }
         stats[0] = t;
         prm[2] = b ? 1.0 : 0.0;      // a non-finite centre (NaN / inf data): the candidate filter stands down
+        if (nlist) { nlist[0] = 0; nlist[1] = 0; }
     }
     if (shiftc) {
         // the two largest shifts of all centres (kmeans_bounds_kernel: a sample's lower bound gives way by the largest shift among the
@@ -1765,7 +1767,7 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 // reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 1024 (the
 // range of the kernels that use it).  Bitonic sort in the LDS.
 #ifndef KM_BND_BETA
-#define KM_BND_BETA 0.1                  // the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u instead of 2 u
+#define KM_BND_BETA 0.06                 // the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u instead of 2 u
 #endif
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf) {
@@ -1865,22 +1867,34 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * KM_BND_TILE;
     int count = 0;
-    // a thread takes four consecutive positions per round (16-byte loads and stores; the arrays are the arena's: aligned)
-    for (int r = 0; r < KM_BND_TILE / 1024; ++r) {
+    // a thread takes four consecutive positions per round (16-byte loads and stores; the arrays are the arena's: aligned); the loads of
+    // all four rounds are requested before the first is worked on
+    constexpr int ROUNDS = KM_BND_TILE / 1024;
+    int A[ROUNDS][4];
+    float U[ROUNDS][4], L[ROUNDS][4];
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
         const int64_t p0 = base + r * 1024 + threadIdx.x * 4;
-        int a4[4] = {0, 0, 0, 0};
-        float u4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, l4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        const bool whole = p0 + 3 < N;
-        if (whole) {
+        if (p0 + 3 < N) {
             const int4 av = *reinterpret_cast<const int4*>(labels + p0);
             const float4 uv = *reinterpret_cast<const float4*>(ub + p0), lv = *reinterpret_cast<const float4*>(lb + p0);
-            a4[0] = av.x; a4[1] = av.y; a4[2] = av.z; a4[3] = av.w;
-            u4[0] = uv.x; u4[1] = uv.y; u4[2] = uv.z; u4[3] = uv.w;
-            l4[0] = lv.x; l4[1] = lv.y; l4[2] = lv.z; l4[3] = lv.w;
+            A[r][0] = av.x; A[r][1] = av.y; A[r][2] = av.z; A[r][3] = av.w;
+            U[r][0] = uv.x; U[r][1] = uv.y; U[r][2] = uv.z; U[r][3] = uv.w;
+            L[r][0] = lv.x; L[r][1] = lv.y; L[r][2] = lv.z; L[r][3] = lv.w;
         } else {
-            for (int j = 0; j < 4; ++j)
-                if (p0 + j < N) { a4[j] = labels[p0 + j]; u4[j] = ub[p0 + j]; l4[j] = lb[p0 + j]; }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool in = p0 + j < N;
+                A[r][j] = in ? labels[p0 + j] : 0; U[r][j] = in ? ub[p0 + j] : 0.0f; L[r][j] = in ? lb[p0 + j] : 0.0f;
+            }
         }
+    }
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int64_t p0 = base + r * 1024 + threadIdx.x * 4;
+        int (&a4)[4] = A[r];
+        float (&u4)[4] = U[r], (&l4)[4] = L[r];
+        const bool whole = p0 + 3 < N;
         unsigned act = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -2622,7 +2636,8 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
         const bool use_list = bounds && bounds->use_list;
         float* ubo = bounds ? bounds->ub : nullptr;
         float* lbo = bounds ? bounds->lb : nullptr;
-        const double tscale = bounds ? (1.0 + KM_BND_BETA) * (1.0 + KM_BND_BETA) : 1.0;
+        const double beta = bounds ? (bounds->beta >= 0.0 ? bounds->beta : KM_BND_BETA) : 0.0;
+        const double tscale = (1.0 + beta) * (1.0 + beta);
 #define KM2_LAUNCH(NS_, LIST_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)kmeans_assign_lds_kernel<NS_, LIST_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2); \
         if (e_ != hipSuccess) return e_; \
@@ -2688,8 +2703,7 @@ hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, f
 size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
     if (!b.ub || !b.lb || !b.shiftc || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
-    hipError_t e = hipMemsetAsync(b.nlist, 0, 2 * sizeof(int), st);
-    if (e != hipSuccess) return e;
+    // (b.nlist was zeroed by the M-step's launch_kmeans_average)
     hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(256), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
                        prm, b.list, b.nlist);
     return hipGetLastError();
@@ -2709,8 +2723,8 @@ hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, 
 // M-step, second half: red -> Cnew [k][n], c2 (packed table), stats[0] = squared shift against Cold, [2] = changed labels, [3] = empty clusters,
 // prm[2] (non-finite centre), prm[3] (hold); mode: see kmeans_average_kernel
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
-                                 double* c2, double* stats, double* prm, int mode, float* shiftc) {
-    hipLaunchKernelGGL(kmeans_average_kernel, dim3(1), dim3(1024), 0, st, n, k, red, fix, Cold, Cnew, c2, stats, prm, mode, shiftc);
+                                 double* c2, double* stats, double* prm, int mode, float* shiftc, int* nlist) {
+    hipLaunchKernelGGL(kmeans_average_kernel, dim3(1), dim3(1024), 0, st, n, k, red, fix, Cold, Cnew, c2, stats, prm, mode, shiftc, nlist);
     return hipGetLastError();
 }
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,

@@ -11,7 +11,9 @@ tools/pmc_pass.sh $out/pmc/sq2 "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE
 tools/pmc_pass.sh $out/pmc/sq3 "SQ_INST_CYCLES_SALU SQ_INST_CYCLES_SMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC SQ_INSTS_FLAT SQ_WAVES_EQ_64" -- $cmd || echo "sq3 failed"
 tools/pmc_pass.sh $out/pmc/sq4 "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_LDS_MEM_VIOLATIONS SQ_LDS_ATOMIC_RETURN" -- $cmd || echo "sq4 failed"
 tools/pmc_pass.sh $out/pmc/sq5 "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_IFETCH" -- $cmd || echo "sq5 failed"
-python3 tools/pmc_summary.py $out/pmc "${KERNEL:-kmeans_assign_lds_kernel<12>}" > $out/pmc_summary.json
+# the E-step kernel: all its launches together (the mean per E-step of the loop: list form, plain form and the first full scan), the two
+# forms apart, and the bounds kernel that makes the list
+python3 tools/pmc_summary.py $out/pmc "${KERNEL:-kmeans_assign_lds_kernel}" "kmeans_assign_lds_kernel<12, true>" "kmeans_assign_lds_kernel<12, false>" kmeans_bounds_kernel > $out/pmc_summary.json
 rm -rf $out/pmc/*/
 python3 - $out/pmc_summary.json <<'PY'
 import json, sys
