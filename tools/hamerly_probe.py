@@ -49,6 +49,7 @@ def scan(C):
 
 
 betas = (0.0, 0.1, 0.25, 0.5, 1e9)
+TOP = int(os.environ.get("PROBE_TOP", "0"))
 KNS = [int(v) for v in os.environ.get("PROBE_KNS", "").split(",") if v]
 KN = int(os.environ.get("PROBE_KN", "0"))       # > 0: the lower bound decays by the largest shift among the KN nearest centres of the sample's own
                                                 # (the others are held off by the triangle inequality through the own centre) instead of the largest of all
@@ -77,6 +78,14 @@ for it in range(1, iters + 1):
         Dn, In = torch.sort(torch.cdist(C, C), dim=1)
         for kn in KNS:
             multi.append((p[In[:, 1:kn + 1]].max(dim=1).values[lab], Dn[:, kn + 1][lab]))
+    top_rule = None
+    if TOP > 0:
+        # the TOP largest shifts apart: such a mover counts for a sample only if it is near the sample's own centre
+        tv, ti = torch.topk(p, TOP + 1)
+        pr = p.clone(); pr[ti[:TOP]] = 0.0
+        m_rest = pr.max()                                           # largest shift among the other centres
+        Dm = torch.cdist(C, C[ti[:TOP]])                            # [k][TOP] distances from every centre to the movers
+        top_rule = (m_rest, tv[:TOP], ti[:TOP], Dm)
     lab_n, d1, d2 = scan(C)
     changed = (lab_n != lab).float().mean().item() * 100
     da = (Xc - C[lab]).norm(dim=1)                               # exact distance to the old centre (tightening)
@@ -88,6 +97,13 @@ for it in range(1, iters + 1):
             l = torch.minimum(l, far - u)
         for (mk, fk) in multi:
             l = torch.maximum(l, torch.minimum(lb[b] - mk, fk - u))
+        if top_rule is not None:
+            m_rest, tv, ti, Dm = top_rule
+            l = lb[b] - m_rest
+            for t in range(TOP):
+                cand = torch.maximum(lb[b] - tv[t], Dm[lab, t] - u)
+                cand = torch.where(lab == ti[t], torch.full_like(cand, float("inf")), cand)
+                l = torch.minimum(l, cand)
         f1 = u >= l
         f2 = f1 & (da >= l)
         line += f"  {f1.float().mean().item() * 100:6.2f} / {f2.float().mean().item() * 100:6.2f}"
