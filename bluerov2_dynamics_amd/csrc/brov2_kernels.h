@@ -113,7 +113,8 @@ hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* 
 struct KmBounds {
     float* ub = nullptr;            // [N] >= distance to the own centre
     float* lb = nullptr;            // [N] <= distance to every other centre
-    const float* shiftc = nullptr;  // [k + 4] from launch_kmeans_average
+    const float* shiftc = nullptr;  // [k + kmeans_bounds_tail()] from launch_kmeans_average
+    const float* mvd = nullptr;     // [k][4] from launch_kmeans_cdist: distances to the centres that moved most
     int* list = nullptr;            // [kmeans_bounds_list_words(N)]
     int* nlist = nullptr;           // [2]
     double beta = -1.0;             // >= 0: the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u (default KM_BND_BETA)
@@ -128,7 +129,9 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
                                 const unsigned long long* Nk = nullptr, const float* Pf = nullptr, const KmBounds* bounds = nullptr);
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr);
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr,
+                               const float* shiftc = nullptr, float* mvd = nullptr);
+int kmeans_bounds_tail();
 // E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
 int kmeans_pk_blocks(int64_t N, int n, int k);
 int kmeans_pk_epochs(int64_t N, int n, int k);

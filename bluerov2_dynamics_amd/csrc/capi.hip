@@ -1644,7 +1644,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) +
-                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 2 * Arena::al((size_t)k * 8) + 1024 : 0) + 8192);
+                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 3 * Arena::al((size_t)k * 16 + 64) + 1024 : 0) + 8192);
     if (rc) return rc;
     unsigned long long* partial = a.take<unsigned long long>(pw_max);
     long long* red = a.take<long long>(rwords);
@@ -1663,7 +1663,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     float* d2 = nullptr;
     float *d2s[2] = {nullptr, nullptr}, *ubs[2] = {nullptr, nullptr}, *lbs[2] = {nullptr, nullptr};      // per position: two copies each, swapped by a re-sort
     long long* tot = nullptr;
-    float* shiftc = nullptr;
+    float *shiftc = nullptr, *mvd = nullptr;
     int *blist = nullptr, *nlist = nullptr;
     unsigned *kin = nullptr, *kout = nullptr, *vin = nullptr, *vout = nullptr;
     void* stmp = nullptr;
@@ -1678,7 +1678,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         for (int q = 0; q < 2; ++q) { ubs[q] = a.take<float>(N); lbs[q] = a.take<float>(N); }
         blist = a.take<int>(lwords);
         tot = a.take<long long>(rwords);
-        shiftc = a.take<float>((size_t)k + 4);
+        shiftc = a.take<float>((size_t)k + kmeans_bounds_tail());
+        mvd = a.take<float>((size_t)k * 4 + 4);
         nlist = a.take<int>(64);
     }
     if (mean_host) {
@@ -1741,7 +1742,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         const bool with_bounds = bnd && filtered && Pc != nullptr;
         e_list = false;
         if (with_bounds) {
-            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.beta = bounds_beta; kb.shiftc = shiftc; kb.list = blist; kb.nlist = nlist;
+            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.beta = bounds_beta; kb.shiftc = shiftc; kb.mvd = mvd; kb.list = blist; kb.nlist = nlist;
             kb.use_list = use_list && bounds_valid;
             if (kb.use_list) {
                 hipError_t e = launch_kmeans_bounds(c->stream, N, k, Lc, kb, prm);
@@ -1776,7 +1777,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             want_sort = false;
             moved = 0.0;
         }
-        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd));
         // hs still holds the statistics of the iteration before this one (the host has not waited yet): few changed labels -> list form
         use_list = bnd && it >= 2 && hs[2] <= bounds_rate * n_all;
         HIPCK(c, e_step(true));
@@ -1789,7 +1790,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
-            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf));
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd));
             bounds_valid = false;                       // relocated centres jumped: a full E-step, whose sums start the totals afresh
             HIPCK(c, e_step(true));
         }

@@ -1516,6 +1516,8 @@ __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblo
     }
 }
 
+constexpr int KM_BND_TOP = 4;                          // movers that kmeans_bounds_kernel takes apart (a float4 of centre distances per cluster)
+constexpr int KM_BND_TAIL = 2 * KM_BND_TOP + 4;
 // New centres from the totals, one block of 1024 threads (thread = centre): mean = total / s_j / count (scikit-learn multiplies by
 // 1 / count: `_average_centers`), NaN for a poisoned cluster; stats[0] = sum of squared centre shifts (fixed tree), stats[2] =
 // changed labels, stats[3] = empty clusters; the packed table Ct; prm[2] != 0 when a centre is not finite.
@@ -1526,8 +1528,8 @@ __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblo
 __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, const long long* __restrict__ red, const double* __restrict__ fix,
                                                               const double* __restrict__ Cold, double* __restrict__ Cnew, double* __restrict__ Ct,
                                                               double* __restrict__ stats, double* __restrict__ prm, int mode,
-                                                              float* __restrict__ shiftc /* [k + 4] or nullptr: |c_new - c_old| of every centre, rounded UP; then the
-                                                                 largest, the second largest (over the OTHER centres) and the index of the largest (distance bounds) */,
+                                                              float* __restrict__ shiftc /* [k + KM_BND_TAIL] or nullptr: |c_new - c_old| of every centre, rounded UP; then the
+                                                                 KM_BND_TOP largest, their centres' indices, and the largest of the rest (distance bounds) */,
                                                               int* __restrict__ nlist /* or nullptr: the counter of kmeans_bounds_kernel's list, zeroed here for the next one */) {
     const int np1 = n + 1;
     __shared__ double sh_d[16];
@@ -1591,8 +1593,6 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
     // pass 3: shifts, packed table, finiteness
     double shift2 = 0.0;
     int bad = 0;
-    float m1 = -1.0f, m2 = -1.0f;                      // this thread's largest and second largest shift, and where the largest is
-    int i1 = -1;
     bool snan = false;
     for (int c = threadIdx.x; c < k; c += 1024) {
         double cc[KM_NMAX];
@@ -1605,8 +1605,6 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
             const float f = (float)sqrt(sh) * 1.000001f + 1.0e-37f;
             shiftc[c] = f;
             if (!(f == f)) snan = true;
-            else if (f > m1) { m2 = m1; m1 = f; i1 = c; }
-            else if (f > m2) m2 = f;
         }
         const double q = km_pack_centre(n, cc, Ct + (int64_t)c * 16);
         if (!(q - q == 0.0)) bad = 1;
@@ -1623,30 +1621,46 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
         if (nlist) { nlist[0] = 0; nlist[1] = 0; }
     }
     if (shiftc) {
-        // the two largest shifts of all centres (kmeans_bounds_kernel: a sample's lower bound gives way by the largest shift among the
-        // OTHER centres): merged over the wave, then over the 16 waves; a NaN shift poisons both
-        for (int off = 32; off > 0; off >>= 1) {
-            const float o1 = __shfl_down(m1, off), o2 = __shfl_down(m2, off);
-            const int oi = __shfl_down(i1, off);
-            if (o1 > m1) { m2 = fmaxf(m1, o2); m1 = o1; i1 = oi; } else m2 = fmaxf(m2, o1);
-        }
-        __shared__ float sh_m1[16], sh_m2[16];
-        __shared__ int sh_i1[16], sh_nan[16];
+        // the KM_BND_TOP largest shifts, whose centres they are, and the largest of the rest (kmeans_bounds_kernel): wave 0 picks them one
+        // after the other from the values the block has just written (equal values: the lower index).  A NaN shift poisons them all.
+        __shared__ int sh_nan[16];
         const unsigned long long nanm = __ballot(snan);
-        if (lane == 0) { sh_m1[w] = m1; sh_m2[w] = m2; sh_i1[w] = i1; sh_nan[w] = nanm != 0ull; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            float a1 = -1.0f, a2 = -1.0f;
-            int ai = -1, an = 0;
-            for (int q = 0; q < 16; ++q) {
-                if (sh_m1[q] > a1) { a2 = fmaxf(a1, sh_m2[q]); a1 = sh_m1[q]; ai = sh_i1[q]; } else a2 = fmaxf(a2, sh_m1[q]);
-                an |= sh_nan[q];
+        if (lane == 0) sh_nan[w] = nanm != 0ull;
+        __syncthreads();                               // (shiftc[0 .. k) is this block's own: visible behind the barrier)
+        if (w == 0) {
+            int an = 0;
+            for (int q = 0; q < 16; ++q) an |= sh_nan[q];
+            int picked[KM_BND_TOP + 1];
+            float pv[KM_BND_TOP + 1];
+#pragma unroll
+            for (int r = 0; r <= KM_BND_TOP; ++r) {
+                float bv = -1.0f;
+                int bi = 0x7fffffff;
+                for (int c = lane; c < k; c += 64) {
+                    bool taken = false;
+#pragma unroll
+                    for (int q = 0; q < r; ++q) taken = taken || picked[q] == c;
+                    const float v = shiftc[c];
+                    if (!taken && v > bv) { bv = v; bi = c; }      // c ascends within a lane: the first of equal values stays
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_down(bv, off);
+                    const int oi = __shfl_down(bi, off);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                picked[r] = __builtin_amdgcn_readfirstlane(bi);
+                pv[r] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bv)));
+                if (picked[r] == 0x7fffffff) { picked[r] = -1; pv[r] = 0.0f; }      // fewer centres than picks
             }
-            const float nanf_ = __builtin_nanf("");
-            shiftc[k] = an ? nanf_ : fmaxf(a1, 0.0f);
-            shiftc[k + 1] = an ? nanf_ : fmaxf(a2, 0.0f);
-            shiftc[k + 2] = __int_as_float(ai);
-            shiftc[k + 3] = 0.0f;
+            if (lane == 0) {
+                const float nanf_ = __builtin_nanf("");
+#pragma unroll
+                for (int r = 0; r < KM_BND_TOP; ++r) {
+                    shiftc[k + r] = an ? nanf_ : pv[r];
+                    shiftc[k + KM_BND_TOP + r] = __int_as_float(picked[r]);
+                }
+                shiftc[k + 2 * KM_BND_TOP] = an ? nanf_ : pv[KM_BND_TOP];
+            }
         }
     }
 }
@@ -1770,9 +1784,22 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 #define KM_BND_BETA 0.06                 // the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u instead of 2 u
 #endif
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
-                                                           unsigned long long* __restrict__ Nk, float* __restrict__ Pf) {
+                                                           unsigned long long* __restrict__ Nk, float* __restrict__ Pf,
+                                                           const float* __restrict__ shiftc, float* __restrict__ mvd) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
+    if (mvd && threadIdx.x < KM_BND_TOP) {
+        // distance bounds: from this centre to the KM_BND_TOP centres that moved most (kmeans_average_kernel), rounded DOWN
+        const int c = __float_as_int(shiftc[k + KM_BND_TOP + threadIdx.x]);
+        float v = __builtin_inff();                    // no such mover: it constrains nothing
+        if ((unsigned)c < (unsigned)k) {
+            double q = 0.0;
+            for (int j = 0; j < n; ++j) { const double d = Ct[a * 16 + j] - Ct[c * 16 + j]; q = fma(d, d, q); }
+            v = (float)(sqrt(q) * 0.999999);
+            v = v > 0.0f ? v * 0.9999999f : v;
+        }
+        mvd[a * KM_BND_TOP + threadIdx.x] = v;
+    }
     __shared__ unsigned long long keys[1024];
     const bool sorting = Nk != nullptr && kp <= 1024;
     for (int c = threadIdx.x; c < kp; c += 256) {
@@ -1843,8 +1870,9 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
 // pair, the float runner-up with the screening's error, and for the centres outside the scanned prefix the triangle inequality
 // through the reference centre).  After an M-step every centre has moved by shift_c (kmeans_average_kernel):
 //     ub' = ub + shift_a
-//     lb' = lb - max{shift_c : c != a}
-// (Hamerly's bounds.  The largest shift is a single outlying cluster's on the config-3 data, 1.5 % of a cluster radius per iteration
+//     lb' = min( lb - (largest shift but the KM_BND_TOP largest),  min over those movers t != a of  max(lb - shift_t, d(c_a, c_t) - ub') )
+// (Hamerly's bounds with the few largest movers taken apart: such a centre has come closer by its own shift -- unless it is far from
+// the sample's own centre NOW, and then it is at least d(c_a, c_t) - ub' away whatever it did.  The largest shift is a single outlying cluster's on the config-3 data, 1.5 % of a cluster radius per iteration
 // at iteration 70 against a median of 0.2 %; restricting it to the K nearest centres of a -- the others held off by the triangle
 // inequality through c_a -- was probed for K = 8 ... 256, alone and all at once, and buys nothing in 12 dimensions with 512
 // centres: the 65th nearest centre of a cluster is hardly farther than its 2nd; tools/hamerly_probe.py.)  While ub' + margin < lb' the sample's
@@ -1855,11 +1883,16 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
 // All float operations round away from "skip".  NaN anywhere (a fresh sample, a poisoned centre) fails the test.
 constexpr int KM_BND_TILE = 4096;
 __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, const int* __restrict__ labels, float* __restrict__ ub, float* __restrict__ lb,
-                                                            const float* __restrict__ shiftc /* [k + 4]: kmeans_average_kernel */,
+                                                            const float* __restrict__ shiftc /* [k + KM_BND_TAIL]: kmeans_average_kernel */,
+                                                            const float* __restrict__ mvd /* [k][KM_BND_TOP]: kmeans_cdist_kernel */,
                                                             const double* __restrict__ prm, int* __restrict__ list, int* __restrict__ nlist) {
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation
-    const float smax1 = shiftc[k], smax2 = shiftc[k + 1];
-    const int smaxi = __float_as_int(shiftc[k + 2]);
+    float mv_s[KM_BND_TOP];
+    int mv_c[KM_BND_TOP];
+#pragma unroll
+    for (int t = 0; t < KM_BND_TOP; ++t) { mv_s[t] = shiftc[k + t]; mv_c[t] = __float_as_int(shiftc[k + KM_BND_TOP + t]); }
+    const float m_rest = shiftc[k + 2 * KM_BND_TOP];
+    const bool poisoned = !(m_rest == m_rest);         // a NaN shift (kmeans_average_kernel sets them all): every sample is evaluated
     __shared__ int buf[KM_BND_TILE + 64];
     __shared__ int wcnt[4];
     __shared__ int s_off;
@@ -1903,9 +1936,16 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
             const int a = a4[j];
             if ((unsigned)a < (unsigned)k) {
                 const float u = (u4[j] + shiftc[a]) * 1.0000003f + 1.0e-37f;
-                float l = l4[j] - (a == smaxi ? smax2 : smax1);
+                // every centre but the movers gives way by at most m_rest; mover t by its own shift -- or it is far from c_a NOW
+                float l = l4[j] - m_rest;
+                const float4 dm = *reinterpret_cast<const float4*>(mvd + a * KM_BND_TOP);
+                const float dmv[KM_BND_TOP] = {dm.x, dm.y, dm.z, dm.w};
+#pragma unroll
+                for (int t = 0; t < KM_BND_TOP; ++t)
+                    if (a != mv_c[t]) l = fminf(l, fmaxf(l4[j] - mv_s[t], dmv[t] - u));
                 l = l > 0.0f ? l * 0.9999997f : l;
-                if (u + margin < l) { active = false; u4[j] = u; l4[j] = l; }     // (false for any NaN)
+                // (fminf / fmaxf drop a NaN operand: a sample without bounds, a poisoned shift must not slip through them)
+                if (!poisoned && l4[j] == l4[j] && u + margin < l) { active = false; u4[j] = u; l4[j] = l; }
             }
             act |= active ? 1u << j : 0u;
         }
@@ -2695,17 +2735,20 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
 #undef PK_LAUNCH
     return hipGetLastError();
 }
-hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf) {
+hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf, const float* shiftc,
+                               float* mvd) {
     if (Pf && (!Nk || n > KM_PK_NMAX)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf);
+    if (mvd && !shiftc) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd);
     return hipGetLastError();
 }
+int kmeans_bounds_tail() { return KM_BND_TAIL; }
 size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
-    if (!b.ub || !b.lb || !b.shiftc || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    if (!b.ub || !b.lb || !b.shiftc || !b.mvd || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     // (b.nlist was zeroed by the M-step's launch_kmeans_average)
     hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(256), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
-                       prm, b.list, b.nlist);
+                       b.mvd, prm, b.list, b.nlist);
     return hipGetLastError();
 }
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {

@@ -33,6 +33,10 @@ N = Xc.shape[0]
 x2 = (Xc * Xc).sum(dim=1)
 
 
+SECOND = torch.empty(Xc.shape[0], dtype=torch.int64, device=dev)      # id of the second closest centre, distance to the third (last scan)
+THIRD = torch.empty(Xc.shape[0], dtype=torch.float64, device=dev)
+
+
 def scan(C):
     """labels, distance to the closest and second closest centre"""
     lab = torch.empty(N, dtype=torch.int64, device=dev)
@@ -41,10 +45,12 @@ def scan(C):
     c2 = (C * C).sum(dim=1)
     for s in range(0, N, 1 << 20):
         D = (x2[s:s + (1 << 20), None] + c2[None, :] - 2.0 * (Xc[s:s + (1 << 20)] @ C.T)).clamp_min_(0.0)
-        v, i = torch.topk(D, 2, dim=1, largest=False)
+        v, i = torch.topk(D, 3, dim=1, largest=False)
         lab[s:s + (1 << 20)] = i[:, 0]
         d1[s:s + (1 << 20)] = v[:, 0].sqrt()
         d2[s:s + (1 << 20)] = v[:, 1].sqrt()
+        SECOND[s:s + (1 << 20)] = i[:, 1]
+        THIRD[s:s + (1 << 20)] = v[:, 2].sqrt()
     return lab, d1, d2
 
 
@@ -56,6 +62,10 @@ KN = int(os.environ.get("PROBE_KN", "0"))       # > 0: the lower bound decays by
 lab, d1, d2 = scan(C)
 ub = {b: d1.clone() for b in betas}
 lb = {b: torch.minimum(d2, (1.0 + 2.0 * b) * d1) for b in betas}
+# two lower bounds (PROBE_ELKAN=1): l1 for the runner-up alone (gives way by ITS shift), l2 for all the others (by the largest shift)
+ELKAN = os.environ.get("PROBE_ELKAN") == "1"
+if ELKAN:
+    e_u, e_l1, e_b, e_l2 = d1.clone(), d2.clone(), SECOND.clone(), torch.minimum(THIRD, 1.12 * d1 + 0 * d1 + 1e9)
 print("iter changed%  " + "  ".join(f"b={b:g}: fail% / after-tighten%" for b in betas), flush=True)
 for it in range(1, iters + 1):
     sums = torch.zeros((k, n), dtype=torch.float64, device=dev).index_add_(0, lab, Xc)
@@ -113,6 +123,17 @@ for it in range(1, iters + 1):
             line += f" (!{wrong})"
         ub[b] = torch.where(f2, d1, torch.where(f1, da, u))
         lb[b] = torch.where(f2, torch.minimum(d2, (1.0 + 2.0 * b) * d1), l)
+    if ELKAN:
+        u = e_u + pa
+        l1 = e_l1 - p[e_b]
+        l2 = e_l2 - top[0]
+        f1 = u >= torch.minimum(l1, l2)
+        wrong = ((~f1) & (lab_n != lab)).sum().item()
+        line += f"   two bounds: fail {f1.float().mean().item() * 100:6.2f} %" + (f" (!{wrong})" if wrong else "")
+        e_u = torch.where(f1, d1, u)
+        e_l1 = torch.where(f1, d2, l1)
+        e_b = torch.where(f1, SECOND, e_b)
+        e_l2 = torch.where(f1, THIRD, l2)
     print(line + f"   max shift {top[0].item():.2e}  median shift {p.median().item():.2e}  median r {d1.median().item():.2e}", flush=True)
     lab = lab_n
 # candidates a scan radius costs: centres within 2 (1 + beta) r of the sample's own centre
