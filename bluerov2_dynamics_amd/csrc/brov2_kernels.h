@@ -140,7 +140,8 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
                                    int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
                                    const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf);
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats, long long* tot = nullptr, int delta = 0);
+                                const int* block_changed, long long* red, double* stats, long long* tot = nullptr, int delta = 0,
+                                const int* nlist = nullptr);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
                                  double* c2, double* stats, double* prm, int mode, float* shiftc = nullptr, int* nlist = nullptr);
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,

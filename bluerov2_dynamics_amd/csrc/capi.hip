@@ -1756,7 +1756,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                                     with_bounds ? &kb : nullptr);
     };
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats, tot, e_list ? 1 : 0));
+        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats, tot, e_list ? 1 : 0, nlist));
         if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
         HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0, shiftc, nlist));
         HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));

@@ -1089,7 +1089,14 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         block_changed[blockIdx.x] = ch;
     }
     km_flush(sums, partial, ep, k, n, false);
-    km_zero_epochs(partial, ep + 1, nepochs, k, n);
+    if constexpr (LIST) {
+        // only the epochs the longest-running block reaches: kmeans_reduce_kernel derives the same number from the list's length
+        const int64_t passes = (M + stride - 1) / stride;
+        const int used = (int)((passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES);
+        km_zero_epochs(partial, ep + 1, used < nepochs ? (used > 1 ? used : 1) : nepochs, k, n);
+    } else {
+        km_zero_epochs(partial, ep + 1, nepochs, k, n);
+    }
 }
 
 // ---- E-step, third form (round 4): candidates screened in PACKED fp32, the exact arithmetic only for the winner ------------------
@@ -1476,8 +1483,15 @@ __device__ __forceinline__ double km_pack_centre(int n, const double* __restrict
 __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblocks, int n, int k, const u64* __restrict__ partial,
                                                             const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
                                                             long long* __restrict__ red, double* __restrict__ stats, long long* __restrict__ tot,
-                                                            int delta) {
+                                                            int delta, const int* __restrict__ nlist, int span) {
     const int np1 = n + 1;
+    if (nlist) {
+        // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
+        const int64_t passes = ((int64_t)nlist[0] + span - 1) / span;
+        const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
+        const int tables = nblocks * (int)(used > 1 ? used : 1);
+        nparts = tables < nparts ? tables : nparts;
+    }
     const int c = blockIdx.x;
     const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
     __shared__ long long part[16][17][2];
@@ -2759,8 +2773,9 @@ int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
 // M-step, first half: partials (nparts = blocks x epochs tables) -> red [kmeans_red_words] (128-bit totals as int64 limb pairs; tail: changed
 // labels) and stats[1] = inertia.  A sharded run all-reduces red with SUM (int64) before the second half.
 hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats, long long* tot, int delta) {
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats, tot, delta);
+                                const int* block_changed, long long* red, double* stats, long long* tot, int delta, const int* nlist) {
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats, tot, delta,
+                       delta ? nlist : nullptr, nblocks * KM_THREADS);
     return hipGetLastError();
 }
 // M-step, second half: red -> Cnew [k][n], c2 (packed table), stats[0] = squared shift against Cold, [2] = changed labels, [3] = empty clusters,
