@@ -118,6 +118,10 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
                         "(sorted sample order; with the distance bounds most E-steps evaluate only the samples whose bounds fail: fewer "
                         "instructions AND less time than the plain loop -- the fraction says how full the issue slots are, not how much work was avoided), "
                         "time = this run's",
+                "algorithmic": {"flop_per_sample": 2.0 * kk * 12, "unit": "TFLOP/s", "achieved": rows * 2.0 * kk * 12 / (ms_per_step * 1e-3) / 1e12,
+                                "note": "the reference's E-step (scikit-learn: one N x k x n product per iteration) / this run's time per E + M step -- "
+                                        "credit for the candidate filter, the packed-fp32 screening and the distance bounds, NOT a roofline "
+                                        "fraction (exceeds the fp64 peak: most of that arithmetic is never done; labels are the full scan's)"},
                 "traffic": ({"bytes_per_e_step": d["hbm_total_GB_per_launch"] * 1e9, "read_GB": d.get("hbm_read_GB_per_launch_corrected_x2"),
                              "write_GB": d.get("hbm_write_GB_per_launch"), "algorithmic_GB": rows * (12 * 8 + 4 + 4 + 4 + 4) / 1e9,
                              "note": "FETCH_SIZE (x 2: the gfx950 correction, profiles/r04_fetch_probe.txt) + WRITE_SIZE per E-step of the recorded run; "
