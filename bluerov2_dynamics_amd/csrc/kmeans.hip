@@ -598,11 +598,6 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     // M: the positions this launch walks (LIST: the entries of the list, whole waves); a slot beyond the end repeats the last one
     const int64_t M = LIST ? (int64_t)nlist[0] : N;
     auto slot = [&](int64_t base) { const int64_t i = base + threadIdx.x; return i < M ? i : M - 1; };
-    // position of a slot (LIST: through the list; ~p marks padding)
-    auto position = [&](int64_t base) -> int64_t {
-        if constexpr (LIST) { const int e = list[slot(base)]; return (int64_t)(e < 0 ? ~e : e); }
-        else return slot(base);
-    };
     auto load_rows = [&](int64_t ii, int prow, double (&xr)[NX], int& lab) {
         const double* row = X + (perm ? (int64_t)prow : ii) * xstride;
         if (vec) {
@@ -1508,7 +1503,7 @@ __global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblo
     part[sr][j][0] = (long long)(a >> 64);
     part[sr][j][1] = (long long)(u64)a;
     __syncthreads();
-    if (threadIdx.x <= n) {
+    if ((int)threadIdx.x <= n) {
         __int128 t = 0;
         for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
         if (tot) {
@@ -1989,7 +1984,7 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     }
     if (count == 0) return;                           // (block-uniform)
     const int padded = (count + 63) & ~63;
-    if (threadIdx.x < padded - count) buf[count + threadIdx.x] = ~buf[count - 1];
+    if ((int)threadIdx.x < padded - count) buf[count + threadIdx.x] = ~buf[count - 1];
     if (threadIdx.x == 0) s_off = atomicAdd(nlist, padded);
     __syncthreads();
     int* out = list + s_off;
@@ -2231,7 +2226,7 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
     }
     __syncthreads();
-    if (threadIdx.x <= PP_LMAX && (threadIdx.x < L || threadIdx.x == PP_LMAX)) {
+    if ((int)threadIdx.x <= PP_LMAX && ((int)threadIdx.x < L || (int)threadIdx.x == PP_LMAX)) {
         double a = 0.0;
         for (int w = 0; w < BT / 64; ++w) a += red[w][threadIdx.x];
         S[(int64_t)threadIdx.x * nchunks + blockIdx.x] = a;
