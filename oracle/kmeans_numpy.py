@@ -211,3 +211,26 @@ def lloyd_fixed_point(X, C0, max_iter=300, tol_abs=0.0, allreduce=None, far_rows
             break
         labels_old = labels
     return C, e_step(X, C), n_iter, nreloc
+
+
+# ---- distance bounds of the sorted loop (csrc/kmeans.hip: kmeans_bounds_kernel, round 4), restated for a property test ----------------
+BND_TOP = 4          # movers taken apart (kmeans.hip: KM_BND_TOP)
+
+
+def bounds_step(ub, lb, labels, C_old, C_new):
+    """One M-step's effect on Hamerly's bounds, as the device applies it: ub >= d(x, c_a) grows by the own centre's shift; lb <= d(x, c)
+    for every other centre gives way by the largest shift among the centres that are not among the BND_TOP largest movers, and for
+    each of those movers t != a by its own shift -- unless the mover is far from the sample's own centre NOW:
+        lb' = min(lb - m_rest, min_t max(lb - shift_t, d(c_a', c_t') - ub')).
+    Returns (ub', lb').  (Exact arithmetic here; the device rounds every step away from "skip".)"""
+    shift = np.sqrt(((C_new - C_old) ** 2).sum(axis=1))
+    order = np.argsort(-shift, kind="stable")
+    movers = order[:BND_TOP]
+    m_rest = shift[order[BND_TOP]] if len(shift) > BND_TOP else 0.0
+    ubn = ub + shift[labels]
+    lbn = lb - m_rest
+    for t in movers:
+        dm = np.sqrt(((C_new[labels] - C_new[t]) ** 2).sum(axis=1))
+        cand = np.maximum(lb - shift[t], dm - ubn)
+        lbn = np.where(labels == t, lbn, np.minimum(lbn, cand))
+    return ubn, lbn

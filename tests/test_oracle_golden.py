@@ -287,3 +287,40 @@ def test_kmeans_oracle_restates_sklearns_empty_cluster_rules():
     mean = X.mean(0)
     C, lab, _, n_iter, nrel = kn.lloyd(X - mean, C0 - mean, 300, 1e-4 * np.mean(np.var(X, axis=0)))
     assert n_iter == km.n_iter_ and nrel >= 1 and np.array_equal(lab, km.labels_) and np.max(np.abs(C + mean - km.cluster_centers_)) < 1e-12
+
+
+def test_distance_bounds_never_hide_a_label_change():
+    """The rule kmeans_bounds_kernel applies between two E-steps (csrc/kmeans.hip, round 4; restated in oracle/kmeans_numpy.py:
+    bounds_step): starting from exact bounds, moved through ten M-steps WITHOUT re-evaluation, the upper bound stays above the true
+    distance to the sample's centre and the lower bound below the true distance to every other centre -- so a sample the rule
+    would skip (ub < lb) has the label the full scan gives.  Random data, several seeds; the samples the rule skips are counted so
+    that the test cannot pass vacuously."""
+    from oracle import kmeans_numpy as kn
+    skipped = 0
+    for seed in range(4):
+        rng = np.random.default_rng(seed)
+        n, k, N = (5, 24, 4000) if seed % 2 == 0 else (12, 40, 6000)
+        X = np.cumsum(rng.normal(0, 0.05, (N, n)), 0)
+        X -= X.mean(0)
+        C = X[rng.choice(N, k, replace=False)].copy()
+        for _ in range(4):                              # a few iterations first: later shifts are of a realistic size
+            C, _ = kn.m_step(X, C, kn.e_step(X, C))
+        lab = kn.e_step(X, C)
+        D = np.sqrt(((X[:, None, :] - C[None, :, :]) ** 2).sum(-1))
+        ub = D[np.arange(N), lab].copy()
+        Dm = D.copy(); Dm[np.arange(N), lab] = np.inf
+        lb = Dm.min(axis=1)
+        labels0 = lab.copy()                            # the bounds refer to THESE labels throughout
+        for it in range(10):
+            C_new, _ = kn.m_step(X, C, kn.e_step(X, C))
+            ub, lb = kn.bounds_step(ub, lb, labels0, C, C_new)
+            C = C_new
+            D = np.sqrt(((X[:, None, :] - C[None, :, :]) ** 2).sum(-1))
+            own = D[np.arange(N), labels0]
+            Dm = D.copy(); Dm[np.arange(N), labels0] = np.inf
+            assert np.all(ub >= own - 1e-12), (seed, it, float(np.max(own - ub)))
+            assert np.all(lb <= Dm.min(axis=1) + 1e-12), (seed, it, float(np.max(lb - Dm.min(axis=1))))
+            safe = ub < lb
+            assert np.array_equal(kn.e_step(X, C)[safe], labels0[safe]), (seed, it)
+            skipped += int(safe.sum())
+    assert skipped > 10000
