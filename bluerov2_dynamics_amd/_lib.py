@@ -316,7 +316,9 @@ class Context:
         self.check(self.lib.edmdc_lift_cache(self.h, c_void_p(device_ptr or 0), int(nbytes if device_ptr else 0)), "edmdc_lift_cache")
 
     def set_kmeans_variant(self, variant: int):
-        """Lloyd's loop: 0 = candidate filter on sorted samples (default), 1 = full scan, 2 = filter without sorting (include/brov2.h)."""
+        """Lloyd's loop: 0 = candidate filter on sorted samples, packed-fp32 screening and distance bounds (default), 1 = full scan,
+        2 = filter without sorting; + 4 / 16 / 64 / 128 / 256 select the independent second implementations and switch the screening
+        (128) or the bounds (256) off, + 8 / 32 concern the seeding -- all with the same labels and centres (include/brov2.h)."""
         self.check(self.lib.edmdc_set_kmeans_variant(self.h, int(variant)), "edmdc_set_kmeans_variant")
 
     def set_kmeans_far_select(self, numpy_rule: bool):

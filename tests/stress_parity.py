@@ -237,8 +237,9 @@ def applies():
 
 
 def lloyds():
-    """Lloyd with the per-wave candidate filter (LDS / DPP kernel, sorted private copy from 2^18 samples on) == Lloyd with the full
-    scan in the scalar-record kernel: identical labels and iteration counts."""
+    """Lloyd with the per-wave candidate filter (LDS / DPP kernel; from 2^18 samples on the sorted order, the packed-fp32 screening and
+    the distance bounds -- BROV2_KM_BOUNDS_RATE=1 in the environment forces their list form from the first sorted iteration) == Lloyd
+    with the full scan in the scalar-record kernel == the mask form without screening: identical labels, iteration counts, centres."""
     n, ties, t0 = 0, 0, time.time()
     ctxs = []
     for v in (0, 5, 16 + 128):
