@@ -86,15 +86,29 @@ class KoopmanEDMDc:
         self.lift_dim_ = self.state_dim + self.centers_.shape[0]
 
     def fit_multi(self, X_list, U_list, centers=None) -> None:
-        """Fit from several independent trajectories without cross-bag transitions (reference :113-152)."""
+        """Fit from several independent trajectories without cross-bag transitions (reference :113-152).  The list may be ragged
+        (any lengths; bags with fewer than two states contribute no pair, :131-132, but their states are clustered, :125).
+        The whole list is uploaded ONCE, bag by bag into one device buffer (engine.upload_bags: no stacked copy on the host); k-means,
+        the ragged Gram (edmdc_gram_ragged_dev) and the solve run on that resident copy, whatever the number of bags."""
         assert len(X_list) == len(U_list) and len(X_list) > 0
+        n, r = self.state_dim, self.input_dim
         for X, U in zip(X_list, U_list):
-            assert X.shape[1] == self.state_dim and U.shape[1] == self.input_dim
-        if centers is None:
-            X_all = np.vstack([X for X in X_list if len(X) > 0])
-            centers = _kmeans_centers(X_all, self.n_rbfs, self.kmeans)
-        self.centers_ = np.asarray(centers, dtype=float)
-        self._solve(list(X_list), list(U_list))
+            assert X.shape[1] == n and U.shape[1] == r
+        ctx = engine.default_context()
+        Xd, Ud, off = engine.upload_bags(X_list, U_list, n, r, ctx=ctx)
+        lens = np.diff(off)
+        if off[-1] == 0 or not (lens >= 2).any():
+            # np.vstack of an empty list (reference :125 when every bag is empty, :140 when no bag holds a pair)
+            raise ValueError("need at least one array to concatenate")
+        if centers is None and self.kmeans == "sklearn":
+            centers = _kmeans_centers(Xd.cpu().numpy(), self.n_rbfs, "sklearn")
+        import torch
+        Cd = None if centers is None else torch.from_numpy(np.ascontiguousarray(np.asarray(centers, dtype=float))).to(Xd.device)
+        k = self.n_rbfs if centers is None else Cd.shape[0]
+        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 0, 0, k, self.gamma, self.ridge, order="fit_multi", centers=Cd, ctx=ctx, pinv=self.pinv,
+                                             bag_offsets=off)
+        self.centers_ = C.cpu().numpy() if centers is None else np.asarray(centers, dtype=float)
+        self.lift_dim_ = self.state_dim + self.centers_.shape[0]
 
     def _solve(self, X_list, U_list, fit_order=False):
         GtG, GtY, _ = engine.gram(X_list, U_list, self.centers_, self.gamma)

@@ -112,6 +112,15 @@ SIGNATURES = {
                                   i64, i64, i64, i64, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
     "edmdc_gram_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                       i64, i64, i64, i64, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "edmdc_gram_ragged": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                         i64, c_void_p, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "edmdc_gram_ragged_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                             i64, c_void_p, c_void_p, c_void_p, ctypes.c_int, c_void_p, c_void_p]),
+    "edmdc_pinv_apply_ragged": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                               i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edmdc_pinv_apply_ragged_dev": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                                   i64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "brov_upload_bags": (ctypes.c_int, [c_void_p, i64, c_void_p, c_void_p, c_void_p, ctypes.c_int, c_void_p]),
     "edmdc_set_chunk_rows": (ctypes.c_int, [c_void_p, i64]),
     "edmdc_kmeans_lloyd": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, ctypes.c_int, c_void_p, c_void_p, c_void_p, ctypes.c_int,
                                           ctypes.c_double, c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int)]),

@@ -52,9 +52,13 @@ hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma
 // Device-native lifted rows for `rows` consecutive state rows starting at global row `row0`
 // (bag structure: state row index = b * xs + t, t in [0, L]; input row = b * us + t, t < L).
 // Rows >= total_rows (and gap rows t > L) are written as zeros with weight 0.
+// pairflag != nullptr: ragged bags -- X / U hold the bags' rows one after the other (U row-aligned with X), pairflag[g] = 1 when rows
+// (g, g + 1) belong to one bag (launch_bag_pairflags); pass xs > total_rows and L = xs - 1.
 hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double gamma, const double* C,
                                   int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
-                                  const double* X, const double* U, double* Zrows, double* wrow);
+                                  const double* X, const double* U, double* Zrows, double* wrow, const unsigned char* pairflag = nullptr);
+// pairflag[g] = 1 for every row g < total_rows that has a successor in its own bag: bag b = rows [offsets[b], offsets[b + 1])
+hipError_t launch_bag_pairflags(hipStream_t st, int64_t nbags, const int64_t* d_offsets, int64_t total_rows, unsigned char* pairflag);
 // Gram task table (device copy owned by the ctx) and sizes.
 // partial: [ntasks][nslab][24 tiles][64 lanes][4] doubles.
 // mode 0: tasks of G^T[G|Y]; mode 1: tasks of W^T Y (edmdc_pinv_apply)

@@ -2,6 +2,7 @@
 // ZOH discretisation, host<->device staging around the kernels of rollout.hip / edmdc.hip /
 // controls.hip / propagate.hip.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include <new>
 #include <string>
 #include <ctime>
+#include <thread>
 #include <vector>
 
 #include "../../include/brov2.h"
@@ -48,7 +50,7 @@ struct brov_ctx {
     char* lift_cache = nullptr;   // caller-owned device buffer (edmdc_lift_cache), nullptr = off
     size_t lift_cache_cap = 0;
     bool lift_cache_valid = false;
-    struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; } lift_key = {};
+    struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; uint64_t bag_hash; } lift_key = {};
     int kmeans_variant = 0;       // Lloyd: 0 = candidate filter on sorted samples, 1 = full scan, 2 = filter in the caller's order; + 4 = scalar-record kernel
     int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
     void* d_tasks[3] = {nullptr, nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply), [2] G^T G alone
@@ -64,6 +66,9 @@ struct brov_ctx {
     double* h_io = nullptr;           // pinned, device-mapped staging of the per-call entry points (brov_rhs / brov_thruster_forces with a
     double* d_io = nullptr;           // handful of vehicles): the kernel reads and writes host memory, no copy calls; d_io = its device alias
     unsigned long long io_seq = 0;    // sequence number of the last per-call launch (completion flags at the end of the staging block)
+    char* h_stage[2] = {nullptr, nullptr};        // pinned staging blocks of brov_upload_bags (created on first use)
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};  // "the DMA that read block i has finished"
+    int upload_threads = 0;                       // host threads packing a block (0 = not probed yet)
     double* h_stats = nullptr;        // pinned: per-iteration statistics of the Lloyd loop come back while the next E-step runs
     hipEvent_t ev_stats = nullptr;
     brov_far_select_fn far_select = nullptr;      // rows an empty cluster is relocated to (edmdc_set_kmeans_far_select); nullptr = descending selection
@@ -153,6 +158,12 @@ struct LiftCacheDisarm {
     explicit LiftCacheDisarm(brov_ctx* ctx) : c(ctx) { c->lift_cache_valid = false; }
     ~LiftCacheDisarm() { c->lift_cache_valid = false; }
 };
+
+// ... and the same holds for buffers that come from brov_malloc (the Python host paths stage their lists there): freeing or
+// overwriting one through this library while it is a key of the armed cache disarms it.
+static void lift_cache_touch(brov_ctx* c, const void* p) {
+    if (c->lift_cache_valid && p && (p == c->lift_key.X || p == c->lift_key.U || p == c->lift_key.C)) c->lift_cache_valid = false;
+}
 
 // ---- small dense helpers (host, fp64) -------------------------------------------------------
 void matmul(int n, const double* A, const double* B, double* C) {
@@ -485,6 +496,10 @@ void brov_destroy(brov_ctx* c) {
     if (c->ev_stats) (void)hipEventDestroy(c->ev_stats);
     if (c->h_stats) (void)hipHostFree(c->h_stats);
     if (c->h_io) (void)hipHostFree(c->h_io);
+    for (int i = 0; i < 2; ++i) {
+        if (c->h_stage[i]) (void)hipHostFree(c->h_stage[i]);
+        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
+    }
     for (int i = 0; i < 3; ++i) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
         if (c->side[i]) (void)hipStreamDestroy(c->side[i]);
@@ -584,12 +599,14 @@ int brov_malloc(brov_ctx* c, size_t bytes, void** dptr) {
 int brov_free(brov_ctx* c, void* dptr) {
     if (!c) return BROV_ERR_ARG;
     DeviceGuard g(c);
+    lift_cache_touch(c, dptr);
     if (dptr) HIPCK(c, hipFree(dptr));
     return BROV_OK;
 }
 int brov_memcpy_h2d(brov_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return BROV_ERR_ARG;
     DeviceGuard g(c);
+    lift_cache_touch(c, dst);
     HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
@@ -604,7 +621,120 @@ int brov_memcpy_d2h(brov_ctx* c, void* dst, const void* src, size_t bytes) {
 int brov_memset(brov_ctx* c, void* dst, int value, size_t bytes) {
     if (!c || (bytes && !dst)) return BROV_ERR_ARG;
     DeviceGuard g(c);
+    lift_cache_touch(c, dst);
     HIPCK(c, hipMemsetAsync(dst, value, bytes, c->stream));
+    return BROV_OK;
+}
+
+// ---- a list of host arrays into one device buffer (fit_multi's X_list / U_list) ------------------------------------------------
+// The reference stacks its trajectory list on the host (np.vstack, Koopman/koopmanEDMDc.py:125,140-142).  Here every bag goes
+// straight to its place in ONE device buffer: a few host threads pack the bags into a pinned block while the DMA engine moves the
+// block before it (two blocks in flight), so the list costs about one pass of host memcpy instead of a stack + a pageable upload.
+constexpr size_t UPLOAD_BLOCK = (size_t)32 << 20;       // bytes per pinned staging block
+constexpr size_t UPLOAD_GAP_MAX = 4096;                 // a hole of at most this many bytes between two bags' destinations is zero-filled
+constexpr size_t UPLOAD_DIRECT_MIN = (size_t)16 << 20;  // a contiguous run this long skips the staging block (the runtime pins it in place)
+
+static int upload_thread_count() {
+    unsigned hc = std::thread::hardware_concurrency();
+    int n = hc ? (int)hc : 1;
+    // containers: the cgroup quota, not the host's core count, is what this process may use
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        long long per = 0;
+        if (std::fscanf(f, "%63s %lld", q, &per) == 2 && std::strcmp(q, "max") != 0 && per > 0) {
+            const long long qq = std::atoll(q);
+            if (qq > 0) { const int lim = (int)((qq + per / 2) / per); if (lim >= 1 && lim < n) n = lim; }
+        }
+        std::fclose(f);
+    }
+    if (n > 6) n = 6;                                   // the copy is memory-bound: more threads add nothing
+    return n < 1 ? 1 : n;
+}
+
+int brov_upload_bags(brov_ctx* c, int64_t nbags, const double* const* bag_ptrs, const int64_t* bag_rows, const int64_t* dst_rows,
+                     int cols, double* d_dst) {
+    if (!c || nbags < 0 || cols < 1 || (nbags && (!bag_ptrs || !bag_rows || !dst_rows || !d_dst)))
+        return fail(c, BROV_ERR_ARG, "brov_upload_bags: bad argument");
+    struct Piece { const char* src; size_t bytes; size_t dst; };        // dst = byte offset in d_dst
+    std::vector<Piece> pieces;
+    pieces.reserve((size_t)nbags);
+    const size_t rowb = (size_t)cols * 8;
+    for (int64_t b = 0; b < nbags; ++b) {
+        if (bag_rows[b] < 0 || dst_rows[b] < 0) return fail(c, BROV_ERR_ARG, "brov_upload_bags: negative row count or offset");
+        if (bag_rows[b] == 0) continue;
+        if (!bag_ptrs[b]) return fail(c, BROV_ERR_ARG, "brov_upload_bags: null bag");
+        const Piece pc = {reinterpret_cast<const char*>(bag_ptrs[b]), (size_t)bag_rows[b] * rowb, (size_t)dst_rows[b] * rowb};
+        if (!pieces.empty()) {
+            Piece& q = pieces.back();
+            if (pc.dst < q.dst + q.bytes) return fail(c, BROV_ERR_ARG, "brov_upload_bags: destinations must ascend without overlap");
+            if (q.src + q.bytes == pc.src && q.dst + q.bytes == pc.dst) { q.bytes += pc.bytes; continue; }   // views of one array
+        }
+        pieces.push_back(pc);
+    }
+    if (pieces.empty()) return BROV_OK;
+    DeviceGuard g(c);
+    lift_cache_touch(c, d_dst);
+    for (int i = 0; i < 2; ++i) {
+        if (!c->h_stage[i]) HIPCK(c, hipHostMalloc((void**)&c->h_stage[i], UPLOAD_BLOCK, hipHostMallocDefault));
+        if (!c->ev_stage[i]) HIPCK(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+    }
+    if (c->upload_threads == 0) c->upload_threads = upload_thread_count();
+    // a block = consecutive (parts of) pieces whose destinations are contiguous up to small holes: one DMA per block
+    struct Part { const char* src; size_t bytes; size_t at; };          // at = offset in the staging block; src == nullptr: zeros
+    std::vector<Part> parts;
+    size_t ip = 0, done_in_piece = 0;
+    int slot = 0;
+    bool used[2] = {false, false};
+    while (ip < pieces.size()) {
+        if (done_in_piece == 0 && pieces[ip].bytes >= UPLOAD_DIRECT_MIN) {     // e.g. a list of views that tile one big array
+            HIPCK(c, hipMemcpyAsync(reinterpret_cast<char*>(d_dst) + pieces[ip].dst, pieces[ip].src, pieces[ip].bytes, hipMemcpyHostToDevice, c->stream));
+            ++ip;
+            continue;
+        }
+        parts.clear();
+        const size_t dst0 = pieces[ip].dst + done_in_piece;
+        size_t fill = 0;
+        while (ip < pieces.size() && fill < UPLOAD_BLOCK) {
+            const Piece& pc = pieces[ip];
+            if (done_in_piece == 0 && pc.bytes >= UPLOAD_DIRECT_MIN && fill > 0) break;     // goes direct, after this block
+            const size_t want_at = pc.dst + done_in_piece - dst0;      // where this piece's next byte belongs in the block
+            if (want_at > fill) {                                       // a hole before it
+                if (want_at - fill > UPLOAD_GAP_MAX || want_at >= UPLOAD_BLOCK) break;
+                parts.push_back({nullptr, want_at - fill, fill});
+                fill = want_at;
+            }
+            const size_t take = std::min(pc.bytes - done_in_piece, UPLOAD_BLOCK - fill);
+            parts.push_back({pc.src + done_in_piece, take, fill});
+            fill += take;
+            done_in_piece += take;
+            if (done_in_piece == pc.bytes) { ++ip; done_in_piece = 0; }
+        }
+        char* stage = c->h_stage[slot];
+        if (used[slot]) HIPCK(c, hipEventSynchronize(c->ev_stage[slot]));      // the DMA that last read this block
+        // pack: the parts are cut into equal byte ranges, one per thread
+        const int nt = (fill >= ((size_t)4 << 20)) ? c->upload_threads : 1;
+        auto pack = [&](size_t lo, size_t hi) {
+            for (const Part& pt : parts) {
+                const size_t a0 = std::max(lo, pt.at), a1 = std::min(hi, pt.at + pt.bytes);
+                if (a0 >= a1) continue;
+                if (pt.src) std::memcpy(stage + a0, pt.src + (a0 - pt.at), a1 - a0);
+                else std::memset(stage + a0, 0, a1 - a0);
+            }
+        };
+        if (nt <= 1) pack(0, fill);
+        else {
+            std::vector<std::thread> th;
+            const size_t per = ((fill + nt - 1) / nt + 63) & ~(size_t)63;
+            for (int t = 1; t < nt; ++t) th.emplace_back(pack, std::min(fill, per * t), std::min(fill, per * (t + 1)));
+            pack(0, std::min(fill, per));
+            for (auto& t : th) t.join();
+        }
+        HIPCK(c, hipMemcpyAsync(reinterpret_cast<char*>(d_dst) + dst0, stage, fill, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, hipEventRecord(c->ev_stage[slot], c->stream));
+        used[slot] = true;
+        slot ^= 1;
+    }
+    HIPCK(c, hipStreamSynchronize(c->stream));      // the staging blocks may be reused by the next call; the data is in place on return
     return BROV_OK;
 }
 
@@ -1012,19 +1142,65 @@ static int ensure_partial(brov_ctx* c, size_t pdoubles) {
     return BROV_OK;
 }
 
-int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
-                   int64_t xs, int64_t us, const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
-    int rc = edmdc_shape_ok(c, n, r, k);
-    if (rc) return rc;
-    if (nbags < 0 || L < 0 || !d_C || !d_GtG || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
-        return fail(c, BROV_ERR_ARG, "edmdc_gram_dev: bad argument");
+// How the rows of X / U split into bags.  Uniform: nbags bags of L pairs, bag b = state rows b xs .. b xs + L and input rows
+// b us .. b us + L - 1 (edmdc_gram_dev).  Ragged: the bags' rows one after the other, bag b = rows offsets[b] .. offsets[b + 1] - 1 of X
+// and of U (row-aligned: U's row at the last state of a bag is never read, the `U[:-1]` of Koopman/koopmanEDMDc.py:138) -- the trajectory
+// list fit_multi takes (edmdc_gram_ragged_dev).  Either way a lifted chunk is `chunk` consecutive rows and a pair never crosses a bag.
+struct BagLayout {
+    int64_t nbags = 0, L = 0, xs = 0, us = 0;
+    int64_t total_rows = 0;
+    const int64_t* offsets_host = nullptr;      // ragged: [nbags + 1], validated by bag_layout_ragged
+    uint64_t hash = 0;                          // ragged: fingerprint of the offsets (part of the lift-cache key)
+    bool ragged() const { return offsets_host != nullptr; }
+    size_t scratch_bytes() const { return ragged() ? Arena::al((size_t)(nbags + 1) * 8) + Arena::al((size_t)total_rows + 16) : 0; }
+};
+
+static void bag_layout_uniform(int64_t nbags, int64_t L, int64_t xs, int64_t us, BagLayout* bl) {
+    if (nbags <= 1) { xs = L + 1; us = L; }
+    bl->nbags = nbags; bl->L = L; bl->xs = xs; bl->us = us;
+    bl->total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+}
+
+static int bag_layout_ragged(brov_ctx* c, int64_t nbags, const int64_t* off, BagLayout* bl, const char* who) {
+    if (nbags < 0 || !off) return fail(c, BROV_ERR_ARG, std::string(who) + ": bad bag list");
+    if (off[0] != 0) return fail(c, BROV_ERR_ARG, std::string(who) + ": bag_offsets[0] must be 0");
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t b = 0; b <= nbags; ++b) {
+        if (b && off[b] < off[b - 1]) return fail(c, BROV_ERR_ARG, std::string(who) + ": bag_offsets must not decrease");
+        h = (h ^ (uint64_t)off[b]) * 1099511628211ull;
+    }
+    bl->nbags = nbags;
+    bl->xs = (int64_t)1 << 62;                  // one "bag" longer than any data: every row below total_rows is a state row,
+    bl->L = bl->xs - 1;                         // the pair flags say where the real bags end
+    bl->us = 0;
+    bl->total_rows = off[nbags];
+    bl->offsets_host = off;
+    bl->hash = h | 1;
+    return BROV_OK;
+}
+
+// the pair flags of a ragged bag list in the call's arena (nullptr for a uniform layout)
+static int bag_pairflags(brov_ctx* c, Arena& a, const BagLayout& bl, const unsigned char** out) {
+    *out = nullptr;
+    if (!bl.ragged()) return BROV_OK;
+    int64_t* d_off = a.take<int64_t>((size_t)bl.nbags + 1);
+    unsigned char* pf = a.take<unsigned char>((size_t)bl.total_rows + 16);
+    HIPCK(c, hipMemcpyAsync(d_off, bl.offsets_host, (size_t)(bl.nbags + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, launch_bag_pairflags(c->stream, bl.nbags, d_off, bl.total_rows, pf));
+    HIPCK(c, hipStreamSynchronize(c->stream));  // the offsets are the caller's (host) array: it may go away when the call returns
+    *out = pf;
+    return BROV_OK;
+}
+
+static int gram_core(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, const BagLayout& bl,
+                     const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
     const int mode = d_GtY ? 0 : 2;                     // no G^T Y wanted (fit()'s Gram pass): the staircase over the G tiles alone
     DeviceGuard g(c);
     const EdmdcShape s = edmdc_shape(n, r, k);
-    rc = ensure_tasks(c, s, mode);
+    int rc = ensure_tasks(c, s, mode);
     if (rc) return rc;
-    if (nbags <= 1) { xs = L + 1; us = L; }
-    const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t L = bl.L, xs = bl.xs, us = bl.us;
+    const int64_t total_rows = bl.total_rows;
     const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;   // rows that can start a pair
     int nslab = 0, ntasks = 0;
     const size_t pdoubles = gram_partial_doubles(s, mode, &ntasks, &nslab);
@@ -1034,10 +1210,13 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
     if (chunk > (total_pairs_rows + 3) / 4 * 4) chunk = (total_pairs_rows + 3) / 4 * 4;
     if (chunk < 4) chunk = 4;
     Arena a(c);
-    rc = a.reserve(Arena::al((size_t)(chunk + 8) * s.width * 8) + Arena::al((chunk + 8) * 8));
+    rc = a.reserve(Arena::al((size_t)(chunk + 8) * s.width * 8) + Arena::al((chunk + 8) * 8) + bl.scratch_bytes());
     if (rc) return rc;
     double* dZ = a.take<double>((size_t)(chunk + 8) * s.width);
     double* dw = a.take<double>(chunk + 8);
+    const unsigned char* pf = nullptr;
+    rc = bag_pairflags(c, a, bl, &pf);
+    if (rc) return rc;
     // lifted-row cache (edmdc_lift_cache): when every chunk of this call fits, lift straight into the cache slots
     c->lift_cache_valid = false;
     const int64_t nchunks = total_pairs_rows > 0 ? (total_pairs_rows + chunk - 1) / chunk : 0;
@@ -1054,16 +1233,39 @@ int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double*
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
         double* z = caching ? reinterpret_cast<double*>(c->lift_cache + (size_t)ci * slot) : dZ;
         double* w = caching ? z + (size_t)(chunk + 8) * s.width : dw;
-        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w));
+        HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w, pf));
         HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[mode], c->d_tasks[mode], npairs, z, z, w, c->d_partial, first ? 0 : 1));
         first = 0;
     }
     if (caching) {
-        c->lift_key = {d_X, d_U, d_C, n, r, k, gamma, nbags, L, xs, us, chunk};
+        c->lift_key = {d_X, d_U, d_C, n, r, k, gamma, bl.nbags, L, xs, us, chunk, bl.hash};
         c->lift_cache_valid = true;
     }
     HIPCK(c, launch_gram_finish_tasks(c->stream, s, c->ntasks[mode], c->d_tasks[mode], c->d_partial, accumulate, d_GtG, d_GtY));
     return BROV_OK;
+}
+
+int edmdc_gram_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
+                   int64_t xs, int64_t us, const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !d_C || !d_GtG || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_gram_dev: bad argument");
+    BagLayout bl;
+    bag_layout_uniform(nbags, L, xs, us, &bl);
+    return gram_core(c, n, r, k, gamma, d_C, bl, d_X, d_U, accumulate, d_GtG, d_GtY);
+}
+
+int edmdc_gram_ragged_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, const int64_t* bag_offsets,
+                          const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (!d_C || !d_GtG) return fail(c, BROV_ERR_ARG, "edmdc_gram_ragged_dev: bad argument");
+    BagLayout bl;
+    rc = bag_layout_ragged(c, nbags, bag_offsets, &bl, "edmdc_gram_ragged_dev");
+    if (rc) return rc;
+    if (bl.total_rows > 1 && (!d_X || (r && !d_U))) return fail(c, BROV_ERR_ARG, "edmdc_gram_ragged_dev: bad argument");
+    return gram_core(c, n, r, k, gamma, d_C, bl, d_X, d_U, accumulate, d_GtG, d_GtY);
 }
 
 int edmdc_gram_decomposition(int n, int r, int k, int* ntasks, int* nslabs) {
@@ -1144,18 +1346,15 @@ int edmdc_set_apply_variant(brov_ctx* c, int variant) {
 }
 
 // ---- fit()'s own association: M = (P G^T) Y  (Koopman/koopmanEDMDc.py:97) ------------------------------------------
-int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
-                         int64_t xs, int64_t us, const double* d_X, const double* d_U, const double* P_host, double* d_M) {
-    int rc = edmdc_shape_ok(c, n, r, k);
-    if (rc) return rc;
-    if (nbags < 0 || L < 0 || !d_C || !P_host || !d_M || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
-        return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_dev: bad argument");
+static int apply_core(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, const BagLayout& bl,
+                      const double* d_X, const double* d_U, const double* P_host, double* d_M) {
+    int rc = BROV_OK;
     DeviceGuard g(c);
     const EdmdcShape s = edmdc_shape(n, r, k);
     rc = ensure_tasks(c, s, 1);
     if (rc) return rc;
-    if (nbags <= 1) { xs = L + 1; us = L; }
-    const int64_t total_rows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
+    const int64_t nbags = bl.nbags, L = bl.L, xs = bl.xs, us = bl.us;
+    const int64_t total_rows = bl.total_rows;
     const int64_t total_pairs_rows = total_rows > 0 ? total_rows - 1 : 0;
     int nslab = 0, ntasks = 0;
     const size_t pdoubles = gram_partial_doubles(s, 1, &ntasks, &nslab);
@@ -1166,12 +1365,15 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
     if (chunk < 4) chunk = 4;
     const int W = s.width;
     Arena a(c);
-    rc = a.reserve(2 * Arena::al((size_t)(chunk + 8) * W * 8) + Arena::al((chunk + 8) * 8) + Arena::al((size_t)(W + 8) * W * 8));
+    rc = a.reserve(2 * Arena::al((size_t)(chunk + 8) * W * 8) + Arena::al((chunk + 8) * 8) + Arena::al((size_t)(W + 8) * W * 8) + bl.scratch_bytes());
     if (rc) return rc;
     double* dZ = a.take<double>((size_t)(chunk + 8) * W);
     double* dWr = a.take<double>((size_t)(chunk + 8) * W);
     double* dw = a.take<double>(chunk + 8);
     double* dPt = a.take<double>((size_t)(W + 8) * W);      // 8 rows of padding: wrows_kernel prefetches two K-steps past the last feature
+    const unsigned char* pf = nullptr;
+    rc = bag_pairflags(c, a, bl, &pf);
+    if (rc) return rc;
     {   // PdT[f][j] = P[ref(j)][ref(f)]: P^T permuted to the device feature order, zero for padding features
         std::vector<double> h((size_t)(W + 8) * W, 0.0);
         const int p = s.p;
@@ -1190,7 +1392,7 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
     // the lifted rows edmdc_gram_dev left in the cache for exactly these arguments (edmdc_lift_cache): no second lift
     const brov_ctx::LiftKey& lk = c->lift_key;
     const bool cached = c->lift_cache_valid && lk.X == d_X && lk.U == d_U && lk.C == d_C && lk.n == n && lk.r == r && lk.k == k &&
-                        lk.gamma == gamma && lk.nbags == nbags && lk.L == L && lk.xs == xs && lk.us == us && lk.chunk == chunk;
+                        lk.gamma == gamma && lk.nbags == nbags && lk.L == L && lk.xs == xs && lk.us == us && lk.chunk == chunk && lk.bag_hash == bl.hash;
     const size_t slot = lift_slot_bytes(chunk, W);
     CallTimer t(c);
     if (total_pairs_rows == 0) HIPCK(c, hipMemsetAsync(c->d_partial, 0, pdoubles * 8, c->stream));
@@ -1201,7 +1403,7 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
         const int64_t rows_lift = (npairs + 3) / 4 * 4 + 1;
         double* z = cached ? reinterpret_cast<double*>(c->lift_cache + (size_t)ci * slot) : dZ;
         double* w = cached ? z + (size_t)(chunk + 8) * W : dw;
-        if (!cached) HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w));
+        if (!cached) HIPCK(c, launch_lift_rows_total(c->stream, s, gamma, d_C, r0, rows_lift, total_rows, L, xs, us, d_X, d_U, z, w, pf));
         HIPCK(c, launch_rows_times_pt(c->stream, s, rows_lift, z, dPt, dWr, c->apply_variant));
         HIPCK(c, launch_gram_chunk_tasks(c->stream, s, c->ntasks[1], c->d_tasks[1], npairs, dWr, z, w, c->d_partial, first ? 0 : 1));
         first = 0;
@@ -1210,16 +1412,35 @@ int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const d
     return BROV_OK;
 }
 
-int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
-                     const double* X, const double* U, const double* P, double* M) {
+int edmdc_pinv_apply_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, int64_t L,
+                         int64_t xs, int64_t us, const double* d_X, const double* d_U, const double* P_host, double* d_M) {
     int rc = edmdc_shape_ok(c, n, r, k);
     if (rc) return rc;
-    if (nbags < 0 || L < 0 || !C || !P || !M || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply: bad argument");
+    if (nbags < 0 || L < 0 || !d_C || !P_host || !d_M || (nbags && L && (!d_X || (r && !d_U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_dev: bad argument");
+    BagLayout bl;
+    bag_layout_uniform(nbags, L, xs, us, &bl);
+    return apply_core(c, n, r, k, gamma, d_C, bl, d_X, d_U, P_host, d_M);
+}
+
+int edmdc_pinv_apply_ragged_dev(brov_ctx* c, int n, int r, int k, double gamma, const double* d_C, int64_t nbags, const int64_t* bag_offsets,
+                                const double* d_X, const double* d_U, const double* P_host, double* d_M) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (!d_C || !P_host || !d_M) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_ragged_dev: bad argument");
+    BagLayout bl;
+    rc = bag_layout_ragged(c, nbags, bag_offsets, &bl, "edmdc_pinv_apply_ragged_dev");
+    if (rc) return rc;
+    if (bl.total_rows > 1 && (!d_X || (r && !d_U))) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_ragged_dev: bad argument");
+    return apply_core(c, n, r, k, gamma, d_C, bl, d_X, d_U, P_host, d_M);
+}
+
+// host forms: the arrays are staged in device allocations of their own for the duration of the call
+static int apply_host(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const BagLayout& bl, int64_t urows,
+                      const double* X, const double* U, const double* P, double* M) {
     DeviceGuard g(c);
     LiftCacheDisarm disarm(c);
-    if (nbags <= 1) { xs = L + 1; us = L; }
-    const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
-    const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
+    const int64_t xrows = bl.total_rows;
     const int d = n + k, p = d + r;
     double *dX = nullptr, *dU = nullptr, *dC = nullptr, *dM = nullptr;
     auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dC); (void)hipFree(dM); };
@@ -1232,7 +1453,7 @@ int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const doubl
     if (urows && r) HIPCK_CLEAN(hipMemcpyAsync(dU, U, (size_t)urows * r * 8, hipMemcpyHostToDevice, c->stream));
     HIPCK_CLEAN(hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
     HIPCK_CLEAN(hipMemsetAsync(dM, 0, (size_t)p * d * 8, c->stream));
-    rc = edmdc_pinv_apply_dev(c, n, r, k, gamma, dC, nbags, L, xs, us, dX, dU, P, dM);
+    int rc = apply_core(c, n, r, k, gamma, dC, bl, dX, dU, P, dM);
     if (rc) { cleanup(); return rc; }
     HIPCK_CLEAN(hipMemcpyAsync(M, dM, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK_CLEAN(hipStreamSynchronize(c->stream));
@@ -1240,18 +1461,36 @@ int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const doubl
     return BROV_OK;
 }
 
-int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
-               const double* X, const double* U, int accumulate, double* GtG, double* GtY) {
+int edmdc_pinv_apply(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
+                     const double* X, const double* U, const double* P, double* M) {
     int rc = edmdc_shape_ok(c, n, r, k);
     if (rc) return rc;
-    if (nbags < 0 || L < 0 || !C || !GtG || !GtY || (nbags && L && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_gram: bad argument");
+    if (nbags < 0 || L < 0 || !C || !P || !M || (nbags && L && (!X || (r && !U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply: bad argument");
+    BagLayout bl;
+    bag_layout_uniform(nbags, L, xs, us, &bl);
+    return apply_host(c, n, r, k, gamma, C, bl, nbags > 0 ? (nbags - 1) * bl.us + L : 0, X, U, P, M);
+}
+
+int edmdc_pinv_apply_ragged(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, const int64_t* bag_offsets,
+                            const double* X, const double* U, const double* P, double* M) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (!C || !P || !M) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_ragged: bad argument");
+    BagLayout bl;
+    rc = bag_layout_ragged(c, nbags, bag_offsets, &bl, "edmdc_pinv_apply_ragged");
+    if (rc) return rc;
+    if (bl.total_rows > 1 && (!X || (r && !U))) return fail(c, BROV_ERR_ARG, "edmdc_pinv_apply_ragged: bad argument");
+    return apply_host(c, n, r, k, gamma, C, bl, bl.total_rows, X, U, P, M);
+}
+
+static int gram_host(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const BagLayout& bl, int64_t urows,
+                     const double* X, const double* U, int accumulate, double* GtG, double* GtY) {
     DeviceGuard g(c);
     LiftCacheDisarm disarm(c);
-    if (nbags <= 1) { xs = L + 1; us = L; }
-    const int64_t xrows = nbags > 0 ? (nbags - 1) * xs + L + 1 : 0;
-    const int64_t urows = nbags > 0 ? (nbags - 1) * us + L : 0;
+    const int64_t xrows = bl.total_rows;
     const int d = n + k, p = d + r;
-    // inputs live in plain device allocations (the arena is used by edmdc_gram_dev itself)
+    // inputs live in plain device allocations (the arena is used by gram_core itself)
     double *dX = nullptr, *dU = nullptr, *dC = nullptr, *dG = nullptr, *dY = nullptr;
     auto cleanup = [&]() { (void)hipFree(dX); (void)hipFree(dU); (void)hipFree(dC); (void)hipFree(dG); (void)hipFree(dY); };
     HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)(xrows > 0 ? xrows : 1) * n * 8));
@@ -1269,13 +1508,36 @@ int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, 
         HIPCK_CLEAN(hipMemsetAsync(dG, 0, (size_t)p * p * 8, c->stream));
         HIPCK_CLEAN(hipMemsetAsync(dY, 0, (size_t)p * d * 8, c->stream));
     }
-    rc = edmdc_gram_dev(c, n, r, k, gamma, dC, nbags, L, xs, us, dX, dU, accumulate, dG, dY);
+    int rc = gram_core(c, n, r, k, gamma, dC, bl, dX, dU, accumulate, dG, dY);
     if (rc) { cleanup(); return rc; }
     HIPCK_CLEAN(hipMemcpyAsync(GtG, dG, (size_t)p * p * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK_CLEAN(hipMemcpyAsync(GtY, dY, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCK_CLEAN(hipStreamSynchronize(c->stream));
     cleanup();
     return BROV_OK;
+}
+
+int edmdc_gram(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, int64_t L, int64_t xs, int64_t us,
+               const double* X, const double* U, int accumulate, double* GtG, double* GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (nbags < 0 || L < 0 || !C || !GtG || !GtY || (nbags && L && (!X || (r && !U))) || (nbags > 1 && (xs < L + 1 || us < L)))
+        return fail(c, BROV_ERR_ARG, "edmdc_gram: bad argument");
+    BagLayout bl;
+    bag_layout_uniform(nbags, L, xs, us, &bl);
+    return gram_host(c, n, r, k, gamma, C, bl, nbags > 0 ? (nbags - 1) * bl.us + L : 0, X, U, accumulate, GtG, GtY);
+}
+
+int edmdc_gram_ragged(brov_ctx* c, int n, int r, int k, double gamma, const double* C, int64_t nbags, const int64_t* bag_offsets,
+                      const double* X, const double* U, int accumulate, double* GtG, double* GtY) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (!C || !GtG || !GtY) return fail(c, BROV_ERR_ARG, "edmdc_gram_ragged: bad argument");
+    BagLayout bl;
+    rc = bag_layout_ragged(c, nbags, bag_offsets, &bl, "edmdc_gram_ragged");
+    if (rc) return rc;
+    if (bl.total_rows > 1 && (!X || (r && !U))) return fail(c, BROV_ERR_ARG, "edmdc_gram_ragged: bad argument");
+    return gram_host(c, n, r, k, gamma, C, bl, bl.total_rows, X, U, accumulate, GtG, GtY);
 }
 
 // ---- lifted propagation: evaluate / multistep_rmse / simulate ---------------------------------------

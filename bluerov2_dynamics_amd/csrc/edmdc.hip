@@ -257,7 +257,10 @@ constexpr int LIFT_TAIL_BLOCK = 256;
 __global__ void __launch_bounds__(LIFT_TAIL_BLOCK) lift_tail_kernel(EdmdcShape s, int64_t row0, int64_t rows, int64_t total_rows, int64_t L,
                                                                    int64_t xs_, int64_t us, const double* __restrict__ X,
                                                                    const double* __restrict__ U, double* __restrict__ Zrows,
-                                                                   double* __restrict__ wrow) {
+                                                                   double* __restrict__ wrow, const unsigned char* __restrict__ pf) {
+    // pf != nullptr: ragged bags (fit_multi's trajectory list, Koopman/koopmanEDMDc.py:129-138).  X and U are the bags' rows one after
+    // the other, U row-aligned with X, pf[g] = 1 when rows (g, g + 1) are a pair of one bag; the host passes xs_ > total_rows and
+    // L = xs_ - 1, so that every row below total_rows is a state row of "bag 0".
     const int n = s.n, W = s.width;
     constexpr int RT = 64;                             // rows per block
     const int64_t l0 = (int64_t)blockIdx.x * RT;
@@ -273,30 +276,50 @@ __global__ void __launch_bounds__(LIFT_TAIL_BLOCK) lift_tail_kernel(EdmdcShape s
             // (bag, step) of this row from the block's first row: at most a few wraps per 64 rows
             int64_t tt = t + (l - l0), bb = bag;
             while (tt >= xs_) { tt -= xs_; ++bb; }
+            const bool pair = pf ? (g + 1 < total_rows && pf[g] != 0) : (tt < L);     // rows (g, g + 1) are x_t, x_{t+1} of one bag
             for (int jj = j; jj < tp; jj += (tp <= LIFT_TAIL_BLOCK ? tp : LIFT_TAIL_BLOCK)) {
                 double v = 0.0;
                 if (g < total_rows && tt <= L) {
                     if (jj < n) v = X[g * n + jj];
-                    else if (jj < n + s.r) { if (tt < L) v = U[(bb * us + tt) * s.r + (jj - n)]; }
-                    else if (s.xplus && jj < n + s.r + n && tt < L && g + 1 < total_rows) v = X[(g + 1) * n + (jj - n - s.r)];
+                    else if (jj < n + s.r) { if (pair) v = U[(pf ? g : bb * us + tt) * s.r + (jj - n)]; }
+                    else if (s.xplus && jj < n + s.r + n && pair && g + 1 < total_rows) v = X[(g + 1) * n + (jj - n - s.r)];
                 }
                 Zrows[l * W + s.kp + jj] = v;
             }
-            if (j == 0) wrow[l] = (g < total_rows && tt < L) ? 1.0 : 0.0;
+            if (j == 0) wrow[l] = (g < total_rows && pair) ? 1.0 : 0.0;
         }
     }
 }
 hipError_t launch_lift_rows_total(hipStream_t st, const EdmdcShape& s, double gamma, const double* C,
                                   int64_t row0, int64_t rows, int64_t total_rows, int64_t L, int64_t xs, int64_t us,
-                                  const double* X, const double* U, double* Zrows, double* wrow) {
+                                  const double* X, const double* U, double* Zrows, double* wrow, const unsigned char* pairflag) {
     if (rows <= 0) return hipSuccess;
     if (s.n > LIFT_NMAX || s.tailp > 256 || xs < 2 || total_rows < 1) return hipErrorInvalidValue;
     const int ngroups = (s.kp + LIFT_BLOCK * LIFT_NC - 1) / (LIFT_BLOCK * LIFT_NC);
     const dim3 grid((unsigned)((rows + 63) / 64), (unsigned)ngroups);
-    hipLaunchKernelGGL(lift_tail_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(LIFT_TAIL_BLOCK), 0, st, s, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    hipLaunchKernelGGL(lift_tail_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(LIFT_TAIL_BLOCK), 0, st, s, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow, pairflag);
     if (s.n == 12) hipLaunchKernelGGL(lift_rows_kernel<12>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     else if (s.n == 13) hipLaunchKernelGGL(lift_rows_kernel<13>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
     else hipLaunchKernelGGL(lift_rows_kernel<0>, grid, dim3(LIFT_BLOCK), 0, st, s, gamma, C, row0, rows, total_rows, L, xs, us, X, U, Zrows, wrow);
+    return hipGetLastError();
+}
+
+// Ragged bags (fit_multi's X_list / U_list, Koopman/koopmanEDMDc.py:129-138: "if len(X) < 2: continue", Z = lift(X[:-1]),
+// Zp = lift(X[1:]), U[:-1]): one byte per row, 1 = (g, g + 1) is a pair.  Rows start as 1 (memset by the launcher); the last row of
+// every non-empty bag is cleared.  A bag of one row is its own last row: no pair starts or ends there.
+__global__ void __launch_bounds__(256) bag_pairflags_kernel(int64_t nbags, const int64_t* __restrict__ off, int64_t total_rows,
+                                                            unsigned char* __restrict__ pf) {
+    const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbags) return;
+    const int64_t e = off[b + 1];
+    if (e > off[b] && e >= 1 && e <= total_rows) pf[e - 1] = 0;
+}
+hipError_t launch_bag_pairflags(hipStream_t st, int64_t nbags, const int64_t* d_offsets, int64_t total_rows, unsigned char* pairflag) {
+    if (total_rows <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(pairflag, 1, (size_t)total_rows, st);
+    if (e != hipSuccess) return e;
+    if (nbags > 0)
+        hipLaunchKernelGGL(bag_pairflags_kernel, dim3((unsigned)((nbags + 255) / 256)), dim3(256), 0, st, nbags, d_offsets, total_rows, pairflag);
     return hipGetLastError();
 }
 

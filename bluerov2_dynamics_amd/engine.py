@@ -14,7 +14,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "gtg_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "gram_ragged_dev", "pinv_apply_ragged_dev", "upload_bags", "BagTable", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "gtg_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
@@ -195,28 +195,123 @@ def lift(X, C, gamma, ctx=None):
     return Z
 
 
+class BagTable:
+    """The bookkeeping of a trajectory list (fit_multi's X_list / U_list, Koopman/koopmanEDMDc.py:113-152) for brov_upload_bags and the
+    ragged Gram: `offsets` int64 [nbags + 1] of the stacked states, `lens` = rows per bag, `u_rows` = rows of each U that go next to them
+    (U is stored ROW-ALIGNED with X; like the reference -- `U[:-1]` next to `X[:-1]` -- a bag needs len(U) >= len(X) - 1, rows past
+    len(X) are ignored), and the host addresses of the bags (C-contiguous fp64; anything else is converted and kept alive here)."""
+
+    def __init__(self, X_list, U_list, n, r):
+        nb = len(X_list)
+        nd, f64 = np.ndarray, np.float64
+        self.keep = []
+        lens, urows, px, pu = [0] * nb, [0] * nb, [0] * nb, [0] * nb
+        for b in range(nb):                      # ~1.3 us per bag: one __array_interface__ dict per array carries dtype, layout, shape, address
+            X, U = X_list[b], U_list[b]
+            ai = X.__array_interface__ if type(X) is nd else None
+            if ai is None or ai["typestr"] != "<f8" or ai["strides"] is not None:
+                X = np.ascontiguousarray(X, dtype=f64)
+                self.keep.append(X)
+                ai = X.__array_interface__
+            au = U.__array_interface__ if type(U) is nd else None
+            if au is None or au["typestr"] != "<f8" or au["strides"] is not None:
+                U = np.ascontiguousarray(U, dtype=f64)
+                self.keep.append(U)
+                au = U.__array_interface__
+            sx, su = ai["shape"], au["shape"]
+            if len(sx) != 2 or sx[1] != n or len(su) != 2 or su[1] != r:
+                raise AssertionError(f"bag {b}: X {sx} / U {su} do not match state_dim {n} / input_dim {r}")
+            lx, lu = sx[0], su[0]
+            if lx >= 2 and lu < lx - 1:
+                raise ValueError(f"bag {b}: U has {lu} rows, needs at least len(X) - 1 = {lx - 1}")
+            lens[b], urows[b] = lx, (lu if lu < lx else lx)
+            px[b], pu[b] = ai["data"][0], au["data"][0]
+        self.n, self.r, self.nbags = n, r, nb
+        self.lens = np.array(lens, dtype=np.int64)
+        self.u_rows = np.array(urows, dtype=np.int64)
+        self.offsets = np.zeros(nb + 1, dtype=np.int64)
+        np.cumsum(self.lens, out=self.offsets[1:])
+        self.x_ptrs = np.array(px, dtype=np.uint64)
+        self.u_ptrs = np.array(pu, dtype=np.uint64)
+        self.rows = int(self.offsets[-1])
+        self.pairs = int(np.maximum(self.lens - 1, 0).sum())
+
+    def upload_into(self, dX, dU, ctx):
+        """brov_upload_bags twice: the states of all bags into dX [rows, n], the inputs row-aligned into dU [rows, r] (device pointers)."""
+        if self.nbags == 0 or self.rows == 0:
+            return
+        dst = np.ascontiguousarray(self.offsets[:-1])
+        ctx.check(ctx.lib.brov_upload_bags(ctx.h, self.nbags, self.x_ptrs.ctypes.data, self.lens.ctypes.data, dst.ctypes.data, self.n, dX),
+                  "brov_upload_bags")
+        if self.r:
+            ctx.check(ctx.lib.brov_upload_bags(ctx.h, self.nbags, self.u_ptrs.ctypes.data, self.u_rows.ctypes.data, dst.ctypes.data, self.r, dU),
+                      "brov_upload_bags")
+
+
+def upload_bags(X_list, U_list, n, r, device=None, ctx=None):
+    """fit_multi's trajectory list in HBM, uploaded once: (Xd [rows, n], Ud [rows, r] row-aligned with Xd, offsets int64 [nbags + 1])
+    as torch CUDA tensors.  Xd is np.vstack(X_list) (Koopman/koopmanEDMDc.py:125); no stacked copy is formed on the host."""
+    import torch
+    ctx = ctx or default_context(device)
+    ctx.use_torch_stream()
+    dev = torch.device("cuda", ctx.device)
+    bt = BagTable(X_list, U_list, n, r)
+    rows = bt.rows
+    Xd = torch.empty((rows, n), dtype=torch.float64, device=dev)
+    # rows of U that no bag provides (len(U) == len(X) - 1) stay as allocated: the kernels never read the input next to a bag's last state
+    Ud = torch.empty((rows, r), dtype=torch.float64, device=dev)
+    bt.upload_into(Xd.data_ptr(), Ud.data_ptr(), ctx)
+    return Xd, Ud, bt.offsets
+
+
+class _DevBuf:
+    """brov_malloc'ed scratch of the torch-free host entry points (freed on exit)."""
+
+    def __init__(self, ctx, *sizes):
+        self.ctx, self.ptrs = ctx, []
+        try:
+            for nbytes in sizes:
+                p_ = ctypes.c_void_p()
+                ctx.check(ctx.lib.brov_malloc(ctx.h, max(int(nbytes), 8), ctypes.byref(p_)), "brov_malloc")
+                self.ptrs.append(p_.value)
+        except Exception:
+            self.close()
+            raise
+
+    def close(self):
+        for p_ in self.ptrs:
+            self.ctx.lib.brov_free(self.ctx.h, p_)
+        self.ptrs = []
+
+    def __enter__(self):
+        return self.ptrs
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+
 def gram(X_list, U_list, C, gamma, ctx=None):
-    """G^T G [p,p] and G^T Y [p,d] over bags (no cross-bag pairs) -- fit / fit_multi normal equations."""
+    """G^T G [p,p] and G^T Y [p,d] over bags (no cross-bag pairs) -- fit / fit_multi normal equations
+    (Koopman/koopmanEDMDc.py:89-97,129-147).  Host arrays in and out; the whole list is uploaded once (brov_upload_bags) and goes
+    through ONE ragged Gram call (edmdc_gram_ragged_dev), whatever the number of bags."""
     ctx = ctx or default_context()
     ctx.use_null_stream()
     C = as_f64(C)
     k, n = C.shape
     r = np.asarray(U_list[0]).shape[1]
     d, p = n + k, n + k + r
+    bt = BagTable(X_list, U_list, n, r)
+    rows, off, npairs = bt.rows, bt.offsets, bt.pairs
     GtG = np.zeros((p, p))
     GtY = np.zeros((p, d))
-    npairs = 0
-    acc = 0
-    for X, U in zip(X_list, U_list):
-        if len(X) < 2:
-            continue
-        X = as_f64(X)
-        L = len(X) - 1
-        Uc = as_f64(as_f64(U)[:L])           # keep a named reference: only its address crosses the ABI
-        ctx.check(ctx.lib.edmdc_gram(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(Uc),
-                                     acc, _hptr(GtG), _hptr(GtY)), "edmdc_gram")
-        acc = 1
-        npairs += L
+    with _DevBuf(ctx, rows * n * 8, rows * r * 8, k * n * 8, p * p * 8, p * d * 8) as (dX, dU, dC, dG, dY):
+        bt.upload_into(dX, dU, ctx)
+        ctx.check(ctx.lib.brov_memcpy_h2d(ctx.h, dC, _hptr(C), k * n * 8), "brov_memcpy_h2d")
+        ctx.check(ctx.lib.edmdc_gram_ragged_dev(ctx.h, n, r, k, float(gamma), dC, bt.nbags, off.ctypes.data, dX, dU, 0, dG, dY),
+                  "edmdc_gram_ragged_dev")
+        ctx.check(ctx.lib.brov_memcpy_d2h(ctx.h, _hptr(GtG), dG, p * p * 8), "brov_memcpy_d2h")
+        ctx.check(ctx.lib.brov_memcpy_d2h(ctx.h, _hptr(GtY), dY, p * d * 8), "brov_memcpy_d2h")
     return GtG, GtY, npairs
 
 
@@ -256,6 +351,36 @@ def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, acc
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     ctx.check(ctx.lib.edmdc_gram_dev(ctx.h, n, r, k, float(gamma), _dptr(C), int(nbags), int(L), int(x_bag_stride), int(u_bag_stride),
                                      _dptr(X), _dptr(U), int(bool(accumulate)), _dptr(GtG), _dptr(GtY)), "edmdc_gram_dev")
+
+
+def _offsets(bag_offsets):
+    off = np.ascontiguousarray(np.asarray(bag_offsets, dtype=np.int64))
+    assert off.ndim == 1 and off.size >= 1
+    return off
+
+
+def gram_ragged_dev(X, U, C, gamma, bag_offsets, GtG, GtY, accumulate=False, ctx=None):
+    """Device Gram over a RAGGED bag list (fit_multi): X [rows,n] the stacked states, U [rows,r] row-aligned with X, bag b = rows
+    bag_offsets[b] .. bag_offsets[b+1]-1 (host int64 array) -- see edmdc_gram_ragged_dev in include/brov2.h.  GtY=None: G^T G alone."""
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    off = _offsets(bag_offsets)
+    n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
+    assert X.shape[0] == off[-1] and U.shape[0] == off[-1], "X / U rows must equal bag_offsets[-1]"
+    ctx.check(ctx.lib.edmdc_gram_ragged_dev(ctx.h, n, r, k, float(gamma), _dptr(C), off.size - 1, off.ctypes.data, _dptr(X), _dptr(U),
+                                            int(bool(accumulate)), _dptr(GtG), _dptr(GtY)), "edmdc_gram_ragged_dev")
+
+
+def pinv_apply_ragged_dev(X, U, C, gamma, bag_offsets, P, M, ctx=None):
+    """pinv_apply_dev for the ragged bag list of gram_ragged_dev."""
+    ctx = ctx or default_context(X.device.index)
+    ctx.use_torch_stream()
+    off = _offsets(bag_offsets)
+    n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
+    P = as_f64(P)
+    assert P.shape == (n + k + r, n + k + r) and tuple(M.shape) == (n + k + r, n + k)
+    ctx.check(ctx.lib.edmdc_pinv_apply_ragged_dev(ctx.h, n, r, k, float(gamma), _dptr(C), off.size - 1, off.ctypes.data, _dptr(X), _dptr(U),
+                                                  _hptr(P), _dptr(M)), "edmdc_pinv_apply_ragged_dev")
 
 
 def kmeans_lloyd(X, C_init, max_iter=300, tol_abs=0.0, mean=None, ctx=None):
@@ -383,7 +508,7 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
 
 def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
     """M [p,d] = (P G^T) Y evaluated in that order over bags (KoopmanEDMDc.fit's association,
-    Koopman/koopmanEDMDc.py:97), P [p,p] = pinv(G^T G + ridge I) from the host."""
+    Koopman/koopmanEDMDc.py:97), P [p,p] = pinv(G^T G + ridge I) from the host.  One upload, one ragged call."""
     ctx = ctx or default_context()
     ctx.use_null_stream()
     C = as_f64(C)
@@ -392,17 +517,15 @@ def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
     r = np.asarray(U_list[0]).shape[1]
     d, p = n + k, n + k + r
     assert P.shape == (p, p)
+    bt = BagTable(X_list, U_list, n, r)
+    rows, off = bt.rows, bt.offsets
     M = np.zeros((p, d))
-    for X, U in zip(X_list, U_list):
-        if len(X) < 2:
-            continue
-        X = as_f64(X)
-        L = len(X) - 1
-        Uc = as_f64(as_f64(U)[:L])
-        Mi = np.empty((p, d))
-        ctx.check(ctx.lib.edmdc_pinv_apply(ctx.h, n, r, k, float(gamma), _hptr(C), 1, L, L + 1, L, _hptr(X), _hptr(Uc),
-                                           _hptr(P), _hptr(Mi)), "edmdc_pinv_apply")
-        M += Mi
+    with _DevBuf(ctx, rows * n * 8, rows * r * 8, k * n * 8, p * d * 8) as (dX, dU, dC, dM):
+        bt.upload_into(dX, dU, ctx)
+        ctx.check(ctx.lib.brov_memcpy_h2d(ctx.h, dC, _hptr(C), k * n * 8), "brov_memcpy_h2d")
+        ctx.check(ctx.lib.edmdc_pinv_apply_ragged_dev(ctx.h, n, r, k, float(gamma), dC, bt.nbags, off.ctypes.data, dX, dU, _hptr(P), dM),
+                  "edmdc_pinv_apply_ragged_dev")
+        ctx.check(ctx.lib.brov_memcpy_d2h(ctx.h, _hptr(M), dM, p * d * 8), "brov_memcpy_d2h")
     return M
 
 
@@ -433,8 +556,22 @@ def pinv_sym_device(G, ridge, rcond=1e-15):
     return (Q * winv) @ Q.T
 
 
+def pinv_sym_host(G, ridge, rcond=1e-15):
+    """pinv(G + ridge I) of the symmetric p x p Gram on the HOST through a symmetric eigendecomposition (LAPACK syevd) with
+    numpy.linalg.pinv's cut-off: for a symmetric matrix the singular values are |eigenvalues| and V diag(1/s) U^T = Q diag(1/w) Q^T, so
+    this is the same matrix as the reference's `pinv(...)` (Koopman/koopmanEDMDc.py:97,147) up to the rounding of two different
+    LAPACK drivers (6e-12 .. 5e-10 relative on the bench shapes, tools/time_pinv_options.py) at 13 ms instead of 29 ms for p = 520."""
+    A = G + ridge * np.eye(G.shape[0])
+    w, Q = np.linalg.eigh(0.5 * (A + A.T))
+    aw = np.abs(w)
+    keep = aw > rcond * aw.max()
+    winv = np.zeros_like(w)
+    winv[keep] = 1.0 / w[keep]
+    return (Q * winv) @ Q.T
+
+
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None, lift_cache=False, pinv="host"):
+            timings=None, lift_cache=False, pinv="host", bag_offsets=None):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
@@ -444,7 +581,8 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
     45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
     so it pays for repeated fits in one process, not for a single one; off by default.  pinv="host": numpy.linalg.pinv like the
-    reference (:97/:147); "device": pinv_sym_device (opt-in)."""
+    reference (:97/:147); "device": pinv_sym_device (opt-in).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
+    of nbags bags of L pairs -- X [rows, n] the stacked states, U [rows, r] row-aligned with X (upload_bags); nbags / L are ignored."""
     import time
     import torch
     ctx = ctx or default_context(X.device.index)
@@ -485,23 +623,29 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     try:
         if cache_buf is not None:
             ctx.lift_cache(cache_buf.data_ptr(), need)
-        gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
+        if bag_offsets is not None:
+            gram_ragged_dev(X, U, C, gamma, bag_offsets, GtG, GtY, ctx=ctx)
+        else:
+            gram_dev(X, U, C, gamma, nbags, L, L + 1, L, GtG, GtY, ctx=ctx)
         if getattr(ctx, "timing", False):
             tm["gram_kernel_ms"] = ctx.last_kernel_ms()
         if pinv == "device":
             t2 = tick()
             P = pinv_sym_device(GtG, ridge).cpu().numpy()
-        elif pinv == "host":
+        elif pinv in ("host", "eigh"):
             Gh = GtG.cpu().numpy()
             t2 = tick()
             with _blas_threads():
-                P = np.linalg.pinv(Gh + ridge * np.eye(p))
+                P = np.linalg.pinv(Gh + ridge * np.eye(p)) if pinv == "host" else pinv_sym_host(Gh, ridge)
         else:
-            raise ValueError("pinv must be 'host' or 'device'")
+            raise ValueError("pinv must be 'host', 'eigh' or 'device'")
         t3 = time.perf_counter()
         if order == "fit":
             M = torch.empty((p, d), dtype=torch.float64, device=X.device)
-            pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
+            if bag_offsets is not None:
+                pinv_apply_ragged_dev(X, U, C, gamma, bag_offsets, P, M, ctx=ctx)
+            else:
+                pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
             Mt = M.cpu().numpy().T
         else:
             with _blas_threads():

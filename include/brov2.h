@@ -128,6 +128,13 @@ BROV_API int brov_free(brov_ctx* ctx, void* dptr);
 BROV_API int brov_memcpy_h2d(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
 BROV_API int brov_memcpy_d2h(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
 BROV_API int brov_memset(brov_ctx* ctx, void* dst, int value, size_t bytes);
+/* A list of host arrays into ONE device buffer -- what KoopmanEDMDc.fit_multi's np.vstack of its trajectory list becomes
+ * (Koopman/koopmanEDMDc.py:125,140-142).  Bag b = bag_rows[b] rows of `cols` contiguous doubles at bag_ptrs[b]; it is written to
+ * d_dst + dst_rows[b] * cols.  The destinations must ascend without overlap (holes are allowed; small ones are zero-filled, larger ones
+ * left untouched).  Packed through two pinned staging blocks by a few host threads while the previous block is in flight; the data is
+ * in place when the call returns. */
+BROV_API int brov_upload_bags(brov_ctx* ctx, int64_t nbags, const double* const* bag_ptrs, const int64_t* bag_rows,
+                              const int64_t* dst_rows, int cols, double* d_dst);
 
 /* ---- Fossen RHS / rollouts ------------------------------------------------------------ */
 /* Batched dynamics(): xdot[b] = f(x[b], u[b]).  Replaces BlueROV2.dynamics
@@ -197,6 +204,20 @@ BROV_API int edmdc_gram(brov_ctx* ctx, int n, int r, int k, double gamma, const 
 BROV_API int edmdc_gram_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
                    int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
                    const double* d_X, const double* d_U, int accumulate, double* d_GtG, double* d_GtY);
+/* The same normal-equation blocks for a RAGGED list of trajectories -- fit_multi(X_list, U_list), Koopman/koopmanEDMDc.py:113-152:
+ * "Each (X, U) is a bag/rollout.  We never create cross-bag transitions"; a bag with fewer than 2 states contributes nothing (:131-132),
+ * bag b contributes the pairs (X_b[t], U_b[t], X_b[t+1]), t = 0 .. len(X_b) - 2 (:133-138).
+ * Data: the bags' rows one after the other.  X [rows][n] = np.vstack(X_list) (:125 -- also what the reference clusters for its centres),
+ * U [rows][r] ROW-ALIGNED with X (U_b[t] next to X_b[t]; the row next to the last state of a bag is never read -- the reference drops it
+ * with U[:-1]), bag b = rows bag_offsets[b] .. bag_offsets[b + 1] - 1, bag_offsets [nbags + 1] on the HOST in both forms (metadata: it is
+ * validated there -- bag_offsets[0] = 0, non-decreasing -- and rows = bag_offsets[nbags]).  Empty bags and one-row bags are allowed.
+ * One call lifts every state once, whatever the number of bags: no per-bag launch, allocation or copy. */
+BROV_API int edmdc_gram_ragged(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+                               int64_t nbags, const int64_t* bag_offsets, const double* X, const double* U,
+                               int accumulate, double* GtG, double* GtY);
+BROV_API int edmdc_gram_ragged_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
+                                   int64_t nbags, const int64_t* bag_offsets, const double* d_X, const double* d_U,
+                                   int accumulate, double* d_GtG, double* d_GtY /* NULL: G^T G alone */);
 /* Rows lifted per chunk by edmdc_gram* (workspace = rows * padded_width * 8 bytes). */
 BROV_API int edmdc_set_chunk_rows(brov_ctx* ctx, int64_t rows);
 
@@ -256,6 +277,15 @@ BROV_API int edmdc_pinv_apply(brov_ctx* ctx, int n, int r, int k, double gamma, 
 BROV_API int edmdc_pinv_apply_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
                                   int64_t nbags, int64_t L, int64_t x_bag_stride, int64_t u_bag_stride,
                                   const double* d_X, const double* d_U, const double* P_host, double* d_M);
+
+/* edmdc_pinv_apply for the ragged bag list of edmdc_gram_ragged (fit()'s product order over fit_multi's data: what a caller gets who
+ * wants the better-conditioned association on a trajectory list). */
+BROV_API int edmdc_pinv_apply_ragged(brov_ctx* ctx, int n, int r, int k, double gamma, const double* C,
+                                     int64_t nbags, const int64_t* bag_offsets, const double* X, const double* U,
+                                     const double* P, double* M);
+BROV_API int edmdc_pinv_apply_ragged_dev(brov_ctx* ctx, int n, int r, int k, double gamma, const double* d_C,
+                                         int64_t nbags, const int64_t* bag_offsets, const double* d_X, const double* d_U,
+                                         const double* P_host, double* d_M);
 
 /* Work decomposition of edmdc_gram / edmdc_gram_dev for a shape (no device work; for roofline accounting): the normal
  * equations G^T[G|Y] (Koopman/koopmanEDMDc.py:129-147) are computed as ntasks blocks of 4 x 6 tiles of 16 x 16 per slab of

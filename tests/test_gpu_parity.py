@@ -1343,6 +1343,141 @@ def test_gram_tail_layouts(eng):
         assert np.array_equal(GtG, GtG.T)
 
 
+def _ragged_bags(rng, nbags, n, r, lo, hi, short=40):
+    """Random-walk trajectories of unequal lengths (some empty, some with a single state): what fit_multi is handed."""
+    lens = rng.integers(lo, hi + 1, nbags)
+    lens[rng.choice(nbags, short, replace=False)] = rng.integers(0, 2, short)          # bags without a pair (reference :131-132)
+    Xs, Us = [], []
+    for L in lens:
+        x0 = rng.normal(0, 0.6, (1, n))
+        Xs.append(x0 + np.cumsum(rng.normal(0, 0.03, (int(L), n)), axis=0))
+        Us.append(rng.uniform(-1, 1, (int(L), r)))
+    return Xs, Us, lens
+
+
+def test_fit_multi_ragged_2000_bags_one_upload(eng):
+    """fit_multi(X_list, U_list) on a ragged trajectory list (Koopman/koopmanEDMDc.py:113-152): 2 000 bags of 2..700 states, forty of
+    them with 0 or 1 state, through ONE upload (brov_upload_bags) and ONE ragged Gram call (edmdc_gram_ragged_dev).
+    (1) the uploaded buffer is np.vstack(X_list); (2) G^T G, G^T Y against the NumPy restatement of the reference's per-bag loop at
+    1e-12; (3) the plain-C host entry edmdc_gram_ragged gives the same bits; (4) a uniform list through the ragged call equals
+    edmdc_gram_dev bit for bit; (5) KoopmanEDMDc.fit_multi's A, B against the restated solve; (6) fit()'s product order over the same
+    bags (edmdc_pinv_apply_ragged_dev) against NumPy; (7) bad offsets are refused."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    from oracle import edmdc_numpy as ek
+    rng = np.random.default_rng(2000)
+    n, r, k, gamma, ridge = 12, 8, 40, 0.7, 1e-3
+    Xs, Us, lens = _ragged_bags(rng, 2000, n, r, 2, 700)
+    assert (lens < 2).sum() >= 30 and lens.max() >= 690
+    ctx = _lib.default_context(0)
+    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx)
+    Xall = np.vstack([x for x in Xs if len(x)])
+    assert np.array_equal(Xd.cpu().numpy(), Xall) and np.array_equal(Ud.cpu().numpy(), np.vstack([u for u in Us if len(u)]))
+    assert np.array_equal(off, np.concatenate([[0], np.cumsum(lens)]))
+    C = Xall[rng.choice(len(Xall), k, replace=False)] + rng.normal(0, 0.01, (k, n))
+    Go, Yo, npairs = ek.gram(Xs, Us, C, gamma)
+    assert npairs == int(np.maximum(lens - 1, 0).sum())
+    GtG, GtY, np_ = eng.gram(Xs, Us, C, gamma)
+    assert np_ == npairs
+    assert np.linalg.norm(GtG - Go) <= 1e-12 * np.linalg.norm(Go) and np.linalg.norm(GtY - Yo) <= 1e-12 * np.linalg.norm(Yo)
+    assert np.array_equal(GtG, GtG.T)
+    # (3) the host entry point a plain-C caller would use
+    p, d = n + k + r, n + k
+    G2, Y2 = np.zeros((p, p)), np.zeros((p, d))
+    Uall = np.ascontiguousarray(Ud.cpu().numpy())
+    ctx.use_null_stream()
+    ctx.check(ctx.lib.edmdc_gram_ragged(ctx.h, n, r, k, gamma, C.ctypes.data, len(Xs), off.ctypes.data, Xall.ctypes.data, Uall.ctypes.data,
+                                        0, G2.ctypes.data, Y2.ctypes.data), "edmdc_gram_ragged")
+    assert np.array_equal(G2, GtG) and np.array_equal(Y2, GtY)
+    # inputs one row shorter than the states (U[:-1] is all the reference reads): the same blocks
+    G3, Y3, _ = eng.gram(Xs, [u[:max(len(u) - 1, 0)] for u in Us], C, gamma)
+    assert np.array_equal(G3, GtG) and np.array_equal(Y3, GtY)
+    # (4) a uniform list: ragged call == bag-layout call, bit for bit
+    nb, L = 37, 129
+    Xu = [x[:L + 1] for x in Xs if len(x) >= L + 1][:nb]
+    Uu = [u[:L + 1] for u in Us if len(u) >= L + 1][:nb]
+    assert len(Xu) == nb
+    Xud, Uud, offu = eng.upload_bags(Xu, Uu, n, r, ctx=ctx)
+    Cd = torch.from_numpy(C).cuda()
+    Ga, Ya, Gb, Yb = (torch.zeros(s_, dtype=torch.float64, device="cuda") for s_ in ((p, p), (p, d), (p, p), (p, d)))
+    eng.gram_ragged_dev(Xud, Uud, Cd, gamma, offu, Ga, Ya, ctx=ctx)
+    Uc = torch.stack([Uud[i * (L + 1): i * (L + 1) + L] for i in range(nb)]).reshape(-1, r).contiguous()
+    eng.gram_dev(Xud, Uc, Cd, gamma, nb, L, L + 1, L, Gb, Yb, ctx=ctx)
+    assert torch.equal(Ga, Gb) and torch.equal(Ya, Yb)
+    # (5) the public class on the ragged list, centres given
+    m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge)
+    m.fit_multi(Xs, Us, centers=C)
+    Ao, Bo = ek.solve_AB(Go, Yo, ridge, d)
+    assert rel_err(m.A_, Ao) < 1e-8 and rel_err(m.B_, Bo) < 1e-8 and m.lift_dim_ == d
+    # ... and with its own centres: KMeans over ALL states of the list, single-state bags included (reference :125)
+    m.fit_multi(Xs[:300], Us[:300])
+    Xall300 = np.vstack([x for x in Xs[:300] if len(x)])
+    from sklearn.cluster import KMeans
+    Ck = KMeans(n_clusters=k, n_init="auto", random_state=0).fit(Xall300).cluster_centers_
+    assert rel_err(m.centers_, Ck) < 1e-9
+    # (6) fit()'s association (P G^T) Y over the same bags
+    P = np.linalg.pinv(Go + ridge * np.eye(p))
+    sub = slice(0, 400)
+    Gs = np.vstack([np.hstack([ek.lift(x[:-1], C, gamma), u[:len(x) - 1]]) for x, u in zip(Xs[sub], Us[sub]) if len(x) >= 2])
+    Ys = np.vstack([ek.lift(x[1:], C, gamma) for x in Xs[sub] if len(x) >= 2])
+    Mo = (P @ Gs.T) @ Ys
+    M = eng.pinv_apply(Xs[sub], Us[sub], C, gamma, P)
+    assert np.linalg.norm(M - Mo) <= 1e-11 * np.linalg.norm(Mo)
+    # (7) offsets that are not offsets
+    bad = off.copy(); bad[0] = 1
+    assert ctx.lib.edmdc_gram_ragged(ctx.h, n, r, k, gamma, C.ctypes.data, len(Xs), bad.ctypes.data, Xall.ctypes.data, Uall.ctypes.data, 0,
+                                     G2.ctypes.data, Y2.ctypes.data) == -1
+    bad = off.copy(); bad[5] = bad[4] - 1
+    assert ctx.lib.edmdc_gram_ragged(ctx.h, n, r, k, gamma, C.ctypes.data, len(Xs), bad.ctypes.data, Xall.ctypes.data, Uall.ctypes.data, 0,
+                                     G2.ctypes.data, Y2.ctypes.data) == -1
+    assert b"bag_offsets" in ctx.lib.brov_last_error(ctx.h)
+    # the reference raises where np.vstack has nothing to stack: every bag empty (:125), no bag with a pair (:140)
+    with pytest.raises(ValueError):
+        m.fit_multi([np.zeros((0, n))], [np.zeros((0, r))], centers=C)
+    with pytest.raises(ValueError):
+        m.fit_multi([Xs[0][:1], Xs[1][:1]], [Us[0][:1], Us[1][:1]], centers=C)
+
+
+def test_upload_bags_blocks_holes_and_views(eng):
+    """brov_upload_bags: more than one 32 MB staging block (threads + double buffering), bags that are consecutive views of one array
+    (coalesced), small holes (zero-filled) and a large hole (left untouched), empty bags, a non-contiguous and a float32 bag (converted
+    by the Python layer)."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.default_context(0)
+    ctx.use_torch_stream()
+    rng = np.random.default_rng(5)
+    n, r = 12, 8
+    base = rng.normal(size=(900_000, n))                      # 86 MB: three staging blocks
+    cuts = np.sort(rng.choice(np.arange(1, len(base)), 2500, replace=False))
+    cuts = np.concatenate([[0], cuts, [len(base)]])
+    Xs = [base[a:b] for a, b in zip(cuts[:-1], cuts[1:])]     # views of one array
+    Xs[7] = np.asfortranarray(Xs[7])                          # not C-contiguous
+    Xs[9] = Xs[9].astype(np.float32)                          # wrong dtype: converted, not reinterpreted
+    Xs.insert(100, np.zeros((0, n)))
+    Us = [rng.uniform(-1, 1, (max(len(x) - 1, 0), r)) for x in Xs]        # one row short: a hole of 64 bytes after every bag
+    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx)
+    want = np.vstack([np.asarray(x, dtype=float) for x in Xs if len(x)])
+    assert np.array_equal(Xd.cpu().numpy(), want)
+    Uh = Ud.cpu().numpy()
+    for b in (0, 1, 7, 99, 100, 101, len(Xs) - 1):
+        a, e = off[b], off[b + 1]
+        if e - a >= 2:
+            assert np.array_equal(Uh[a:e - 1], Us[b])
+    # a large hole stays as it was; destinations that overlap or descend are refused
+    dst = torch.full((1000, 4), 7.0, dtype=torch.float64, device="cuda")
+    A_, B_ = np.arange(40.0).reshape(10, 4), -np.arange(80.0).reshape(20, 4)
+    ptr = np.array([A_.ctypes.data, B_.ctypes.data], dtype=np.uint64)
+    rows = np.array([10, 20], dtype=np.int64)
+    at = np.array([5, 600], dtype=np.int64)
+    ctx.check(ctx.lib.brov_upload_bags(ctx.h, 2, ptr.ctypes.data, rows.ctypes.data, at.ctypes.data, 4, dst.data_ptr()), "brov_upload_bags")
+    h = dst.cpu().numpy()
+    assert np.array_equal(h[5:15], A_) and np.array_equal(h[600:620], B_) and (h[:5] == 7).all() and (h[15:600] == 7).all() and (h[620:] == 7).all()
+    at2 = np.array([5, 10], dtype=np.int64)
+    assert ctx.lib.brov_upload_bags(ctx.h, 2, ptr.ctypes.data, rows.ctypes.data, at2.ctypes.data, 4, dst.data_ptr()) == -1
+
+
 def test_fit_keeps_the_references_own_product_order(eng):
     """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
     (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
@@ -1395,11 +1530,12 @@ def test_fit_keeps_the_references_own_product_order(eng):
             ("def", X[:ntr], U[:ntr], Xt, Ut, int(g["def_k"]), float(g["def_gamma"]), float(g["def_ridge"]), g["def_centers"], g["def_ms_rmse"]),
             ("tank", X[:ntr], U[:ntr], Xt, Ut, int(g["tank_k"]), float(g["tank_gamma"]), float(g["tank_ridge"]), g["tank_centers"], g["tank_ms_rmse"]),
             ("small", Xs[:ns], Us[:ns], Xs[ns:], Us[ns:], 200, 1.0, 1e-8, g["small_centers"], g["small_ms_rmse"])):
-        md = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=kk, gamma=gg, ridge=rr, pinv="device")
-        md.fit(Xa, Ua, centers=cc)
-        errd = np.abs(np.array([md.multistep_rmse(Xb, Ub, H) for H in (1, 10, 100)]) - ref)
-        print(f"device pinv, {tag}: |dRMSE| H=1/10/100 =", errd)
-        assert np.max(errd) < 1e-6, (tag, errd)
+        for how in ("device", "eigh", "host"):
+            md = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=kk, gamma=gg, ridge=rr, pinv=how)
+            md.fit(Xa, Ua, centers=cc)
+            errd = np.abs(np.array([md.multistep_rmse(Xb, Ub, H) for H in (1, 10, 100)]) - ref)
+            print(f"pinv = {how}, {tag}: |dRMSE| H=1/10/100 =", errd)
+            assert np.max(errd) < 1e-6, (tag, how, errd)
 
 
 def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):

@@ -1,0 +1,86 @@
+"""Child process of bench.py's `recorded_shape` leg: KoopmanEDMDc.fit() at the size the reference's own log quotes
+(training/best_results.txt:761,798: N = 45 823 samples, n = 12, r = 8, 500 RBFs, gamma = 3, ridge = 0.1 -- the settings of
+training/train_tank_brov2_full_comparison.py:40-44) on HOST arrays, as the FIRST thing a fresh process does, then again (warm).
+
+    python tools/bench_fit_child.py gpu <data.npz> [pinv]     the drop-in class (libbrov2.so)
+    python tools/bench_fit_child.py cpu <data.npz>            the NumPy / scikit-learn restatement of the reference's fit() in its own
+                                                              shape (oracle/edmdc_numpy.py; bench.py's cpu_baseline leg -- the parent
+                                                              sets OMP_NUM_THREADS=4, the reference's import-time default,
+                                                              Koopman/koopmanEDMDc.py:23-25)
+Prints one JSON object on the last line of stdout."""
+import json
+import os
+import sys
+import time
+
+T_START = time.perf_counter()
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+
+
+def main():
+    mode, path = sys.argv[1], sys.argv[2]
+    import numpy as np
+    z = np.load(path)
+    out = {"mode": mode}
+    cases = [("thruster_12_8", z["X"], z["U"])]
+    if "Xq" in z.files:
+        cases.append(("quaternion_13_6", z["Xq"], z["Uq"]))
+    k, gamma, ridge = int(z["k"]), float(z["gamma"]), float(z["ridge"])
+    Hs = (1, 10, 100)
+    if mode == "gpu":
+        pinv = sys.argv[3] if len(sys.argv) > 3 else "host"
+        t0 = time.perf_counter()
+        from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc     # imports torch, binds libbrov2.so lazily
+        out["import_s"] = time.perf_counter() - t0
+        out["pinv"] = pinv
+        for name, X, U in cases:
+            n, r = X.shape[1], U.shape[1]
+            calls, first_done = [], None
+            for rep in range(3 if name == cases[0][0] else 2):
+                m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge, pinv=pinv)
+                t0 = time.perf_counter()
+                m.fit(X, U)
+                calls.append(time.perf_counter() - t0)
+                if rep == 0 and name == cases[0][0]:
+                    first_done = time.perf_counter() - T_START        # interpreter start -> imports -> data -> first fit() returned
+            t0 = time.perf_counter()
+            scores = [m.multistep_rmse(X, U, H) for H in Hs]
+            sc_s = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            scores = [m.multistep_rmse(X, U, H) for H in Hs]
+            sc2_s = time.perf_counter() - t0
+            out[name] = {"rows": int(X.shape[0]), "n": n, "r": r, "k": k, "fit_calls_s": calls,
+                         "process_start_to_first_fit_done_s": first_done,
+                         "multistep_rmse_H1_10_100": scores, "multistep_rmse_three_calls_s": [sc_s, sc2_s],
+                         "finite": bool(np.isfinite(m.A_).all() and np.isfinite(m.B_).all()),
+                         "checksum": float(np.abs(m.A_).sum() + np.abs(m.B_).sum())}
+        out["process_total_s"] = time.perf_counter() - T_START
+    else:
+        from sklearn.cluster import KMeans
+        from oracle import edmdc_numpy as ek
+        try:
+            from threadpoolctl import threadpool_info
+            out["threadpools"] = [{"api": t_["user_api"], "threads": t_["num_threads"]} for t_ in threadpool_info()]
+        except Exception:
+            out["threadpools"] = None
+        out["OMP_NUM_THREADS"] = os.environ.get("OMP_NUM_THREADS")
+        name, X, U = cases[0]
+        calls, stages = [], None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            C = KMeans(n_clusters=k, n_init="auto", random_state=0).fit(X).cluster_centers_        # Koopman/koopmanEDMDc.py:85
+            t1 = time.perf_counter()
+            A, B = ek.fit_single(X, U, C, gamma, ridge)                                            # :88-101, the reference's own order
+            t2 = time.perf_counter()
+            calls.append(t2 - t0)
+            stages = {"kmeans_s": t1 - t0, "lift_gram_pinv_products_s": t2 - t1}
+        t0 = time.perf_counter()
+        s10 = ek.multistep_rmse(X, U, C, gamma, A, B, 10)
+        out[name] = {"rows": int(X.shape[0]), "fit_calls_s": calls, "stages_second_call": stages, "multistep_rmse_H10": s10,
+                     "multistep_rmse_H10_s": time.perf_counter() - t0, "checksum": float(np.abs(A).sum() + np.abs(B).sum())}
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
