@@ -142,8 +142,13 @@ SIGNATURES = {
     "edmdc_set_apply_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "edmdc_lift_cache": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_size_t]),
     "edmdc_set_kmeans_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
+    "edmdc_set_kmeans_bounds_rate": (ctypes.c_int, [c_void_p, ctypes.c_double]),
+    "brov_experiments_build": (ctypes.c_int, []),
+    "brov_set_rollout_variant": (ctypes.c_int, [c_void_p, ctypes.c_int]),
     "edmdc_set_kmeans_far_select": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "edmdc_kmeans_relocations": (ctypes.c_int, [c_void_p]),
+    "edmdc_kmeans_loop_info": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_int)]),
+    "edmdc_far_select_numpy": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p]),
     "edmdc_set_kmeans_allreduce": (ctypes.c_int, [c_void_p, c_void_p, c_void_p]),
     "edmdc_set_kmeans_shard": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, i64, i64]),
     "brov_comm_available": (ctypes.c_int, []),
@@ -325,20 +330,36 @@ class Context:
         self.check(self.lib.edmdc_lift_cache(self.h, c_void_p(device_ptr or 0), int(nbytes if device_ptr else 0)), "edmdc_lift_cache")
 
     def set_kmeans_variant(self, variant: int):
-        """Lloyd's loop: 0 = candidate filter on sorted samples, packed-fp32 screening and distance bounds (default), 1 = full scan,
-        2 = filter without sorting; + 4 / 16 / 64 / 128 / 256 select the independent second implementations and switch the screening
-        (128) or the bounds (256) off, + 8 / 32 concern the seeding -- all with the same labels and centres (include/brov2.h)."""
+        """Lloyd's loop (include/brov2.h: edmdc_set_kmeans_variant): 0 = default (candidate filter on sorted samples, packed-fp32
+        screening, distance bounds), + 1 = full scan, + 2 = filter without the sorted order, + 4 = distance bounds off -- all with the
+        same labels and centres.  (An experiments build accepts more bits: KMV_* in csrc/capi.hip.)"""
         self.check(self.lib.edmdc_set_kmeans_variant(self.h, int(variant)), "edmdc_set_kmeans_variant")
 
+    def set_kmeans_bounds_rate(self, rate: float):
+        """Share of labels changed per iteration below which the E-steps walk the list of failed bounds only (default 0.03; speed only)."""
+        self.check(self.lib.edmdc_set_kmeans_bounds_rate(self.h, float(rate)), "edmdc_set_kmeans_bounds_rate")
+
+    def set_rollout_variant(self, variant: int):
+        """Thruster-model rollouts: 0 = two-wave kernel (default), 1 = one-lane kernel (second implementation)."""
+        self.check(self.lib.brov_set_rollout_variant(self.h, int(variant)), "brov_set_rollout_variant")
+
     def set_kmeans_far_select(self, numpy_rule: bool):
-        """True (default): the empty-cluster relocation picks its rows with np.argpartition, like scikit-learn; False: the
-        library's own descending selection (ties by ascending row), which does not depend on NumPy's introselect."""
+        """True (default): the empty-cluster relocation picks its rows by calling np.argpartition on this host, like scikit-learn here;
+        False: the library's own rule -- a restatement of NumPy's (non-SIMD) introselect, what a plain-C caller gets
+        (include/brov2.h: edmdc_set_kmeans_far_select, edmdc_far_select_numpy).  Sharded runs apply whichever is set to the
+        distances of all ranks' rows."""
         fn = ctypes.cast(_NUMPY_FAR_SELECT, c_void_p) if numpy_rule else None
         self.check(self.lib.edmdc_set_kmeans_far_select(self.h, fn, None), "edmdc_set_kmeans_far_select")
 
     def kmeans_relocations(self) -> int:
         """Iterations of the last Lloyd call in which empty clusters were relocated."""
         return int(self.lib.edmdc_kmeans_relocations(self.h))
+
+    def kmeans_loop_info(self) -> dict:
+        """How the last Lloyd call ran (include/brov2.h: edmdc_kmeans_loop_info)."""
+        v = (ctypes.c_int * 4)()
+        self.check(self.lib.edmdc_kmeans_loop_info(self.h, v), "edmdc_kmeans_loop_info")
+        return dict(relocations=v[0], resorts=v[1], first_resort_iteration=v[2], list_form_e_steps=v[3])
 
     def set_kmeans_allreduce(self, fn):
         """Sharded Lloyd (include/brov2.h: edmdc_set_kmeans_allreduce).  fn(device_ptr: int, count: int, op: int) combines the

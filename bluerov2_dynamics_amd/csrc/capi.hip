@@ -51,7 +51,8 @@ struct brov_ctx {
     size_t lift_cache_cap = 0;
     bool lift_cache_valid = false;
     struct LiftKey { const void *X, *U, *C; int n, r, k; double gamma; int64_t nbags, L, xs, us, chunk; uint64_t bag_hash; } lift_key = {};
-    int kmeans_variant = 0;       // Lloyd: 0 = candidate filter on sorted samples, 1 = full scan, 2 = filter in the caller's order; + 4 = scalar-record kernel
+    int kmeans_variant = 0;       // edmdc_set_kmeans_variant: KMV_* bits below
+    double km_bounds_rate = 0.03; // edmdc_set_kmeans_bounds_rate
     int apply_variant = 0;        // edmdc_pinv_apply: 0 = wrows_kernel (tuned), 1 = the round-2 kernel (second implementation of the tests)
     void* d_tasks[3] = {nullptr, nullptr, nullptr};      // Gram task tables: [0] G^T[G|Y], [1] W^T Y (edmdc_pinv_apply), [2] G^T G alone
     EdmdcShape task_shape[3] = {};
@@ -80,9 +81,31 @@ struct brov_ctx {
     int km_rank = 0, km_world = 1;                // this rank's place in a sharded k-means
     long long km_n_global = 0;                    // rows over all ranks
     int kmeans_relocations = 0;       // relocations of empty clusters in the last edmdc_kmeans_lloyd(_dev) call
+    int km_info[4] = {0, 0, 0, 0};    // of the last Lloyd call: [1] re-sorts of the sample order, [2] iteration of the first one, [3] E-steps in list form
     int prop_groups = 2;              // window groups of edmdc_multistep_se, 1..4 (BROV2_PROP_GROUPS; 1 = everything on the ctx stream)
     int xcd_round_robin = -1;         // -1 not probed, 0 no, 1 yes: blockIdx % 8 groups blocks by XCD (speed only)
     char arch[64] = {0};
+};
+
+// edmdc_set_kmeans_variant.  The public surface is three bits (include/brov2.h); the others select the independent second
+// implementations of single stages and exist only in a -DBROV2_EXPERIMENTS=1 build (tools/, A/B runs, the cross-checks of the test
+// suite when it is pointed at such a library): same labels, same centres, bit for bit, whatever is set.
+enum : int {
+    KMV_FULL_SCAN = 1,          // E-step over all k centres (no candidate filter), the caller's order
+    KMV_UNSORTED = 2,           // candidate filter in the caller's order (no sorted sample order)
+    KMV_NO_BOUNDS = 4,          // distance bounds off: every E-step visits every sample
+    KMV_PUBLIC = 7,
+    KMV_PP_UNSCREENED = 8,      // seeding: every row through its fp64 distances (no float screening)
+    KMV_MASK_FILTER = 16,       // the round-3 form of the candidate filter alone (label groups, masks over all centres)
+    KMV_PP_SHARD_KERNELS = 32,  // a single rank's seeding through the kernels of the sharded run
+    KMV_PK_STANDALONE = 64,     // sorted loop: the stand-alone packed-fp32 kernel (the form k = 513..1024 always takes)
+    KMV_NO_SCREENING = 128,     // packed-fp32 screening off: fp64 evaluation of every candidate
+    KMV_SCALAR_RECORDS = 256,   // centre records through scalar registers (the kernel k > 1024 / n = 15 always take)
+#ifdef BROV2_EXPERIMENTS
+    KMV_ACCEPTED = 511,
+#else
+    KMV_ACCEPTED = KMV_PUBLIC,
+#endif
 };
 
 namespace {
@@ -468,11 +491,15 @@ int brov_create(int device_id, brov_ctx** out) {
     // gram_kernel / propagate_kernel group work items by blockIdx % 8 so that blocks sharing an XCD share rows through its
     // L2.  That placement is observed behaviour, not a HIP guarantee: probe it once and remember (speed only, never correctness).
     c->xcd_round_robin = probe_xcd_round_robin(nullptr);
+#ifdef BROV2_EXPERIMENTS
+    // run-time knobs of the experiments build (tools/): the default build reads no environment variable but BROV2_QUIET (below) and
+    // BROV2_RCCL_LIBRARY (comm.hip), both described in include/brov2.h
     if (const char* e = std::getenv("BROV2_ROLLOUT_SINGLE_LANE")) c->single_lane = (e[0] == '1');
     if (const char* e = std::getenv("BROV2_APPLY_SIMPLE")) c->apply_variant = (e[0] == '1');
-    if (const char* e = std::getenv("BROV2_KMEANS_PLAIN")) c->kmeans_variant = (e[0] == '1');
-    if (const char* e = std::getenv("BROV2_KMEANS_VARIANT")) { const int v = std::atoi(e); if (v >= 0 && v <= 254 && (v & 3) != 3) c->kmeans_variant = v; }      // experiments
+    if (const char* e = std::getenv("BROV2_KMEANS_VARIANT")) { const int v = std::atoi(e); if (v >= 0 && v <= KMV_ACCEPTED && (v & 3) != 3) c->kmeans_variant = v; }
     if (const char* e = std::getenv("BROV2_PROP_GROUPS")) { const int g = std::atoi(e); if (g >= 1 && g <= 4) c->prop_groups = g; }
+    if (const char* e = std::getenv("BROV2_KM_BOUNDS_RATE")) c->km_bounds_rate = std::atof(e);
+#endif
     if (c->xcd_round_robin != 1 && std::getenv("BROV2_QUIET") == nullptr)
         std::fprintf(stderr, "[libbrov2] note: workgroups are not dealt round-robin over the XCDs on device %d (probe=%d); "
                              "the XCD-aware block mappings lose their L2 sharing (results unaffected)\n", device_id, c->xcd_round_robin);
@@ -1297,10 +1324,27 @@ int edmdc_lift_cache(brov_ctx* c, void* d_buffer, size_t bytes) {
 }
 
 int edmdc_set_kmeans_variant(brov_ctx* c, int variant) {
-    if (!c || variant < 0 || variant > 510 || (variant & 3) == 3)
-        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 or 2, optionally + 4, + 8, + 16, + 32, + 64, + 128 and / or + 256");
+    if (!c || variant < 0 || (variant & ~KMV_ACCEPTED) != 0 || (variant & 3) == 3)
+        return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_variant: variant must be 0, 1 (full scan) or 2 (no sorted order), optionally + 4 (distance bounds off)");
     c->kmeans_variant = variant;
     return BROV_OK;
+}
+int edmdc_set_kmeans_bounds_rate(brov_ctx* c, double rate) {
+    if (!c || !(rate >= 0.0) || rate > 1.0) return fail(c, BROV_ERR_ARG, "edmdc_set_kmeans_bounds_rate: rate must lie in [0, 1]");
+    c->km_bounds_rate = rate;
+    return BROV_OK;
+}
+int brov_set_rollout_variant(brov_ctx* c, int variant) {
+    if (!c || variant < 0 || variant > 1) return fail(c, BROV_ERR_ARG, "brov_set_rollout_variant: variant must be 0 or 1");
+    c->single_lane = variant;
+    return BROV_OK;
+}
+int brov_experiments_build(void) {
+#ifdef BROV2_EXPERIMENTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 int edmdc_set_kmeans_far_select(brov_ctx* c, brov_far_select_fn fn, void* user) {
@@ -1310,6 +1354,17 @@ int edmdc_set_kmeans_far_select(brov_ctx* c, brov_far_select_fn fn, void* user) 
     return BROV_OK;
 }
 int edmdc_kmeans_relocations(brov_ctx* c) { return c ? c->kmeans_relocations : 0; }
+int edmdc_kmeans_loop_info(brov_ctx* c, int info[4]) {
+    if (!c || !info) return BROV_ERR_ARG;
+    info[0] = c->kmeans_relocations; info[1] = c->km_info[1]; info[2] = c->km_info[2]; info[3] = c->km_info[3];
+    return BROV_OK;
+}
+static void far_select_default(const double* dist, int64_t N, int n_empty, int64_t* out);
+int edmdc_far_select_numpy(const double* distances, int64_t N, int n_empty, int64_t* far_rows_out) {
+    if (!distances || !far_rows_out || N < 1 || n_empty < 1 || n_empty > N) return BROV_ERR_ARG;
+    far_select_default(distances, N, n_empty, far_rows_out);
+    return BROV_OK;
+}
 int edmdc_set_kmeans_allreduce(brov_ctx* c, brov_allreduce_fn fn, void* user) {
     if (!c) return BROV_ERR_ARG;
     c->km_allreduce = fn;
@@ -1698,30 +1753,113 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
 #ifndef KM_SORT_RATE
 #define KM_SORT_RATE 0.2
 #endif
-// `_relocate_empty_clusters_dense`'s choice of rows, `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`, is NumPy's introselect:
-// which of several equal distances it returns, and in which order the n_empty largest come out, is a property of that
-// implementation (and of the SIMD path the host CPU selects).  The Python layer therefore installs a callback that calls
-// np.argpartition itself (engine.py); without one the rows are the n_empty largest distances in descending order, equal
-// distances by ascending row -- identical whenever n_empty = 1 and the maximum is unique.
-static void far_select_default(const double* dist, int64_t N, int n_empty, int64_t* out) {
-    std::vector<int64_t> idx;
-    idx.reserve((size_t)n_empty + 1);
-    auto before = [&](int64_t a, int64_t b) {            // a is "farther" than b (NaN = farthest, like NumPy's sort order)
-        const double da = dist[a], db = dist[b];
-        const bool na = da != da, nb = db != db;
-        if (na != nb) return na;
-        if (!na && da != db) return da > db;
-        return a < b;
-    };
-    for (int64_t i = 0; i < N; ++i) {
-        if ((int)idx.size() == n_empty && !before(i, idx.back())) continue;
-        size_t pos = idx.size();
-        idx.push_back(i);
-        while (pos > 0 && before(i, idx[pos - 1])) { idx[pos] = idx[pos - 1]; --pos; }
-        idx[pos] = i;
-        if ((int)idx.size() > n_empty) idx.pop_back();
+// `_relocate_empty_clusters_dense`'s choice of rows is `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]`
+// (sklearn/cluster/_k_means_common.pyx): WHICH of several equal distances it returns, and in which order the n_empty largest come
+// out (= which empty cluster gets which row), are properties of NumPy's selection algorithm.  NumPy has two: its own introselect
+// (numpy/_core/src/npysort/selection.cpp: median-of-3 quickselect on the index array, median-of-medians-of-5 once the depth limit
+// 2 floor(log2 N) is spent, an O(n kth) selection when kth is within 3 of the range's start, a plain maximum scan for kth = N - 1) --
+// what runs wherever no SIMD kernel is dispatched -- and, on x86 hosts with AVX-512 / AVX2, x86-simd-sort's vectorised argselect,
+// whose order differs (seen in this container: 7 largest of 1 000 values come out as rows 51, 423, 758 ... against 689, 243, 51 ...).
+// The reference's result is therefore host-dependent.  This is the former, restated: the library's rule for plain-C callers and for
+// sharded runs, pinned by tests/golden/farselect.npz (np.argpartition itself with its SIMD dispatch disabled,
+// tools/gen_farselect_golden.py).  The Python layer may install a callback that calls np.argpartition on the host at hand instead
+// (edmdc_set_kmeans_far_select): then the rows are scikit-learn's on THAT host, whatever it dispatches.
+namespace npysel {
+struct Sel {
+    const double* v;
+    int64_t* t;                                            // the index array being partitioned ("tosort")
+    // NumPy's order for floating point: NaNs are the largest (npy::double_tag::less)
+    static bool less(double a, double b) { return a < b || (b != b && a == a); }
+    double at(int64_t i) const { return v[t[i]]; }
+    void swap(int64_t i, int64_t j) { const int64_t x = t[i]; t[i] = t[j]; t[j] = x; }
+
+    void dumb_select(int64_t base, int64_t num, int64_t kth) {
+        for (int64_t i = 0; i <= kth; ++i) {
+            int64_t minidx = i;
+            double minval = at(base + i);
+            for (int64_t k = i + 1; k < num; ++k)
+                if (less(at(base + k), minval)) { minidx = k; minval = at(base + k); }
+            swap(base + i, base + minidx);
+        }
     }
-    for (int q = 0; q < n_empty; ++q) out[q] = q < (int)idx.size() ? idx[q] : 0;
+    void median3_swap(int64_t low, int64_t mid, int64_t high) {
+        if (less(at(high), at(mid))) swap(high, mid);
+        if (less(at(high), at(low))) swap(high, low);
+        if (less(at(low), at(mid))) swap(low, mid);        // the median goes to low ...
+        swap(mid, low + 1);                                // ... the smallest of the three to low + 1
+    }
+    int64_t median5(int64_t b) {
+        if (less(at(b + 1), at(b + 0))) swap(b + 1, b + 0);
+        if (less(at(b + 4), at(b + 3))) swap(b + 4, b + 3);
+        if (less(at(b + 3), at(b + 0))) swap(b + 3, b + 0);
+        if (less(at(b + 4), at(b + 1))) swap(b + 4, b + 1);
+        if (less(at(b + 2), at(b + 1))) swap(b + 2, b + 1);
+        if (less(at(b + 3), at(b + 2))) return less(at(b + 3), at(b + 1)) ? 1 : 3;
+        return 2;
+    }
+    void unguarded_partition(double pivot, int64_t* ll, int64_t* hh) {
+        for (;;) {
+            do { ++*ll; } while (less(at(*ll), pivot));
+            do { --*hh; } while (less(pivot, at(*hh)));
+            if (*hh < *ll) break;
+            swap(*ll, *hh);
+        }
+    }
+    int64_t median_of_median5(int64_t base, int64_t num) {
+        const int64_t nmed = num / 5;
+        for (int64_t i = 0, subleft = 0; i < nmed; ++i, subleft += 5) {
+            const int64_t m = median5(base + subleft);
+            swap(base + subleft + m, base + i);
+        }
+        if (nmed > 2) introselect(base, nmed, nmed / 2);
+        return nmed / 2;
+    }
+    // partitions t[base .. base + num) so that position base + kth holds what a sort would put there
+    void introselect(int64_t base, int64_t num, int64_t kth) {
+        int64_t low = 0, high = num - 1;
+        if (kth - low < 3) { dumb_select(base + low, high - low + 1, kth - low); return; }
+        if (kth == num - 1) {                              // (NumPy: "useful to check if NaN present via partition(d, (x, -1))")
+            int64_t maxidx = low;
+            double maxval = at(base + low);
+            for (int64_t k = low + 1; k < num; ++k)
+                if (!less(at(base + k), maxval)) { maxidx = k; maxval = at(base + k); }
+            swap(base + kth, base + maxidx);
+            return;
+        }
+        int depth_limit = 0;
+        for (uint64_t u = (uint64_t)num; u >>= 1;) ++depth_limit;
+        depth_limit *= 2;
+        for (; low + 1 < high;) {
+            int64_t ll = low + 1, hh = high;
+            if (depth_limit > 0 || hh - ll < 5) {
+                median3_swap(base + low, base + low + (high - low) / 2, base + high);
+            } else {
+                const int64_t mid = ll + median_of_median5(base + ll, hh - ll);
+                swap(base + mid, base + low);
+                --ll;
+                ++hh;
+            }
+            --depth_limit;
+            int64_t al = base + ll, ah = base + hh;
+            unguarded_partition(at(base + low), &al, &ah);
+            ll = al - base; hh = ah - base;
+            swap(base + low, base + hh);
+            if (hh >= kth) high = hh - 1;
+            if (hh <= kth) low = ll;
+        }
+        if (high == low + 1 && less(at(base + high), at(base + low))) swap(base + high, base + low);
+    }
+};
+}  // namespace npysel
+
+static void far_select_default(const double* dist, int64_t N, int n_empty, int64_t* out) {
+    if (n_empty <= 0 || N <= 0) return;
+    if (n_empty > N) n_empty = (int)N;
+    std::vector<int64_t> idx((size_t)N);
+    for (int64_t i = 0; i < N; ++i) idx[(size_t)i] = i;
+    npysel::Sel s{dist, idx.data()};
+    s.introselect(0, N, N - n_empty);                      // np.argpartition(distances, -n_empty)
+    for (int q = 0; q < n_empty; ++q) out[q] = idx[(size_t)(N - 1 - q)];      // [:-n_empty-1:-1]
 }
 
 // The rare path of the M-step: stats[3] = n_empty > 0.  The E-step that was queued behind the M-step has returned at once (hold), so
@@ -1817,32 +1955,43 @@ static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d
                 apply(new_ids[q], lab[(size_t)far[q]], qv);
             }
         } else {
-            std::vector<char> taken((size_t)N, 0);
+            // Sharded: the selection rule looks at the distances of ALL rows in global row order (np.argpartition's result depends on where
+            // the values sit, not only on what they are), so the ranks' distance arrays are put side by side first -- one all-reduce (sum)
+            // of N_global words in which every rank fills its own rows with the bit patterns and leaves zeros elsewhere (80 MB at 1e7
+            // rows: this path runs when a cluster runs empty, i.e. hardly ever) -- and every rank then applies the same rule to the same
+            // array: the rows of the unsharded run, callback or library rule alike.
+            const int64_t Ng = c->km_n_global > 0 ? (int64_t)c->km_n_global : N;
+            if (c->km_row_offset + N > Ng) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: edmdc_set_kmeans_shard does not cover this rank's rows"); }
+            if (n_empty > Ng) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: more empty clusters than samples"); }
+            std::vector<double> gdist((size_t)Ng, 0.0);
+            {
+                long long* d_all = nullptr;
+                if (hipMalloc((void**)&d_all, (size_t)Ng * 8) != hipSuccess) { cleanup(); return fail(c, BROV_ERR_NOMEM, "edmdc_kmeans_lloyd: no memory for the gathered distances"); }
+                bool ok = hipMemsetAsync(d_all, 0, (size_t)Ng * 8, c->stream) == hipSuccess &&
+                          hipMemcpyAsync(d_all + c->km_row_offset, d_dist, (size_t)N * 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+                const int arc = ok ? c->km_allreduce(c->km_allreduce_user, d_all, Ng, 0) : 1;
+                ok = ok && arc == 0 && hipMemcpyAsync(gdist.data(), d_all, (size_t)Ng * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                     hipStreamSynchronize(c->stream) == hipSuccess;
+                (void)hipFree(d_all);
+                if (!ok) { cleanup(); return fail(c, arc ? BROV_ERR_COMM : BROV_ERR_HIP, "edmdc_kmeans_lloyd: gathering the distances of the ranks failed"); }
+            }
+            std::vector<int64_t> far((size_t)n_empty);
+            if (c->far_select) {
+                if (c->far_select(c->far_select_user, gdist.data(), Ng, n_empty, far.data()) != 0) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback failed"); }
+                for (int64_t r : far) if (r < 0 || r >= Ng) { cleanup(); return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd: the far-sample callback returned a row out of range"); }
+            } else {
+                far_select_default(gdist.data(), Ng, n_empty, far.data());
+            }
             for (int q = 0; q < n_empty; ++q) {
-                // this rank's farthest remaining row (NaN = farthest; equal distances: the lowest row)
-                int64_t best = -1;
-                for (int64_t i = 0; i < N; ++i) {
-                    if (taken[i]) continue;
-                    if (best < 0) { best = i; continue; }
-                    const double a = dist[i], bb = dist[best];
-                    const bool na = a != a, nb = bb != bb;
-                    if ((na && !nb) || (!na && !nb && a > bb)) best = i;
-                }
-                long long w[2] = {0, 0};
-                if (best >= 0) { const double dv = dist[best] != dist[best] ? __builtin_inf() : dist[best]; std::memcpy(&w[0], &dv, 8); }
-                const long long mine = w[0];
-                EXCH(w, 1, 1);
-                const bool holder = best >= 0 && mine == w[0];
-                long long key[1] = {holder ? ((1ll << 62) - (c->km_row_offset + best)) : 0ll};
-                EXCH(key, 1, 1);
-                const bool owner = holder && key[0] == (1ll << 62) - (c->km_row_offset + best);
+                // the owner of the row sends its label and fixed-point coordinates (sum: the other ranks hold zeros)
+                const int64_t lrow = far[q] - c->km_row_offset;
+                const bool owner = lrow >= 0 && lrow < N;
                 long long msg[18];
                 for (long long& v : msg) v = 0;
                 if (owner) {
-                    if (quantise_row(best, msg)) { cleanup(); return fail(c, BROV_ERR_HIP, "edmdc_kmeans_lloyd: reading a far row failed"); }
-                    msg[16] = lab[(size_t)best];
+                    if (quantise_row(lrow, msg)) { cleanup(); return fail(c, BROV_ERR_HIP, "edmdc_kmeans_lloyd: reading a far row failed"); }
+                    msg[16] = lab[(size_t)lrow];
                     msg[17] = 1;
-                    taken[best] = 1;
                 }
                 EXCH(msg, 18, 0);
                 if (msg[17] != 1) { cleanup(); return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: the ranks disagree about a relocated row"); }
@@ -1867,7 +2016,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         return fail(c, BROV_ERR_ARG, "edmdc_kmeans_lloyd_dev: bad argument (need 1<=n<=15, k*(n+1)*8 <= 150 KiB of LDS)");
     DeviceGuard g(c);
     const int variant = c->kmeans_variant & 3;
-    const bool scalar_records = (c->kmeans_variant & 4) != 0;     // the E-step kernel with scalar centre records (kmeans.hip)
+    const bool scalar_records = (c->kmeans_variant & KMV_SCALAR_RECORDS) != 0;     // the E-step kernel with scalar centre records (kmeans.hip)
     const int nb = kmeans_blocks(N, n, k, scalar_records);
     const int nparts = nb * kmeans_epochs(N, n, k, scalar_records);
     const size_t pwords = kmeans_partial_words(N, n, k, scalar_records), rwords = kmeans_red_words(n, k);
@@ -1878,23 +2027,22 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // through it.  Worth it only at size.
     // k = 513 ... 1024 (n = 12 / 13): beyond the LDS / DPP kernel's table; the packed-fp32 kernel (kmeans_assign_pk_kernel) reads the same order
     // and the same sorted rows with only the member sums in the LDS.  + 128 (screening off) or + 4 keeps the scalar-record kernel there.
-    const bool big = !scalar_records && !kmeans_reads_through_perm(n, k, false) && kmeans_pk_supported(n, k) && (c->kmeans_variant & (16 | 128)) == 0;
+    const bool big = !scalar_records && !kmeans_reads_through_perm(n, k, false) && kmeans_pk_supported(n, k) && (c->kmeans_variant & (KMV_MASK_FILTER | KMV_NO_SCREENING)) == 0;
     const bool sorting = filter && variant == 0 && (kmeans_reads_through_perm(n, k, scalar_records) || big) && N >= ((int64_t)1 << 18) && N < ((int64_t)1 << 31);
     const size_t sort_tmp = sorting ? kmeans_sort_temp_bytes(N) : 0;
     // single-reference form of the filter (kmeans.hip, round 4): sorted rows of the centre distances for the LDS / DPP kernel; + 16 in the
     // k-means variant keeps the mask form of round 3 alone (the independent second implementation of the filter)
-    const bool nbr = filter && (kmeans_reads_through_perm(n, k, scalar_records) || (big && sorting)) && (c->kmeans_variant & 16) == 0;
+    const bool nbr = filter && (kmeans_reads_through_perm(n, k, scalar_records) || (big && sorting)) && (c->kmeans_variant & KMV_MASK_FILTER) == 0;
     const size_t kp_ = (size_t)((k + 255) & ~255);
     // third form of the E-step (kmeans.hip): candidates screened in packed fp32, exact arithmetic for the winner; for the loop's sorted
     // order.  + 64 in the k-means variant selects it.
-    const bool pk = nbr && sorting && ((c->kmeans_variant & 64) != 0 || big) && kmeans_pk_supported(n, k);
+    const bool pk = nbr && sorting && ((c->kmeans_variant & KMV_PK_STANDALONE) != 0 || big) && kmeans_pk_supported(n, k);
     // ... and the same screening as an evaluation path INSIDE the LDS / DPP kernel (its prefetching, its LDS-resident exact records): the
     // default for the sorted loop; + 128 switches it off (fp64 evaluation of every candidate, the form of round 3 and early round 4)
-    const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & 128) == 0 && kmeans_pk_supported(n, k) && kmeans_reads_through_perm(n, k, scalar_records);
+    const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & KMV_NO_SCREENING) == 0 && kmeans_pk_supported(n, k) && kmeans_reads_through_perm(n, k, scalar_records);
     // distance bounds (kmeans.hip: kmeans_bounds_kernel): once few labels change per iteration, an E-step visits only the samples whose
     // bounds fail and the M-step adds their CHANGES to the totals it keeps; + 256 in the k-means variant (or BROV2_KM_BOUNDS=0) switches it off
-    bool bnd = pk_lds && (c->kmeans_variant & 256) == 0;
-    if (const char* e = std::getenv("BROV2_KM_BOUNDS")) bnd = bnd && std::atoi(e) != 0;
+    const bool bnd = pk_lds && (c->kmeans_variant & KMV_NO_BOUNDS) == 0;
     const size_t lwords = bnd ? kmeans_bounds_list_words(N) : 0;
     const int nb_pk = pk ? kmeans_pk_blocks(N, n, k) : 0;
     const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N, n, k) : 0;
@@ -1978,9 +2126,12 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // (with the distance bounds an E-step visits a fraction of the samples while a sort still handles them all: later sorts -- 0.03: 169 ms per
     // 300 iterations at 1e7 x 12, k = 512; 0.06: 165; 0.1: 166.5; 0.2: 177.5)
     double sort_moved = bnd ? 2.0 * KM_SORT_MOVED : KM_SORT_MOVED, sort_rate = KM_SORT_RATE;
-    if (const char* e = std::getenv("BROV2_KM_SORT_MOVED")) sort_moved = std::atof(e);      // experiments (tools/time_lloyd_ab.py)
+#ifdef BROV2_EXPERIMENTS
+    if (const char* e = std::getenv("BROV2_KM_SORT_MOVED")) sort_moved = std::atof(e);      // (tools/time_lloyd_ab.py)
     if (const char* e = std::getenv("BROV2_KM_SORT_RATE")) sort_rate = std::atof(e);
+#endif
     c->kmeans_relocations = 0;
+    c->km_info[1] = c->km_info[2] = c->km_info[3] = 0;
     // the first E-step has no labels to start from: full scan; from then on the candidate filter (kmeans.hip) unless switched off
     HIPCK(c, launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, nullptr, prm, fix, d2, scalar_records, nullptr));
     int e_nparts = nparts, e_nb = nb;                  // geometry of the E-step whose partials are waiting (the packed-fp32 kernel has its own)
@@ -1988,11 +2139,13 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // since the centres were last changed behind the loop's back (relocation); e_list: the E-step whose partials are waiting walked the list
     int bcur = 0;
     bool bounds_valid = false, e_list = false, any_list = false, use_list = false;
-    double bounds_rate = 0.03;                          // list form once at most this share of the labels changed in the last summed iteration
-    if (const char* e = std::getenv("BROV2_KM_BOUNDS_RATE")) bounds_rate = std::atof(e);
-    const bool bounds_log = std::getenv("BROV2_KM_BOUNDS_LOG") != nullptr;
+    const double bounds_rate = c->km_bounds_rate;       // list form once at most this share of the labels changed in the last summed iteration
+    bool bounds_log = false;
     double bounds_beta = -1.0;
-    if (const char* e = std::getenv("BROV2_KM_BOUNDS_BETA")) bounds_beta = std::atof(e);      // experiments (tools/time_lloyd_ab.py)
+#ifdef BROV2_EXPERIMENTS
+    bounds_log = std::getenv("BROV2_KM_BOUNDS_LOG") != nullptr;
+    if (const char* e = std::getenv("BROV2_KM_BOUNDS_BETA")) bounds_beta = std::atof(e);      // (tools/time_lloyd_ab.py)
+#endif
     const double n_all = (c->km_allreduce && c->km_n_global > 0) ? (double)c->km_n_global : (double)N;
     auto e_step = [&](bool filtered) -> hipError_t {
         if (filtered && pk) {
@@ -2010,6 +2163,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                 hipError_t e = launch_kmeans_bounds(c->stream, N, k, Lc, kb, prm);
                 if (e != hipSuccess) return e;
                 e_list = any_list = true;
+                ++c->km_info[3];
             }
             bounds_valid = true;                        // (a full pass writes them all; a list pass keeps them)
         }
@@ -2038,6 +2192,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             cur ^= 1;
             want_sort = false;
             moved = 0.0;
+            if (c->km_info[1]++ == 0) c->km_info[2] = it;
         }
         if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd));
         // hs still holds the statistics of the iteration before this one (the host has not waited yet): few changed labels -> list form
@@ -2076,8 +2231,10 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             // per iteration buys nothing (rate 0.2 or 1.0 at moved 0.01: 303-304 ms).  Once a wave with a few moved labels sums its main
             // label over the wave (kmeans.hip: KM2_SUM_MIN) an early order pays after all: 0.03 / 0.05: 274 ms; 0.03 / 0.2: 263.5; 0.03 / 1.0: 264;
             // 0.05 / 0.2: 264; 0.08 / 1.0: 273 (one box).
+            // (hs[2] counts the changed labels of ALL ranks in a sharded run: both gates are shares of all rows -- round-4 advice: against
+            // the local row count the rate gate was `world` times stricter and ranks with unequal shards sorted at different iterations)
             moved += hs[2];
-            if (moved >= sort_moved * (double)N && hs[2] <= sort_rate * (double)N) want_sort = true;
+            if (moved >= sort_moved * n_all && hs[2] <= sort_rate * n_all) want_sort = true;
         }
     }
     if (it > max_iter) it = max_iter;
@@ -2119,7 +2276,7 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     Arena a(c);
     // a float copy of the coordinates screens out the rows a round cannot affect (kmeans.hip, pp_round_kernel); + 8 in the k-means
     // variant: every row goes through the fp64 path
-    const bool screening = (c->kmeans_variant & 8) == 0;
+    const bool screening = (c->kmeans_variant & KMV_PP_UNSCREENED) == 0;
     const size_t nshard = kmeanspp_shard_doubles(sharded ? c->km_world : 1);
     int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) + Arena::al(nshard * 8) +
                        Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + (screening ? Arena::al((size_t)N * n * 4) : 0) + 8192);
@@ -2139,7 +2296,7 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
-        if (sharded || (c->kmeans_variant & 32)) {
+        if (sharded || (c->kmeans_variant & KMV_PP_SHARD_KERNELS)) {
             // rows sharded over ranks (edmdc_set_kmeans_allreduce / edmdc_set_kmeans_shard): two small exchanges per centre; + 32 in the
             // k-means variant sends a single rank through the same kernels (the tests' check of that path against the one above)
             int comm_failed = 0;

@@ -454,6 +454,13 @@ static_assert(KM2_KMAX <= KM_SORT_LABEL_MAX, "the sort keys of the loop's sample
 constexpr int KM2_NMAX = 14;         // slot 15 of a record holds -|c|^2/2 (the seed of the DPP chain), slot n the positive half norm
 typedef double v2d __attribute__((ext_vector_type(2)));
 
+// Operand constraints of the multi-instruction asm blocks of this file (audited in round 5 after the early-clobber fault of round 4):
+//   score_bcast / score2_bcast : outputs "=&v" -- the accumulators are written (seed) while `rec` and x[] are still to be read;
+//   sub_bcast, wave_sum_u64x   : every register the block writes is an in/out operand ("+v": it holds a live input, so no other input
+//                                can share it); wave_sum_u64x clobbers vcc and says so;
+//   v_max_f64 one-liners       : a single instruction reads its sources before it writes -- plain "=v" is right;
+//   pk_issue / pk_wait         : "=&s" destinations (three requests read one address pair one after the other); the window between the
+//                                two statements is checked on the compiler's listing by tools/isa_sload_window.py (a CPU test).
 // x.c - |c|^2/2 for the record held by the DPP rows of `rec`: the seed from slot 15, then fma(x_j, c_j, .) in index order -- one
 // asm block (between separate asm statements the compiler pads with s_nop, and a wave issues one instruction per four cycles).
 // s_nop 1: a DPP read needs two wait states after a VALU write of its source; the compiler does not see into the asm.

@@ -259,9 +259,10 @@ def kmeans_lloyd_sharded(X_local, C0, mean=None, max_iter=300, tol_abs=0.0, grou
     int64) of the member sums -- 2 k (n + 1) + 2 words, 53 KB at k = 512 -- and one all-reduce (MAX) of 16 words before the loop.
     The member sums are integers (csrc/kmeans.hip), so every rank ends with the same centres and they are the centres of the
     unsharded run bit for bit.  Returns (centres [k, n], labels of the local rows, local inertia, n_iter); the inertia of the
-    whole set is the sum over ranks.  An empty cluster is relocated to the farthest rows of the WHOLE set by the library's
-    descending rule (distance, then global row; include/brov2.h: edmdc_set_kmeans_shard) -- the rows an unsharded run picks when
-    its NumPy callback is switched off (Context.set_kmeans_far_select(False)), and NumPy's own whenever the maximum is unique.
+    whole set is the sum over ranks.  Empty clusters are relocated to the farthest rows of the WHOLE set: the ranks' distances are
+    gathered in global row order and every rank applies the ctx's selection rule to them (np.argpartition through the callback by
+    default, like scikit-learn on this host; the library's introselect restatement after Context.set_kmeans_far_select(False)) --
+    the rows, and the centres, of the unsharded run under the same rule (include/brov2.h: edmdc_set_kmeans_shard).
     lloyd_fn(X_local, C0, mean, max_iter, tol_abs, allreduce): the loop itself -- default the HIP path
     (edmdc_kmeans_lloyd_dev with edmdc_set_kmeans_allreduce); the CPU tests inject the oracle's stand-in under gloo.
     force_exchange: install the exchange in a process group of ONE rank too (tests: the all-reduce of the library's own device

@@ -162,6 +162,10 @@ BROV_API int brov_set_di_gains(brov_ctx* ctx, int nu, const double* K_lin, const
  * for the memory-bound cases -- Euler, wrench models -- and lane-per-row accesses for the
  * instruction-bound thruster RK4 kernel; measured in DESIGN.md), 1 = always LDS-staged, 2 = never. */
 BROV_API int brov_set_btu_staging(brov_ctx* ctx, int mode);
+/* Which kernel runs the thruster-model rollouts: 0 = the two-wave kernel (thrust half and body half of a step on two waves that share
+ * a SIMD; default), 1 = the whole step in one lane (the kernel of the wrench / double-integrator models; the independent second
+ * implementation of the parity tests).  Same trajectories to rounding. */
+BROV_API int brov_set_rollout_variant(brov_ctx* ctx, int variant);
 BROV_API int brov_rollout_dev(brov_ctx* ctx, int model, int integrator, int lag_mode, int layout,
                      int64_t B, int64_t T, double dt, const double* d_x0, const double* d_U,
                      double* d_lag_io, double* d_traj, int64_t traj_stride, double* d_xT);
@@ -309,44 +313,47 @@ BROV_API int edmdc_lift_cache(brov_ctx* ctx, void* d_buffer, size_t bytes);
 /* Which kernel forms the rows of W in edmdc_pinv_apply(_dev): 0 = the tuned one (default), 1 = the plain one-row-tile-per-wave
  * form (kept as an independent second implementation for the parity tests; BROV2_APPLY_SIMPLE=1 selects it at brov_create). */
 BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
-/* Lloyd's loop in edmdc_kmeans_lloyd(_dev):
- * 0 = E-step with the per-wave candidate filter (triangle inequality over the centre-centre distances; the same labels as the
- *     full scan bit for bit), visiting the samples in an order kept sorted by (label, distance to the centre) -- a permutation,
- *     re-sorted as labels move; for >= 2^18 samples, n <= 14 and k <= 512 (k <= 1024 for n = 12 or 13); in that order the candidates
- *     of a wave are screened in packed fp32 (two per issue slot, in the frame of the wave's reference centre) and only the pair the
- *     winner is certified to lie in is evaluated in fp64 (n = 12 or 13); the labels are returned in the caller's order -- default;
- * 1 = full scan over all k centres in the caller's order (the independent second implementation; BROV2_KMEANS_PLAIN=1 at brov_create);
- * 2 = candidate filter in the caller's order (no sorting).
- * Adding 4 selects the E-step kernel that takes the centre records through scalar registers (the form of round 2 / early round 3,
- * still the one for k > 1024, n = 15, and k > 512 below 2^18 samples) instead of the LDS-resident table read through DPP: same
- * arithmetic, same labels.
- * Adding 8 makes the k-means++ seeding (edmdc_kmeanspp_dev) take every sample through its fp64 distance evaluation in every round
- * instead of screening rows out with a float copy of the coordinates first: same indices, same centres.
- * Adding 16 keeps the round-3 form of the candidate filter alone (label groups and masks over all centres) instead of trying the
- * single-reference form first (candidates = a prefix of the reference centre's sorted distance row): same labels, same centres.
- * Adding 64 runs the E-steps of the sorted loop (variant 0, n = 12 or 13, 64 <= k <= 1024) through the stand-alone kernel of the
- * packed-fp32 screening (member sums the only LDS table; the form k = 513 ... 1024 always takes) instead of the screening inside the
- * LDS / DPP kernel: the same labels, the same centres.
- * Adding 128 switches the packed-fp32 screening off: every candidate is evaluated in fp64 (the form of round 3 / early round 4; for
- * k > 512 the scalar-record kernel in the caller's order): the same labels, the same centres.
- * Adding 256 switches the distance bounds of the sorted loop off (default on wherever the packed-fp32 screening runs inside the LDS /
- * DPP kernel: n = 12 or 13, k <= 512, >= 2^18 samples): with them, once few labels change per iteration, an E-step visits only the
- * samples whose bounds (Hamerly's: distance to the own centre from above, to every other centre from below, moved by the centres'
- * shifts) cannot rule a change out, and the M-step adds the CHANGES of the integer member sums to the totals it keeps: the same labels,
- * the same centres bit for bit.
- * Adding 32 sends the seeding of a single rank through the kernels of the sharded run (candidate rows from a table, potentials
- * through the per-rank totals): same indices. */
+/* Lloyd's loop in edmdc_kmeans_lloyd(_dev) -- a mask of three bits; every setting gives the same labels and the same centres, bit for bit
+ * (integer member sums), so the non-default ones are the independent second implementations the parity tests compare against:
+ *   0      default: E-step with the per-wave candidate filter (triangle inequality over the centre-centre distances) on a sample order
+ *          kept sorted by (label, distance to the centre) -- a permutation, re-sorted as labels move; candidates screened in packed fp32
+ *          in the frame of the wave's reference centre, exact fp64 only for the certified pair; Hamerly-style distance bounds let an
+ *          E-step visit only the samples whose label could change (sorted order: >= 2^18 samples, n <= 14, k <= 512, or k <= 1024 for
+ *          n = 12 / 13; bounds and screening: n = 12 / 13, k <= 512; anything else falls back to the plainer forms by itself);
+ *   + 1    full scan over all k centres in the caller's order: no filter, no sorting, no bounds;
+ *   + 2    candidate filter in the caller's order (no sorted sample order, hence no screening and no bounds);   (1 + 2 is refused)
+ *   + 4    distance bounds off: every E-step visits every sample.
+ * A library built with -DBROV2_EXPERIMENTS=1 (tools/, A/B measurements; brov_experiments_build() = 1) accepts further bits that swap
+ * single stages for their earlier forms (csrc/capi.hip: KMV_*) and reads its tuning knobs from the environment; the default build
+ * refuses those bits and reads no environment variable except BROV2_QUIET (silences the one note brov_create may print about the XCD
+ * placement probe) and BROV2_RCCL_LIBRARY (below). */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
+/* When the distance bounds take over: an E-step visits only the samples whose bounds fail once at most `rate` of all labels changed in
+ * the iteration before (default 0.03; 1 = from the first sorted iteration on, 0 = never).  Speed only: labels and centres do not depend
+ * on it (tests/test_gpu_parity.py::test_lloyd_distance_bounds_change_nothing runs both ends). */
+BROV_API int edmdc_set_kmeans_bounds_rate(brov_ctx* ctx, double rate);
+BROV_API int brov_experiments_build(void);                          /* 1 for a -DBROV2_EXPERIMENTS=1 library */
 /* Which samples `_relocate_empty_clusters_dense` moves its empty clusters to is
- * `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]` (sklearn/cluster/_k_means_common.pyx): NumPy's introselect decides the
- * order of the n_empty largest and the winner among equal distances.  The Python layer installs a callback that calls
- * np.argpartition itself; without one (fn = NULL) the library takes the n_empty largest distances in descending order, equal
- * ones by ascending row -- the same rows whenever n_empty = 1 and the maximum is unique.  distances [N] (host), rows of the
- * caller's X; far_rows_out [n_empty]; return 0 on success. */
+ * `np.argpartition(distances, -n_empty)[:-n_empty-1:-1]` (sklearn/cluster/_k_means_common.pyx): the selection algorithm decides the
+ * order of the n_empty largest (which empty cluster gets which row) and the winner among equal distances -- and NumPy has two of them:
+ * its own introselect (numpy/_core/src/npysort/selection.cpp) wherever no SIMD kernel is dispatched, x86-simd-sort's argselect on x86
+ * hosts with AVX-512 / AVX2, with different answers.  Without a callback (fn = NULL: plain-C callers) the library applies a restatement
+ * of the FORMER -- NumPy's introselect, step for step, pinned by tests/golden/farselect.npz (np.argpartition with its dispatch
+ * disabled) and exported as edmdc_far_select_numpy.  The Python layer installs a callback that calls np.argpartition on the host at hand,
+ * so that the rows are scikit-learn's on that host whatever it dispatches.  distances [N] (host), rows of the caller's X -- in a sharded
+ * run (edmdc_set_kmeans_shard) the distances of ALL ranks' rows in global row order, N = n_global; far_rows_out [n_empty]; return 0 on
+ * success. */
 typedef int (*brov_far_select_fn)(void* user, const double* distances, int64_t N, int n_empty, int64_t* far_rows_out);
 BROV_API int edmdc_set_kmeans_far_select(brov_ctx* ctx, brov_far_select_fn fn, void* user);
+/* The library's own rule, host only: far_rows_out[q] = np.argpartition(distances, -n_empty)[N - 1 - q] as NumPy's introselect leaves it
+ * (NaN = farthest).  1 <= n_empty <= N. */
+BROV_API int edmdc_far_select_numpy(const double* distances, int64_t N, int n_empty, int64_t* far_rows_out);
 /* relocations of empty clusters during the last edmdc_kmeans_lloyd(_dev) call (iterations in which at least one took place) */
 BROV_API int edmdc_kmeans_relocations(brov_ctx* ctx);
+/* How the last edmdc_kmeans_lloyd(_dev) call ran (speed only; none of it changes a result): info[0] = iterations with a relocation,
+ * info[1] = re-sorts of the sample order, info[2] = iteration of the first re-sort (0 = none), info[3] = E-steps that visited only the
+ * samples whose distance bounds failed.  Ranks of a sharded run report the same numbers. */
+BROV_API int edmdc_kmeans_loop_info(brov_ctx* ctx, int info[4]);
 /* Sharded Lloyd: every rank calls edmdc_kmeans_lloyd_dev on its own rows with the same initial centres; `fn` is called on the
  * ctx stream's behalf with a DEVICE buffer that has to be combined over all ranks in place before work queued later on the ctx
  * stream reads it: op 0 = sum of `count` int64, op 1 = maximum of `count` uint64.  One call with op 1 (16 words) before the loop,
@@ -360,9 +367,11 @@ BROV_API int edmdc_set_kmeans_allreduce(brov_ctx* ctx, brov_allreduce_fn fn, voi
  *   edmdc_kmeanspp_dev seeds over ALL rows -- first_index and the returned indices are global, k <= n_global, every rank passes the
  *     same first_index and uniforms (drawn for n_global rows) and ends with the same centres; two small exchanges per centre (the
  *     ranks' partial potentials, the rows of the next candidates);
- *   edmdc_kmeans_lloyd_dev relocates an empty cluster to the farthest rows of the whole set: descending distance, equal distances by
- *     ascending GLOBAL row (three small exchanges per relocated cluster) -- the library's own rule, also for one rank when no
- *     far-select callback is installed, so sharded and unsharded runs relocate the same rows. */
+ *   edmdc_kmeans_lloyd_dev relocates empty clusters to the farthest rows of the WHOLE set: the ranks' distances are put side by side in
+ *     global row order (one all-reduce of n_global words; this path runs when a cluster runs empty, i.e. hardly ever) and every rank applies
+ *     the same selection -- the callback of edmdc_set_kmeans_far_select when one is installed, the library's rule otherwise -- to the same
+ *     array, then the owner of each chosen row sends its label and coordinates (one small exchange per row): the rows, and with them the
+ *     centres, of the unsharded run under the same rule. */
 BROV_API int edmdc_set_kmeans_shard(brov_ctx* ctx, int rank, int world, int64_t row_offset, int64_t n_global);
 
 /* ---- multi-GPU: one process per GPU, RCCL over xGMI ----------------------------------------

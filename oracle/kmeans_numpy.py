@@ -24,10 +24,121 @@ def far_rows_numpy(distances, n_empty):
     return np.argpartition(distances, -n_empty)[:-n_empty - 1:-1]
 
 
-def far_rows_sorted(distances, n_empty):
-    """The library's fallback rule (csrc/capi.hip: far_select_default): descending distance, equal ones by ascending row."""
-    order = np.lexsort((np.arange(len(distances)), -distances))
-    return order[:n_empty]
+def _less(a, b):
+    """NumPy's order for floating point: NaNs are the largest (npy::double_tag::less)."""
+    return a < b or (b != b and a == a)
+
+
+class _Introselect:
+    """NumPy's OWN selection algorithm on an index array (numpy/_core/src/npysort/selection.cpp, `introselect_<Tag, arg=true>`):
+    median-of-3 quickselect, median of medians of 5 once 2 floor(log2 n) partitions are spent, an O(n kth) selection when kth is within 3
+    of the range's start, a maximum scan for kth = n - 1.  This is what np.argpartition runs where no SIMD kernel is dispatched, and
+    the rule the library restates (csrc/capi.hip: npysel); pinned by tests/golden/farselect.npz (NumPy itself with its dispatch off)."""
+
+    def __init__(self, v):
+        self.v = [float(x) for x in v]
+        self.t = list(range(len(v)))
+        self.used_median_of_medians = False
+
+    def at(self, i):
+        return self.v[self.t[i]]
+
+    def swap(self, i, j):
+        self.t[i], self.t[j] = self.t[j], self.t[i]
+
+    def dumb_select(self, base, num, kth):
+        for i in range(kth + 1):
+            minidx, minval = i, self.at(base + i)
+            for k in range(i + 1, num):
+                if _less(self.at(base + k), minval):
+                    minidx, minval = k, self.at(base + k)
+            self.swap(base + i, base + minidx)
+
+    def median3_swap(self, low, mid, high):
+        if _less(self.at(high), self.at(mid)):
+            self.swap(high, mid)
+        if _less(self.at(high), self.at(low)):
+            self.swap(high, low)
+        if _less(self.at(low), self.at(mid)):
+            self.swap(low, mid)
+        self.swap(mid, low + 1)
+
+    def median5(self, b):
+        at, swap = self.at, self.swap
+        if _less(at(b + 1), at(b)):
+            swap(b + 1, b)
+        if _less(at(b + 4), at(b + 3)):
+            swap(b + 4, b + 3)
+        if _less(at(b + 3), at(b)):
+            swap(b + 3, b)
+        if _less(at(b + 4), at(b + 1)):
+            swap(b + 4, b + 1)
+        if _less(at(b + 2), at(b + 1)):
+            swap(b + 2, b + 1)
+        if _less(at(b + 3), at(b + 2)):
+            return 1 if _less(at(b + 3), at(b + 1)) else 3
+        return 2
+
+    def median_of_median5(self, base, num):
+        self.used_median_of_medians = True
+        nmed = num // 5
+        for i in range(nmed):
+            m = self.median5(base + 5 * i)
+            self.swap(base + 5 * i + m, base + i)
+        if nmed > 2:
+            self.select(base, nmed, nmed // 2)
+        return nmed // 2
+
+    def select(self, base, num, kth):
+        low, high = 0, num - 1
+        if kth - low < 3:
+            self.dumb_select(base + low, high - low + 1, kth - low)
+            return
+        if kth == num - 1:
+            maxidx, maxval = low, self.at(base + low)
+            for k in range(low + 1, num):
+                if not _less(self.at(base + k), maxval):
+                    maxidx, maxval = k, self.at(base + k)
+            self.swap(base + kth, base + maxidx)
+            return
+        depth_limit = 2 * (int(num).bit_length() - 1)
+        while low + 1 < high:
+            ll, hh = low + 1, high
+            if depth_limit > 0 or hh - ll < 5:
+                self.median3_swap(base + low, base + low + (high - low) // 2, base + high)
+            else:
+                mid = ll + self.median_of_median5(base + ll, hh - ll)
+                self.swap(base + mid, base + low)
+                ll -= 1
+                hh += 1
+            depth_limit -= 1
+            pivot = self.at(base + low)
+            while True:                                   # unguarded_partition_
+                ll += 1
+                while _less(self.at(base + ll), pivot):
+                    ll += 1
+                hh -= 1
+                while _less(pivot, self.at(base + hh)):
+                    hh -= 1
+                if hh < ll:
+                    break
+                self.swap(base + ll, base + hh)
+            self.swap(base + low, base + hh)
+            if hh >= kth:
+                high = hh - 1
+            if hh <= kth:
+                low = ll
+        if high == low + 1 and _less(self.at(base + high), self.at(base + low)):
+            self.swap(base + high, base + low)
+
+
+def far_rows_introselect(distances, n_empty):
+    """`np.argpartition(distances, -n_empty)[:-n_empty-1:-1]` as NumPy's own (non-SIMD) introselect returns it: the library's rule
+    (csrc/capi.hip: far_select_default) for callers without the NumPy callback and for sharded runs."""
+    N = len(distances)
+    s = _Introselect(distances)
+    s.select(0, N, N - n_empty)
+    return np.array(s.t[::-1][:n_empty], dtype=np.int64)
 
 
 def e_step(X, C):
@@ -150,10 +261,13 @@ def from_limbs(buf, k, n):
     return tot, cnt, int(buf[-2])
 
 
-def lloyd_fixed_point(X, C0, max_iter=300, tol_abs=0.0, allreduce=None, far_rows=far_rows_sorted):
+def lloyd_fixed_point(X, C0, max_iter=300, tol_abs=0.0, allreduce=None, far_rows=far_rows_introselect, shard=None):
     """The device loop (edmdc_kmeans_lloyd_dev) restated: X = this rank's centred rows, C0 the common initial centres.
     allreduce(int64 array, op) combines a buffer over the ranks in place (op 0: sum, op 1: max) -- None: one rank.
-    Returns (centres, labels, n_iter, relocations).  Empty clusters are relocated on one rank only (as in the library)."""
+    shard = (global index of this rank's first row, rows over all ranks) for a sharded run.
+    Returns (centres, labels, n_iter, relocations).  Empty clusters, sharded: the ranks' distances are put side by side in global row
+    order (a sum in which every rank fills its own rows), every rank applies `far_rows` to that array, and the owner of each chosen row
+    sends its label and fixed-point coordinates -- as csrc/capi.hip: kmeans_relocate does."""
     X = np.ascontiguousarray(X, dtype=float)
     N, n = X.shape
     k = len(C0)
@@ -178,17 +292,31 @@ def lloyd_fixed_point(X, C0, max_iter=300, tol_abs=0.0, allreduce=None, far_rows
         tot, cnt, changed = from_limbs(buf, k, n)
         empty = [c for c in range(k) if cnt[c] == 0]
         if empty:
+            local = ((X - C[labels]) ** 2).sum(axis=1)
+            row0 = 0
             if allreduce is not None:
-                raise RuntimeError("an empty cluster in a sharded run")
-            distances = ((X - C[labels]) ** 2).sum(axis=1)
+                row0, Ng = shard
+                g = np.zeros(Ng, dtype=np.int64)
+                g[row0:row0 + N] = local.view(np.int64)
+                allreduce(g, 0)
+                distances = g.view(np.float64)
+            else:
+                distances = local
             if np.max(distances) != 0:
                 far = far_rows(distances, len(empty))
                 for idx, new_c in enumerate(empty):
-                    fi = int(far[idx])
-                    old_c = int(labels[fi])
+                    fi = int(far[idx]) - row0
+                    msg = np.zeros(18, dtype=np.int64)
+                    if 0 <= fi < N:
+                        msg[:n] = Q[fi]
+                        msg[16], msg[17] = labels[fi], 1
+                    if allreduce is not None:
+                        allreduce(msg, 0)
+                    assert msg[17] == 1, "exactly one rank owns a relocated row"
+                    old_c = int(msg[16])
                     for j in range(n):
-                        tot[old_c][j] -= int(Q[fi, j])
-                        tot[new_c][j] = int(Q[fi, j])
+                        tot[old_c][j] -= int(msg[j])
+                        tot[new_c][j] = int(msg[j])
                     cnt[new_c] = 1
                     cnt[old_c] -= 1
                 nreloc += 1

@@ -1,6 +1,6 @@
 """One rank of the multi-GPU rehearsal (child process of tests/test_multigpu.py; one process per GPU).
 
-    python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON]
+    python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON] [BOUNDS_RATE]
 
 MODE "torch": torch.distributed (backend nccl = RCCL), RENDEZVOUS = TCP port on 127.0.0.1.
 MODE "gloo" : torch.distributed over gloo, every rank on the SAME GPU (cuda:RANK mod the device count) -- the rehearsal a one-GPU box allows.
@@ -25,6 +25,7 @@ def main():
     mode, rank, world, rdv, out = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
     Bt = int(sys.argv[6]) if len(sys.argv) > 6 else 1536
     T = int(sys.argv[7]) if len(sys.argv) > 7 else 40
+    bounds_rate = float(sys.argv[8]) if len(sys.argv) > 8 else None       # edmdc_set_kmeans_bounds_rate (1.0: list form from the first sorted iteration)
     import torch
     ndev = torch.cuda.device_count()                    # does not initialise the GPU on this image
     dev_id = rank % max(ndev, 1)
@@ -33,6 +34,8 @@ def main():
     from bluerov2_dynamics_amd import _lib, engine
     from bluerov2_dynamics_amd import dist as bd
     ctx = _lib.default_context(dev_id)
+    if bounds_rate is not None:
+        ctx.set_kmeans_bounds_rate(bounds_rate)
     n, r, k, gamma, ridge, dt = 12, 8, 48, 1.0, 1e-3, 0.02
 
     def rollouts(b0, nb):
@@ -99,11 +102,17 @@ def main():
     # trajectories, which every rank holds) -- the same bits on every rank and for every world size
     mean_h = Xc.view(-1, n).mean(dim=0).cpu().numpy()
     C0 = Cdup - torch.from_numpy(mean_h).to(dev)       # duplicate centres: empty clusters in the first iteration -> the sharded relocation
-    ctx.set_kmeans_far_select(False)                   # the library's own relocation rule: the one a sharded run applies
     if comm is not None:
         ctx.kmeans_use_comm(comm)
         ctx.set_kmeans_shard(rank, world, b0 * (T + 1), Bt * (T + 1))
+    # (round 5) a sharded run applies the ctx's selection rule to the distances of ALL ranks' rows: first the library's own rule
+    # (NumPy's introselect restated: what a plain-C caller gets), then the default -- np.argpartition on this host through the callback
+    ctx.set_kmeans_far_select(False)
+    Ck_lib, _, _, iters_lib = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx)
+    reloc_lib = ctx.kmeans_relocations()
+    ctx.set_kmeans_far_select(True)
     Ck, labels_k, inertia_k, iters_k = bd.kmeans_lloyd_sharded(X.view(-1, n), C0, mean=mean_h, max_iter=25, tol_abs=0.0, ctx=ctx)
+    loop_info = ctx.kmeans_loop_info()
     forced = False
     if mode == "torch" and world == 1:
         # one rank, backend nccl: the same loop once more with the exchange installed -- every all-reduce of the loop goes through RCCL
@@ -122,7 +131,8 @@ def main():
     torch.cuda.synchronize()
     np.savez(out, GtG=GtG.cpu().numpy(), GtY=GtY.cpu().numpy(), A=A, B=B, Af=Af, Bf=Bf, b0=b0, b1=b1, device=dev_id,
              Ck=Ck.cpu().numpy(), iters_k=iters_k, inertia_k=inertia_k, labels_k=labels_k.cpu().numpy(), reloc_k=ctx.kmeans_relocations(),
-             Cs=Cs.cpu().numpy(), idx_s=idx_s, forced_exchange=forced)
+             Cs=Cs.cpu().numpy(), idx_s=idx_s, forced_exchange=forced, Ck_lib=Ck_lib.cpu().numpy(), iters_lib=iters_lib, reloc_lib=reloc_lib,
+             ridge=ridge, resorts=loop_info["resorts"], first_resort=loop_info["first_resort_iteration"], list_e_steps=loop_info["list_form_e_steps"])
     if mode in ("torch", "gloo"):
         import torch.distributed as dist
         dist.barrier()

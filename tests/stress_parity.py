@@ -238,13 +238,17 @@ def applies():
 
 def lloyds():
     """Lloyd with the per-wave candidate filter (LDS / DPP kernel; from 2^18 samples on the sorted order, the packed-fp32 screening and
-    the distance bounds -- BROV2_KM_BOUNDS_RATE=1 in the environment forces their list form from the first sorted iteration) == Lloyd
-    with the full scan in the scalar-record kernel == the mask form without screening: identical labels, iteration counts, centres."""
+    the distance bounds -- `lloyds_list` as the family name forces their list form from the first sorted iteration) == Lloyd with the
+    full scan == the filter in the caller's order without bounds (an experiments build: the full scan in the scalar-record kernel and
+    the mask form without screening instead): identical labels, iteration counts, centres."""
     n, ties, t0 = 0, 0, time.time()
     ctxs = []
-    for v in (0, 5, 16 + 128):
+    exp = bool(_lib.load_library().brov_experiments_build())
+    for v in ((0, 257, 16 + 128) if exp else (0, 1, 2 + 4)):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
+        if LIST_FORM:
+            c.set_kmeans_bounds_rate(1.0)
         ctxs.append(c)
     while time.time() - t0 < budget:
         N = int(rng.choice([70, 1000, 4097, 30000, 120000, 270000]))
@@ -274,8 +278,20 @@ def lloyds():
     print(f"Lloyd      : {n} cases, candidate filter == full scan (labels, iterations, centres bit for bit), {ties} excused", flush=True)
 
 
+LIST_FORM = False
+
+
+def lloyds_list():
+    global LIST_FORM
+    LIST_FORM = True
+    try:
+        lloyds()
+    finally:
+        LIST_FORM = False
+
+
 if __name__ == "__main__":
-    fams = dict(applies=applies, lloyds=lloyds, rollouts=rollouts, windows=windows, grams=grams, multistep=multistep, kmeanspp=kmeanspp)
+    fams = dict(applies=applies, lloyds=lloyds, lloyds_list=lloyds_list, rollouts=rollouts, windows=windows, grams=grams, multistep=multistep, kmeanspp=kmeanspp)
     for name in (sys.argv[3].split(",") if len(sys.argv) > 3 else list(fams)):
         fams[name]()
     print("stress parity: ok")

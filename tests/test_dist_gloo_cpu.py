@@ -110,11 +110,19 @@ def test_two_rank_fit_equals_single_process():
 
 
 # ---- sharded Lloyd (round 4): one integer all-reduce per iteration; the oracle's fixed-point stand-in runs the loop on the CPU ----
-def _standin_lloyd(X_local, C0, mean, max_iter, tol_abs, allreduce):
+def _standin_lloyd(X_local, C0, mean, max_iter, tol_abs, allreduce, far_rows=None):
     from oracle import kmeans_numpy as kn
     ar = None if allreduce is None else (lambda buf, op: allreduce(torch.from_numpy(buf), op))      # shares the buffer's memory
     Xc = X_local.numpy() - (0.0 if mean is None else mean)
-    C, labels, n_iter, _ = kn.lloyd_fixed_point(Xc, C0.numpy(), max_iter, tol_abs, allreduce=ar)
+    shard = None
+    if allreduce is not None:                              # this rank's place: rows of the ranks before it, rows of all
+        sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(dist.get_world_size())]
+        dist.all_gather(sizes, torch.tensor([len(Xc)], dtype=torch.int64))
+        sizes = [int(t) for t in sizes]
+        shard = (sum(sizes[:dist.get_rank()]), sum(sizes))
+    C, labels, n_iter, nreloc = kn.lloyd_fixed_point(Xc, C0.numpy(), max_iter, tol_abs, allreduce=ar, shard=shard,
+                                                     far_rows=far_rows or kn.far_rows_introselect)
+    _standin_lloyd.relocations = nreloc
     return torch.from_numpy(C), torch.from_numpy(labels), 0.0, n_iter
 
 
@@ -166,3 +174,72 @@ def test_two_rank_lloyd_equals_single_process_bit_for_bit():
     # ... and the fixed-point loop agrees with the floating-point restatement of scikit-learn's loop to rounding
     Cs, labs, _, its, _ = kn.lloyd(X - X.mean(0), C0, 40, 0.0)
     assert its == it1 and np.array_equal(labs, lab1) and np.max(np.abs(Cs - C1)) < 1e-13
+
+
+# ---- an empty cluster in a sharded run (round 5): the far rows are chosen over ALL ranks' rows by the rule of the unsharded run ----------
+def _reloc_case():
+    g = load_golden("edmdc.npz")
+    X = g["X"][:1600]
+    C0 = X[np.random.RandomState(2).choice(len(X), 24, replace=False)].copy()
+    C0[3] += 60.0; C0[11] -= 45.0; C0[20] += 25.0          # three initial centres far from all data: three empty clusters at once
+    return X, C0
+
+
+def _km_reloc_worker(rank, world, port, q):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from bluerov2_dynamics_amd import dist as bd
+        from oracle import kmeans_numpy as kn
+        X, C0 = _reloc_case()
+        r0, r1 = bd.shard_range(len(X), rank, world)
+        Xl = torch.from_numpy(X[r0:r1].copy())
+        tol_abs = 1e-4 * float(np.mean(np.var(X, axis=0)))
+        out = [rank]
+        for rule in (kn.far_rows_numpy, kn.far_rows_introselect):
+            fn = lambda *a, _r=rule: _standin_lloyd(*a, far_rows=_r)
+            C, labels, _, n_iter = bd.kmeans_lloyd_sharded(Xl, torch.from_numpy(C0 - X.mean(0)), mean=X.mean(0), max_iter=300, tol_abs=tol_abs, lloyd_fn=fn)
+            out += [C.numpy(), n_iter, _standin_lloyd.relocations]
+        q.put(tuple(out))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        import traceback
+        q.put((rank, "error", traceback.format_exc() + repr(e)))
+        raise
+
+
+def test_two_rank_relocation_of_three_empty_clusters_equals_sklearn():
+    """Three clusters run empty in the first iteration of a run sharded over two ranks.  With scikit-learn's own expression as the rule
+    (np.argpartition on the gathered distances: what the Python layer's callback does) both ranks end with scikit-learn's centres and
+    iteration count -- not merely with those of the one-rank run --; with the library's rule (NumPy's introselect restated) they end
+    with the centres of the one-process run under that rule, bit for bit."""
+    import warnings
+    from sklearn.cluster import KMeans
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_km_reloc_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for r in res:
+        assert not (isinstance(r[1], str) and r[1] == "error"), r[2]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    from oracle import kmeans_numpy as kn
+    X, C0 = _reloc_case()
+    mean = X.mean(0)
+    tol_abs = 1e-4 * float(np.mean(np.var(X, axis=0)))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = KMeans(n_clusters=len(C0), init=C0, n_init=1, max_iter=300, tol=1e-4).fit(X)
+    (_, Ca0, ita0, nra0, Cb0, itb0, nrb0), (_, Ca1, ita1, nra1, Cb1, itb1, nrb1) = res
+    assert nra0 > 0 and nrb0 > 0
+    assert np.array_equal(Ca0, Ca1) and np.array_equal(Cb0, Cb1)
+    assert ita0 == ref.n_iter_ and np.max(np.abs(Ca0 + mean - ref.cluster_centers_)) < 1e-12           # scikit-learn's, on this host
+    for rule, C2, it2 in ((kn.far_rows_numpy, Ca0, ita0), (kn.far_rows_introselect, Cb0, itb0)):
+        C1, _, it1, nr1 = kn.lloyd_fixed_point(X - mean, C0 - mean, 300, tol_abs, far_rows=rule)
+        assert nr1 > 0 and it1 == it2 and np.array_equal(C1, C2)                                           # the one-process run, same rule

@@ -16,6 +16,13 @@ TOL_CALL = 1e-11
 TOL_TRAJ = 1e-9
 
 
+def _experiments():
+    """1 when the loaded libbrov2.so is a -DBROV2_EXPERIMENTS=1 build ($BROV2_LIBRARY=build_variants/experiments/libbrov2.so): the
+    k-means tests then also run the earlier forms of single stages (KMV_* in csrc/capi.hip) as further independent implementations."""
+    from bluerov2_dynamics_amd import _lib
+    return bool(_lib.load_library().brov_experiments_build())
+
+
 @pytest.fixture(scope="module")
 def eng():
     from bluerov2_dynamics_amd import engine
@@ -59,7 +66,8 @@ def test_c_abi_rejects_bad_arguments_with_a_message():
         lib.brov_rhs(h, 0, -3, P(x), P(u), 0.02, None, P(xT)),
         lib.edmdc_lift(h, 4, 12, 0, 1.0, P(x), P(x), P(x)),                                       # k = 0
         lib.edmdc_lift(h, 4, 40, 8, 1.0, P(x), P(x), P(x)),                                       # n beyond the supported 16
-        lib.edmdc_set_apply_variant(h, 2), lib.edmdc_set_kmeans_variant(h, -1),                    # round 3: unknown variants
+        lib.edmdc_set_apply_variant(h, 2), lib.edmdc_set_kmeans_variant(h, -1), lib.edmdc_set_kmeans_variant(h, 3),   # unknown variants
+        lib.edmdc_set_kmeans_variant(h, 1024), lib.brov_set_rollout_variant(h, 2),
         lib.edmdc_lift_cache(h, ctypes.c_void_p(8), 1 << 20),                                      # buffer not 16-byte aligned
         lib.edmdc_pinv_apply_dev(h, 12, 8, 16, 1.0, None, 1, 3, 4, 3, None, None, None, None),      # NULL everything
     ]
@@ -631,8 +639,10 @@ def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
     # coordinates (pp_round_kernel): the same indices and centres with the screening switched off (variant + 8), on trajectory-
     # like data where most rows are screened out, on tiny-scale data, and with a NaN row
     from bluerov2_dynamics_amd import _lib
+    from sklearn.cluster import kmeans_plusplus as _kpp
     plain = _lib.Context(0)
-    plain.set_kmeans_variant(8)
+    if _experiments():
+        plain.set_kmeans_variant(8)                   # KMV_PP_UNSCREENED
     for N, n, k, scale in ((300000, 12, 512, 1.0), (50000, 13, 100, 1e-4), (20000, 3, 40, 30.0)):
         X = (np.cumsum(rng.normal(0, 0.05, (N, n)), 0) + 0.3 * np.sin(np.arange(N)[:, None] * rng.uniform(0.001, 0.01, n))) * scale
         if n == 3:
@@ -643,10 +653,15 @@ def test_gpu_kmeanspp_picks_sklearns_seeds(eng):
         Cp, idxp = eng.kmeanspp_dev(Xd, k, mean=mean, random_state=1, ctx=plain)
         assert np.array_equal(idx, idxp), (N, n, k, int(np.sum(idx != idxp)))
         assert np.array_equal(C.cpu().numpy(), Cp.cpu().numpy(), equal_nan=True)
+        if not np.isnan(X).any():                     # ... and scikit-learn's own, at the size where most rows are screened out
+            C_ref, idx_ref = _kpp(X - mean, k, random_state=np.random.RandomState(1))
+            assert np.array_equal(idx, idx_ref) and np.array_equal(C.cpu().numpy(), C_ref), (N, n, k, int(np.sum(idx != idx_ref)))
     plain.close()
-    # the kernels of the sharded seeding (candidate rows from a table, potentials through per-rank totals) on one rank: variant + 32
+    # the kernels of the sharded seeding (candidate rows from a table, potentials through per-rank totals) on one rank: the worker of
+    # tests/test_multigpu.py runs them at world size 1 through the exchange; an experiments build can select them directly
     sh = _lib.Context(0)
-    sh.set_kmeans_variant(32)
+    if _experiments():
+        sh.set_kmeans_variant(32)                     # KMV_PP_SHARD_KERNELS
     for N, n, k in ((30011, 12, 512), (8193, 13, 40), (70000, 5, 100), (60, 12, 20)):
         X = np.concatenate([rng.normal(m, 0.4, (N // 5 + 1, n)) for m in rng.uniform(-2, 2, (5, n))])[:N]
         mean = X.mean(0)
@@ -666,13 +681,15 @@ def test_lloyd_candidate_filter_gives_the_full_scans_labels(eng):
     against the full scan over all k centres: the SAME labels bit for bit, the same iteration count, the same centres bit for bit
     (integer member sums).  Trajectory-ordered data (few label groups per wave),
     shuffled data (more than 8 groups: the wave falls back to the full scan), duplicate centres (exact score ties: the lowest
-    index must win in both), k not a multiple of 64, n = 13, and a NaN row.  Both E-step kernels: centre records from the LDS
-    through DPP (variants 0-2) and through scalar registers (variants 4-6); n = 15 only exists in the second; k = 513 ... 1024 at >= 2^18 samples runs the packed-fp32
-    kernel (variants 0, 64) against the scalar-record one (the others)."""
+    index must win in both), k not a multiple of 64, n = 13, and a NaN row.  The shapes pick the kernels: centre records from the LDS
+    through DPP (k <= 512, n <= 14), through scalar registers (n = 15, k > 512 below 2^18 samples), the packed-fp32 kernel
+    (k = 513 ... 1024 at >= 2^18 samples) -- each against the full scan.  The public variants: 0 default, 1 full scan, 2 filter in the
+    caller's order, + 4 distance bounds off; an experiments build adds the earlier forms of single stages (+ 256 scalar records, + 16 mask
+    form only, + 64 stand-alone packed-fp32 kernel, + 128 screening off)."""
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(21)
     ctxs = []
-    for v in (0, 1, 2, 4, 5, 6, 16, 18, 64, 128, 256):                                 # filter + sorted order, full scan, filter in the caller's order; + 4 scalar records; + 16 mask form only
+    for v in (0, 1, 2, 4, 6) + ((256, 257, 258, 16, 18, 64, 128) if _experiments() else ()):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
@@ -726,6 +743,28 @@ def _sk_lloyd(X, C0, max_iter=300, tol=1e-4):
         return KMeans(n_clusters=len(C0), init=C0, n_init=1, max_iter=max_iter, tol=tol).fit(X)
 
 
+NPY_GENERIC = "AVX512F AVX512CD AVX512_KNL AVX512_KNM AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
+
+
+def _sk_lloyd_generic_numpy(X, C0, max_iter=300, tol=1e-4):
+    """scikit-learn's KMeans in a child process whose NumPy has its SIMD dispatch disabled: np.argpartition is then NumPy's own
+    introselect -- the selection the library's rule restates -- instead of the host's x86-simd-sort kernel.  Returns (centres, n_iter)."""
+    import os, subprocess, sys, tempfile
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "in.npz"), X=X, C0=C0)
+        code = ("import numpy as np, warnings, sys\n"
+                "from sklearn.cluster import KMeans\n"
+                "from numpy._core._multiarray_umath import __cpu_features__ as f\n"
+                "assert not (f['AVX512_SKX'] or f['AVX2'])\n"
+                "z = np.load(sys.argv[1] + '/in.npz')\n"
+                "warnings.simplefilter('ignore')\n"
+                f"m = KMeans(n_clusters=len(z['C0']), init=z['C0'], n_init=1, max_iter={max_iter}, tol={tol}).fit(z['X'])\n"
+                "np.savez(sys.argv[1] + '/out.npz', C=m.cluster_centers_, it=m.n_iter_)\n")
+        subprocess.check_call([sys.executable, "-c", code, td], env=dict(os.environ, NPY_DISABLE_CPU_FEATURES=NPY_GENERIC))
+        z = np.load(os.path.join(td, "out.npz"))
+        return z["C"], int(z["it"])
+
+
 def test_lloyd_empty_clusters_follow_sklearn(eng):
     """scikit-learn 1.7.2's handling of empty clusters, which the reference inherits (Koopman/koopmanEDMDc.py:85,126):
     `_relocate_empty_clusters_dense` (the n_empty samples farthest from their centres become the empty clusters' only members),
@@ -737,7 +776,7 @@ def test_lloyd_empty_clusters_follow_sklearn(eng):
     from oracle import kmeans_numpy as kn
     rng = np.random.default_rng(3)
     ctxs = []
-    for v in (0, 1, 5):
+    for v in (0, 1, 257 if _experiments() else 2):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         ctxs.append(c)
@@ -775,13 +814,21 @@ def test_lloyd_empty_clusters_follow_sklearn(eng):
             got.append(C)
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[2]), name
     assert np.array_equal(eng.kmeans_lloyd(Xq, cases[3][2], max_iter=5, tol_abs=0.0)[0][1], [0.0, 0.0, 16.0, 0.0])
-    # the library's own selection rule (no NumPy callback): the same rows when there is one empty cluster and no tie
-    name, X, C0, _ = cases[2]
-    mean = X.mean(0)
+    # The library's own selection rule (no NumPy callback: what a plain-C caller gets) is NumPy's introselect restated
+    # (csrc/capi.hip: npysel; pinned on the CPU by tests/golden/farselect.npz): with THREE and TWO empty clusters it gives the rows --
+    # and the assignment of rows to empty clusters -- of scikit-learn wherever NumPy runs that algorithm, i.e. scikit-learn in a process
+    # with NumPy's SIMD dispatch off; and the oracle's restatement with the same rule agrees.  (On this host scikit-learn itself may hand
+    # the same rows to the empty clusters in another order: x86-simd-sort -- the default callback reproduces that, first part above.)
     ctxs[0].set_kmeans_far_select(False)
-    C, _, _, n_iter = eng.kmeans_lloyd(X, C0 - mean, max_iter=300, tol_abs=1e-4 * np.mean(np.var(X, axis=0)), mean=mean, ctx=ctxs[0])
-    ref = _sk_lloyd(X, C0)
-    assert n_iter == ref.n_iter_ and rel_err(C + mean, ref.cluster_centers_) < 1e-12
+    for name, X, C0, _ in cases[:3]:
+        mean = X.mean(0)
+        tol_abs = 1e-4 * np.mean(np.var(X, axis=0))
+        C, _, _, n_iter = eng.kmeans_lloyd(X, C0 - mean, max_iter=300, tol_abs=tol_abs, mean=mean, ctx=ctxs[0])
+        Cg, itg = _sk_lloyd_generic_numpy(X, C0)
+        assert n_iter == itg and rel_err(C + mean, Cg) < 1e-12, (name, n_iter, itg, rel_err(C + mean, Cg))
+        Co, _, _, ito, nro = kn.lloyd(X - mean, C0 - mean, 300, tol_abs, far_rows=kn.far_rows_introselect)
+        assert ito == n_iter and nro > 0 and rel_err(Co, C) < 1e-12, name
+        assert ctxs[0].kmeans_relocations() > 0
     for c in ctxs:
         c.close()
 
@@ -814,14 +861,14 @@ def test_kmeans_with_more_clusters_than_distinct_points(eng):
 def test_lloyd_distance_bounds_change_nothing(eng, monkeypatch):
     """The sorted loop's distance bounds (csrc/kmeans.hip: kmeans_bounds_kernel; round 4): once few labels change per iteration an
     E-step visits only the samples whose bounds fail and the M-step adds the CHANGES of their integer member sums to the totals it
-    keeps.  Labels, centres (bit for bit), iteration count and inertia must be those of the loop without bounds (variant + 256) and
-    of the full scan (variant 5) -- with the list form switched on as early as it can be (BROV2_KM_BOUNDS_RATE = 1: from the first
+    keeps.  Labels, centres (bit for bit), iteration count and inertia must be those of the loop without bounds (variant + 4) and
+    of the full scan (variant 1) -- with the list form switched on as early as it can be (edmdc_set_kmeans_bounds_rate(1): from the first
     sorted iteration, when most bounds still fail), at its default threshold, over re-sorts, through an empty cluster's relocation
     (duplicate initial centres) in mid-run, and to convergence (strict: no label changes)."""
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(77)
     ctxs = []
-    for v in (0, 256, 5):
+    for v in (0, 4, 257 if _experiments() else 1):
         c = _lib.Context(0)
         c.set_kmeans_variant(v)
         c.set_kmeans_far_select(False)
@@ -839,20 +886,21 @@ def test_lloyd_distance_bounds_change_nothing(eng, monkeypatch):
     cases.append((blobs[rng.permutation(len(blobs))], blobs[rng.choice(len(blobs), 64, replace=False)].copy()))
     for ci, (X, C0) in enumerate(cases):
         mean = X.mean(0)
-        for rate in ("1.0", None):
-            if rate is None:
-                monkeypatch.delenv("BROV2_KM_BOUNDS_RATE", raising=False)
-            else:
-                monkeypatch.setenv("BROV2_KM_BOUNDS_RATE", rate)
+        for rate in (1.0, 0.03):
+            ctxs[0].set_kmeans_bounds_rate(rate)
             for max_iter in (9, 60):
                 (Ca, la, ia, na), (Cb, lb_, ib, nb_), (Cc, lc, ic, nc) = [eng.kmeans_lloyd(X, C0 - mean, max_iter=max_iter, tol_abs=0.0, mean=mean, ctx=c) for c in ctxs]
                 assert na == nb_ == nc, (ci, rate, max_iter, na, nb_, nc)
                 assert np.array_equal(la, lb_) and np.array_equal(la, lc), (ci, rate, max_iter, int(np.sum(la != lb_)), int(np.sum(la != lc)))
                 assert np.array_equal(Ca, Cb) and np.array_equal(Ca, Cc), (ci, rate, max_iter)
                 assert abs(ia - ib) <= 1e-10 * abs(ib) and abs(ia - ic) <= 1e-10 * abs(ic), (ci, rate, max_iter, ia, ib, ic)
+                if len(X) >= (1 << 18) and max_iter == 60:
+                    info = ctxs[0].kmeans_loop_info()
+                    assert info["list_form_e_steps"] > 0 and info["resorts"] > 0, (ci, rate, info)      # the path under test has run
         if ci == 3:
             assert ctxs[0].kmeans_relocations() > 0
-    monkeypatch.delenv("BROV2_KM_BOUNDS_RATE", raising=False)
+    with pytest.raises(_lib.BrovError):
+        ctxs[0].set_kmeans_bounds_rate(1.5)
     for c in ctxs:
         c.close()
 
@@ -1709,14 +1757,12 @@ def test_two_wave_rollout_kernel_edge_cases(eng, fc):
     """rollout_pair_kernel (thruster model; time-major layouts and, round 3, the caller layout BTU) at the edges: zero and one step, one trajectory, batches that
     are not a multiple of the 256 trajectories of a workgroup, strided trajectory storage, both integrators, both lag modes,
     both time-major layouts, lag state in and out -- against the C oracle; and against the one-lane kernel
-    (BROV2_ROLLOUT_SINGLE_LANE, read at context creation) on the same data."""
-    import os
+    (brov_set_rollout_variant(ctx, 1)) on the same data."""
     from bluerov2_dynamics_amd import _lib
     rng = np.random.default_rng(77)
     dt = 0.02
-    os.environ["BROV2_ROLLOUT_SINGLE_LANE"] = "1"
     ctx1 = _lib.Context(0)
-    del os.environ["BROV2_ROLLOUT_SINGLE_LANE"]
+    ctx1.set_rollout_variant(1)
     ctx2 = _lib.Context(0)
     for B, T, stride in ((1, 0, 1), (1, 1, 1), (3, 7, 1), (257, 5, 2), (300, 64, 7), (513, 130, 1)):
         X0 = rng.uniform(-0.4, 0.4, (B, 12))

@@ -24,11 +24,12 @@ def _free_port():
     return p
 
 
-def _run(mode, world, tmp, total=1536, horizon=40):
+def _run(mode, world, tmp, total=1536, horizon=40, bounds_rate=None):
     rdv = str(_free_port()) if mode in ("torch", "gloo") else os.path.join(tmp, f"id_{mode}_{world}")
     outs = [os.path.join(tmp, f"{mode}_{world}_{r}.npz") for r in range(world)]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), rdv, outs[r], str(total), str(horizon)], env=env,
+    extra = [] if bounds_rate is None else [str(bounds_rate)]
+    procs = [subprocess.Popen([sys.executable, WORKER, mode, str(r), str(world), rdv, outs[r], str(total), str(horizon)] + extra, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     logs = []
     for p in procs:
@@ -52,14 +53,22 @@ def _check(res, one, shared_gpu=False, solves=True):
         # every rank solved the same reduced system: identical A, B bit for bit, both product orders
         for key in ("A", "B", "Af", "Bf"):
             assert np.array_equal(z[key], res[0][key]), key
-        # against the 1-rank solve: the Grams differ by the order of their additions (1e-13 relative) and the pinv of this small,
-        # ill-conditioned system (48 RBFs over 40-step trajectories from one initial state, ridge 1e-3) amplifies that to ~1e-6
-        # (first seen when the test first ran with 2 ranks, round 4: 5.7e-7)
-        # (solves=False: a size the k-means checks below want -- its larger, no better conditioned system sits right at that bound)
-        assert not solves or (np.max(np.abs(z["A"] - one["A"])) < 1e-5 and np.max(np.abs(z["Af"] - one["Af"])) < 1e-5)
+        # against the 1-rank solve, through a quantity the conditioning of this small system (48 RBFs over 40-step trajectories from one
+        # initial state: the pinv amplifies the 1e-13 of the Grams' addition order to ~1e-6 in A itself, 5.7e-7 seen in round 4) does not
+        # amplify: (G^T G + ridge I) applied to the DIFFERENCE of the solutions, relative to G^T Y -- a dropped row or a wrong shard
+        # boundary shows at 1 / rows ~ 1e-5, the bound is 1e-8 (round-4 advice: the 1e-5 bound on A could not have caught that)
+        if solves:
+            K = one["GtG"] + float(one["ridge"]) * np.eye(one["GtG"].shape[0])
+            for ka, kb in (("A", "B"), ("Af", "Bf")):
+                dM = np.hstack([z[ka] - one[ka], z[kb] - one[kb]]).T              # [p, d]
+                assert np.linalg.norm(K @ dM) <= 1e-8 * scale_y, (ka, np.linalg.norm(K @ dM) / scale_y)
         # sharded Lloyd (integer member sums): the 1-rank centres BIT FOR BIT on every rank, the same iteration count
         assert np.array_equal(z["Ck"], one["Ck"]) and int(z["iters_k"]) == int(one["iters_k"])
         assert int(z["reloc_k"]) == int(one["reloc_k"]) > 0          # duplicate initial centres: the (sharded) relocation has run
+        # ... and under the library's own selection rule as well (the first run of the worker): same bits, same counts
+        assert np.array_equal(z["Ck_lib"], one["Ck_lib"]) and int(z["iters_lib"]) == int(one["iters_lib"]) and int(z["reloc_lib"]) == int(one["reloc_lib"]) > 0
+        # the sorted order and the list form engage at the same iterations as in the one-rank run (the gates are shares of ALL rows)
+        assert int(z["resorts"]) == int(one["resorts"]) and int(z["first_resort"]) == int(one["first_resort"]) and int(z["list_e_steps"]) == int(one["list_e_steps"])
         # sharded k-means++ seeding: the same global sample indices and centres on every rank as the one-rank seeding
         assert np.array_equal(z["idx_s"], one["idx_s"]) and np.array_equal(z["Cs"], one["Cs"])
     assert abs(sum(float(z["inertia_k"]) for z in res) - float(one["inertia_k"])) <= 1e-10 * float(one["inertia_k"])
@@ -86,13 +95,13 @@ def test_two_ranks_sharing_one_gpu_over_gloo(tmp_path):
     _check(_run("gloo", 3, str(tmp_path)), one, shared_gpu=True)
 
 
-def test_two_ranks_sharded_lloyd_with_distance_bounds(tmp_path, monkeypatch):
+def test_two_ranks_sharded_lloyd_with_distance_bounds(tmp_path):
     """The same rehearsal at a size where the loop keeps its sorted order and its distance bounds (>= 2^18 rows per rank; the list
     form forced from the first sorted iteration): every rank adds the CHANGES of its own samples to its own kept totals, the ranks'
     totals are all-reduced as before -- centres, labels and iteration count of the one-rank run bit for bit."""
-    monkeypatch.setenv("BROV2_KM_BOUNDS_RATE", "1.0")
-    one = _run("torch", 1, str(tmp_path), total=13312, horizon=40)[0]
-    _check(_run("gloo", 2, str(tmp_path), total=13312, horizon=40), one, shared_gpu=True, solves=False)
+    one = _run("torch", 1, str(tmp_path), total=13312, horizon=40, bounds_rate=1.0)[0]
+    assert int(one["list_e_steps"]) > 0 and int(one["resorts"]) > 0
+    _check(_run("gloo", 2, str(tmp_path), total=13312, horizon=40, bounds_rate=1.0), one, shared_gpu=True, solves=False)
 
 
 def _ngpu():

@@ -324,3 +324,35 @@ def test_distance_bounds_never_hide_a_label_change():
             assert np.array_equal(kn.e_step(X, C)[safe], labels0[safe]), (seed, it)
             skipped += int(safe.sum())
     assert skipped > 10000
+
+
+def test_far_row_selection_is_numpys_own_introselect():
+    """The rows `_relocate_empty_clusters_dense` moves empty clusters to are np.argpartition(distances, -n_empty)[:-n_empty-1:-1].
+    tests/golden/farselect.npz holds NumPy's own answers with its SIMD dispatch DISABLED (tools/gen_farselect_golden.py), i.e. of its
+    introselect: the oracle's restatement and the library's (edmdc_far_select_numpy, host only: no GPU needed) must both reproduce every
+    case -- uniform values, many ties, NaNs, sorted / reversed / constant input, and Musser's median-of-3 killer, which takes the
+    median-of-medians branch.  The fixture also records what THIS build host's NumPy returns with its dispatch on: it differs in half of
+    the cases (x86-simd-sort), which is why the rule is pinned to the algorithm and the Python layer keeps a callback for the host's own."""
+    import ctypes
+    from bluerov2_dynamics_amd import _lib
+    from oracle import kmeans_numpy as kn
+    lib = _lib.load_library()
+    g = load_golden("farselect.npz")
+    names = sorted(k[:-2] for k in g.files if k.endswith("_d"))
+    assert len(names) >= 20
+    used_mom = 0
+    for nm in names:
+        d, ne, want = np.ascontiguousarray(g[nm + "_d"]), int(g[nm + "_n"]), g[nm + "_far"]
+        sel = kn._Introselect(d)
+        sel.select(0, len(d), len(d) - ne)
+        used_mom += int(sel.used_median_of_medians)
+        assert np.array_equal(np.array(sel.t[::-1][:ne]), want), nm
+        out = np.empty(ne, dtype=np.int64)
+        assert lib.edmdc_far_select_numpy(d.ctypes.data, len(d), ne, out.ctypes.data) == 0
+        assert np.array_equal(out, want), nm
+        # whatever the order, the rows are the n_empty largest (NaN = largest)
+        key = np.where(np.isnan(d), np.inf, d)
+        assert np.sort(key[out])[0] >= np.sort(key)[-ne] 
+    assert used_mom >= 2                                          # the killer cases reach the median of medians of 5
+    assert any(not np.array_equal(g[nm + "_far"], g[nm + "_far_simd"]) for nm in names) or len(g["simd_host_features"]) == 0
+    assert lib.edmdc_far_select_numpy(None, 5, 1, None) == -1

@@ -1,5 +1,5 @@
 """BASELINE config 4's rollout leg at one GPU: 2^20 trajectories x 500 RK4 steps in the caller layout [B][T][8] / [B][T+1][12]:
-the AR(1) command fill and the rollout, two-wave kernel against the one-lane kernel (BROV2_ROLLOUT_SINGLE_LANE=1) and the
+the AR(1) command fill and the rollout, two-wave kernel against the one-lane kernel (brov_set_rollout_variant 1) and the
 LDS-staged one.  Run on the GPU box:  python3 tools/time_cfg4_rollout.py [B] [T]"""
 import os, sys, time
 import torch
@@ -31,10 +31,8 @@ for dist in ("ar1", "iid"):
 engine.fill_controls_dev(U, "btu", "ar1", seed=0xC0F4, b0=0, T_total=T, ctx=ctx)
 ref = None
 for name, env, mode in (("two-wave, lane-per-row", None, 0), ("one-lane, lane-per-row", "1", 2), ("one-lane, LDS-staged", "1", 1)):
-    if env:
-        os.environ["BROV2_ROLLOUT_SINGLE_LANE"] = env
     c = _lib.Context(0)
-    os.environ.pop("BROV2_ROLLOUT_SINGLE_LANE", None)
+    c.set_rollout_variant(1 if env else 0)
     c.set_btu_staging(mode)
     for integ in ("rk4", "euler"):
         for store in (True, False):

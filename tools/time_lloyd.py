@@ -24,8 +24,10 @@ res = {}
 runs = (("filtered", 0), ("full scan", 1), ("filtered", 0))
 if len(sys.argv) > 3 and sys.argv[3] == "default":        # the shipped loop only (counter runs: every launch of the kernel is a filtered one but the first)
     runs = (("filtered", int(os.environ.get("BROV2_KMEANS_VARIANT", "0"))),)
-if len(sys.argv) > 3 and sys.argv[3] == "all":            # + the caller's order, and the scalar-record kernel (variant + 4)
-    runs += (("filtered, caller's order", 2), ("scalar records: filtered", 4), ("scalar records: full scan", 5), ("scalar records: caller's order", 6))
+if len(sys.argv) > 3 and sys.argv[3] == "all":            # + the caller's order, bounds off, and (experiments build: BROV2_LIBRARY=build_variants/experiments/libbrov2.so) the scalar-record kernel
+    runs += (("filtered, caller's order", 2), ("distance bounds off", 4))
+    if _lib.load_library().brov_experiments_build():
+        runs += (("scalar records: filtered", 256), ("scalar records: full scan", 257), ("scalar records: caller's order", 258))
 for name, v in runs:
     ctx.set_kmeans_variant(v)
     tm = {}
