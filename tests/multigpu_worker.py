@@ -1,6 +1,6 @@
 """One rank of the multi-GPU rehearsal (child process of tests/test_multigpu.py; one process per GPU).
 
-    python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON] [BOUNDS_RATE]
+    python tests/multigpu_worker.py MODE RANK WORLD RENDEZVOUS OUT [TOTAL_ROLLOUTS] [HORIZON] [BOUNDS_RATE] [KMEANS_K]
 
 MODE "torch": torch.distributed (backend nccl = RCCL), RENDEZVOUS = TCP port on 127.0.0.1.
 MODE "gloo" : torch.distributed over gloo, every rank on the SAME GPU (cuda:RANK mod the device count) -- the rehearsal a one-GPU box allows.
@@ -26,6 +26,7 @@ def main():
     Bt = int(sys.argv[6]) if len(sys.argv) > 6 else 1536
     T = int(sys.argv[7]) if len(sys.argv) > 7 else 40
     bounds_rate = float(sys.argv[8]) if len(sys.argv) > 8 else None       # edmdc_set_kmeans_bounds_rate (1.0: list form from the first sorted iteration)
+    km_k = int(sys.argv[9]) if len(sys.argv) > 9 else 48                  # clusters of the k-means leg (>= 64: candidate filter, sorted order, bounds)
     import torch
     ndev = torch.cuda.device_count()                    # does not initialise the GPU on this image
     dev_id = rank % max(ndev, 1)
@@ -49,7 +50,8 @@ def main():
 
     Xc, _ = rollouts(0, 64)
     idx = torch.from_numpy(np.random.RandomState(0).choice(64 * (T + 1), k, replace=False)).to(dev)
-    Cdup = Xc.view(-1, n)[idx].contiguous()             # any rows: several are the common initial state -- duplicate centres (k-means leg)
+    idxk = idx if km_k == k else torch.from_numpy(np.random.RandomState(0).choice(64 * (T + 1), km_k, replace=False)).to(dev)
+    Cdup = Xc.view(-1, n)[idxk].contiguous()            # any rows: several are the common initial state -- duplicate centres (k-means leg)
     idx1 = torch.from_numpy(np.random.RandomState(0).choice(64 * T, k, replace=False)).to(dev)
     C = Xc[:, 1:, :].reshape(-1, n)[idx1].contiguous()  # rows after the first step: distinct centres, a well-conditioned Gram (fit legs)
     b0, b1 = bd.shard_range(Bt, rank, world)
@@ -122,9 +124,9 @@ def main():
         forced = True
     # ... and the k-means++ seeding over all ranks' rows: scikit-learn's random stream for Bt (T + 1) rows, two small exchanges per centre
     if comm is not None:
-        Cs, idx_s = engine.kmeanspp_dev(X.view(-1, n), k, mean=mean_h, random_state=3, ctx=ctx, n_global=Bt * (T + 1))
+        Cs, idx_s = engine.kmeanspp_dev(X.view(-1, n), km_k, mean=mean_h, random_state=3, ctx=ctx, n_global=Bt * (T + 1))
     else:
-        Cs, idx_s = bd.kmeanspp_sharded(X.view(-1, n), k, mean=mean_h, random_state=3, ctx=ctx)
+        Cs, idx_s = bd.kmeanspp_sharded(X.view(-1, n), km_k, mean=mean_h, random_state=3, ctx=ctx)
     if comm is not None:
         ctx.kmeans_use_comm(None)
         ctx.set_kmeans_shard()
