@@ -168,12 +168,14 @@ size_t kmeanspp_sum_doubles(int64_t N);
 size_t kmeanspp_state_bytes();
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                            long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
-                           void* state, double* C, long long* indices, float* Xf);
+                           void* state, double* C, long long* indices, float* Xf, void* rowbuf = nullptr);
+// scratch of the seeding's row level (a ball, the largest closest and the sum of closest per row of 16 samples): bytes, 256-aligned pieces
+size_t kmeanspp_row_bytes(int64_t N, int n);
 
 size_t kmeanspp_shard_doubles(int world);
 hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                                    long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
                                    void* state, double* C, long long* indices, float* Xf, int world, int rank, long long row0,
-                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed);
+                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed, void* rowbuf = nullptr);
 
 }  // namespace brov

@@ -2279,7 +2279,7 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     const bool screening = (c->kmeans_variant & KMV_PP_UNSCREENED) == 0;
     const size_t nshard = kmeanspp_shard_doubles(sharded ? c->km_world : 1);
     int rc = a.reserve(Arena::al((size_t)N * n * 8) + 2 * Arena::al((size_t)N * 8) + Arena::al(nsum * 8) + Arena::al(nu * 8) + Arena::al(nshard * 8) +
-                       Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + (screening ? Arena::al((size_t)N * n * 4) : 0) + 8192);
+                       Arena::al((size_t)k * 8) + Arena::al(kmeanspp_state_bytes()) + (screening ? Arena::al((size_t)N * n * 4) + Arena::al(kmeanspp_row_bytes(N, n)) : 0) + 8192);
     if (rc) return rc;
     double* Xt = a.take<double>((size_t)N * n);
     double* xsq = a.take<double>(N);
@@ -2290,6 +2290,7 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     char* state = a.take<char>(kmeanspp_state_bytes());
     double* dmean = a.take<double>(16);
     float* Xf = screening ? a.take<float>((size_t)N * n) : nullptr;
+    char* rowbuf = screening ? a.take<char>(kmeanspp_row_bytes(N, n)) : nullptr;      // row level of the screening (kmeans.hip: PPRows)
     double* dshard = a.take<double>(nshard);
     if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
     if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, c->stream));
@@ -2302,11 +2303,11 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
             int comm_failed = 0;
             HIPCK(c, launch_kmeanspp_sharded(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
                                              closest, dsum, state, d_C, dind, Xf, sharded ? c->km_world : 1, sharded ? c->km_rank : 0,
-                                             sharded ? c->km_row_offset : 0, dshard, c->km_allreduce, c->km_allreduce_user, &comm_failed));
+                                             sharded ? c->km_row_offset : 0, dshard, c->km_allreduce, c->km_allreduce_user, &comm_failed, rowbuf));
             if (comm_failed) return fail(c, BROV_ERR_COMM, "edmdc_kmeanspp_dev: an exchange between the ranks failed");
         } else {
             HIPCK(c, launch_kmeanspp(c->stream, N, n, k, n_trials, d_X, xstride, mean_host ? dmean : nullptr, (long long)first_index, du, Xt, xsq,
-                                     closest, dsum, state, d_C, dind, Xf));
+                                     closest, dsum, state, d_C, dind, Xf, rowbuf));
         }
     }
     if (indices_host) {

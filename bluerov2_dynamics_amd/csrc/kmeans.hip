@@ -2048,6 +2048,11 @@ struct PPState {                      // device-resident scalars of the seeding 
     long long cand[2][PP_LMAX];       // candidate sample indices: round c reads [(c - 1) & 1], draws the next round's into [c & 1]
     long long last;                   // sample index of the centre chosen last
     unsigned long long xmax_bits;     // max |x_i|^2 (finite rows) as the bit pattern of a non-negative double: the scale of the screening margin
+    // the rows of the round's points as pp_round_kernel stages them ([16 coordinates | |x|^2 | pad]): written by the kernel that chooses
+    // them (pp_decide / pp_first), so that the 2 400 blocks of a round read them directly instead of through an index (one dependent
+    // load less at the head of every block)
+    double crow[2][PP_LMAX][PP_CW];
+    double lastrow[PP_CW];
 };
 
 // |x|^2 accumulated in coordinate order with FMAs: pp_transpose stores it, pp_round recomputes it from the coordinates it has
@@ -2120,34 +2125,116 @@ __device__ __forceinline__ double pp_dist(const double x[KM_NMAX], Row&& crow, d
     return d > 0.0 ? d : 0.0;
 }
 
+// Round 5: a second, coarser level in front of the float screening.  On trajectory-ordered data 16 consecutive samples are
+// neighbours, so every ROW of PP_ROW = 16 samples (one 128-byte line of each fp64 coordinate array) carries a ball -- centre (floats,
+// coordinate-major), radius -- plus the largest sqrt(closest) of its samples and the row's sum of closest: 64 bytes per row = 4 bytes
+// per sample.  If for every point p of the round   |p - centre| - radius >= max sqrt(closest) (1 + 5e-6) + 2.5e-6 R   then no sample
+// of the row is in reach of any point: the owed update changes nothing, every min(closest, d) is closest, and the row contributes its
+// stored sum to every potential WITHOUT its samples being touched (not even closest[]).  From round ~100 on that certifies 85 % of the
+// rows of the config-3 data (tools/kmeanspp_ball_probe.py; the per-sample float test: 97 %), so a round reads ~15 instead of ~60 bytes
+// per sample.  Rows that fail go through the per-sample float screening and, where that fails too, the fp64 path, exactly as before.
+// The chunk sums are formed the same way on every path -- a fixed tree over the 16 lanes of a row, then a fixed order over the 256
+// rows of the chunk -- so that a certified row's stored sum IS what its samples would add: screened and unscreened runs agree bit
+// for bit (an experiments build checks that: KMV_PP_UNSCREENED).
+constexpr int PP_ROW = 16;
+constexpr int PP_NROW = PP_CHUNK / PP_ROW;            // rows per chunk
+struct PPRows {
+    float* rc = nullptr;                              // [n][nrows] ball centres
+    float* rr = nullptr;                              // [nrows] radius: >= |x_i - centre| for every sample of the row (fp64 against the stored centre, rounded up)
+    float* rs = nullptr;                              // [nrows] >= sqrt(closest_i) for every sample of the row
+    double* rsum = nullptr;                           // [nrows] sum over the row of closest_i (the tree of pp_row_sum)
+};
+size_t kmeanspp_row_bytes(int64_t N, int n) {
+    const size_t nr = (size_t)((N + PP_ROW - 1) / PP_ROW);
+    return ((size_t)n * nr * 4 + 255) / 256 * 256 + 2 * ((nr * 4 + 255) / 256 * 256) + (nr * 8 + 255) / 256 * 256;
+}
+static PPRows pp_rows_from(void* buf, int64_t N, int n) {
+    PPRows r;
+    if (!buf) return r;
+    const size_t nr = (size_t)((N + PP_ROW - 1) / PP_ROW);
+    char* p = static_cast<char*>(buf);
+    r.rc = reinterpret_cast<float*>(p); p += ((size_t)n * nr * 4 + 255) / 256 * 256;
+    r.rr = reinterpret_cast<float*>(p); p += (nr * 4 + 255) / 256 * 256;
+    r.rs = reinterpret_cast<float*>(p); p += (nr * 4 + 255) / 256 * 256;
+    r.rsum = reinterpret_cast<double*>(p);
+    return r;
+}
+// the sum over the 16 lanes of a row, in every lane of it: a butterfly (partners add the same two numbers: the same bits in both)
+__device__ __forceinline__ double pp_row_sum(double v) {
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+// ball of every row: centre = the mean of its samples (as floats), radius against that stored centre
+template <int NS>
+__global__ void __launch_bounds__(256) pp_rowball_kernel(int64_t N, int n, const double* __restrict__ Xt, PPRows rows) {
+    const int64_t nrows = (N + PP_ROW - 1) / PP_ROW;
+    const int64_t R = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (R >= nrows) return;
+    const int64_t i0 = R * PP_ROW;
+    const int cnt = (int)((N - i0) < PP_ROW ? (N - i0) : PP_ROW);
+    constexpr int NJ = NS > 0 ? NS : KM_NMAX;
+    // two sweeps over the row's 16 x n values (the second one hits the cache): centre, then squared distances to the STORED centre
+    double d2[PP_ROW];
+#pragma unroll
+    for (int q = 0; q < PP_ROW; ++q) d2[q] = 0.0;
+#pragma unroll 1
+    for (int j = 0; j < NJ; ++j) {
+        if (!(NS > 0 || j < n)) break;
+        double x[PP_ROW], m = 0.0;
+#pragma unroll
+        for (int q = 0; q < PP_ROW; ++q) { x[q] = q < cnt ? Xt[(int64_t)j * N + i0 + q] : 0.0; m += x[q]; }
+        m /= (double)cnt;
+        const float cf = (m - m == 0.0) ? (float)m : 0.0f;      // (a NaN / inf sample: its distance below is not finite and the row is never certified)
+        rows.rc[(int64_t)j * nrows + R] = cf;
+#pragma unroll
+        for (int q = 0; q < PP_ROW; ++q) { const double e = x[q] - (double)cf; d2[q] = fma(e, e, d2[q]); }
+    }
+    double r2 = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int q = 0; q < PP_ROW; ++q) {
+        if (q >= cnt) continue;
+        if (!(d2[q] - d2[q] == 0.0)) bad = true;
+        r2 = d2[q] > r2 ? d2[q] : r2;
+    }
+    rows.rr[R] = bad ? __builtin_nanf("") : (float)sqrt(r2) * 1.000001f + 1.0e-37f;
+}
+
 // upd: 0 = closest stands (round 1: it already holds d(., centre 0)); 1 = closest_i = d(x_i, x_last) (before round 1);
 //      2 = closest_i = min(closest_i, d(x_i, x_last)).
 // S[t][chunk] = sum over the chunk of min(closest_i, d(x_i, cand_t)), t < L;  S[PP_LMAX][chunk] = sum of closest_i.
-// One block per 4096-sample chunk, 256 threads x 16 samples, fixed reduction tree.
-// BT threads per block: 256 at size (HBM-bound, many blocks per CU); 1024 when the whole sample set is a few chunks -- a thread then
-// walks 4 samples instead of 16, and at ~1.5 us of exposed load latency per sample that is a good part of a round (36 658 rows: 41 -> 34 us
-// per centre; the rest are the short dependent chains of staging, reduction and pp_decide)
-template <int NS, int BT>
+// One block per 4096-sample chunk = 256 rows of 16 samples.  BT threads per block: 256 at size (HBM-bound, many blocks per CU); 1024
+// when the whole sample set is a few chunks (64 rows per pass instead of 16: the exposed latency of a pass is a good part of a round
+// there -- 36 658 rows: 41 -> 34 us per centre in round 3).
+template <int NS, int BT, int LM /* trials the registers are sized for: 8 (k <= 1096) or PP_LMAX */>
 __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, int nchunks, const double* __restrict__ Xt,
                                                              const double* __restrict__ xsq, const PPState* __restrict__ st, int par, int upd,
                                                              double* __restrict__ closest, double* __restrict__ S,
                                                              const float* __restrict__ Xf /* [n][N] float copy of Xt, or nullptr: no screening */,
-                                                             const double* __restrict__ crow /* sharded run: the round's rows [PP_LMAX + 1][PP_CW] (nullptr: from Xt through st) */) {
+                                                             const double* __restrict__ crow /* sharded run: the round's rows [PP_LMAX + 1][PP_CW] (nullptr: from Xt through st) */,
+                                                             PPRows rows /* rc == nullptr: no row level */) {
     // candidate rows in LDS: [trial][16 coordinates | norm | pad]; row L = the centre chosen last.  A compiler-level memory
     // barrier in front of every trial keeps their reads where they are used: as plain loop invariants the compiler hoisted
     // all 16 x 17 of them into registers (256 VGPRs + scratch, one wave per SIMD).
     constexpr int CSW = KM_NMAX + 2;
     __shared__ double cs[(PP_LMAX + 1) * CSW];
-    __shared__ double red[BT / 64][PP_LMAX + 1];
     __shared__ float csf[(PP_LMAX + 1) * KM_NMAX];    // the same rows as floats (screening)
+    // what every row of the chunk adds to S[t][chunk], t < L; row L: to the sum of closest.  Dynamic ((L + 1) x 256 doubles: 18 KB at
+    // k = 512 instead of 34 KB for the 16 trials the loop allows): the LDS is what limits the blocks per CU here.
+    extern __shared__ double rowval_dyn[];
+    double (*rowval)[PP_NROW] = reinterpret_cast<double (*)[PP_NROW]>(rowval_dyn);
+    __shared__ unsigned short todo[PP_NROW];          // rows the ball test did not certify, in position order
+    __shared__ int wcnt[4];
     for (int e = threadIdx.x; e < (L + 1) * CSW; e += BT) {
         const int t = e / CSW, j = e % CSW;
         if (crow) {
             // sharded run: a candidate lives on ONE rank; its row was exchanged (pp_decide_sh_kernel) -- slot KM_NMAX holds |x|^2
             cs[e] = j <= KM_NMAX ? crow[(t < L ? t : PP_LMAX) * PP_CW + j] : 0.0;
         } else {
-            const int64_t ci = t < L ? st->cand[par][t] : st->last;
-            cs[e] = j < KM_NMAX ? ((NS > 0 ? j < NS : j < n) ? Xt[(int64_t)j * N + ci] : 0.0) : (j == KM_NMAX ? xsq[ci] : 0.0);
+            cs[e] = j <= KM_NMAX ? (t < L ? st->crow[par][t][j] : st->lastrow[j]) : 0.0;
         }
         if (j < KM_NMAX) csf[t * KM_NMAX + j] = (float)cs[e];
     }
@@ -2158,49 +2245,150 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
     // implies true d >= closest by more than (1e-6 R)^2, ten orders above the rounding of the fp64 formula (float inputs err by
     // 6e-8 R per coordinate, the float arithmetic by 1e-6 relative).  Decided per row of 16 lanes (one 128-byte line of every
     // fp64 coordinate array); a row that is not certified goes through the fp64 path below unchanged.
-    const bool screening = Xf != nullptr && upd != 1 && L > 0;
+    const bool screening = Xf != nullptr && rows.rsum != nullptr && upd != 1 && L > 0;      // (a screened row adds its STORED sum: the row data is part of it)
+    const bool balls = screening && rows.rc != nullptr;
     const int npts = upd == 2 ? L + 1 : L;            // row L (the last centre) only when its update is owed
     float rmarg = 0.0f;
     if (screening) rmarg = 2.5e-6f * (float)sqrt(2.0 * __longlong_as_double((long long)st->xmax_bits)) * 1.000001f + 1.0e-37f;
     __syncthreads();
 
-    double acc[PP_LMAX], acc0 = 0.0;
-#pragma unroll
-    for (int t = 0; t < PP_LMAX; ++t) acc[t] = 0.0;
-    const int64_t base = (int64_t)blockIdx.x * PP_CHUNK;
     constexpr int NF = NS > 0 ? NS : KM_NMAX;
-#pragma unroll 1
-    for (int q = 0; q < PP_CHUNK / BT; ++q) {
-        const int64_t i = base + q * BT + threadIdx.x;
-        bool need = i < N;
-        double old = (upd == 1 || i >= N) ? 0.0 : closest[i];
-        if (screening) {
-            bool certified = true;                    // lanes beyond N do not ask for anything
-            if (i < N) {
-                float xf[NF];
+    const int64_t nrows = (N + PP_ROW - 1) / PP_ROW;
+    const int64_t R0 = (int64_t)blockIdx.x * PP_NROW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    // ---- level 1: one thread per row of the chunk
+    int ntodo;
+    {
+        bool open = false;                             // the row needs its samples looked at
+        const int r = threadIdx.x;
+        if (r < PP_NROW) {
+            const int64_t R = R0 + r;
+            if (R >= nrows) {
+                for (int t = 0; t <= L; ++t) rowval[t][r] = 0.0;
+            } else {
+                open = true;
+                if (balls) {
+                    float m[NF];
 #pragma unroll
-                for (int j = 0; j < NF; ++j) xf[j] = (NS > 0 || j < n) ? Xf[(int64_t)j * N + i] : 0.0f;
-                const float so = sqrtf((float)old * 1.0000003f + 1.0e-37f) * 1.000005f + rmarg;
-                const float thr = so * so * 1.0000003f;
-                float dmin = 3.0e38f;
+                    for (int j = 0; j < NF; ++j) m[j] = (NS > 0 || j < n) ? rows.rc[(int64_t)j * nrows + R] : 0.0f;
+                    // |x - p| >= |centre - p| - radius for every sample of the row; the float distance errs by 1e-6 relative, its inputs
+                    // by 6e-8 R per coordinate: both inside the margin the per-sample test uses
+                    const float need_d = rows.rs[R] * 1.000005f + rmarg + rows.rr[R];
+                    const float thr = need_d * need_d * 1.0000006f;
+                    float dmin = 3.0e38f;
 #pragma unroll 1
-                for (int t = 0; t < npts; ++t) {
-                    const float* row = csf + t * KM_NMAX;
-                    float d = 0.0f;
+                    for (int t = 0; t < npts; ++t) {
+                        const float* row = csf + t * KM_NMAX;
+                        float d = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < NF; ++j) { const float e = xf[j] - row[j]; d = fmaf(e, e, d); }
-                    dmin = fminf(dmin, d);            // a NaN distance is ignored by fminf: guard below
-                    if (!(d == d)) dmin = 0.0f;
+                        for (int j = 0; j < NF; ++j) { const float e = m[j] - row[j]; d = fmaf(e, e, d); }
+                        dmin = fminf(dmin, d);
+                        if (!(d == d)) dmin = 0.0f;
+                    }
+                    if (dmin >= thr) {                 // (false for a NaN radius / bound)
+                        open = false;
+                        const double v = rows.rsum[R];
+                        for (int t = 0; t < L; ++t) rowval[t][r] = v;
+                        rowval[L][r] = v;
+                    }
                 }
-                certified = dmin >= thr;              // false for a NaN threshold
             }
-            unsigned long long b = __ballot(!certified);
-            b |= b >> 8; b |= b >> 4; b |= b >> 2; b |= b >> 1;            // bit 16 r = some lane of row r is not certified
-            need = need && ((b >> (threadIdx.x & 48)) & 1ull);
         }
-        if (need) {
-            double x[KM_NMAX];
-            pp_load_col<NS>(Xt, N, n, i, x);
+        const unsigned long long ob = __ballot(open);
+        if (wv < 4 && lane == 0) wcnt[wv] = __builtin_popcountll(ob);
+        __syncthreads();
+        if (r < PP_NROW && open) {
+            int at = __builtin_popcountll(ob & ((1ull << lane) - 1ull));
+            for (int q = 0; q < wv; ++q) at += wcnt[q];
+            todo[at] = (unsigned short)r;
+        }
+        ntodo = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        __syncthreads();
+    }
+    // ---- level 2: the open rows through the per-sample float test, BT / 16 rows per step, a lane per sample; PP_UNR steps have
+    // their loads in flight together (a block is a chain of short dependent phases: every step saved is ~2 us of exposed latency, and
+    // 2 400 blocks go through the chip in a few rounds).  Rows in which a lane fails go on to the fp64 list.
+    constexpr int RPP = BT / PP_ROW;
+    constexpr int PP_UNR = BT >= 1024 ? 1 : 2;
+    __shared__ unsigned short todo2[PP_NROW];
+    __shared__ int s_n2;
+    const int l16 = threadIdx.x & 15;
+    int n2 = ntodo;
+    const unsigned short* list2 = todo;                // without screening every open row takes the fp64 path
+    if (screening) {
+        if (threadIdx.x == 0) s_n2 = 0;
+        __syncthreads();
+#pragma unroll 1
+        for (int q0 = 0; q0 < ntodo; q0 += RPP * PP_UNR) {
+            float xf[PP_UNR][NF];
+            double old[PP_UNR];
+            int rr_[PP_UNR];
+            bool val_[PP_UNR], act_[PP_UNR];
+#pragma unroll
+            for (int u = 0; u < PP_UNR; ++u) {
+                const int slot = q0 + u * RPP + (threadIdx.x >> 4);
+                act_[u] = slot < ntodo;
+                rr_[u] = act_[u] ? todo[slot] : 0;
+                const int64_t i = (R0 + rr_[u]) * PP_ROW + l16;
+                val_[u] = act_[u] && i < N;
+                old[u] = val_[u] ? closest[i] : 0.0;
+#pragma unroll
+                for (int j = 0; j < NF; ++j) xf[u][j] = (val_[u] && (NS > 0 || j < n)) ? Xf[(int64_t)j * N + i] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < PP_UNR; ++u) {
+                bool certified = true;                // lanes without a sample do not ask for anything
+                if (val_[u]) {
+                    const float so = sqrtf((float)old[u] * 1.0000003f + 1.0e-37f) * 1.000005f + rmarg;
+                    const float thr = so * so * 1.0000003f;
+                    float dmin = 3.0e38f;
+#pragma unroll 1
+                    for (int t = 0; t < npts; ++t) {
+                        const float* row = csf + t * KM_NMAX;
+                        float d = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < NF; ++j) { const float e = xf[u][j] - row[j]; d = fmaf(e, e, d); }
+                        dmin = fminf(dmin, d);        // a NaN distance is ignored by fminf: guard below
+                        if (!(d == d)) dmin = 0.0f;
+                    }
+                    certified = dmin >= thr;          // false for a NaN threshold
+                }
+                unsigned long long b = __ballot(!certified);
+                b |= b >> 8; b |= b >> 4; b |= b >> 2; b |= b >> 1;        // bit 16 g = some lane of the wave's row g is not certified
+                const bool rowneed = ((b >> (threadIdx.x & 48)) & 1ull) != 0ull;
+                if (act_[u] && l16 == 0) {
+                    if (rowneed) {
+                        todo2[atomicAdd(&s_n2, 1)] = (unsigned short)rr_[u];     // (any order: a row's result goes to its own slot)
+                    } else {
+                        // every sample of the row certified: closest stands, and the stored sum is the row's sum
+                        const double v = rows.rsum[R0 + rr_[u]];
+                        for (int t = 0; t < L; ++t) rowval[t][rr_[u]] = v;
+                        rowval[L][rr_[u]] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        n2 = s_n2;
+        list2 = todo2;
+    }
+    // ---- the fp64 path for the rows that are left, BT / 16 per pass: the owed update, the trials' values, the row's sums
+    auto fp64_load = [&](int q0, int& r, bool& active, bool& valid, int64_t& i, double& old, double (&x)[KM_NMAX]) {
+        const int slot = q0 + (threadIdx.x >> 4);
+        active = slot < n2;
+        r = active ? list2[slot] : 0;
+        i = (R0 + r) * PP_ROW + l16;
+        valid = active && i < N;
+        old = (upd == 1 || !valid) ? 0.0 : closest[i];
+#pragma unroll
+        for (int j = 0; j < KM_NMAX; ++j) x[j] = (valid && (NS > 0 ? (j < NS) : (j < n))) ? Xt[(int64_t)j * N + i] : 0.0;
+    };
+    auto fp64_work = [&](int r, bool active, bool valid, int64_t i, double old, const double (&x)[KM_NMAX]) {
+        const int64_t R = R0 + r;
+        double v0 = old, vt[LM];
+#pragma unroll
+        for (int t = 0; t < LM; ++t) vt[t] = old;  // no sample: zeros
+        if (valid) {
             const double xx = pp_norm2<NS>(x);
             if (upd) {
                 asm volatile("" ::: "memory");
@@ -2208,35 +2396,56 @@ __global__ void __launch_bounds__(BT) pp_round_kernel(int64_t N, int n, int L, i
                 const double d = pp_dist<NS>(x, [&](int j) { return row[j]; }, row[KM_NMAX], xx);
                 if (upd == 1 || d < old) { old = d; closest[i] = d; }     // np.minimum(closest, d); unchanged values are not rewritten
             }
-            acc0 += old;
+            v0 = old;
 #pragma unroll
-            for (int t = 0; t < PP_LMAX; ++t) {
+            for (int t = 0; t < LM; ++t) {
+                vt[t] = old;
                 if (t < L) {
                     asm volatile("" ::: "memory");
                     const double* row = cs + t * CSW;
                     const double d = pp_dist<NS>(x, [&](int j) { return row[j]; }, row[KM_NMAX], xx);
-                    acc[t] += old < d ? old : d;
+                    vt[t] = old < d ? old : d;
                 }
             }
-        } else if (i < N) {
-            // certified: every min(old, d) is old -- the same value enters the same sum at the same place
-            acc0 += old;
-#pragma unroll
-            for (int t = 0; t < PP_LMAX; ++t)
-                if (t < L) acc[t] += old;
         }
-    }
+        const double s0 = pp_row_sum(v0);
 #pragma unroll
-    for (int t = 0; t <= PP_LMAX; ++t) {
-        double a = t < PP_LMAX ? acc[t] : acc0;
-        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
-        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][t] = a;
+        for (int t = 0; t < LM; ++t)
+            if (t < L) vt[t] = pp_row_sum(vt[t]);
+        float mx = (float)v0;                          // the row's largest closest, for the ball test of later rounds (a NaN shows in s0)
+        mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 2)); mx = fmaxf(mx, __shfl_xor(mx, 1));
+        if (active && l16 == 0) {
+#pragma unroll
+            for (int t = 0; t < LM; ++t)
+                if (t < L) rowval[t][r] = vt[t];
+            rowval[L][r] = s0;
+            if (rows.rsum) {
+                rows.rsum[R] = s0;
+                // >= sqrt(closest_i): (float) rounds to nearest, the factors cover that and sqrtf; NaN stays NaN (never certified)
+                rows.rs[R] = (s0 - s0 == 0.0) ? sqrtf(mx * 1.0000003f + 1.0e-37f) * 1.0000003f : __builtin_nanf("");
+            }
+        }
+    };
+#pragma unroll 1
+    for (int q0 = 0; q0 < n2; q0 += RPP) {
+        // (two passes with their loads in flight together were tried: 144 VGPRs, three blocks per CU instead of four, 76 against 58 us
+        // per late round -- this kernel lives on the number of blocks a CU holds)
+        int ra;
+        bool aa, va;
+        int64_t ia;
+        double oa, xa[KM_NMAX];
+        fp64_load(q0, ra, aa, va, ia, oa, xa);
+        fp64_work(ra, aa, va, ia, oa, xa);
     }
     __syncthreads();
-    if ((int)threadIdx.x <= PP_LMAX && ((int)threadIdx.x < L || (int)threadIdx.x == PP_LMAX)) {
+    // ---- the chunk's sums: lane l adds rows l, l + 64, l + 128, l + 192, then a fixed tree; a wave per trial
+    for (int t = wv; t <= L; t += BT / 64) {
+        const int tr = t < L ? t : PP_LMAX;
         double a = 0.0;
-        for (int w = 0; w < BT / 64; ++w) a += red[w][threadIdx.x];
-        S[(int64_t)threadIdx.x * nchunks + blockIdx.x] = a;
+#pragma unroll
+        for (int q = 0; q < PP_NROW / 64; ++q) a += rowval[t][lane + 64 * q];
+        for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off);
+        if (lane == 0) S[(int64_t)tr * nchunks + blockIdx.x] = a;
     }
 }
 
@@ -2401,6 +2610,8 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
         }
         __syncthreads();
         if (blockIdx.x == 0 && tid < n) C[(int64_t)c * n + tid] = X[s_last * xstride + tid] - (mean ? mean[tid] : 0.0);
+        if (blockIdx.x == 0 && tid < PP_CW)          // the next round's "centre chosen last", as pp_round_kernel stages it
+            st->lastrow[tid] = tid < KM_NMAX ? ((NS > 0 ? tid < NS : tid < n) ? Xt[(int64_t)tid * N + s_last] : 0.0) : (tid == KM_NMAX ? xsq[s_last] : 0.0);
     } else {
         if (tid == 0) { s_row = PP_LMAX; s_last = -1; s_pot = 0.0; }
         __syncthreads();
@@ -2419,13 +2630,19 @@ __global__ void __launch_bounds__(PD_THREADS) pp_decide_kernel(int64_t N, int n,
     pp_find_sample<NS>(N, n, nchunks, v, prefix, last >= 0, cl, cn, Xt, xsq, closest, vals, wtot, wfirst, &s_found);
     __syncthreads();
     if (tid == 0) st->cand[c & 1][trial] = s_found;
+    if (tid < PP_CW) {
+        const long long f = s_found;
+        st->crow[c & 1][trial][tid] = tid < KM_NMAX ? ((NS > 0 ? tid < NS : tid < n) ? Xt[(int64_t)tid * N + f] : 0.0) : (tid == KM_NMAX ? xsq[f] : 0.0);
+    }
 }
 
-__global__ void pp_first_kernel(int n, long long first, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
-                                PPState* __restrict__ st, double* __restrict__ C, long long* __restrict__ indices) {
+__global__ void pp_first_kernel(int n, int64_t N, long long first, const double* __restrict__ X, int64_t xstride, const double* __restrict__ mean,
+                                const double* __restrict__ Xt, const double* __restrict__ xsq, PPState* __restrict__ st, double* __restrict__ C,
+                                long long* __restrict__ indices) {
     const int t = threadIdx.x;
     if (t == 0) { st->last = first; st->pot = 0.0; indices[0] = first; }
     if (t < n) C[t] = X[first * xstride + t] - (mean ? mean[t] : 0.0);
+    if (t < PP_CW) st->lastrow[t] = t < KM_NMAX ? (t < n ? Xt[(int64_t)t * N + first] : 0.0) : (t == KM_NMAX ? xsq[first] : 0.0);
 }
 
 int kmeanspp_chunks(int64_t N) { return (int)((N + PP_CHUNK - 1) / PP_CHUNK); }
@@ -2436,7 +2653,7 @@ size_t kmeanspp_state_bytes() { return sizeof(PPState); }
 // [kmeanspp_sum_doubles(N)]; C: device [k][n]; indices: device [k] (int64)
 hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                            long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
-                           void* state, double* C, long long* indices, float* Xf) {
+                           void* state, double* C, long long* indices, float* Xf, void* rowbuf) {
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;      // prefix table + the chunk's values: N <= 3e7
@@ -2446,20 +2663,24 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     if (e0 != hipSuccess) return e0;
     const unsigned nb = (unsigned)((N + PP_THREADS - 1) / PP_THREADS);
     const bool small = nchunks <= 256 && N > 2048;     // fewer chunks than CUs (and more than a few waves of samples): latency, not bandwidth
+    const PPRows rows = pp_rows_from(Xf ? rowbuf : nullptr, N, n);
+    const unsigned nrb = (unsigned)(((N + PP_ROW - 1) / PP_ROW + 255) / 256);
 #define PP_DISPATCH(NS_) do { \
         hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq, Xf, ps); \
-        hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, first, X, xstride, mean, ps, C, indices); \
+        if (rows.rc) hipLaunchKernelGGL(pp_rowball_kernel<NS_>, dim3(nrb), dim3(256), 0, st, N, n, Xt, rows); \
+        hipLaunchKernelGGL(pp_first_kernel, dim3(1), dim3(64), 0, st, n, N, first, X, xstride, mean, Xt, xsq, ps, C, indices); \
         if (k > 1) { \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024, PP_LMAX>), dim3(nchunks), dim3(1024), PP_NROW * 8, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr, rows); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS, 8>), dim3(nchunks), dim3(PP_THREADS), PP_NROW * 8, st, N, n, 0, nchunks, Xt, xsq, ps, 0, 1, closest, S, Xf, nullptr, rows); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(L), dim3(PD_THREADS), lds, st, N, n, nchunks, L, 0, 1, u, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } \
         for (int c = 1; c < k; ++c) { \
             const int draw = c + 1 < k ? 1 : 0; \
-            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024>), dim3(nchunks), dim3(1024), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr); \
-            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr); \
+            if (small) hipLaunchKernelGGL((pp_round_kernel<NS_, 1024, PP_LMAX>), dim3(nchunks), dim3(1024), (size_t)(L + 1) * PP_NROW * 8, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr, rows); \
+            else if (L <= 8) hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS, 8>), dim3(nchunks), dim3(PP_THREADS), (size_t)(L + 1) * PP_NROW * 8, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr, rows); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS, PP_LMAX>), dim3(nchunks), dim3(PP_THREADS), (size_t)(L + 1) * PP_NROW * 8, st, N, n, L, nchunks, Xt, xsq, ps, (c - 1) & 1, c == 1 ? 0 : 2, closest, S, c >= PP_SCREEN_FROM ? Xf : nullptr, nullptr, rows); \
             hipLaunchKernelGGL(pp_decide_kernel<NS_>, dim3(draw ? L : 1), dim3(PD_THREADS), lds, st, N, n, nchunks, L, c, draw, u + (size_t)c * L, Xt, xsq, closest, S, X, xstride, mean, ps, C, indices); \
         } } while (0)
     if (n == 12) PP_DISPATCH(12); else if (n == 13) PP_DISPATCH(13); else PP_DISPATCH(0);
@@ -2588,8 +2809,10 @@ size_t kmeanspp_shard_doubles(int world) { return (size_t)world * PP_SROWS + 2 *
 hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int L, const double* X, int64_t xstride, const double* mean,
                                    long long first, const double* u, double* Xt, double* xsq, double* closest, double* S,
                                    void* state, double* C, long long* indices, float* Xf, int world, int rank, long long row0,
-                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed) {
+                                   double* shard, int (*exch)(void*, void*, int64_t, int), void* user, int* comm_failed, void* rowbuf) {
     if (n > KM_NMAX || L > PP_LMAX || L < 1 || world < 1 || rank < 0 || rank >= world || N < 1) return hipErrorInvalidValue;
+    const PPRows rows = pp_rows_from(Xf ? rowbuf : nullptr, N, n);
+    const unsigned nrb = (unsigned)(((N + PP_ROW - 1) / PP_ROW + 255) / 256);
     *comm_failed = 0;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;
@@ -2610,6 +2833,7 @@ hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int 
         hipError_t e_ = hipFuncSetAttribute((const void*)pp_decide_sh_kernel<NS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL(pp_transpose_kernel<NS_>, dim3(nb), dim3(PP_THREADS), 0, st, N, n, X, xstride, mean, Xt, xsq, Xf, ps); \
+        if (rows.rc) hipLaunchKernelGGL(pp_rowball_kernel<NS_>, dim3(nrb), dim3(256), 0, st, N, n, Xt, rows); \
         if (Xf && !exchange(&ps->xmax_bits, 1, 1)) return hipSuccess;        /* the scale of the screening margin: over all ranks */ \
         if ((e_ = hipMemsetAsync(crow[1], 0, crow_bytes, st)) != hipSuccess) return e_; \
         hipLaunchKernelGGL(pp_first_sh_kernel<NS_>, dim3(1), dim3(64), 0, st, N, n, first, row0, Xt, xsq, crow[1]); \
@@ -2620,8 +2844,10 @@ hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int 
             const int draw = c + 1 < k ? 1 : 0; \
             const int Lc = c == 0 ? 0 : L; \
             const double* cur = crow[(c + 1) & 1];                       /* round c reads T[(c - 1) & 1], written by decide(c - 1) (c = 0: pp_first) */ \
-            hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS>), dim3(nchunks), dim3(PP_THREADS), 0, st, N, n, Lc, nchunks, Xt, xsq, ps, 0, \
-                               c == 0 ? 1 : (c == 1 ? 0 : 2), closest, S, (c >= PP_SCREEN_FROM) ? Xf : nullptr, cur); \
+            if (Lc <= 8) hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS, 8>), dim3(nchunks), dim3(PP_THREADS), (size_t)(Lc + 1) * PP_NROW * 8, st, N, n, Lc, nchunks, Xt, xsq, ps, 0, \
+                               c == 0 ? 1 : (c == 1 ? 0 : 2), closest, S, (c >= PP_SCREEN_FROM) ? Xf : nullptr, cur, rows); \
+            else hipLaunchKernelGGL((pp_round_kernel<NS_, PP_THREADS, PP_LMAX>), dim3(nchunks), dim3(PP_THREADS), (size_t)(Lc + 1) * PP_NROW * 8, st, N, n, Lc, nchunks, Xt, xsq, ps, 0, \
+                               c == 0 ? 1 : (c == 1 ? 0 : 2), closest, S, (c >= PP_SCREEN_FROM) ? Xf : nullptr, cur, rows); \
             if ((e_ = hipMemsetAsync(tot, 0, tot_bytes, st)) != hipSuccess) return e_; \
             hipLaunchKernelGGL(pp_tot_kernel, dim3(1), dim3(PD_THREADS), 0, st, nchunks, Lc, S, tot + (size_t)rank * PP_SROWS); \
             if (!exchange(tot, (int64_t)world * PP_SROWS, 0)) return hipSuccess; \
