@@ -122,7 +122,7 @@ struct KmBounds {
     int* list = nullptr;            // [kmeans_bounds_list_words(N)]
     int* nlist = nullptr;           // [2]
     double beta = -1.0;             // >= 0: the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u (default KM_BND_BETA)
-    bool use_list = false;          // the E-step visits the list only and its partials are CHANGES (launch_kmeans_reduce: delta)
+    bool use_list = false;          // the E-step visits the list only and its partials are CHANGES (launch_kmeans_mstep: delta)
 };
 size_t kmeans_bounds_list_words(int64_t N);
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm);
@@ -143,11 +143,31 @@ bool kmeans_pk_supported(int n, int k);
 hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, const double* X, int64_t xstride, const double* mean, const double* c2,
                                    int* labels, unsigned long long* partial, double* block_inertia, int* block_changed, const double* prm,
                                    const double* fix, float* d2out, const int* perm, const unsigned long long* Nk, const float* Pf);
-hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats, long long* tot = nullptr, int delta = 0,
-                                const int* nlist = nullptr);
 hipError_t launch_kmeans_average(hipStream_t st, int n, int k, const long long* red, const double* fix, const double* Cold, double* Cnew,
                                  double* c2, double* stats, double* prm, int mode, float* shiftc = nullptr, int* nlist = nullptr);
+// the M-step as one launch (kmeans.hip: kmeans_mstep_kernel): phases 1 = sums, 2 = centres + tail (from `red`), 3 = both
+struct KmMstepArgs {
+    int nparts = 0, nblocks = 0, n = 0, k = 0;
+    const unsigned long long* partial = nullptr;
+    const double* block_inertia = nullptr;
+    const int* block_changed = nullptr;
+    long long* red = nullptr;
+    long long* tot = nullptr;
+    int delta = 0;
+    int* nlist = nullptr;               // the counter of the bounds list (read when delta, zeroed for the next list)
+    const double* fix = nullptr;
+    const double* Cold = nullptr;
+    double* Cnew = nullptr;
+    double* Ct = nullptr;
+    double* stats = nullptr;
+    double* prm = nullptr;
+    float* shiftc = nullptr;
+    float* mvd = nullptr;
+    double* scratch = nullptr;          // [kmeans_mstep_scratch_doubles(k)], zeroed once before the loop (its ticket word)
+    double* hstats = nullptr;           // pinned, device-mapped [4] or nullptr
+};
+size_t kmeans_mstep_scratch_doubles(int k);
+hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& a, int phases);
 hipError_t launch_kmeans_reloc_dist(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* mean, const double* Cold,
                                     const int* labels, const int* perm, double* dist_row, int* lab_row);
 

@@ -70,7 +70,8 @@ struct brov_ctx {
     char* h_stage[2] = {nullptr, nullptr};        // pinned staging blocks of brov_upload_bags (created on first use)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};  // "the DMA that read block i has finished"
     int upload_threads = 0;                       // host threads packing a block (0 = not probed yet)
-    double* h_stats = nullptr;        // pinned: per-iteration statistics of the Lloyd loop come back while the next E-step runs
+    double* h_stats = nullptr;        // pinned, device-mapped: the M-step stores an iteration's statistics there while the next E-step is queued
+    double* d_stats_map = nullptr;    // its device alias
     hipEvent_t ev_stats = nullptr;
     brov_far_select_fn far_select = nullptr;      // rows an empty cluster is relocated to (edmdc_set_kmeans_far_select); nullptr = descending selection
     void* far_select_user = nullptr;
@@ -2054,7 +2055,8 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) +
-                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 3 * Arena::al((size_t)k * 16 + 64) + 1024 : 0) + 8192);
+                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 3 * Arena::al((size_t)k * 16 + 64) + 1024 : 0) +
+                       Arena::al(kmeans_mstep_scratch_doubles(k) * 8) + 8192);
     if (rc) return rc;
     unsigned long long* partial = a.take<unsigned long long>(pw_max);
     long long* red = a.take<long long>(rwords);
@@ -2069,6 +2071,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     double* fix = a.take<double>(32);                  // fixed-point scales of the member sums
     unsigned long long* rng = a.take<unsigned long long>(16);
     double* dmean = a.take<double>(16);
+    double* ms_scratch = a.take<double>(kmeans_mstep_scratch_doubles(k));      // the fused M-step's per-centre shifts / flags and its arrival ticket
     int *Ls[2] = {nullptr, nullptr}, *Ps[2] = {nullptr, nullptr};
     float* d2 = nullptr;
     float *d2s[2] = {nullptr, nullptr}, *ubs[2] = {nullptr, nullptr}, *lbs[2] = {nullptr, nullptr};      // per position: two copies each, swapped by a re-sort
@@ -2097,8 +2100,15 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     HIPCK(c, hipMemsetAsync(d_labels, 0xFF, N * sizeof(int32_t), c->stream));
-    if (!c->h_stats) HIPCK(c, hipHostMalloc((void**)&c->h_stats, 8 * sizeof(double), hipHostMallocDefault));
+    if (!c->h_stats) {
+        HIPCK(c, hipHostMalloc((void**)&c->h_stats, 8 * sizeof(double), hipHostMallocMapped));
+        HIPCK(c, hipHostGetDevicePointer((void**)&c->d_stats_map, c->h_stats, 0));      // the M-step stores the iteration's statistics there itself
+    }
     if (!c->ev_stats) HIPCK(c, hipEventCreateWithFlags(&c->ev_stats, hipEventDisableTiming));
+    if (!c->side[0]) HIPCK(c, hipStreamCreateWithFlags(&c->side[0], hipStreamNonBlocking));
+    if (!c->ev_fork) HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    if (!c->ev_join[0]) HIPCK(c, hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming));
+    HIPCK(c, hipMemsetAsync(ms_scratch, 0, kmeans_mstep_scratch_doubles(k) * 8, c->stream));
     CallTimer t(c);
     double* prm = stats + 4;
     const double* mp = mean_host ? dmean : nullptr;
@@ -2147,8 +2157,15 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     if (const char* e = std::getenv("BROV2_KM_BOUNDS_BETA")) bounds_beta = std::atof(e);      // (tools/time_lloyd_ab.py)
 #endif
     const double n_all = (c->km_allreduce && c->km_n_global > 0) ? (double)c->km_n_global : (double)N;
+    // (the centre distances on a side stream beside the bounds pass: measured and left off -- both kernels slow each other down, 75 + 69 us
+    // against 31 + 61 one after the other, and with the two event hand-overs 300 iterations take 153 ms instead of 150.5)
+    bool cdist_forked = false, cdist_beside = false;
+#ifdef BROV2_EXPERIMENTS
+    if (const char* e = std::getenv("BROV2_KM_CDIST_BESIDE")) cdist_beside = std::atoi(e) != 0;
+#endif
     auto e_step = [&](bool filtered) -> hipError_t {
         if (filtered && pk) {
+            if (cdist_forked) { cdist_forked = false; if (hipStreamWaitEvent(c->stream, c->ev_join[0], 0) != hipSuccess) return hipErrorUnknown; }
             e_nparts = nparts_pk; e_nb = nb_pk;
             return launch_kmeans_assign_pk(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, prm, fix, d2, Pc, Nk, Pf);
         }
@@ -2167,15 +2184,28 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             }
             bounds_valid = true;                        // (a full pass writes them all; a list pass keeps them)
         }
+        if (cdist_forked) {                             // the centre distances were queued on the side stream (beside the bounds pass): join
+            cdist_forked = false;
+            if (hipStreamWaitEvent(c->stream, c->ev_join[0], 0) != hipSuccess) return hipErrorUnknown;
+        }
         return launch_kmeans_assign(c->stream, N, n, k, d_X, xstride, mp, c2, Lc, partial, binert, bchg, filtered && filter ? Dc : nullptr, prm, fix,
                                     bnd ? d2s[bcur] : d2, scalar_records, filtered ? Pc : nullptr, filtered ? Nk : nullptr, filtered && pk_lds ? Pf : nullptr,
                                     with_bounds ? &kb : nullptr);
     };
     for (it = 1; it <= max_iter; ++it) {
-        HIPCK(c, launch_kmeans_reduce(c->stream, e_nparts, e_nb, n, k, partial, binert, bchg, red, stats, tot, e_list ? 1 : 0, nlist));
-        if (c->km_allreduce && c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
-        HIPCK(c, launch_kmeans_average(c->stream, n, k, red, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, 0, shiftc, nlist));
-        HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+        // the M-step: one launch (kmeans.hip: kmeans_mstep_kernel) -- sums, centres, the iteration's statistics straight into the host's
+        // pinned block; a sharded run all-reduces the sums between its two halves
+        KmMstepArgs ma;
+        ma.nparts = e_nparts; ma.nblocks = e_nb; ma.n = n; ma.k = k; ma.partial = partial; ma.block_inertia = binert; ma.block_changed = bchg;
+        ma.red = red; ma.tot = tot; ma.delta = e_list ? 1 : 0; ma.nlist = nlist; ma.fix = fix; ma.Cold = Cb[cc]; ma.Cnew = Cb[cc ^ 1]; ma.Ct = c2;
+        ma.stats = stats; ma.prm = prm; ma.shiftc = shiftc; ma.mvd = mvd; ma.scratch = ms_scratch; ma.hstats = c->d_stats_map;
+        if (c->km_allreduce) {
+            HIPCK(c, launch_kmeans_mstep(c->stream, ma, 1));
+            if (c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
+            HIPCK(c, launch_kmeans_mstep(c->stream, ma, 2));
+        } else {
+            HIPCK(c, launch_kmeans_mstep(c->stream, ma, 3));
+        }
         HIPCK(c, hipEventRecord(c->ev_stats, c->stream));
         if (want_sort) {
             // (label, distance) of the E-step that has just been summed up; labels and permutation move together
@@ -2194,9 +2224,23 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             moved = 0.0;
             if (c->km_info[1]++ == 0) c->km_info[2] = it;
         }
-        if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd));
         // hs still holds the statistics of the iteration before this one (the host has not waited yet): few changed labels -> list form
         use_list = bnd && it >= 2 && hs[2] <= bounds_rate * n_all;
+        if (filter) {
+            // centre distances, sorted rows, pair records: 32 us of short dependent phases in k blocks, needed by the E-step but not by the
+            // bounds pass (whose mover distances the M-step has left): on the side stream, beside it
+            const bool beside = cdist_beside && bnd && use_list && bounds_valid && Pc != nullptr;
+            hipStream_t cs_ = beside ? c->side[0] : c->stream;
+            if (beside) {
+                HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
+                HIPCK(c, hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
+            }
+            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr));
+            if (beside) {
+                HIPCK(c, hipEventRecord(c->ev_join[0], c->side[0]));
+                cdist_forked = true;
+            }
+        }
         HIPCK(c, e_step(true));
         HIPCK(c, hipEventSynchronize(c->ev_stats));
         for (int q = 0; q < 4; ++q) hs[q] = c->h_stats[q];

@@ -562,7 +562,7 @@ __device__ __forceinline__ void pk_pair(const PkRec& r, const v2f (&xx)[NS], flo
 
 // LIST (round 4, distance bounds): the pass walks the positions kmeans_bounds_kernel has listed (entry p, or ~p: a padding lane that
 // loads p's row and counts for nothing) instead of all N, its member sums are the CHANGES (a sample that moves takes its
-// fixed-point coordinates from the old cluster to the new one; kmeans_reduce_kernel adds them to the kept totals), and labels,
+// fixed-point coordinates from the old cluster to the new one; kmeans_mstep_kernel adds them to the kept totals), and labels,
 // sort keys and bounds are written per listed position.  ubo / lbo != nullptr (either form): the packed-fp32 path leaves the sample's
 // bounds there (NaN from every other path: such a sample is evaluated again next time), and the prefix is cut at 2 (1 + beta) u
 // instead of 2 u (tscale = (1 + beta)^2): what lies beyond it is then at least (1 + 2 beta) u from every lane -- a lower bound worth keeping.
@@ -1012,7 +1012,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         bool sent = false;
         if constexpr (LIST) {
             // CHANGES of the member sums: a sample that moved leaves its old cluster and joins the new one (two's-complement words:
-            // the block's partial table holds signed differences; kmeans_reduce_kernel adds them to the totals it keeps)
+            // the block's partial table holds signed differences; kmeans_mstep_kernel adds them to the totals it keeps)
             sent = true;
             if (live && ol != bi && (unsigned)ol < (unsigned)k) {
                 u64* sn = sums + bi * np1;
@@ -1092,7 +1092,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     }
     km_flush(sums, partial, ep, k, n, false);
     if constexpr (LIST) {
-        // only the epochs the longest-running block reaches: kmeans_reduce_kernel derives the same number from the list's length
+        // only the epochs the longest-running block reaches: kmeans_mstep_kernel derives the same number from the list's length
         const int64_t passes = (M + stride - 1) / stride;
         const int used = (int)((passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES);
         km_zero_epochs(partial, ep + 1, used < nepochs ? (used > 1 ? used : 1) : nepochs, k, n);
@@ -1473,65 +1473,8 @@ __device__ __forceinline__ double km_pack_centre(int n, const double* __restrict
     return q;
 }
 
-// One 256-thread block per centre: adds up the partials of all blocks and epochs (thread = (slot j, sub-range of the partials),
-// eight loads in flight) as 128-bit integers -- any grouping gives the same total -- and leaves them in red [k][n+1][2].
-// The second wave of block 0 sums the E-step's per-block statistics: inertia (fp64, lane l takes blocks l, l + 64, ...; fixed
-// tree: the same bits for the same launch geometry) into stats[1], changed labels into the tail of red (an integer, so that it
-// takes part in the all-reduce of a sharded run).
-// `tot` (round 4, distance bounds): this rank's own totals, kept from iteration to iteration.  delta = 0: the partials are the sums
-// over ALL samples (tot = their total); delta = 1: the partials are the CHANGES of an E-step that visited only the samples whose
-// bounds failed -- what a sample that moved took from its old cluster and brought to its new one, integers like the sums themselves
-// -- and tot += their total: the same 128-bit integers as a fresh summation, bit for bit.  red = tot either way.
-__global__ void __launch_bounds__(256) kmeans_reduce_kernel(int nparts, int nblocks, int n, int k, const u64* __restrict__ partial,
-                                                            const double* __restrict__ block_inertia, const int* __restrict__ block_changed,
-                                                            long long* __restrict__ red, double* __restrict__ stats, long long* __restrict__ tot,
-                                                            int delta, const int* __restrict__ nlist, int span) {
-    const int np1 = n + 1;
-    if (nlist) {
-        // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
-        const int64_t passes = ((int64_t)nlist[0] + span - 1) / span;
-        const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
-        const int tables = nblocks * (int)(used > 1 ? used : 1);
-        nparts = tables < nparts ? tables : nparts;
-    }
-    const int c = blockIdx.x;
-    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
-    __shared__ long long part[16][17][2];
-    __int128 a = 0;
-    if (j <= n) {
-        for (int b0 = sr; b0 < nparts; b0 += 16 * 8) {
-            long long v[8];
-#pragma unroll
-            for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nparts ? (long long)partial[((int64_t)b * k + c) * np1 + j] : 0ll; }
-#pragma unroll
-            for (int q = 0; q < 8; ++q) a += (__int128)v[q];
-        }
-    }
-    part[sr][j][0] = (long long)(a >> 64);
-    part[sr][j][1] = (long long)(u64)a;
-    __syncthreads();
-    if ((int)threadIdx.x <= n) {
-        __int128 t = 0;
-        for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
-        if (tot) {
-            if (delta) t += km_load128(tot + ((int64_t)c * np1 + threadIdx.x) * 2);
-            km_store128(tot + ((int64_t)c * np1 + threadIdx.x) * 2, t);
-        }
-        km_store128(red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
-    }
-    if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
-        const int l = threadIdx.x & 63;
-        double in = 0.0;
-        long long ch = 0;
-        for (int b = l; b < nblocks; b += 64) { in += block_inertia[b]; ch += block_changed[b]; }
-        for (int off = 32; off > 0; off >>= 1) {
-            in += __shfl_down(in, off);
-            ch += __shfl_down(ch, off);
-        }
-        if (l == 0) { stats[1] = in; red[(int64_t)k * np1 * 2] = ch; red[(int64_t)k * np1 * 2 + 1] = 0; }
-    }
-}
-
+// (the sums of the M-step -- one 256-thread block per centre over the partials of all blocks and epochs -- are phase 1 of
+// kmeans_mstep_kernel below)
 constexpr int KM_BND_TOP = 4;                          // movers that kmeans_bounds_kernel takes apart (a float4 of centre distances per cluster)
 constexpr int KM_BND_TAIL = 2 * KM_BND_TOP + 4;
 // New centres from the totals, one block of 1024 threads (thread = centre): mean = total / s_j / count (scikit-learn multiplies by
@@ -1680,6 +1623,268 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
         }
     }
 }
+
+// ---- the M-step as two launches -- k blocks, then one (round 5): the partial tables' sums, the new centre of every cluster in the block that has just
+// summed it, and kmeans_average_kernel's global tail in the block that finishes last.  Per iteration the loop used to queue reduce (9 us)
+// -> average (29 us: one block, a thread per centre walking its thirteen totals) -> a 32-byte copy to the host -> centre distances ->
+// bounds -> E-step, ~100 us of launch boundaries and short serial kernels around 400 us of work.  Here: phase 1 (the block of centre c)
+// = the 128-bit totals (any grouping of integer additions gives the same bits); phase 2 (same block) = mean, shift, packed table row -- the
+// arithmetic of kmeans_average_kernel, pass 1 and 3, for one centre; tail (a second launch of ONE block) = the sum
+// of the squared shifts IN THE ORDER kmeans_average_kernel adds them (the stopping rule compares it with the tolerance: a sharded run,
+// which still needs its all-reduce between the two phases and therefore launches this kernel twice, must stop at the same iteration),
+// the count of empty clusters, the movers of the distance bounds and every centre's distance to them (what kmeans_cdist_kernel used
+// to add), and the four statistics the host waits for -- stored straight into its pinned, device-mapped block (no copy in the stream).
+// phases: 1 = sums only (sharded: all-reduce `red` next), 2 = centres + tail from `red`, 3 = both.
+//
+// Phase 1 in detail: one 256-thread block per centre adds up the partials of all blocks and epochs (thread = (slot j, sub-range of the partials),
+// eight loads in flight) as 128-bit integers -- any grouping gives the same total -- and leaves them in red [k][n+1][2].
+// The second wave of block 0 sums the E-step's per-block statistics: inertia (fp64, lane l takes blocks l, l + 64, ...; fixed
+// tree: the same bits for the same launch geometry) into stats[1], changed labels into the tail of red (an integer, so that it
+// takes part in the all-reduce of a sharded run).
+// `tot` (round 4, distance bounds): this rank's own totals, kept from iteration to iteration.  delta = 0: the partials are the sums
+// over ALL samples (tot = their total); delta = 1: the partials are the CHANGES of an E-step that visited only the samples whose
+// bounds failed -- what a sample that moved took from its old cluster and brought to its new one, integers like the sums themselves
+// -- and tot += their total: the same 128-bit integers as a fresh summation, bit for bit.  red = tot either way.
+struct KmMstep {
+    // sums
+    int nparts, nblocks, n, k;
+    const u64* partial;
+    const double* block_inertia;
+    const int* block_changed;
+    long long* red;
+    long long* tot;
+    int delta;
+    const int* nlist_in;
+    int span;
+    // centres
+    const double* fix;
+    const double* Cold;
+    double* Cnew;
+    double* Ct;
+    double* stats;
+    double* prm;
+    float* shiftc;                  // [k + KM_BND_TAIL] or nullptr
+    float* mvd;                     // [k][KM_BND_TOP] or nullptr
+    int* nlist;                     // zeroed for the next kmeans_bounds_kernel, or nullptr
+    double* shift2;                 // [k] scratch: squared shift of every centre
+    int* flags;                     // [k] scratch: bit 0 empty, bit 1 not finite
+    unsigned* ticket;               // device-wide arrival counter (zero between launches)
+    double* hstats;                 // pinned, device-mapped [4], or nullptr
+};
+__global__ void __launch_bounds__(256) kmeans_mstep_kernel(KmMstep a, int phases) {
+    const int n = a.n, k = a.k, np1 = n + 1;
+    const int c = blockIdx.x;
+    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
+    __shared__ long long part[16][17][2];
+    __shared__ double s_cc[KM_NMAX];
+    __shared__ long long s_cw[2];
+    __int128 t = 0;
+    if (phases == 4) goto tail;
+    if (phases & 1) {
+        int nparts = a.nparts;
+        if (a.nlist_in) {
+            // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
+            const int64_t passes = ((int64_t)a.nlist_in[0] + a.span - 1) / a.span;
+            const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
+            const int tables = a.nblocks * (int)(used > 1 ? used : 1);
+            nparts = tables < nparts ? tables : nparts;
+        }
+        __int128 s = 0;
+        if (j <= n) {
+            for (int b0 = sr; b0 < nparts; b0 += 16 * 8) {
+                long long v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nparts ? (long long)a.partial[((int64_t)b * k + c) * np1 + j] : 0ll; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += (__int128)v[q];
+            }
+        }
+        part[sr][j][0] = (long long)(s >> 64);
+        part[sr][j][1] = (long long)(u64)s;
+        __syncthreads();
+        if ((int)threadIdx.x <= n) {
+            for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
+            if (a.tot) {
+                if (a.delta) t += km_load128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2);
+                km_store128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2, t);
+            }
+            km_store128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
+        }
+        if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
+            const int l = threadIdx.x & 63;
+            double in = 0.0;
+            long long ch = 0;
+            for (int b = l; b < a.nblocks; b += 64) { in += a.block_inertia[b]; ch += a.block_changed[b]; }
+            for (int off = 32; off > 0; off >>= 1) {
+                in += __shfl_down(in, off);
+                ch += __shfl_down(ch, off);
+            }
+            if (l == 0) { a.stats[1] = in; a.red[(int64_t)k * np1 * 2] = ch; a.red[(int64_t)k * np1 * 2 + 1] = 0; }
+        }
+    }
+    if (!(phases & 2)) return;
+    // ---- this centre: kmeans_average_kernel's pass 1 and pass 3 (mode 0)
+    if (!(phases & 1) && (int)threadIdx.x <= n) t = km_load128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2);     // (sharded: the all-reduced totals)
+    if ((int)threadIdx.x == n) { s_cw[0] = (long long)(t >> 64); s_cw[1] = (long long)(u64)t; }
+    __syncthreads();
+    {
+        const __int128 cw = ((__int128)s_cw[0] << 64) + (__int128)(u64)s_cw[1];
+        const long long cnt = (long long)(cw & (KM_POISON - 1));
+        const bool poisoned = (cw >> 40) != 0;
+        const bool empty = !(cnt > 0 || poisoned);
+        if ((int)threadIdx.x < n) {
+            const int jj = threadIdx.x;
+            double v;
+            if (!empty) v = poisoned ? __builtin_nan("") : (km_to_double(t) * a.fix[16 + jj]) / (double)cnt;
+            else v = a.Cold[(int64_t)c * n + jj];          // an empty cluster keeps its old centre for now (the host relocates)
+            a.Cnew[(int64_t)c * n + jj] = v;
+            s_cc[jj] = v;
+        } else if (threadIdx.x < KM_NMAX) {
+            s_cc[threadIdx.x] = 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double cc[KM_NMAX];
+            for (int q = 0; q < KM_NMAX; ++q) cc[q] = s_cc[q];
+            double sh = 0.0;
+            for (int q = 0; q < n; ++q) { const double dd = cc[q] - a.Cold[(int64_t)c * n + q]; sh = fma(dd, dd, sh); }
+            a.shift2[c] = sh;
+            // >= the true shift: sh carries n roundings of 2^-53; NaN (a poisoned centre) stays NaN and fails every bound test
+            if (a.shiftc) a.shiftc[c] = (float)sqrt(sh) * 1.000001f + 1.0e-37f;
+            const double qn = km_pack_centre(n, cc, a.Ct + (int64_t)c * 16);
+            a.flags[c] = (empty ? 1 : 0) | (!(qn - qn == 0.0) ? 2 : 0);
+        }
+    }
+    return;
+    // ---- the iteration's global part: a launch of its own, one block (phases = 4).  (First built as the tail of the same launch, run by
+    // the last block to take a device-wide ticket: 61 us per M-step against 38 for the two kernels of round 4 -- a release / acquire
+    // between blocks on different XCDs means L2 write-backs and invalidations, which a kernel boundary does once.)
+tail:
+    __shared__ double sh_d[16];
+    __shared__ int sh_em[4], sh_bad[4], sh_nan[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    {
+        // the squared shifts in kmeans_average_kernel's order: its thread v (of 1024) adds its centres v, v + 1024, ...; a shuffle tree
+        // over each of its 16 waves; the 16 wave sums one after the other
+        for (int vw = w; vw < 16; vw += 4) {
+            double v = 0.0;
+            for (int cc = 64 * vw + lane; cc < k; cc += 1024) v += a.shift2[cc];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+            if (lane == 0) sh_d[vw] = v;
+        }
+        int em = 0, bad = 0, snan = 0;
+        for (int cc = threadIdx.x; cc < k; cc += 256) {
+            const int f = a.flags[cc];
+            em += f & 1;
+            bad |= (f >> 1) & 1;
+            if (a.shiftc) { const float sv = a.shiftc[cc]; snan |= !(sv == sv); }
+        }
+        for (int off = 32; off > 0; off >>= 1) { em += __shfl_down(em, off); bad |= __shfl_down(bad, off); snan |= __shfl_down(snan, off); }
+        if (lane == 0) { sh_em[w] = em; sh_bad[w] = bad; sh_nan[w] = snan; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double tsum = 0.0;
+        for (int q = 0; q < 16; ++q) tsum += sh_d[q];
+        const int em = sh_em[0] + sh_em[1] + sh_em[2] + sh_em[3];
+        const int bad = sh_bad[0] | sh_bad[1] | sh_bad[2] | sh_bad[3];
+        a.stats[0] = tsum;
+        a.stats[2] = (double)a.red[(int64_t)k * np1 * 2];
+        a.stats[3] = (double)em;
+        a.prm[3] = em > 0 ? 1.0 : 0.0;                  // hold: the queued E-step returns at once, the host relocates
+        a.prm[2] = bad ? 1.0 : 0.0;                     // a non-finite centre (NaN / inf data): the candidate filter stands down
+        if (a.nlist) { a.nlist[0] = 0; a.nlist[1] = 0; }
+        if (a.hstats) {
+            a.hstats[0] = tsum; a.hstats[1] = a.stats[1]; a.hstats[2] = a.stats[2]; a.hstats[3] = (double)em;
+            __threadfence_system();
+        }
+    }
+    if (a.shiftc) {
+        // the KM_BND_TOP largest shifts, whose centres they are, and the largest of the rest (kmeans_bounds_kernel): wave 0 picks them one
+        // after the other (equal values: the lower index).  A NaN shift poisons them all.
+        __shared__ int s_pick[KM_BND_TOP];
+        if (w == 0) {
+            const int an = sh_nan[0] | sh_nan[1] | sh_nan[2] | sh_nan[3];
+            int picked[KM_BND_TOP + 1];
+            float pv[KM_BND_TOP + 1];
+#pragma unroll
+            for (int r = 0; r <= KM_BND_TOP; ++r) {
+                float bv = -1.0f;
+                int bi = 0x7fffffff;
+                for (int cc = lane; cc < k; cc += 64) {
+                    bool taken = false;
+#pragma unroll
+                    for (int q = 0; q < r; ++q) taken = taken || picked[q] == cc;
+                    const float v = a.shiftc[cc];
+                    if (!taken && v > bv) { bv = v; bi = cc; }      // cc ascends within a lane: the first of equal values stays
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    const float ov = __shfl_down(bv, off);
+                    const int oi = __shfl_down(bi, off);
+                    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                }
+                picked[r] = __builtin_amdgcn_readfirstlane(bi);
+                pv[r] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(bv)));
+                if (picked[r] == 0x7fffffff) { picked[r] = -1; pv[r] = 0.0f; }      // fewer centres than picks
+            }
+            if (lane == 0) {
+                const float nanf_ = __builtin_nanf("");
+#pragma unroll
+                for (int r = 0; r < KM_BND_TOP; ++r) {
+                    a.shiftc[k + r] = an ? nanf_ : pv[r];
+                    a.shiftc[k + KM_BND_TOP + r] = __int_as_float(picked[r]);
+                    s_pick[r] = picked[r];
+                }
+                a.shiftc[k + 2 * KM_BND_TOP] = an ? nanf_ : pv[KM_BND_TOP];
+            }
+        }
+        __syncthreads();
+        if (a.mvd) {
+            // every centre's distance to the movers, rounded DOWN (kmeans_bounds_kernel: a mover far from a sample's own centre NOW): the
+            // movers' rows in the LDS, a thread per centre with its own row in registers
+            __shared__ double s_mv[KM_BND_TOP][KM_NMAX];
+            if (threadIdx.x < KM_BND_TOP * KM_NMAX) {
+                const int r = threadIdx.x / KM_NMAX, jj = threadIdx.x % KM_NMAX;
+                const int cm = s_pick[r];
+                s_mv[r][jj] = ((unsigned)cm < (unsigned)k && jj < n) ? a.Ct[cm * 16 + jj] : 0.0;
+            }
+            __syncthreads();
+            for (int ca = threadIdx.x; ca < k; ca += 256) {
+                double row[KM_NMAX];
+#pragma unroll
+                for (int jj = 0; jj < KM_NMAX; ++jj) row[jj] = jj < n ? a.Ct[ca * 16 + jj] : 0.0;
+                float out[KM_BND_TOP];
+#pragma unroll
+                for (int r = 0; r < KM_BND_TOP; ++r) {
+                    float v = __builtin_inff();         // no such mover: it constrains nothing
+                    if ((unsigned)s_pick[r] < (unsigned)k) {
+                        double q = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < KM_NMAX; ++jj)
+                            if (jj < n) { const double d = row[jj] - s_mv[r][jj]; q = fma(d, d, q); }
+                        v = (float)(sqrt(q) * 0.999999);
+                        v = v > 0.0f ? v * 0.9999999f : v;
+                    }
+                    out[r] = v;
+                }
+                *reinterpret_cast<float4*>(a.mvd + ca * KM_BND_TOP) = make_float4(out[0], out[1], out[2], out[3]);
+            }
+        }
+    }
+}
+hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& h, int phases) {
+    KmMstep a;
+    a.nparts = h.nparts; a.nblocks = h.nblocks; a.n = h.n; a.k = h.k;
+    a.partial = h.partial; a.block_inertia = h.block_inertia; a.block_changed = h.block_changed; a.red = h.red; a.tot = h.tot;
+    a.delta = h.delta; a.nlist_in = h.delta ? h.nlist : nullptr; a.span = h.nblocks * KM_THREADS;
+    a.fix = h.fix; a.Cold = h.Cold; a.Cnew = h.Cnew; a.Ct = h.Ct; a.stats = h.stats; a.prm = h.prm; a.shiftc = h.shiftc; a.mvd = h.mvd;
+    a.nlist = h.nlist; a.shift2 = h.scratch; a.flags = reinterpret_cast<int*>(h.scratch + h.k); a.ticket = reinterpret_cast<unsigned*>(h.scratch + h.k) + h.k;
+    a.hstats = h.hstats;
+    if (phases & 3) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(h.k), dim3(256), 0, st, a, phases & 3);
+    if (phases & 2) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(1), dim3(256), 0, st, a, 4);
+    return hipGetLastError();
+}
+size_t kmeans_mstep_scratch_doubles(int k) { return (size_t)k + ((size_t)k + 2) / 2 + 2; }
 
 // ---- before the loop: the range of every (centred) coordinate -> fixed-point scales; max |x|^2 -> margins of the candidate filter ----
 // rng [16] (zeroed by the caller): bit patterns of non-negative doubles, atomicMax'd -- slots 0..n-1: max_i |x_ij - mean_j| over the finite
@@ -2997,14 +3202,6 @@ int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
     const int64_t need = (N + KM_THREADS - 1) / KM_THREADS;
     const int cap = kmeans_lds_form(n, k, scalar_records) ? KM2_BLOCKS : KM_BLOCKS;
     return need < cap ? (int)(need > 0 ? need : 1) : cap;
-}
-// M-step, first half: partials (nparts = blocks x epochs tables) -> red [kmeans_red_words] (128-bit totals as int64 limb pairs; tail: changed
-// labels) and stats[1] = inertia.  A sharded run all-reduces red with SUM (int64) before the second half.
-hipError_t launch_kmeans_reduce(hipStream_t st, int nparts, int nblocks, int n, int k, const unsigned long long* partial, const double* block_inertia,
-                                const int* block_changed, long long* red, double* stats, long long* tot, int delta, const int* nlist) {
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(k), dim3(256), 0, st, nparts, nblocks, n, k, partial, block_inertia, block_changed, red, stats, tot, delta,
-                       delta ? nlist : nullptr, nblocks * KM_THREADS);
-    return hipGetLastError();
 }
 // M-step, second half: red -> Cnew [k][n], c2 (packed table), stats[0] = squared shift against Cold, [2] = changed labels, [3] = empty clusters,
 // prm[2] (non-finite centre), prm[3] (hold); mode: see kmeans_average_kernel

@@ -95,7 +95,7 @@ def _device_apply(X, U, C, gamma, nbags, L, xs, us, P):
 
 
 def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, deterministic=False, order="fit_multi", apply_fn=None,
-                allreduce=None):
+                allreduce=None, pinv="eigh"):
     """EDMDc fit over trajectories sharded across ranks.
 
     X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);
@@ -120,11 +120,11 @@ def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, det
     allreduce(GtG, GtY)
     d = n + C.shape[0]
     if order == "fit_multi":
-        return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d)
+        return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d, pinv=pinv)
     if order != "fit":
         raise ValueError("order must be 'fit' or 'fit_multi'")
     with engine._blas_threads():
-        P = np.linalg.pinv(GtG.cpu().numpy() + ridge * np.eye(GtG.shape[0]))
+        P = engine._host_pinv(GtG.cpu().numpy(), ridge, pinv)
     M = (apply_fn or _device_apply)(X_local, U_local, C, gamma, nb, L, L + 1, L, P)
     pad = M.new_zeros(1)                                   # the collective takes two tensors; the second one is a dummy
     allreduce(M, pad)

@@ -571,7 +571,7 @@ def pinv_sym_host(G, ridge, rcond=1e-15):
 
 
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None, lift_cache=False, pinv="host", bag_offsets=None):
+            timings=None, lift_cache=False, pinv="eigh", bag_offsets=None):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
@@ -580,8 +580,12 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     the stopping rule fired before max_iter.  lift_cache=True: keep the lifted rows of the Gram pass in HBM for the apply pass
     when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
     45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
-    so it pays for repeated fits in one process, not for a single one; off by default.  pinv="host": numpy.linalg.pinv like the
-    reference (:97/:147); "device": pinv_sym_device (opt-in).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
+    so it pays for repeated fits in one process, not for a single one; off by default.  pinv: how the p x p solve is done -- "eigh"
+    (default since round 5): pinv_sym_host, a symmetric eigendecomposition on the host with numpy.linalg.pinv's cut-off (the same matrix
+    as the reference's pinv up to the rounding of another LAPACK driver: |dRMSE| <= 4e-10 / 9e-11 / 3.2e-8 against the reference's own
+    scores on the three fixture cases, where the reference's call itself gives 4e-10 / 2e-11 / 6.5e-9; 13 instead of 29 ms at p = 520);
+    "host": numpy.linalg.pinv itself (:97/:147); "device": pinv_sym_device (torch.linalg.eigh: 12 ms, but its first call in a process
+    costs 0.2 s).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
     of nbags bags of L pairs -- X [rows, n] the stacked states, U [rows, r] row-aligned with X (upload_bags); nbags / L are ignored."""
     import time
     import torch
@@ -708,22 +712,30 @@ class _blas_threads:
         return False
 
 
-def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None):
+def _host_pinv(G, ridge, pinv):
+    if pinv == "host":
+        return np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
+    if pinv in ("eigh", "device"):          # (the device form is fit_dev's; the host-list paths take the host's eigendecomposition)
+        return pinv_sym_host(G, ridge)
+    raise ValueError("pinv must be 'host', 'eigh' or 'device'")
+
+
+def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="eigh"):
     """(A, B) exactly as KoopmanEDMDc.fit associates the product (Koopman/koopmanEDMDc.py:97-101):
     M = (pinv(G^T G + ridge I) @ G.T) @ Y, the pinv on the host (numpy, like the reference), the two large products on
     the GPU.  Better conditioned than fit_multi's pinv(.) @ (G^T Y): at the class defaults (k = 200, ridge = 1e-8) the two
     differ by 1e-6 in the H = 100 RMSE."""
     with _blas_threads():
-        P = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0]))
+        P = _host_pinv(GtG, ridge, pinv)
     M = pinv_apply(X_list, U_list, C, gamma, P, ctx=ctx).T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
 
 
-def solve_AB(GtG, GtY, ridge, d):
+def solve_AB(GtG, GtY, ridge, d, pinv="eigh"):
     """Host solve of the ridge normal equations exactly as the reference does it
     (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
     with _blas_threads():
-        M = np.linalg.pinv(GtG + ridge * np.eye(GtG.shape[0])) @ GtY
+        M = _host_pinv(GtG, ridge, pinv) @ GtY
     M = M.T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
 
