@@ -2364,12 +2364,20 @@ static PPRows pp_rows_from(void* buf, int64_t N, int n) {
     r.rsum = reinterpret_cast<double*>(p);
     return r;
 }
-// the sum over the 16 lanes of a row, in every lane of it: a butterfly (partners add the same two numbers: the same bits in both)
+// the sum over the 16 lanes of a row, in every lane of it: four exchange stages in which partners add the same two numbers (the same
+// bits in both) -- lane ^ 1, lane ^ 2, then the mirror inside each half row (i <-> 7 - i) and inside the row (i <-> 15 - i): DPP
+// controls, i.e. two 32-bit moves and one addition per stage instead of two ds_bpermute round trips
 __device__ __forceinline__ double pp_row_sum(double v) {
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
+    auto stage = [](double x, auto ctrl) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+        const unsigned lo = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)b, decltype(ctrl)::value, 0xF, 0xF, true);
+        const unsigned hi = (unsigned)__builtin_amdgcn_mov_dpp((int)(unsigned)(b >> 32), decltype(ctrl)::value, 0xF, 0xF, true);
+        return x + __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    };
+    v = stage(v, std::integral_constant<int, 0xB1>{});       // quad_perm [1,0,3,2]
+    v = stage(v, std::integral_constant<int, 0x4E>{});       // quad_perm [2,3,0,1]
+    v = stage(v, std::integral_constant<int, 0x141>{});      // row_half_mirror
+    v = stage(v, std::integral_constant<int, 0x140>{});      // row_mirror
     return v;
 }
 // ball of every row: centre = the mean of its samples (as floats), radius against that stored centre
