@@ -2240,9 +2240,13 @@ __global__ void __launch_bounds__(256) kmeans_c2_kernel(int n, int k, const doub
 // (The first version made two passes per centre: update + chunk sums, then the candidates' potentials; 535 us per centre at
 // N = 1e7 against 270 us now.)  Round 3: pp_round screens rows of 16 samples with a float copy of the coordinates before it
 // loads their fp64 ones (see the kernel).  Nothing returns to the host until all k centres are chosen.
-constexpr int PP_CHUNK = 4096;
+#ifndef PP_CHUNK_
+#define PP_CHUNK_ 4096                // (2048: 62 instead of 52 us per late round at 1e7 rows -- a block's fixed phases, not its longest pass, set the pace)
+#endif
+constexpr int PP_CHUNK = PP_CHUNK_;
 constexpr int PP_LMAX = 16;           // trials per centre (k = 512: 8)
 constexpr int PP_THREADS = 256;
+constexpr int PP_PERMAX = (30000000 / PP_CHUNK + 1023) / 1024 + 1;      // chunk sums a thread of pp_decide walks at the 3e7 rows the seeding accepts
 constexpr int PD_THREADS = 1024;      // pp_decide: 4 samples of the chunk per thread
 constexpr int PP_SROWS = PP_LMAX + 1; // rows of S: one per trial + the chunk sums of closest itself (used for the first draw)
 constexpr int PP_CW = KM_NMAX + 2;      // a row of the sharded run's candidate table: 16 coordinates, |x|^2, the GLOBAL sample index (as a double)
@@ -2670,7 +2674,7 @@ __device__ __forceinline__ void pp_chunk_prefix(int nchunks, const double* __res
     const int per = (nchunks + PD_THREADS - 1) / PD_THREADS;
     const int b0 = tid * per < nchunks ? tid * per : nchunks, b1 = b0 + per < nchunks ? b0 + per : nchunks;
     // the thread's segment of chunk sums: loaded together (at most 9: the LDS bound on nchunks / 1024 threads), added in order
-    constexpr int PERMAX = 9;
+    constexpr int PERMAX = PP_PERMAX;
     double seg[PERMAX];
 #pragma unroll
     for (int q = 0; q < PERMAX; ++q) seg[q] = b0 + q < b1 ? cs[b0 + q] : 0.0;
@@ -2870,7 +2874,7 @@ hipError_t launch_kmeanspp(hipStream_t st, int64_t N, int n, int k, int L, const
     if (n > KM_NMAX || L > PP_LMAX || L < 1) return hipErrorInvalidValue;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;      // prefix table + the chunk's values: N <= 3e7
-    if (lds > 100 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > 9) return hipErrorInvalidValue;     // (9: pp_decide's register segment)
+    if (lds > 150 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > PP_PERMAX) return hipErrorInvalidValue;     // (pp_decide's register segment)
     PPState* ps = reinterpret_cast<PPState*>(state);
     hipError_t e0 = hipMemsetAsync(ps, 0, sizeof(PPState), st);
     if (e0 != hipSuccess) return e0;
@@ -3029,7 +3033,7 @@ hipError_t launch_kmeanspp_sharded(hipStream_t st, int64_t N, int n, int k, int 
     *comm_failed = 0;
     const int nchunks = kmeanspp_chunks(N);
     const size_t lds = ((size_t)nchunks + 1 + PP_CHUNK) * 8;
-    if (lds > 100 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > 9) return hipErrorInvalidValue;
+    if (lds > 150 * 1024 || (nchunks + PD_THREADS - 1) / PD_THREADS > PP_PERMAX) return hipErrorInvalidValue;
     PPState* ps = reinterpret_cast<PPState*>(state);
     double* tot = shard;
     double* crow[2] = {shard + (size_t)world * PP_SROWS, shard + (size_t)world * PP_SROWS + (size_t)(PP_LMAX + 1) * PP_CW};
