@@ -70,7 +70,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(parts, files=("r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(parts, files=("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  parts: {kernel name in the summary: launches}; the figure is
     the sum over ALL of them (a fit = lift + tail + Gram per chunk).  PMC counters cannot be read from inside the timed
@@ -99,7 +99,7 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
     if rows != 10_020_000 or kk != 512 or not ms_per_step:
         return None
     cur = kernel_source_sha()
-    for name in ("r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
+    for name in ("r05_lloyd_pmc_summary.json", "r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
         try:
             full = json.load(open(os.path.join(REPO, "profiles", name)))
             d = full.get("kmeans_assign") or full["kmeans_assign_lds_kernel<12>"]      # (all launches of the E-step kernel of the recorded loop)
@@ -108,7 +108,7 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
         rec = full.get("_kernel_source_sha")
         tf = d["SQ_INSTS_VALU"] * 128.0 / (ms_per_step * 1e-3) / 1e12
         lst = full.get("kmeans_assign_lds_kernel<12, true>") or {}
-        return {"kernel": "kmeans_assign_lds_kernel<12, LIST> (+ bounds, reduce / average, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf,
+        return {"kernel": "kmeans_assign_lds_kernel<12, LIST> (+ bounds, M-step, centre distances, re-sorts)", "bound": "valu_fp64_issue", "achieved": tf,
                 "list_form_launches_of_recorded_run": lst.get("launches_SQ_INSTS_VALU"), "list_form_valu_instr_per_e_step": lst.get("SQ_INSTS_VALU"),
                 "peak": PEAK_FP64_VALU_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP64_VALU_TFLOPS, "valu_instr_per_e_step": d["SQ_INSTS_VALU"],
                 "fma_f64_instr_per_e_step": d.get("SQ_INSTS_VALU_FMA_F64"), "ms_per_step": ms_per_step,
@@ -323,7 +323,7 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
             if tag == "N45823":
                 kw.update(Xq=Xq[:rows], Uq=Uq[:rows])
             np.savez(path, **kw)
-            for pinv in (("host", "device") if tag == "N45823" else ("host",)):
+            for pinv in (("eigh", "host", "device") if tag == "N45823" else ("eigh",)):
                 t0 = time.perf_counter()
                 pr = subprocess.run([sys.executable, child, "gpu", path, pinv], capture_output=True, text=True, timeout=600)
                 wall = time.perf_counter() - t0
@@ -356,12 +356,19 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
                 else:
                     leg["cpu_baseline"] = {"error": pr.stderr[-400:]}
         leg["runs"] = runs
-        h = runs.get("N45823_pinv_host", {}).get("thruster_12_8")
-        dv = runs.get("N45823_pinv_device", {}).get("thruster_12_8")
-        if h and dv:
-            leg["pinv_host_vs_device"] = {"warm_call_s_host": h["warm_call_s"], "warm_call_s_device": dv["warm_call_s"],
-                                          "max_abs_drmse_H1_10_100": float(np.max(np.abs(np.array(h["multistep_rmse_H1_10_100"]) - np.array(dv["multistep_rmse_H1_10_100"])))),
-                                          "note": "same data, same centres (device k-means is bit-reproducible): the scores differ by the solve alone"}
+        h = runs.get("N45823_pinv_eigh", {}).get("thruster_12_8")          # the shipped default
+        ref_ = runs.get("N45823_pinv_host", {}).get("thruster_12_8")        # numpy.linalg.pinv itself: the reference's call
+        if ref_:
+            opts = {}
+            for how in ("eigh", "host", "device"):
+                o_ = runs.get(f"N45823_pinv_{how}", {}).get("thruster_12_8")
+                if o_:
+                    opts[how] = {"first_call_s": o_["first_call_s"], "warm_call_s": o_["warm_call_s"],
+                                 "max_abs_drmse_H1_10_100_vs_numpy_pinv": float(np.max(np.abs(np.array(o_["multistep_rmse_H1_10_100"]) - np.array(ref_["multistep_rmse_H1_10_100"]))))}
+            leg["pinv_options"] = {**opts, "default": "eigh",
+                                   "note": "same data, same centres (the device k-means is bit-reproducible): the scores differ by the p x p solve alone; "
+                                           "'eigh' = symmetric eigendecomposition on the host with numpy.linalg.pinv's cut-off (default), 'host' = "
+                                           "numpy.linalg.pinv (the reference's call), 'device' = torch.linalg.eigh on the GPU (first call +0.2 s)"}
         if h:
             leg["value"] = h["samples_per_s_warm"]
             leg["unit"] = "samples/s"
@@ -683,7 +690,7 @@ def main():
             lloyd_ms = ktim.get("lloyd_ms", float("nan"))
             ctx.set_timing(False)
             Cc.copy_(Ck)
-            kmeans_info = {"rows": nb * (L + 1), "k": k, "lloyd_iterations": n_iter, "max_iter": a.kmeans_iters,
+            kmeans_info = {"rows": nb * (L + 1), "k": k, "lloyd_iterations": n_iter, "max_iter": a.kmeans_iters, "loop_info": ctx.kmeans_loop_info(),
                            "lloyd_ms_total": lloyd_ms, "lloyd_ms_per_iteration": lloyd_ms / max(n_iter, 1),
                            "kmeanspp_ms_device": ktim.get("kmeanspp_ms"), "wall_s_seeding_plus_lloyd": time.perf_counter() - tk,
                            "inertia": inertia,
@@ -746,7 +753,7 @@ def main():
         # ---- the call the reference's scripts make: KoopmanEDMDc.fit() (Koopman/koopmanEDMDc.py:72-103; caller
         # training/train_tank_brov2_full_comparison.py:921-930): (a) the public call on host arrays, (b) its stages end to end on the
         # same data device-resident (engine.fit_dev) -- centres with
-        # scikit-learn's stopping rule, G^T[G|Y], host pinv, then fit()'s own product order (P G^T) Y as two MFMA passes
+        # scikit-learn's stopping rule, G^T[G|Y], host solve, then fit()'s own product order (P G^T) Y as two MFMA passes
         # (edmdc_pinv_apply_dev: rows of W = G P^T, then W^T Y); and fit_multi() (:113-152: P (G^T Y), no apply pass)
         if not a.no_fit and world == 1:
             fit_legs = {}
@@ -755,14 +762,14 @@ def main():
             wrows_flop = dec["wrows_items_per_192_rows"] * 24 * 512.0 * W_ / 192.0          # executed MFMA flop per row of W
             wty_flop = dec["wty_tasks"] * 12288.0                                           # executed MFMA flop per pair of W^T Y
             # (a) What a user of the drop-in gets: KoopmanEDMDc(...).fit(X_host, U_host) itself -- host arrays in, upload included, the
-            # default lift_cache=False -- as the FIRST fit of this process (cold: scratch arenas, task tables and torch's allocator have
-            # not seen a fit yet) and once more (warm).  One trajectory of nb (L + 1) states (the class's fit() takes one; timing only).
+            # default lift_cache=False -- as the first fit() of this process (its scratch arenas and task tables have not seen a fit yet;
+            # the process itself is warm -- the cold first call of a fresh process is measured by the recorded_shape leg) and once more.  One trajectory of nb (L + 1) states (the class's fit() takes one; timing only).
             from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
             Xh_ = Xe.view(-1, n).cpu().numpy()
             Uh_ = np.zeros((Xh_.shape[0], r))
             Uh_[: nb * L] = Ue.view(-1, r).cpu().numpy()
             host_call = {}
-            for tag in ("first_call_cold_s", "second_call_s"):
+            for tag in ("first_fit_of_this_process_s", "second_call_s"):
                 mk = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
@@ -771,7 +778,9 @@ def main():
             host_call.update(samples=int(Xh_.shape[0] - 1), samples_per_s_second_call=(Xh_.shape[0] - 1) / host_call["second_call_s"],
                              finite=bool(np.isfinite(mk.A_).all() and np.isfinite(mk.B_).all()),
                              note="KoopmanEDMDc.fit(X, U) with NumPy arrays: H2D upload of 1.6 GB, k-means with scikit-learn's stopping rule, "
-                                  "G^T G, host pinv, (P G^T) Y with a second lift (lift_cache off), download of A, B")
+                                  "G^T G, host solve (symmetric eigendecomposition, pinv's cut-off), (P G^T) Y with a second lift (lift_cache off), "
+                                  "download of A, B.  The process is warm by now (rollouts, Gram, k-means have run): a true first call in a fresh "
+                                  "process is the recorded_shape leg's")
             # ... and fit_multi(X_list, U_list) on config 3 as the reference would hold it: a Python list of 20 000 separately allocated
             # (501, 12) / (501, 8) arrays (Koopman/koopmanEDMDc.py:113-152).  One upload (brov_upload_bags), one ragged Gram.
             X_list = [np.array(Xh_[b * (L + 1):(b + 1) * (L + 1)]) for b in range(nb)]
@@ -815,7 +824,7 @@ def main():
                                      "host_pinv": tmf["pinv_s"] * 1e3,
                                      ("apply_lift_wrows_wty_plus_download" if order == "fit" else "host_P_times_GtY"): tmf["apply_s"] * 1e3},
                        "lloyd_iterations": tmf["lloyd_iterations"], "lloyd_max_iter": a.kmeans_iters, "lloyd_converged": tmf["lloyd_converged"],
-                       "kmeanspp_ms_device": tmf.get("kmeanspp_ms"), "lloyd_ms_device": tmf.get("lloyd_ms"),
+                       "kmeanspp_ms_device": tmf.get("kmeanspp_ms"), "lloyd_ms_device": tmf.get("lloyd_ms"), "lloyd_loop_info": ctx.kmeans_loop_info(),
                        "lloyd_roofline": lloyd_roofline(nb * (L + 1), k, (tmf.get("lloyd_ms") or 0.0) / (tmf["lloyd_iterations"] + 1), tmf["lloyd_iterations"]),
                        "finite": bool(np.isfinite(A_f).all() and np.isfinite(B_f).all()),
                        "samples_per_s_excluding_centres": pairs / (tmf["total_s"] - tmf["centres_s"])}
@@ -836,7 +845,7 @@ def main():
                                        "kernel_ms": apply_kernel_ms, "flop_per_sample": wrows_flop + wty_flop,
                                        "wrows_flop_per_sample": wrows_flop, "wty_flop_per_sample": wty_flop, "decomposition": dec,
                                        "note": "executed MFMA flop of the two passes of (P G^T) Y / time of the whole apply pass (any re-lift included)",
-                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r04_fit_pmc_summary.json", "r03_fit_pmc_summary.json")) if pairs == 10_000_000 else None,
+                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r05_fit_pmc_summary.json", "r04_fit_pmc_summary.json", "r03_fit_pmc_summary.json")) if pairs == 10_000_000 else None,
                                        "algorithmic": {"flop_per_sample": 2.0 * p * p + 2.0 * p * d, "unit": "TFLOP/s",
                                                        "achieved": pairs * (2.0 * p * p + 2.0 * p * d) / (apply_kernel_ms * 1e-3) / 1e12}}
                     leg["ratio_to_full_gram_ms"] = (tmf["total_s"] - tmf["centres_s"]) * 1e3 / (ewall / a.edmdc_steps * 1e3)

@@ -1887,6 +1887,18 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     ef = d["edmdc_fit"]
     assert ef["fit"]["finite"] and ef["fit_multi"]["finite"] and ef["fit"]["fit_samples_per_s"] > 0 and ef["fit"]["lloyd_iterations"] >= 1
     assert ef["fit"]["roofline"]["bound"] == "mfma" and "gram_plus_host_solve_samples_per_s" in d["edmdc"]
+    # round 5: the public fit_multi on a host list of bags, and fit() at the reference's logged size in a fresh child process, the
+    # NumPy / scikit-learn restatement timed beside it
+    hc = ef["host_call"]
+    assert hc["finite"] and hc["fit_multi"]["finite"] and hc["fit_multi"]["bags"] == 80 and hc["fit_multi"]["samples_per_s_second_call"] > 0
+    rs = ef["recorded_shape"]
+    assert rs["data_finite"] and rs["rows_logged_by_the_reference"] == 45823 and rs["value"] > 0 and rs["unit"] == "samples/s"
+    run = rs["runs"]["N45823_pinv_eigh"]
+    assert run["thruster_12_8"]["finite"] and run["quaternion_13_6"]["finite"] and run["thruster_12_8"]["first_call_s"] >= run["thruster_12_8"]["warm_call_s"] > 0
+    assert all(rs["pinv_options"][how]["max_abs_drmse_H1_10_100_vs_numpy_pinv"] < 1e-6 for how in ("eigh", "host", "device"))
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in rs["cpu_baseline"], k
+    assert rs["cpu_baseline"]["kind"] == "port" and rs["cpu_baseline"]["cores"] == 4
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in d["cpu_baseline"] and k in d["edmdc"]["cpu_baseline"], k
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
