@@ -99,5 +99,29 @@ def variant(name, flags_for, verbose=False):
     return lib
 
 
+def bagtable_path():
+    import sysconfig
+    return os.path.join(PKG, "_bagtable" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
+
+
+def build_bagtable(force=False, verbose=False):
+    """gcc the CPython helper csrc/bagtable.c (the header walk of fit_multi's trajectory lists; no arithmetic) into the package
+    directory, next to libbrov2.so.  Optional at run time: engine.BagTable falls back to its Python loop without it."""
+    import sysconfig
+    src, out = os.path.join(CSRC, "bagtable.c"), bagtable_path()
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("no C compiler for the _bagtable helper")
+    cmd = [cc, "-O2", "-shared", "-fPIC", "-I", sysconfig.get_paths()["include"], src, "-o", out + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     print(build_library(force=True, verbose=True))
+    print(build_bagtable(force=True, verbose=True))

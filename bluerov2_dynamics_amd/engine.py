@@ -10,6 +10,10 @@ import os
 import numpy as np
 
 from . import _lib
+try:                                    # optional CPython helper (csrc/bagtable.c, built by _build.build_bagtable): header walk of array lists
+    from . import _bagtable
+except ImportError:
+    _bagtable = None
 from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB, THRUSTER_EULER, WRENCH_EULER,
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
@@ -203,8 +207,11 @@ class BagTable:
 
     def __init__(self, X_list, U_list, n, r):
         nb = len(X_list)
-        nd, f64 = np.ndarray, np.float64
         self.keep = []
+        if _bagtable is not None and nb > 0:
+            self._init_native(X_list, U_list, n, r, nb)
+            return
+        nd, f64 = np.ndarray, np.float64
         lens, urows, px, pu = [0] * nb, [0] * nb, [0] * nb, [0] * nb
         for b in range(nb):                      # ~1.3 us per bag: one __array_interface__ dict per array carries dtype, layout, shape, address
             X, U = X_list[b], U_list[b]
@@ -226,13 +233,46 @@ class BagTable:
                 raise ValueError(f"bag {b}: U has {lu} rows, needs at least len(X) - 1 = {lx - 1}")
             lens[b], urows[b] = lx, (lu if lu < lx else lx)
             px[b], pu[b] = ai["data"][0], au["data"][0]
-        self.n, self.r, self.nbags = n, r, nb
         self.lens = np.array(lens, dtype=np.int64)
         self.u_rows = np.array(urows, dtype=np.int64)
-        self.offsets = np.zeros(nb + 1, dtype=np.int64)
-        np.cumsum(self.lens, out=self.offsets[1:])
         self.x_ptrs = np.array(px, dtype=np.uint64)
         self.u_ptrs = np.array(pu, dtype=np.uint64)
+        self._finish(n, r, nb)
+
+    def _init_native(self, X_list, U_list, n, r, nb):
+        """The same table through the buffer protocol (csrc/bagtable.c): ~60 ns per array instead of ~0.7 us."""
+        f64 = np.float64
+        out = []
+        for seq, ncols in ((X_list, n), (U_list, r)):
+            ptrs, rows = np.zeros(nb, dtype=np.uint64), np.zeros(nb, dtype=np.int64)
+            seq = seq if isinstance(seq, (list, tuple)) else list(seq)
+            start = 0
+            while True:
+                bad = _bagtable.fill(seq, ncols, start, ptrs, rows)
+                if bad < 0:
+                    break
+                a_ = np.ascontiguousarray(seq[bad], dtype=f64)           # not a C-contiguous float64 array (or the wrong shape): convert, check
+                if a_.ndim != 2 or a_.shape[1] != ncols:
+                    raise AssertionError(f"bag {bad}: array of shape {a_.shape} does not match state_dim {n} / input_dim {r}")
+                self.keep.append(a_)
+                if seq is X_list or seq is U_list:
+                    seq = list(seq)
+                seq[bad] = a_
+                start = bad
+            self.keep.append(seq)                                         # the (possibly patched) list keeps its arrays alive
+            out.append((ptrs, rows))
+        (self.x_ptrs, self.lens), (self.u_ptrs, urows) = out
+        short = (self.lens >= 2) & (urows < self.lens - 1)
+        if short.any():
+            b = int(np.argmax(short))
+            raise ValueError(f"bag {b}: U has {int(urows[b])} rows, needs at least len(X) - 1 = {int(self.lens[b]) - 1}")
+        self.u_rows = np.minimum(urows, self.lens)
+        self._finish(n, r, nb)
+
+    def _finish(self, n, r, nb):
+        self.n, self.r, self.nbags = n, r, nb
+        self.offsets = np.zeros(nb + 1, dtype=np.int64)
+        np.cumsum(self.lens, out=self.offsets[1:])
         self.rows = int(self.offsets[-1])
         self.pairs = int(np.maximum(self.lens - 1, 0).sum())
 

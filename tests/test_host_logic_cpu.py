@@ -175,3 +175,41 @@ def test_thruster_geometry_entries_are_views_of_one_block():
         with np.testing.assert_raises(KeyError):
             bad()
     assert lst[6].pop("tag") == 7
+
+
+def test_bag_table_native_helper_equals_the_python_walk():
+    """engine.BagTable (the bookkeeping of fit_multi's trajectory lists for brov_upload_bags) through the CPython helper
+    (csrc/bagtable.c, buffer protocol) and through its Python loop: the same lengths, offsets, input rows and host addresses on a
+    list with empty bags, a Fortran-ordered, a float32 and a nested-list bag, inputs one row short; the same errors."""
+    import ctypes
+    from bluerov2_dynamics_amd import _build, engine
+    _build.build_bagtable()
+    if engine._bagtable is None:                       # (the helper was built after the package had been imported)
+        import importlib
+        engine._bagtable = importlib.import_module("bluerov2_dynamics_amd._bagtable")
+    rng = np.random.default_rng(0)
+    Xs = [rng.normal(size=(int(L), 12)) for L in rng.integers(0, 50, 300)]
+    Us = [rng.normal(size=(len(x), 8)) for x in Xs]
+    Xs[5] = np.asfortranarray(Xs[5])
+    Xs[9] = Xs[9].astype(np.float32)
+    Us[17] = Us[17][:max(len(Us[17]) - 1, 0)]
+    Xs[20] = Xs[20].tolist() if len(Xs[20]) else Xs[20]
+    a = engine.BagTable(Xs, Us, 12, 8)
+    native, engine._bagtable = engine._bagtable, None
+    try:
+        b = engine.BagTable(Xs, Us, 12, 8)
+    finally:
+        engine._bagtable = native
+    for key in ("lens", "u_rows", "offsets"):
+        assert np.array_equal(getattr(a, key), getattr(b, key)), key
+    assert a.rows == b.rows == sum(len(x) for x in Xs) and a.pairs == b.pairs
+    for t in (a, b):
+        for i in range(len(Xs)):
+            if t.lens[i]:
+                got = np.ctypeslib.as_array((ctypes.c_double * int(t.lens[i] * 12)).from_address(int(t.x_ptrs[i]))).reshape(-1, 12)
+                assert np.array_equal(got, np.asarray(Xs[i], dtype=float).reshape(-1, 12)), i
+    for maker in (lambda: engine.BagTable([np.zeros((3, 11))], [np.zeros((3, 8))], 12, 8),):
+        with pytest.raises(AssertionError):
+            maker()
+    with pytest.raises(ValueError):
+        engine.BagTable([np.zeros((5, 12))], [np.zeros((3, 8))], 12, 8)

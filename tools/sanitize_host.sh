@@ -8,10 +8,10 @@
 #   1. tests/test_cabi_cpu.py and tests/test_host_logic_cpu.py (every symbol bound, struct layout, no-GPU failure paths, ...);
 #   2. tools/sanitize_sweep.py: the decomposition / DP entry points and the host-only numerics over a sweep of (n, r, k), dt and
 #      parameter sets, and every entry point's argument validation with a NULL context.
-# Usage: tools/sanitize_host.sh [logfile]      (default profiles/r04_host_sanitizer.txt)
+# Usage: tools/sanitize_host.sh [logfile]      (default profiles/r05_host_sanitizer.txt)
 set -u -o pipefail
 cd "$(dirname "$0")/.."
-LOG=${1:-profiles/r04_host_sanitizer.txt}
+LOG=${1:-profiles/r05_host_sanitizer.txt}
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
 RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 LIB=$(python - <<PY
@@ -27,10 +27,10 @@ PY
   echo "# library: $LIB (host code: $SAN)"
   echo "# runtime: $RT"
   export BROV2_LIBRARY="$LIB" LD_PRELOAD="$RT" ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1:exitcode=97" UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1:exitcode=98"
-  echo "## pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py"
+  echo "## pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py tests/test_oracle_golden.py::test_far_row_selection_is_numpys_own_introselect"
   # (not test_header_is_plain_c_and_links_from_c: it links a gcc-built C program against the library, and a gcc link line has no
   #  sanitizer runtime to resolve the instrumented library's __asan_* / __ubsan_* symbols -- an artefact of this build, not a finding)
-  python -m pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py -q -m "not gpu" -p no:cacheprovider -k "not links_from_c" 2>&1 | tail -15
+  python -m pytest tests/test_cabi_cpu.py tests/test_host_logic_cpu.py tests/test_oracle_golden.py -q -m "not gpu" -p no:cacheprovider -k "not links_from_c and (cabi or host_logic or far_row)" 2>&1 | tail -15
   echo "rc=$?"
   echo "## tools/sanitize_sweep.py"
   python tools/sanitize_sweep.py 2>&1 | tail -25

@@ -75,4 +75,26 @@ for name, (res, args) in _lib.SIGNATURES.items():
     calls += 1
 assert lib.edmdc_kmeans_relocations(None) == 0
 print(f"NULL-context calls: {calls} entry points returned a status")
+
+# round 5: the library's far-row selection (NumPy's introselect restated, host only): the fixture's cases and random ones with ties / NaNs,
+# the result checked for being the n_empty largest
+import os
+g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "farselect.npz"))
+n_sel = 0
+cases = [(np.ascontiguousarray(g[k[:-2] + "_d"]), int(g[k[:-2] + "_n"])) for k in g.files if k.endswith("_d")]
+for _ in range(300):
+    N = int(rng.integers(1, 5000))
+    d = rng.random(N)
+    if rng.random() < 0.4:
+        d = np.round(d, int(rng.integers(0, 3)))
+    if rng.random() < 0.2:
+        d[rng.integers(0, N, max(1, N // 50))] = np.nan
+    cases.append((d, int(rng.integers(1, min(N, 70) + 1))))
+for d, ne in cases:
+    out = np.empty(ne, dtype=np.int64)
+    assert lib.edmdc_far_select_numpy(d.ctypes.data, len(d), ne, out.ctypes.data) == 0
+    key = np.where(np.isnan(d), np.inf, d)
+    assert len(set(out.tolist())) == ne and np.sort(key[out])[0] >= np.sort(key)[-ne]
+    n_sel += 1
+print(f"far-row selection: {n_sel} cases ok")
 print("sanitize sweep: ok")
