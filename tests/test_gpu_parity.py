@@ -1787,6 +1787,70 @@ def test_two_wave_rollout_kernel_edge_cases(eng, fc):
     ctx2.close()
 
 
+def test_ragged_gram_at_config3_size_by_properties(eng):
+    """BASELINE config 3 at full size (20 000 bags x 501 states = 1e7 pairs, k = 512) through the ragged entry points, checked by
+    properties that do not need a CPU answer of that size: (1) the uniform list through edmdc_gram_ragged_dev == edmdc_gram_dev, bit for
+    bit; (2) additivity -- Gram(list) == Gram(first 7 000 bags) + Gram(the rest) to 1e-12 (accumulate = 1); (3) every bag cut to a random
+    length (some to 0 or 1 state): the pair count, symmetry, and the x-x / x-u corners of G^T G and the x-x corner of G^T Y against
+    torch products over exactly those pairs; (4) fit()'s product order over the same ragged list with P = I, i.e. (I G^T) Y, must
+    reproduce the Gram pass's own G^T Y (two different kernels over the same pairs and weights)."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.default_context(0)
+    dev = torch.device("cuda", 0)
+    n, r, k, gamma, nb, L = 12, 8, 512, 1.0, 20000, 500
+    U = torch.empty((nb, L + 1, r), dtype=torch.float64, device=dev)          # row-aligned with X: the last input row of a bag is never read
+    eng.fill_controls_dev(U[:, :L].contiguous(), "btu", "ar1", seed=0xED3D, T_total=L, ctx=ctx)
+    Uc = torch.empty((nb, L, r), dtype=torch.float64, device=dev)
+    eng.fill_controls_dev(Uc, "btu", "ar1", seed=0xED3D, T_total=L, ctx=ctx)
+    U[:, :L] = Uc
+    U[:, L] = float("nan")                                                     # (and must not be: a NaN would show)
+    X = torch.empty((nb, L + 1, n), dtype=torch.float64, device=dev)
+    eng.rollout_dev(_lib.THRUSTER_EULER, "euler", torch.zeros((nb, n), dtype=torch.float64, device=dev), Uc, 0.02, traj=X, layout="btu", ctx=ctx)
+    Xs, Us = X.view(-1, n), U.view(-1, r)
+    g = torch.Generator(device=dev); g.manual_seed(5)
+    C = Xs[torch.randint(0, Xs.shape[0], (k,), device=dev, generator=g)].contiguous()
+    p, d = n + k + r, n + k
+    def blocks():
+        return torch.zeros((p, p), dtype=torch.float64, device=dev), torch.zeros((p, d), dtype=torch.float64, device=dev)
+    off = np.arange(nb + 1, dtype=np.int64) * (L + 1)
+    Ga, Ya = blocks(); Gb, Yb = blocks()
+    eng.gram_ragged_dev(Xs, Us, C, gamma, off, Ga, Ya, ctx=ctx)
+    eng.gram_dev(Xs, Uc.view(-1, r), C, gamma, nb, L, L + 1, L, Gb, Yb, ctx=ctx)
+    assert torch.equal(Ga, Gb) and torch.equal(Ya, Yb) and bool(torch.isfinite(Ga).all())
+    # (2) additivity over a split of the list
+    cut = 7000
+    Gc, Yc = blocks()
+    eng.gram_ragged_dev(Xs[: cut * (L + 1)], Us[: cut * (L + 1)], C, gamma, off[: cut + 1], Gc, Yc, ctx=ctx)
+    eng.gram_ragged_dev(Xs[cut * (L + 1):], Us[cut * (L + 1):], C, gamma, off[cut:] - off[cut], Gc, Yc, accumulate=True, ctx=ctx)
+    assert float((Gc - Ga).norm() / Ga.norm()) < 1e-12 and float((Yc - Ya).norm() / Ya.norm()) < 1e-12
+    # (3) random lengths: rows of bag b beyond len_b are dropped from the stacked arrays
+    rng = np.random.default_rng(9)
+    lens = rng.integers(2, L + 2, nb)
+    lens[rng.choice(nb, 200, replace=False)] = rng.integers(0, 2, 200)
+    keep = torch.from_numpy((np.arange(L + 1)[None, :] < lens[:, None]).reshape(-1)).to(dev)
+    Xr, Ur = Xs[keep].contiguous(), Us[keep].contiguous()
+    offr = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    Gr, Yr = blocks()
+    eng.gram_ragged_dev(Xr, Ur, C, gamma, offr, Gr, Yr, ctx=ctx)
+    assert torch.equal(Gr, Gr.T) and bool(torch.isfinite(Gr).all()) and bool(torch.isfinite(Yr).all())
+    pair = torch.from_numpy((np.arange(L + 1)[None, :] < (lens[:, None] - 1)).reshape(-1)).to(dev)       # rows that start a pair
+    nxt = torch.roll(pair, 1)
+    Xa, Xb_, Ua = Xs[pair], Xs[nxt], Us[pair]
+    assert int(pair.sum()) == int(np.maximum(lens - 1, 0).sum())
+    def chunked(A_, B_):
+        out = torch.zeros((A_.shape[1], B_.shape[1]), dtype=torch.float64, device=dev)
+        for i0 in range(0, A_.shape[0], 1 << 20):
+            out += A_[i0:i0 + (1 << 20)].T @ B_[i0:i0 + (1 << 20)]
+        return out
+    for got, want in ((Gr[:n, :n], chunked(Xa, Xa)), (Gr[:n, d:], chunked(Xa, Ua)), (Gr[d:, d:], chunked(Ua, Ua)), (Yr[:n, :n], chunked(Xa, Xb_)), (Yr[d:, :n], chunked(Ua, Xb_))):
+        assert float((got - want).norm() / want.norm()) < 1e-11
+    # (4) the apply pass with P = I is the Gram's own G^T Y
+    M = torch.zeros((p, d), dtype=torch.float64, device=dev)
+    eng.pinv_apply_ragged_dev(Xr, Ur, C, gamma, offr, np.eye(p), M, ctx=ctx)
+    assert float((M - Yr).norm() / Yr.norm()) < 1e-12
+
+
 def test_config4_shard_rollouts_and_gram(eng, fc):
     """BASELINE config 4 at the per-GPU shard of the 8-GPU run: 131 072 rollouts x 500 RK4 steps (AR(1) commands, global
     trajectory indices of rank 3), trajectories stored [B][T+1][12], local lift + G^T[G|Y].
