@@ -753,8 +753,17 @@ int brov_upload_bags(brov_ctx* c, int64_t nbags, const double* const* bag_ptrs, 
         else {
             std::vector<std::thread> th;
             const size_t per = ((fill + nt - 1) / nt + 63) & ~(size_t)63;
-            for (int t = 1; t < nt; ++t) th.emplace_back(pack, std::min(fill, per * t), std::min(fill, per * (t + 1)));
+            size_t started = per;                      // bytes [0, started) are this thread's and the helpers'
+            try {
+                for (int t = 1; t < nt; ++t) {
+                    th.emplace_back(pack, std::min(fill, per * t), std::min(fill, per * (t + 1)));
+                    started = std::min(fill, per * (t + 1));
+                }
+            } catch (...) {                            // no more threads to be had (a process limit): this thread packs the rest itself
+                c->upload_threads = 1;
+            }
             pack(0, std::min(fill, per));
+            if (started < fill) pack(started, fill);
             for (auto& t : th) t.join();
         }
         HIPCK(c, hipMemcpyAsync(reinterpret_cast<char*>(d_dst) + dst0, stage, fill, hipMemcpyHostToDevice, c->stream));

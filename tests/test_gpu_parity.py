@@ -1787,6 +1787,34 @@ def test_two_wave_rollout_kernel_edge_cases(eng, fc):
     ctx2.close()
 
 
+def test_koopman_options_sklearn_backend_and_solve_options():
+    """The class's optional paths: kmeans="sklearn" (scikit-learn on the host picks the centres, the device does the rest) in fit and
+    fit_multi -- the same centres as the default device k-means to 1e-9 and the same A, B to the conditioning of the solve --, every
+    solve option (eigh / host / device) through fit_multi on a ragged list, inputs longer than the states (rows past len(X) ignored),
+    and a fit of a two-state trajectory."""
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    g = load_golden("edmdc.npz")
+    X, U = g["X"], g["U"]
+    k, gamma, ridge = 24, float(g["gamma"]), 1e-2
+    cuts = [(0, 500), (500, 501), (501, 1300), (1300, 2000)]
+    Xl, Ul = [X[a:b] for a, b in cuts], [np.vstack([U[a:b], np.ones((3, 8))]) for a, b in cuts]         # three extra input rows per bag
+    ref = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge, pinv="host")
+    ref.fit_multi(Xl, [U[a:b] for a, b in cuts])
+    for opts in (dict(kmeans="sklearn"), dict(pinv="eigh"), dict(pinv="device"), dict(kmeans="sklearn", pinv="host")):
+        m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge, **opts)
+        m.fit_multi(Xl, Ul)
+        assert rel_err(m.centers_, ref.centers_) < 1e-9, opts
+        assert rel_err(m.A_, ref.A_) < 1e-6 and rel_err(m.B_, ref.B_) < 1e-6, opts
+    a = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge)
+    b = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge, kmeans="sklearn")
+    a.fit(X[:1500], U[:1500])
+    b.fit(X[:1500], U[:1500])
+    assert rel_err(a.centers_, b.centers_) < 1e-9 and rel_err(a.A_, b.A_) < 1e-6 and rel_err(a.B_, b.B_) < 1e-6
+    t = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=2, gamma=gamma, ridge=ridge)
+    t.fit(X[:2], U[:2])                                    # one pair, two centres (= the two states)
+    assert np.isfinite(t.A_).all() and t.A_.shape == (14, 14) and t.B_.shape == (14, 8)
+
+
 def test_ragged_gram_at_config3_size_by_properties(eng):
     """BASELINE config 3 at full size (20 000 bags x 501 states = 1e7 pairs, k = 512) through the ragged entry points, checked by
     properties that do not need a CPU answer of that size: (1) the uniform list through edmdc_gram_ragged_dev == edmdc_gram_dev, bit for
