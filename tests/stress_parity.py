@@ -85,15 +85,18 @@ def grams():
     while time.time() - t0 < budget:
         n_, r = [(12, 8), (12, 6), (13, 6), (9, 4), (5, 2), (13, 8), (12, 10)][int(rng.integers(0, 7))]
         k = int(rng.choice([1, 7, 16, 17, 48, 100, 200, 257, 500, 512]))
-        nb = int(rng.integers(1, 5))
-        lens = [int(rng.choice([2, 3, 5, 33, 100, 257, 1000])) for _ in range(nb)]
+        nb = int(rng.integers(1, 5)) if rng.random() < 0.6 else int(rng.integers(5, 300))       # (round 5: long ragged lists, bags without a pair)
+        lens = [int(rng.choice([0, 1, 2, 3, 5, 33, 100, 257, 1000] if nb > 4 else [2, 3, 5, 33, 100, 257, 1000])) for _ in range(nb)]
+        if max(lens) < 2:
+            lens[0] = 5
         chunk = int(rng.choice([64, 100, 257, 4096, 1 << 20]))
         ctx.check(ctx.lib.edmdc_set_chunk_rows(ctx.h, chunk), "edmdc_set_chunk_rows")
         Xs = [np.cumsum(rng.normal(0, 0.05, (m, n_)), 0) for m in lens]
+        short = rng.random() < 0.3                      # inputs one row shorter than the states (all the reference reads)
         Us = [rng.uniform(-1, 1, (m, r)) for m in lens]
         C = rng.normal(0, 0.4, (k, n_))
         g = float(rng.choice([0.3, 1.0, 3.0]))
-        GtG, GtY, npairs = engine.gram(Xs, Us, C, g)
+        GtG, GtY, npairs = engine.gram(Xs, [u[:max(len(u) - 1, 0)] for u in Us] if short else Us, C, g)
         Go, Yo, npo = ek.gram(Xs, Us, C, g)
         e = max(np.abs(GtG - Go).max() / np.abs(Go).max(), np.abs(GtY - Yo).max() / max(1e-300, np.abs(Yo).max()))
         assert npairs == npo and np.isfinite(e) and e < 1e-11, ("gram", n_, r, k, lens, chunk, e)
