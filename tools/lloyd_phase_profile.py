@@ -29,7 +29,13 @@ prof.restype = ctypes.c_int
 prof.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 buf = (ctypes.c_ulonglong * 16)()
 names = ["rows load", "label groups", "candidate masks", "evaluation", "labels + member sums"]
-for variant, label in ((0, "sorted, single reference"), (128, "sorted, packed fp32 screening in the LDS kernel")) + (((2, "caller's order"),) if len(sys.argv) > 3 else ()):
+exp = bool(lib.brov_experiments_build())
+runs = ((0, "default: sorted order, packed fp32 screening, distance bounds"), (4, "distance bounds off"))
+if exp:
+    runs += ((128, "sorted, screening off (fp64 evaluation of every candidate)"),)
+if len(sys.argv) > 3:
+    runs += ((2, "caller's order"),)
+for variant, label in runs:
     ctx.set_kmeans_variant(variant)
     tm = {}
     ctx.set_timing(True)
