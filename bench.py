@@ -337,6 +337,7 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
                         f_ = r_[c_]["fit_calls_s"]
                         r_[c_]["first_call_s"] = f_[0]
                         r_[c_]["warm_call_s"] = min(f_[1:])
+                        r_[c_]["warm_call_median_s"] = float(np.median(f_[1:]))
                         r_[c_]["samples_per_s_warm"] = (r_[c_]["rows"] - 1) / min(f_[1:])
                         r_[c_]["samples_per_s_first_call"] = (r_[c_]["rows"] - 1) / f_[0]
                 runs[f"{tag}_pinv_{pinv}"] = r_
@@ -363,7 +364,7 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
             for how in ("eigh", "host", "device"):
                 o_ = runs.get(f"N45823_pinv_{how}", {}).get("thruster_12_8")
                 if o_:
-                    opts[how] = {"first_call_s": o_["first_call_s"], "warm_call_s": o_["warm_call_s"],
+                    opts[how] = {"first_call_s": o_["first_call_s"], "warm_call_s": o_["warm_call_s"], "warm_call_median_s": o_["warm_call_median_s"],
                                  "max_abs_drmse_H1_10_100_vs_numpy_pinv": float(np.max(np.abs(np.array(o_["multistep_rmse_H1_10_100"]) - np.array(ref_["multistep_rmse_H1_10_100"]))))}
             leg["pinv_options"] = {**opts, "default": "eigh",
                                    "note": "same data, same centres (the device k-means is bit-reproducible): the scores differ by the p x p solve alone; "
@@ -372,7 +373,7 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
         if h:
             leg["value"] = h["samples_per_s_warm"]
             leg["unit"] = "samples/s"
-            leg["metric"] = "KoopmanEDMDc.fit samples/s at the reference's logged size (host arrays, warm call; first call beside it)"
+            leg["metric"] = "KoopmanEDMDc.fit samples/s at the reference's logged size (host arrays, fastest of six warm calls; median and first call beside it)"
             leg["vs_reference_logs"] = {"first_call_vs_authors_2.302s": 2.302 / h["first_call_s"], "warm_call_vs_authors_2.302s": 2.302 / h["warm_call_s"],
                                         "first_call_vs_survey_container_5.34s": 5.34 / h["first_call_s"],
                                         "note": "other hardware: orientation only (BASELINE.json publishes no number for this metric)"}

@@ -37,7 +37,7 @@ def main():
         for name, X, U in cases:
             n, r = X.shape[1], U.shape[1]
             calls, first_done = [], None
-            for rep in range(3 if name == cases[0][0] else 2):
+            for rep in range(7 if name == cases[0][0] else 4):
                 m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge, pinv=pinv)
                 t0 = time.perf_counter()
                 m.fit(X, U)
