@@ -305,6 +305,15 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
 // Slot (t+1)&1 was last read during step t-1, i.e. before the barrier the body wave has just passed.  The barrier waits for
 // LDS traffic only (s_waitcnt lgkmcnt(0)): trajectory stores and control loads stay in flight across it.
 // ---------------------------------------------------------------------------------------
+#ifndef BROV_PAIR_EXP
+#define BROV_PAIR_EXP 0          // experiments (tools/build_variants.py): 1 body wave alone, 3 thrust wave alone, 4 pairwise LDS flags
+#endif
+#ifndef BROV_PAIR_RING
+#define BROV_PAIR_RING 2         // exchange slots (the flag form can run the thrust wave further ahead)
+#endif
+#ifndef BROV_PAIR_PRIO
+#define BROV_PAIR_PRIO 0         // 1: s_setprio 3 for the body wave, 0 for the thrust wave
+#endif
 __device__ __forceinline__ void pair_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int INTEG, int LAYOUT, int LAGMODE, bool TRACK, bool GENERIC>
@@ -320,11 +329,18 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
     constexpr int NX = 12, NU = 8, NXP = 6, NUP = 4;
     constexpr int NS = (INTEG == INTEG_RK4) ? 4 : 1;          // dynamics() calls per step
     __shared__ double2 qt[4];
-    __shared__ __attribute__((aligned(16))) double2 xch[2][4][NS * 3][64];     // [slot][pair][stage, channel pair][lane]
+    __shared__ __attribute__((aligned(16))) double2 xch[BROV_PAIR_RING][4][NS * 3][64];     // [slot][pair][stage, channel pair][lane]
+#if BROV_PAIR_EXP == 4
+    __shared__ int pflag[2][4];                               // [produced | consumed][pair]: steps done so far
+    if (threadIdx.x < 8) (&pflag[0][0])[threadIdx.x] = 0;
+#endif
     init_quadrant_table(qt);
     __syncthreads();
     const int wave = threadIdx.x >> 6, pair = wave & 3, lane = threadIdx.x & 63;
     const bool thrust = wave >= 4;                            // wave-uniform
+#if BROV_PAIR_PRIO
+    if (thrust) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+#endif
     const int64_t b_raw = (int64_t)blockIdx.x * 256 + pair * 64 + lane;
     const bool live = b_raw < B;
     const int64_t b = live ? b_raw : B - 1;                   // dead lanes shadow the last trajectory, never store
@@ -368,11 +384,34 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
             }
             lag_step_advance<INTEG, LAGMODE, TRACK, GENERIC>(relaunder(p), lz, fcmd, acmd, Xl);
         };
+#if BROV_PAIR_EXP == 1                                        // experiment: the body wave alone (results are garbage)
+        for (int64_t t = 0; t < T; ++t) pair_barrier();
+        (void)produce;
+#elif BROV_PAIR_EXP == 4                                      // experiment: pairwise flags instead of the workgroup barrier
+        {
+            volatile int* prodf = &pflag[0][pair];
+            volatile int* consf = &pflag[1][pair];
+            int slot = 0;
+            for (int64_t s = 0; s < T; ++s) {
+                if (s >= BROV_PAIR_RING) {
+                    const int need = (int)(s - BROV_PAIR_RING + 1);
+                    int spins = 0;
+                    while (*consf < need && ++spins < (1 << 22)) __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+                produce(slot);
+                asm volatile("" ::: "memory");
+                *prodf = (int)(s + 1);
+                slot = (slot + 1 == BROV_PAIR_RING) ? 0 : slot + 1;
+            }
+        }
+#else
         if (T > 0) produce(0);
         for (int64_t t = 0; t < T; ++t) {
             pair_barrier();
             if (t + 1 < T) produce((int)((t + 1) & 1));
         }
+#endif
         if constexpr (TRACK) { if (live) store_row<24>(lag_io + b * 24, &Xl[0][0]); }
     } else {
         double x[NX];
@@ -398,13 +437,37 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
 #if BROV_CLOCK_STAMPS
         const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
 #endif
+#if BROV_PAIR_EXP == 4
+        volatile int* prodf = &pflag[0][pair];
+        volatile int* consf = &pflag[1][pair];
+        int seen = 0, slot = 0;
+#endif
         for (int64_t t = 0; t < T; ++t) {
+#if BROV_PAIR_EXP == 3                                        // experiment: the thrust wave alone
             pair_barrier();
             const double2* src = &xch[t & 1][pair][0][lane];
+            if (T >= 0) continue;
+#elif BROV_PAIR_EXP == 4
+            {
+                int spins = 0;
+                while (seen < (int)(t + 1) && ++spins < (1 << 22)) { seen = *prodf; if (seen < (int)(t + 1)) __builtin_amdgcn_s_sleep(1); }
+            }
+            asm volatile("" ::: "memory");
+            const double2* src = &xch[slot][pair][0][lane];
+            slot = (slot + 1 == BROV_PAIR_RING) ? 0 : slot + 1;
+#else
+            pair_barrier();
+            const double2* src = &xch[t & 1][pair][0][lane];
+#endif
             integrate_fast<MODEL, INTEG, GENERIC>(h, p, dt, x, [&](int s, double* a) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) { const double2 v = src[((s - 1) * 3 + j) * 64]; a[2 * j] = v.x; a[2 * j + 1] = v.y; }
             }, qt, &tcarry, (t & (TRIG_REFRESH - 1)) == 0);
+#if BROV_PAIR_EXP == 4
+            asm volatile("" ::: "memory");
+            *consf = (int)(t + 1);                            // LDS requests of one wave are served in order: after the step's reads
+            seen = *prodf;                                    // asked for now, looked at when the next step begins
+#endif
             if (traj && --countdown == 0) {
                 countdown = stride;
                 store_state();

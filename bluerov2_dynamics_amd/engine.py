@@ -679,7 +679,7 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
         elif pinv in ("host", "eigh"):
             Gh = GtG.cpu().numpy()
             t2 = tick()
-            with _blas_threads():
+            with _blas_threads(p):
                 P = np.linalg.pinv(Gh + ridge * np.eye(p)) if pinv == "host" else pinv_sym_host(Gh, ridge)
         else:
             raise ValueError("pinv must be 'host', 'eigh' or 'device'")
@@ -692,7 +692,7 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
                 pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
             Mt = M.cpu().numpy().T
         else:
-            with _blas_threads():
+            with _blas_threads(p):
                 Mt = (P @ GtY.cpu().numpy()).T
     finally:
         if cache_buf is not None:              # withdraw the buffer before it goes back to the allocator, whatever happened
@@ -728,11 +728,16 @@ def usable_cores():
 
 
 class _blas_threads:
-    """The host `pinv` of the p x p normal matrix is the one BLAS/LAPACK call left on the fit path.  The reference caps its
+    """The host solve of the p x p normal matrix is the one BLAS/LAPACK call left on the fit path.  The reference caps its
     BLAS at 4 threads on import (Koopman/koopmanEDMDc.py:23-25); left alone, OpenBLAS starts one thread per VISIBLE CPU, and
-    in a container that is granted fewer cores than it sees the solve takes 60-200 ms instead of 33 (p = 532).  Cap the pool
-    at the granted cores (at most 8) for the duration of the solve; no-op when threadpoolctl is missing."""
-    _limit = None
+    in a container that is granted fewer cores than it sees the solve takes 60-200 ms instead of 33 (p = 532).  Cap the pool for
+    the duration of the solve: two threads up to p = 700 (round 5, tools/time_eigh_threads.py on the GPU boxes' hosts: neither syevd
+    nor gesdd at p ~ 520 gains from more -- eigh 18 / 14-17 / 17 / 18 ms, pinv 34 / 29-37 / 37 / 38 ms at 1 / 2 / 4 / 8 threads),
+    the granted cores (at most 8) beyond; no-op when threadpoolctl is missing."""
+    _cores = None
+
+    def __init__(self, p=0):
+        self.p = int(p)
 
     def __enter__(self):
         self._ctx = None
@@ -740,9 +745,10 @@ class _blas_threads:
             from threadpoolctl import threadpool_limits
         except ImportError:
             return self
-        if _blas_threads._limit is None:
-            _blas_threads._limit = min(8, usable_cores())
-        self._ctx = threadpool_limits(limits=_blas_threads._limit, user_api="blas")
+        if _blas_threads._cores is None:
+            _blas_threads._cores = usable_cores()
+        limit = min(2 if self.p <= 700 else 8, _blas_threads._cores)
+        self._ctx = threadpool_limits(limits=limit, user_api="blas")
         self._ctx.__enter__()
         return self
 
@@ -765,7 +771,7 @@ def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="
     M = (pinv(G^T G + ridge I) @ G.T) @ Y, the pinv on the host (numpy, like the reference), the two large products on
     the GPU.  Better conditioned than fit_multi's pinv(.) @ (G^T Y): at the class defaults (k = 200, ridge = 1e-8) the two
     differ by 1e-6 in the H = 100 RMSE."""
-    with _blas_threads():
+    with _blas_threads(GtG.shape[0]):
         P = _host_pinv(GtG, ridge, pinv)
     M = pinv_apply(X_list, U_list, C, gamma, P, ctx=ctx).T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
@@ -774,7 +780,7 @@ def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="
 def solve_AB(GtG, GtY, ridge, d, pinv="eigh"):
     """Host solve of the ridge normal equations exactly as the reference does it
     (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
-    with _blas_threads():
+    with _blas_threads(GtG.shape[0]):
         M = _host_pinv(GtG, ridge, pinv) @ GtY
     M = M.T
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
