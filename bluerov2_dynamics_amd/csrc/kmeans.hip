@@ -49,6 +49,9 @@
 
 namespace brov {
 
+#ifndef KM_FP64_BOUNDS
+#define KM_FP64_BOUNDS 1         // list-form E-step: the fp64 evaluation paths leave distance bounds too (0: NaN, the round-4 behaviour)
+#endif
 #ifndef KM_TWO_CHAINS
 #define KM_TWO_CHAINS 0
 #endif
@@ -692,6 +695,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         // in the row in index order, but they do tie: such waves always take the second form.
         double u2_ref = 0.0;                          // the wave's squared radius about its reference centre (single-reference form)
         double d2_ref = 0.0, t2_ref = 0.0;            // this lane's squared distance to that centre; the squared radius the prefix was cut at
+        // LIST (bounds from every path, round 5): what the selection used last leaves for the centres it did NOT hand to the evaluation --
+        // they are at least sqrt(far_t2) from the centre this lane's squared distance far_d2 refers to (all k evaluated: nothing is left out)
+        float far_t2 = 3.0e38f, far_d2 = 0.0f;
         auto select_by_nbr = [&](int& ncand) -> bool {
             if (a_ref < 0 || __ballot(!((x2 - x2 == 0.0) && centres_finite)) != 0ull) return false;
             const int a = a_ref;
@@ -722,6 +728,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             const unsigned short last = lst[cnt - 1];                      // (cnt >= 1: c_a itself is at distance 0)
             if (lane < 2 * KM2_DEPTH + 2) lst[cnt + lane] = last;          // the tail repeats the last candidate
             ncand = cnt;
+            if constexpr (LIST && KM_FP64_BOUNDS) { far_t2 = __uint_as_float(tb); far_d2 = (float)fmax(d2, 0.0) * 1.0000005f + 1.0e-37f; }
             return true;
         };
         // ---- second form (round 3): label groups, masks over all k centres, candidates in index order
@@ -750,6 +757,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                         ga[g] = a;
                         tf[g] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(t)));
                         ng = g + 1;
+                        if constexpr (LIST && KM_FP64_BOUNDS) { if (mine) { far_t2 = tf[g]; far_d2 = rf; } }
                         remaining &= ~__ballot(mine);
                     }
                 }
@@ -819,15 +827,20 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         double rec[KM2_DEPTH];
         unsigned long long tiem = 0ull;               // lanes that saw a score EQUAL to their running best (first form only)
         unsigned long long tq[KM2_DEPTH] = {0ull, 0ull, 0ull, 0ull};      // ... per position of the trip (the padded tail of a list must not count)
+        // LIST: the runner-up's score is kept too (sec = the largest score among the evaluated candidates but the first best: a repeated
+        // candidate -- the padded tail of a list, a duplicate centre -- can only RAISE it, i.e. lower the bound it gives)
+        double sec = -1.0e300;
         auto eval2 = [&](int d, auto TIE) {          // candidates d and d + 1 of the ring, in this order
             double sa, sb;
             score2_bcast(rec[d], rec[d + 1], x, sa, sb);
             // strict '>' to replace: the first maximum wins, like np.argmin on the distances
             if constexpr (decltype(TIE)::value) tq[d] = __ballot(sa == best);
             baddr = (sa <= best) ? baddr : addr[d];
+            if constexpr (LIST && KM_FP64_BOUNDS) { double lo_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(best), "v"(sa)); asm("v_max_f64 %0, %1, %2" : "=v"(sec) : "v"(sec), "v"(lo_)); }
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sa));
             if constexpr (decltype(TIE)::value) tq[d + 1] = __ballot(sb == best);
             baddr = (sb <= best) ? baddr : addr[d + 1];
+            if constexpr (LIST && KM_FP64_BOUNDS) { double lo_; asm("v_min_f64 %0, %1, %2" : "=v"(lo_) : "v"(best), "v"(sb)); asm("v_max_f64 %0, %1, %2" : "=v"(sec) : "v"(sec), "v"(lo_)); }
             asm("v_max_f64 %0, %1, %2" : "=v"(best) : "v"(best), "v"(sb));
         };
         auto compact = [&]() -> int {
@@ -975,8 +988,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #endif
             if (tiem != 0ull) {                       // an exact tie somewhere: once more in index order
                 best = -1.0e300;
+                sec = -1.0e300;
                 baddr = laneoff;
-                if (select_by_masks()) run_list(compact(), std::false_type{}); else run_all();
+                if (select_by_masks()) run_list(compact(), std::false_type{}); else { far_t2 = 3.0e38f; far_d2 = 0.0f; run_all(); }
             }
         } else if (filtered) {
             const int nc_ = compact();
@@ -988,7 +1002,24 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
 #if KM_PROFILE
             t_acc[13] += 1ull;
 #endif
+            far_t2 = 3.0e38f; far_d2 = 0.0f;
             run_all();
+        }
+        if constexpr (LIST && KM_FP64_BOUNDS) {
+            if (!by_pk && ubo) {
+                // bounds from the fp64 paths too (round 5; until then they left NaN, "evaluate again", and one far-out sample kept the 63
+                // it shares a wave with on the list -- and in the widest, most expensive passes -- for good).  Upper: the exact distance
+                // to the winner.  Lower: the runner-up among the evaluated candidates, exact; every centre that was not evaluated is at
+                // least sqrt(far_t2) from the centre the selection measured this lane's far_d2 against.
+                const double dbest2 = fma(-2.0, best, x2);
+                const double l2 = fma(-2.0, sec, x2) - 4.0 * eps2;
+                const double lfar = sqrt((double)far_t2) * 0.9999999 - sqrt((double)far_d2 + eps2) * 1.0000001;
+                const double lbd = fmin(l2 > 0.0 ? sqrt(fmin(l2, 1.0e300)) : 0.0, lfar);
+                ubv = (float)sqrt(fmax(dbest2, 0.0) + eps2) * 1.0000003f + 1.0e-37f;
+                lbv = (float)fmin(lbd, 3.0e38);
+                lbv = lbv > 0.0f ? lbv * 0.9999997f : lbv;
+                if (!(x2 - x2 == 0.0)) { ubv = __builtin_nanf(""); lbv = __builtin_nanf(""); }      // a non-finite sample: as before
+            }
         }
         const int bi = (int)(baddr >> 7);
         if (base + stride < M) reference_ahead();     // the next pass's labels have arrived during the evaluation
