@@ -169,14 +169,18 @@ __device__ __forceinline__ void trig_full(const double* ang, Trig& t, const doub
 //                version had one per stage: its literals cost 36 SGPR spill reloads and 40 AGPR moves per step).
 //   |d| >= 2^37 or not finite: NaN (np.sin gives NaN for inf/NaN; for finite arguments of that size the reference's
 //                values carry no information about the trajectory either).
+// SHORT (BROV_TRIG_SHORT, round 5): the half-step stages' increments are half the full step's, so their kernels stop one term earlier
+// and the direct range is |d| <= 1/16 -- dropped terms d^9 / 9! and d^10 / 10! are < 4e-17 and < 3e-19 ABSOLUTE there, against the
+// O(1) sines and cosines the increment is combined with; the share of wave-steps that take the halving path stays what it is.
+template <bool SHORT = false>
 __device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Trig& t, double* dpsi = nullptr) {
     double dd[3] = {d[0], d[1], d[2]};
     int k = 0;
     const double m = fmax(fmax(fabs(d[0]), fabs(d[1])), fabs(d[2]));
-    if (!(m <= 0.125)) {                                     // also NaN
+    if (!(m <= (SHORT ? 0.0625 : 0.125))) {                  // also NaN
         int e;
         (void)frexp(m, &e);                                  // m < 2^e
-        k = e + 3;
+        k = e + (SHORT ? 4 : 3);
         double sc = ldexp(1.0, -k);
         if (!(m < 0x1p37)) { sc = __builtin_nan(""); k = 0; }
 #pragma unroll
@@ -186,12 +190,18 @@ __device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Tri
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const double z = dd[i] * dd[i];
-        double ps = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
-        ps = fma(z, ps, 8.33333333332248946124e-03);
+        double ps, pc;
+        if constexpr (SHORT) {
+            ps = fma(z, -1.98412698298579493134e-04, 8.33333333332248946124e-03);
+            pc = fma(z, 2.48015872894767294178e-05, -1.38888888888741095749e-03);
+        } else {
+            ps = fma(z, 2.75573137070700676789e-06, -1.98412698298579493134e-04);
+            ps = fma(z, ps, 8.33333333332248946124e-03);
+            pc = fma(z, -2.75573143513906633035e-07, 2.48015872894767294178e-05);
+            pc = fma(z, pc, -1.38888888888741095749e-03);
+        }
         ps = fma(z, ps, -1.66666666666666324348e-01);
         sd[i] = fma(z * dd[i], ps, dd[i]);                   // sin d
-        double pc = fma(z, -2.75573143513906633035e-07, 2.48015872894767294178e-05);
-        pc = fma(z, pc, -1.38888888888741095749e-03);
         pc = fma(z, pc, 4.16666666666666019037e-02);
         pc = fma(z, pc, -0.5);
         cm[i] = z * pc;                                      // cos d - 1
@@ -211,7 +221,11 @@ __device__ __forceinline__ void trig_delta(const Trig& b, const double d[3], Tri
     if (dpsi) { dpsi[0] = sd[2]; dpsi[1] = cm[2]; }           // sin(d psi), cos(d psi) - 1 (BROV_PSI_FRAME: see integrate_fast)
 }
 
-// 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps
+// 1/x for 1e-7 <= |x| <= 1: v_rcp_f64 seed + two Newton steps  (round 5: one third-order step, y (1 + e + e^2), is an FMA shorter and
+// measured no faster: 11.70 against 11.70 ms per config-2 launch -- the reciprocal sits in the shadow of the stage's other chains)
+#ifndef BROV_TRIG_SHORT
+#define BROV_TRIG_SHORT 1        // shorter sin / cos kernels for the half-step stages of RK4 (trig_delta<SHORT>): 11.70 -> 11.63 ms
+#endif
 __device__ __forceinline__ double recip_fast(double x) {
     double y = __builtin_amdgcn_rcp(x);
     double e = fma(-x, y, 1.0);
@@ -554,13 +568,13 @@ __device__ __forceinline__ void integrate_fast(const HC& h, CFP p, double dt, do
         double dps[2] = {0.0, 0.0};
         // stage state xs = x + c k; for the Euler-angle models the angles enter the RHS only through their sin/cos,
         // which come from the angle increments dl = c k[3..5] (trig_delta), so xs[3..5] is never formed
-        auto stage_state = [&](double c) {
+        auto stage_state = [&](double c, auto HALF) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) {
                 if (ANG && i >= 3 && i < 6) dl[i - 3] = c * k[i];
                 else xs[i] = fma(c, k[i], x[i]);
             }
-            if constexpr (ANG) trig_delta(tb, dl, ts, PSIF ? dps : nullptr);
+            if constexpr (ANG) trig_delta<BROV_TRIG_SHORT && decltype(HALF)::value>(tb, dl, ts, PSIF ? dps : nullptr);
         };
         // horizontal position increment of a later stage: turn its p_dot by the stage's yaw increment, then weight it
         auto add_turned = [&](double w) {
@@ -574,19 +588,19 @@ __device__ __forceinline__ void integrate_fast(const HC& h, CFP p, double dt, do
         // available for the addition theorem; PSIF does the same with the horizontal position
 #pragma unroll
         for (int i = 0; i < NX; ++i) xn[i] = ((CARRY && i >= 3 && i < 6) || (PSIF && i < 2)) ? h6 * k[i] : fma(h6, k[i], x[i]);
-        stage_state(h2);
+        stage_state(h2, std::true_type{});
         accel(2, a);
         rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
 #pragma unroll
         for (int i = PSIF ? 2 : 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
         if constexpr (PSIF) add_turned(h3);
-        stage_state(h2);
+        stage_state(h2, std::true_type{});
         accel(3, a);
         rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
 #pragma unroll
         for (int i = PSIF ? 2 : 0; i < NX; ++i) xn[i] = fma(h3, k[i], xn[i]);
         if constexpr (PSIF) add_turned(h3);
-        stage_state(dt);
+        stage_state(dt, std::false_type{});
         accel(4, a);
         rhs_fast<MODEL, GENERIC, HC, PSIF>(h, p, xs, a, k, ts);
         if constexpr (PSIF) {
