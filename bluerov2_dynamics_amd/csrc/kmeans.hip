@@ -2134,7 +2134,12 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
 // nothing), tiles in the order their blocks finish -- which no result depends on: labels are per sample, the member sums integers.
 // All float operations round away from "skip".  NaN anywhere (a fresh sample, a poisoned centre) fails the test.
 constexpr int KM_BND_TILE = 4096;
-__global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, const int* __restrict__ labels, float* __restrict__ ub, float* __restrict__ lb,
+#ifndef KM_BND_THREADS
+#define KM_BND_THREADS 1024      // one round per block: 2 442 blocks of 256 threads were 1.2 waves of resident blocks (59.6 -> 49.7 us at 1e7 rows)
+#endif
+constexpr int KM_BND_BT = KM_BND_THREADS;
+static_assert(KM_BND_TILE % (4 * KM_BND_BT) == 0 && KM_BND_BT % 64 == 0 && KM_BND_BT <= 1024, "a thread takes four consecutive positions per round");
+__global__ void __launch_bounds__(KM_BND_BT) kmeans_bounds_kernel(int64_t N, int k, const int* __restrict__ labels, float* __restrict__ ub, float* __restrict__ lb,
                                                             const float* __restrict__ shiftc /* [k + KM_BND_TAIL]: kmeans_average_kernel */,
                                                             const float* __restrict__ mvd /* [k][KM_BND_TOP]: kmeans_cdist_kernel */,
                                                             const double* __restrict__ prm, int* __restrict__ list, int* __restrict__ nlist) {
@@ -2146,7 +2151,7 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     const float m_rest = shiftc[k + 2 * KM_BND_TOP];
     const bool poisoned = !(m_rest == m_rest);         // a NaN shift (kmeans_average_kernel sets them all): every sample is evaluated
     __shared__ int buf[KM_BND_TILE + 64];
-    __shared__ int wcnt[4];
+    __shared__ int wcnt[KM_BND_BT / 64];
     __shared__ int s_off;
     const float margin = (float)prm[0] * 1.0001f + 1.0e-37f;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2154,12 +2159,12 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     int count = 0;
     // a thread takes four consecutive positions per round (16-byte loads and stores; the arrays are the arena's: aligned); the loads of
     // all four rounds are requested before the first is worked on
-    constexpr int ROUNDS = KM_BND_TILE / 1024;
+    constexpr int ROUNDS = KM_BND_TILE / (4 * KM_BND_BT);
     int A[ROUNDS][4];
     float U[ROUNDS][4], L[ROUNDS][4];
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int64_t p0 = base + r * 1024 + threadIdx.x * 4;
+        const int64_t p0 = base + r * (4 * KM_BND_BT) + threadIdx.x * 4;
         if (p0 + 3 < N) {
             const int4 av = *reinterpret_cast<const int4*>(labels + p0);
             const float4 uv = *reinterpret_cast<const float4*>(ub + p0), lv = *reinterpret_cast<const float4*>(lb + p0);
@@ -2176,7 +2181,7 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     }
 #pragma unroll
     for (int r = 0; r < ROUNDS; ++r) {
-        const int64_t p0 = base + r * 1024 + threadIdx.x * 4;
+        const int64_t p0 = base + r * (4 * KM_BND_BT) + threadIdx.x * 4;
         int (&a4)[4] = A[r];
         float (&u4)[4] = U[r], (&l4)[4] = L[r];
         const bool whole = p0 + 3 < N;
@@ -2217,12 +2222,13 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
         for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off); if (lane >= off) incl += v; }
         if (lane == 63) wcnt[w] = incl;
         __syncthreads();
-        int at = count + incl - cnt;
-        for (int q = 0; q < w; ++q) at += wcnt[q];
+        int at = count + incl - cnt, tot = 0;
+#pragma unroll
+        for (int q = 0; q < KM_BND_BT / 64; ++q) { const int c = wcnt[q]; at += q < w ? c : 0; tot += c; }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if ((act >> j) & 1u) buf[at++] = (int)(p0 + j);
-        count += wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+        count += tot;
         __syncthreads();
     }
     if (count == 0) return;                           // (block-uniform)
@@ -2231,7 +2237,7 @@ __global__ void __launch_bounds__(256) kmeans_bounds_kernel(int64_t N, int k, co
     if (threadIdx.x == 0) s_off = atomicAdd(nlist, padded);
     __syncthreads();
     int* out = list + s_off;
-    for (int e = threadIdx.x; e < padded; e += 256) out[e] = buf[e];
+    for (int e = threadIdx.x; e < padded; e += KM_BND_BT) out[e] = buf[e];
 }
 
 // packed table from the centres: Ct[c] = [coordinates | half squared norm | zeros | minus the half norm]
@@ -3237,7 +3243,7 @@ size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
     if (!b.ub || !b.lb || !b.shiftc || !b.mvd || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     // (b.nlist was zeroed by the M-step's launch_kmeans_average)
-    hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(256), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
+    hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(KM_BND_BT), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
                        b.mvd, prm, b.list, b.nlist);
     return hipGetLastError();
 }
