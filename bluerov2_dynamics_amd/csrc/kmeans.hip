@@ -49,6 +49,9 @@
 
 namespace brov {
 
+#ifndef KM_LIST_DYNAMIC
+#define KM_LIST_DYNAMIC 1        // list-form E-step: the waves draw their passes from a device-wide counter (0: a fixed share per block, the round-4 form)
+#endif
 #ifndef KM_FP64_BOUNDS
 #define KM_FP64_BOUNDS 1         // list-form E-step: the fp64 evaluation paths leave distance bounds too (0: NaN, the round-4 behaviour)
 #endif
@@ -157,6 +160,12 @@ __device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep
     }
 }
 
+#ifndef KM_BLOCKTIME
+#define KM_BLOCKTIME 0           // experiment build: how evenly the list-form E-step's work falls on blocks and waves (tools/lloyd_balance.py)
+#endif
+#if KM_BLOCKTIME
+__device__ unsigned long long km_blk[8];       // list form: [0] sum of block durations, [1] blocks, [2] sum of the waves' loop times, [3] waves (100 MHz ticks)
+#endif
 #ifndef KM_PROFILE
 #define KM_PROFILE 0
 #endif
@@ -580,6 +589,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                          const int* __restrict__ list, const int* __restrict__ nlist, float* __restrict__ ubo, float* __restrict__ lbo, double tscale) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
+#if KM_BLOCKTIME
+    const unsigned long long bt0 = __builtin_amdgcn_s_memrealtime();
+#endif
     double* tab = lds2;
     u64* sums = reinterpret_cast<u64*>(lds2 + k * 16);
     unsigned short* cand = reinterpret_cast<unsigned short*>(sums + k * (n + 1));      // [16 waves][KM2_LIST]
@@ -625,6 +637,59 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     double xn[NX];
     int oln = -1;
     int64_t base = (int64_t)blockIdx.x * KM_THREADS;
+    // ---- LIST, dynamic assignment (round 5).  With a fixed share per block a launch lasted 306 us where its mean block was busy for 229
+    // and its mean wave for 193 (tools/lloyd_balance.py): a listed pass costs anything between 40 and 512 candidates, and the wide ones
+    // come in runs.  Now a wave's pass is a TICKET = 64 consecutive list entries (the list is whole waves).  The first three tickets of
+    // every wave are fixed -- (q blocks + block) 16 + wave, q = 0 .. 2: the depth of the prefetch chain --, all later ones are drawn from
+    // the device-wide counter nlist[1] (zeroed by the M-step) in BATCHES of 16 per block: a 64-bit LDS word holds (first ticket << 8 |
+    // handed out); the wave that finds it empty draws the next batch (one global atomic per 1 024 entries: a single address serves
+    // 83 per microsecond, tools/atomic_ticket_probe.hip), the others wait on the LDS word for the few microseconds that takes.
+    // The member sums still must not see more than KM_EPOCH_PASSES x KM_THREADS samples between two flushes: a block draws at most
+    // that many entries per EPOCH, then all its waves run dry, meet at a barrier, flush and start the next epoch -- at most as many
+    // epochs as the fixed shares would have used (kmeans_mstep_kernel derives that number from the list's length), which is capacity
+    // enough for the whole list: if tickets were left, every block would have used all of its own.  No result depends on who takes
+    // which ticket: labels and bounds are per position, the member sums integers.
+    constexpr bool DYN = LIST && KM_LIST_DYNAMIC;
+    __shared__ unsigned long long s_tw;               // (first ticket of the block's batch << 8) | tickets handed out (16: none left)
+    __shared__ int s_taken, s_more;
+    const int T = (int)(M >> 6);                      // tickets; a value >= T is "none" (N < 2^31: 32 bits hold every ticket drawn)
+    const int tk_dyn0 = (int)gridDim.x * (3 * (KM_THREADS / 64));
+    constexpr int TK_BATCH = 16, TK_EPOCH = KM_EPOCH_PASSES * (KM_THREADS / 64);
+    int* const tctr = LIST ? const_cast<int*>(nlist) + 1 : nullptr;
+    int used_static = 1;
+    if constexpr (LIST) {
+        const int64_t passes = (M + stride - 1) / stride;
+        const int used = (int)((passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES);
+        used_static = used < nepochs ? (used > 1 ? used : 1) : nepochs;
+    }
+    int tk_cur = T, tk_nx = T, tk_nx2 = T, tk_nx3 = T;       // this pass, the next two, and (drawn during a pass, used at its end) the one after
+    auto take = [&]() -> int {                        // the next ticket of this wave (wave-uniform)
+        int tk = 0;
+        if (lane == 0) {
+            const int none = 0x7ffffff0;
+            for (int tries = 0;; ++tries) {
+                const unsigned long long old = atomicAdd(&s_tw, 1ull);
+                const unsigned cnt = (unsigned)(old & 255ull);
+                if (cnt < (unsigned)TK_BATCH) { tk = (int)(old >> 8) + (int)cnt; break; }
+                if (cnt == (unsigned)TK_BATCH) {
+                    if (atomicAdd(&s_taken, TK_BATCH) + TK_BATCH > TK_EPOCH) {      // this epoch's share is drawn: closed until the flush
+                        atomicExch(&s_tw, (unsigned long long)none << 8);
+                        tk = none;
+                    } else {
+                        tk = tk_dyn0 + atomicAdd(tctr, TK_BATCH);
+                        atomicExch(&s_tw, ((unsigned long long)tk << 8) | 1ull);
+                    }
+                    break;
+                }
+                // another wave of the block is fetching the next batch: a few microseconds.  Bounded all the same -- a wave that gives up
+                // takes "none" and stops drawing; what it would have drawn stays in the counter for the others (never seen)
+                int spins = 0;
+                while ((*reinterpret_cast<volatile unsigned long long*>(&s_tw) & 255ull) >= (unsigned long long)TK_BATCH && ++spins < 4096) __builtin_amdgcn_s_sleep(2);
+                if (tries >= 256) { tk = none; break; }
+            }
+        }
+        return __builtin_amdgcn_readfirstlane(tk);
+    };
     // sample order through `perm`: the row index of a pass is loaded one pass before its rows are (LIST: the list entry one pass
     // before that).  pos_cur / pos_nx / pos_nx2: positions of this pass, the next (rows in flight) and the one after; dead_*: padding
     int pnext = 0;
@@ -635,19 +700,11 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if constexpr (LIST) { const int e = list[slot(b)]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0 || b + threadIdx.x >= M; }
         else { pos = slot(b); dead = b + threadIdx.x >= M; }
     };
-    if (base < M) {
-        entry(base, pos_cur, dead_cur);
-        load_rows(pos_cur, perm ? perm[pos_cur] : 0, xn, oln);
-        if (base + stride < M) {
-            entry(base + stride, pos_nx, dead_nx);
-            if (perm) pnext = perm[pos_nx];
-        }
-        if constexpr (LIST) { if (base + 2 * stride < M) ent_nx2 = list[slot(base + 2 * stride)]; }
-    }
-    // reference centre of the single-reference filter for the pass whose rows are in flight, and the head of its sorted row:
-    // the label most lanes carry (lane 0's, or the next one when fewer than half the lanes share it)
+    auto entry_t = [&](int tk, int64_t& pos, bool& dead) { const int e = list[(int64_t)tk * 64 + lane]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0; };
     int a_nx = -1;
     unsigned long long nk0 = 0ull, nk1 = 0ull;
+    // reference centre of the single-reference filter for the pass whose rows are in flight, and the head of its sorted row:
+    // the label most lanes carry (lane 0's, or the next one when fewer than half the lanes share it)
     auto reference_ahead = [&]() {
         a_nx = -1;
         if (!Nk) return;
@@ -660,11 +717,47 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         nk0 = row[lane];
         nk1 = row[64 + lane];
     };
-    if (base < M) reference_ahead();
 #if KM_PROFILE
     unsigned long long t_acc[16] = {0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull, 0ull};
 #endif
-    for (; base < M; base += stride) {
+    for (;;) {                                        // DYN: one trip per epoch of the block; otherwise a single trip
+    if constexpr (DYN) {
+        // the first three tickets of every wave: fixed in the first epoch, one draw for the whole block in a later one
+        if (threadIdx.x == 0) {
+            s_tw = (unsigned long long)TK_BATCH;
+            s_taken = 3 * (KM_THREADS / 64);
+            s_more = ep == 0 ? (int)blockIdx.x * (KM_THREADS / 64) : tk_dyn0 + atomicAdd(tctr, 3 * (KM_THREADS / 64));
+        }
+        __syncthreads();
+        {
+            const int per = ep == 0 ? (int)gridDim.x * (KM_THREADS / 64) : KM_THREADS / 64;
+            tk_cur = __builtin_amdgcn_readfirstlane(s_more + (int)(threadIdx.x >> 6));       // (wave-uniform, and the compiler should know)
+            tk_nx = tk_cur + per; tk_nx2 = tk_nx + per;
+        }
+        if (tk_cur < T) {
+            entry_t(tk_cur, pos_cur, dead_cur);
+            load_rows(pos_cur, perm[pos_cur], xn, oln);
+            if (tk_nx < T) { entry_t(tk_nx, pos_nx, dead_nx); pnext = perm[pos_nx]; }
+            if (tk_nx2 < T) ent_nx2 = list[(int64_t)tk_nx2 * 64 + lane];
+            reference_ahead();
+        }
+    } else {
+    if (base < M) {
+        entry(base, pos_cur, dead_cur);
+        load_rows(pos_cur, perm ? perm[pos_cur] : 0, xn, oln);
+        if (base + stride < M) {
+            entry(base + stride, pos_nx, dead_nx);
+            if (perm) pnext = perm[pos_nx];
+        }
+        if constexpr (LIST) { if (base + 2 * stride < M) ent_nx2 = list[slot(base + 2 * stride)]; }
+    }
+    if (base < M) reference_ahead();
+    }
+// which of the passes ahead exist (DYN: each stage of the prefetch chain is guarded by its own ticket)
+#define KM_HAS_NX (DYN ? tk_nx < T : base + stride < M)
+#define KM_HAS_NX2 (DYN ? tk_nx2 < T : base + 2 * stride < M)
+#define KM_HAS_NX3 (DYN ? tk_nx3 < T : base + 3 * stride < M)
+    for (; DYN ? tk_cur < T : base < M; base += DYN ? 0 : stride) {      // (a wave's tickets only grow: "none" is never followed by a pass)
 #if KM_PROFILE
         unsigned long long t_prev = __builtin_readcyclecounter();
 #endif
@@ -812,10 +905,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if (!by_nbr && Dc) filtered = select_by_masks();
         KM_STAMP(2);
         // rows of the next pass: in flight during the evaluation (which waits on the LDS only)
-        if (base + stride < M) {
+        if (KM_HAS_NX) {
             load_rows(pos_nx, pnext, xn, oln);
             if constexpr (LIST) {
-                if (base + 2 * stride < M) pnext = perm[ent_nx2 < 0 ? ~ent_nx2 : ent_nx2];
+                if (KM_HAS_NX2) pnext = perm[ent_nx2 < 0 ? ~ent_nx2 : ent_nx2];
             } else {
                 if (perm && base + 2 * stride < M) pnext = perm[slot(base + 2 * stride)];
             }
@@ -1022,7 +1115,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             }
         }
         const int bi = (int)(baddr >> 7);
-        if (base + stride < M) reference_ahead();     // the next pass's labels have arrived during the evaluation
+        if (KM_HAS_NX) reference_ahead();             // the next pass's labels have arrived during the evaluation
+        // DYN: the ticket three passes ahead, drawn as late as the prefetch chain allows (its list entry is asked for at the end of this
+        // pass) -- what a wave holds when the counter runs dry is the launch's tail
+        if constexpr (DYN) tk_nx3 = KM_HAS_NX2 ? take() : T;
         KM_STAMP(3);
         if (live) {
             if (ol != bi) ++changed;
@@ -1094,19 +1190,37 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         // the positions move up a pass
         pos_cur = pos_nx;
         dead_cur = dead_nx;
-        if (base + 2 * stride < M) {
+        if (KM_HAS_NX2) {
             if constexpr (LIST) {
                 pos_nx = (int64_t)(ent_nx2 < 0 ? ~ent_nx2 : ent_nx2);
-                dead_nx = ent_nx2 < 0 || base + 2 * stride + threadIdx.x >= M;
-                if (base + 3 * stride < M) ent_nx2 = list[slot(base + 3 * stride)];
+                dead_nx = ent_nx2 < 0 || (!DYN && base + 2 * stride + threadIdx.x >= M);
+                if (KM_HAS_NX3) ent_nx2 = list[DYN ? (int64_t)tk_nx3 * 64 + lane : slot(base + 3 * stride)];
             } else {
                 entry(base + 2 * stride, pos_nx, dead_nx);
             }
         }
-        if (++pass == KM_EPOCH_PASSES && base + stride < M) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; }
+        if constexpr (DYN) { tk_cur = tk_nx; tk_nx = tk_nx2; tk_nx2 = tk_nx3; }
+        else { if (++pass == KM_EPOCH_PASSES && base + stride < M) { km_flush(sums, partial, ep, k, n, true); ++ep; pass = 0; } }
+    }
+#undef KM_HAS_NX
+#undef KM_HAS_NX2
+#undef KM_HAS_NX3
+    if constexpr (!DYN) break;
+    else {
+        // the block's share of this epoch is drawn, or the list is: every wave has run dry
+        __syncthreads();
+        if (threadIdx.x == 0) s_more = (ep + 1 < used_static && tk_dyn0 + __hip_atomic_load(tctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < T) ? 1 : 0;
+        __syncthreads();
+        if (!s_more) break;
+        km_flush(sums, partial, ep, k, n, true);
+        ++ep;
+    }
     }
 #if KM_PROFILE
     if (threadIdx.x % 64 == 0) for (int q = 0; q < 16; ++q) atomicAdd(&km_prof[q], t_acc[q]);
+#endif
+#if KM_BLOCKTIME
+    if (LIST && lane == 0) { atomicAdd(&km_blk[2], __builtin_amdgcn_s_memrealtime() - bt0); atomicAdd(&km_blk[3], 1ull); }
 #endif
     for (int off = 32; off > 0; off >>= 1) {
         inertia += __shfl_down(inertia, off);
@@ -1114,6 +1228,9 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     }
     if ((threadIdx.x & 63) == 0) { sh_inertia[threadIdx.x >> 6] = inertia; sh_changed[threadIdx.x >> 6] = changed; }
     __syncthreads();
+#if KM_BLOCKTIME
+    if (LIST && threadIdx.x == 0) { atomicAdd(&km_blk[0], __builtin_amdgcn_s_memrealtime() - bt0); atomicAdd(&km_blk[1], 1ull); }
+#endif
     if (threadIdx.x == 0) {
         double in = 0.0;
         int ch = 0;
@@ -1124,9 +1241,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     km_flush(sums, partial, ep, k, n, false);
     if constexpr (LIST) {
         // only the epochs the longest-running block reaches: kmeans_mstep_kernel derives the same number from the list's length
-        const int64_t passes = (M + stride - 1) / stride;
-        const int used = (int)((passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES);
-        km_zero_epochs(partial, ep + 1, used < nepochs ? (used > 1 ? used : 1) : nepochs, k, n);
+        km_zero_epochs(partial, ep + 1, used_static, k, n);
     } else {
         km_zero_epochs(partial, ep + 1, nepochs, k, n);
     }
@@ -1474,6 +1589,15 @@ kmeans_assign_pk_kernel(int64_t N, int n, int k, const double* __restrict__ X, i
 extern "C" __attribute__((visibility("default"))) int brov_debug_kmprof(unsigned long long* out8, int reset) {
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(brov::km_prof), 128) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(brov::km_prof), z, 128) != hipSuccess) return -1; }
+    return 0;
+}
+namespace brov {
+#endif
+#if KM_BLOCKTIME
+}  // namespace brov
+extern "C" __attribute__((visibility("default"))) int brov_debug_kmblk(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(brov::km_blk), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(brov::km_blk), z, 64) != hipSuccess) return -1; }
     return 0;
 }
 namespace brov {
