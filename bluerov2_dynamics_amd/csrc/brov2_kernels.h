@@ -114,13 +114,19 @@ hipError_t launch_kmeans_range(hipStream_t st, int64_t N, int n, const double* X
 hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* rng, double* fix, double* prm);
 // distance bounds of the sorted loop (kmeans.hip: kmeans_bounds_kernel): per-position bounds moved by the centres' shifts; the positions
 // whose bounds fail go to `list` (tiles padded to whole waves with ~position), their number to nlist[0]
+// nlist: [0] the list's entries (one-region form) | [KM_NL_TICKET] tickets drawn by the E-step | [KM_NL_FRONT], [KM_NL_BACK] entries of the two
+// regions (two-region form; [0] stays 0) -- every counter in its own 64-byte line: atomics on one line are served one after the other
+// (83 per microsecond, tools/atomic_ticket_probe.hip), and 2 442 tiles reserving their piece of the list are 29 us of that
+constexpr int KM_NL_TICKET = 16, KM_NL_FRONT = 32, KM_NL_BACK = 48;
 struct KmBounds {
     float* ub = nullptr;            // [N] >= distance to the own centre
     float* lb = nullptr;            // [N] <= distance to every other centre
     const float* shiftc = nullptr;  // [k + kmeans_bounds_tail()] from launch_kmeans_average
     const float* mvd = nullptr;     // [k][4] from launch_kmeans_cdist: distances to the centres that moved most
+    const float* rw2 = nullptr;     // [k] from launch_kmeans_cdist, or nullptr: squared radius beyond which a centre's samples make expensive passes
+                                    //     (given: the list lies in two regions, the tiles with such samples in front; nlist[2] = their entries)
     int* list = nullptr;            // [kmeans_bounds_list_words(N)]
-    int* nlist = nullptr;           // [2]
+    int* nlist = nullptr;           // [64]: counters of the list and of the E-step's tickets, one per 64-byte line (kmeans.hip: KM_NL_*)
     double beta = -1.0;             // >= 0: the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u (default KM_BND_BETA)
     bool use_list = false;          // the E-step visits the list only and its partials are CHANGES (launch_kmeans_mstep: delta)
 };
@@ -134,7 +140,7 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr,
-                               const float* shiftc = nullptr, float* mvd = nullptr);
+                               const float* shiftc = nullptr, float* mvd = nullptr, float* rw2 = nullptr);
 int kmeans_bounds_tail();
 // E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
 int kmeans_pk_blocks(int64_t N, int n, int k);

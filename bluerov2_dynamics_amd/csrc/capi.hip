@@ -2064,7 +2064,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                        2 * Arena::al((size_t)k * n * 8) + Arena::al(filter ? (size_t)k * ((k + 255) & ~255) * 4 : 8) +
                        (nbr ? Arena::al(k * kp_ * 8) : 0) +
                        (sorting ? 9 * Arena::al((size_t)N * 4) + Arena::al(sort_tmp + 256) : 0) +
-                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 3 * Arena::al((size_t)k * 16 + 64) + 1024 : 0) +
+                       (bnd ? 5 * Arena::al((size_t)N * 4) + Arena::al(lwords * 4) + Arena::al(rwords * 8) + 4 * Arena::al((size_t)k * 16 + 64) + 1024 : 0) +
                        Arena::al(kmeans_mstep_scratch_doubles(k) * 8) + 8192);
     if (rc) return rc;
     unsigned long long* partial = a.take<unsigned long long>(pw_max);
@@ -2085,7 +2085,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     float* d2 = nullptr;
     float *d2s[2] = {nullptr, nullptr}, *ubs[2] = {nullptr, nullptr}, *lbs[2] = {nullptr, nullptr};      // per position: two copies each, swapped by a re-sort
     long long* tot = nullptr;
-    float *shiftc = nullptr, *mvd = nullptr;
+    float *shiftc = nullptr, *mvd = nullptr, *rw2 = nullptr;
     int *blist = nullptr, *nlist = nullptr;
     unsigned *kin = nullptr, *kout = nullptr, *vin = nullptr, *vout = nullptr;
     void* stmp = nullptr;
@@ -2102,6 +2102,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         tot = a.take<long long>(rwords);
         shiftc = a.take<float>((size_t)k + kmeans_bounds_tail());
         mvd = a.take<float>((size_t)k * 4 + 4);
+        rw2 = a.take<float>((size_t)k + 4);
         nlist = a.take<int>(64);
     }
     if (mean_host) {
@@ -2183,7 +2184,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         const bool with_bounds = bnd && filtered && Pc != nullptr;
         e_list = false;
         if (with_bounds) {
-            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.beta = bounds_beta; kb.shiftc = shiftc; kb.mvd = mvd; kb.list = blist; kb.nlist = nlist;
+            kb.ub = ubs[bcur]; kb.lb = lbs[bcur]; kb.beta = bounds_beta; kb.shiftc = shiftc; kb.mvd = mvd; kb.rw2 = rw2; kb.list = blist; kb.nlist = nlist;
             kb.use_list = use_list && bounds_valid;
             if (kb.use_list) {
                 hipError_t e = launch_kmeans_bounds(c->stream, N, k, Lc, kb, prm);
@@ -2244,7 +2245,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                 HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCK(c, hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
             }
-            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr));
+            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr, rw2));
             if (beside) {
                 HIPCK(c, hipEventRecord(c->ev_join[0], c->side[0]));
                 cdist_forked = true;
@@ -2260,15 +2261,16 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
-            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd));
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2));
             bounds_valid = false;                       // relocated centres jumped: a full E-step, whose sums start the totals afresh
             HIPCK(c, e_step(true));
         }
         cc ^= 1;
         if (bounds_log && e_list) {
-            int hn[2] = {0, 0};
+            int hn[64] = {0};
             HIPCK(c, hipMemcpy(hn, nlist, sizeof hn, hipMemcpyDeviceToHost));
-            std::fprintf(stderr, "[kmeans bounds] iteration %d: changed %.0f, next E-step walks %d of %lld positions\n", it, hs[2], hn[0], (long long)N);
+            std::fprintf(stderr, "[kmeans bounds] iteration %d: changed %.0f, next E-step walks %d of %lld positions (%d of them in front)\n", it, hs[2],
+                         hn[0] + hn[KM_NL_FRONT] + hn[KM_NL_BACK], (long long)N, hn[KM_NL_FRONT]);
         }
         if (hs[2] == 0.0) { strict = true; break; }      // labels unchanged (sklearn's strict convergence)
         if (hs[0] <= tol_abs) break;

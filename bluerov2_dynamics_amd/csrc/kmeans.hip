@@ -586,7 +586,8 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                          const float* __restrict__ Dc, const double* __restrict__ prm, float* __restrict__ d2out,
                          const int* __restrict__ perm /* position -> row of X (nullptr: identity); labels and d2out are per position */,
                          const double* __restrict__ fix, const unsigned long long* __restrict__ Nk, const float* __restrict__ Pf,
-                         const int* __restrict__ list, const int* __restrict__ nlist, float* __restrict__ ubo, float* __restrict__ lbo, double tscale) {
+                         const int* __restrict__ list, const int* __restrict__ nlist, float* __restrict__ ubo, float* __restrict__ lbo, double tscale,
+                         long long list_cap /* > 0: the list lies in two regions (kmeans_bounds_kernel with rw2) */) {
     extern __shared__ double lds2[];                  // [k][16] packed centre records | [k][n+1] member sums (fixed point) and count | candidate lists
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation (block-uniform)
 #if KM_BLOCKTIME
@@ -618,7 +619,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     for (int j = 0; j < NX; ++j) mm[j] = (mean && (NS > 0 || j < n)) ? mean[j] : 0.0;
     const bool vec = NS > 0 && (NS & 1) == 0 && (reinterpret_cast<uintptr_t>(X) & 15) == 0 && (xstride & 1) == 0;
     // M: the positions this launch walks (LIST: the entries of the list, whole waves); a slot beyond the end repeats the last one
-    const int64_t M = LIST ? (int64_t)nlist[0] : N;
+    const int64_t M = LIST ? (int64_t)nlist[0] + nlist[KM_NL_FRONT] + nlist[KM_NL_BACK] : N;
     auto slot = [&](int64_t base) { const int64_t i = base + threadIdx.x; return i < M ? i : M - 1; };
     auto load_rows = [&](int64_t ii, int prow, double (&xr)[NX], int& lab) {
         const double* row = X + (perm ? (int64_t)prow : ii) * xstride;
@@ -641,7 +642,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     // and its mean wave for 193 (tools/lloyd_balance.py): a listed pass costs anything between 40 and 512 candidates, and the wide ones
     // come in runs.  Now a wave's pass is a TICKET = 64 consecutive list entries (the list is whole waves).  The first three tickets of
     // every wave are fixed -- (q blocks + block) 16 + wave, q = 0 .. 2: the depth of the prefetch chain --, all later ones are drawn from
-    // the device-wide counter nlist[1] (zeroed by the M-step) in BATCHES of 16 per block: a 64-bit LDS word holds (first ticket << 8 |
+    // the device-wide counter nlist[KM_NL_TICKET] (zeroed by the M-step) in BATCHES of 16 per block: a 64-bit LDS word holds (first ticket << 8 |
     // handed out); the wave that finds it empty draws the next batch (one global atomic per 1 024 entries: a single address serves
     // 83 per microsecond, tools/atomic_ticket_probe.hip), the others wait on the LDS word for the few microseconds that takes.
     // The member sums still must not see more than KM_EPOCH_PASSES x KM_THREADS samples between two flushes: a block draws at most
@@ -655,13 +656,17 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     const int T = (int)(M >> 6);                      // tickets; a value >= T is "none" (N < 2^31: 32 bits hold every ticket drawn)
     const int tk_dyn0 = (int)gridDim.x * (3 * (KM_THREADS / 64));
     constexpr int TK_BATCH = 16, TK_EPOCH = KM_EPOCH_PASSES * (KM_THREADS / 64);
-    int* const tctr = LIST ? const_cast<int*>(nlist) + 1 : nullptr;
+    int* const tctr = LIST ? const_cast<int*>(nlist) + KM_NL_TICKET : nullptr;
     int used_static = 1;
     if constexpr (LIST) {
         const int64_t passes = (M + stride - 1) / stride;
         const int used = (int)((passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES);
         used_static = used < nepochs ? (used > 1 ? used : 1) : nepochs;
     }
+    // the list in two regions: tickets below TW in the front one, the others in [list_cap - (M - 64 TW), list_cap)
+    const int TW = (DYN && list_cap > 0) ? nlist[KM_NL_FRONT] >> 6 : T;
+    const int64_t tk_back = (DYN && list_cap > 0) ? (int64_t)list_cap - M : 0;
+    auto tk_index = [&](int tk) -> int64_t { return (int64_t)tk * 64 + (tk < TW ? 0 : tk_back) + lane; };
     int tk_cur = T, tk_nx = T, tk_nx2 = T, tk_nx3 = T;       // this pass, the next two, and (drawn during a pass, used at its end) the one after
     auto take = [&]() -> int {                        // the next ticket of this wave (wave-uniform)
         int tk = 0;
@@ -700,7 +705,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
         if constexpr (LIST) { const int e = list[slot(b)]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0 || b + threadIdx.x >= M; }
         else { pos = slot(b); dead = b + threadIdx.x >= M; }
     };
-    auto entry_t = [&](int tk, int64_t& pos, bool& dead) { const int e = list[(int64_t)tk * 64 + lane]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0; };
+    auto entry_t = [&](int tk, int64_t& pos, bool& dead) { const int e = list[tk_index(tk)]; pos = (int64_t)(e < 0 ? ~e : e); dead = e < 0; };
     int a_nx = -1;
     unsigned long long nk0 = 0ull, nk1 = 0ull;
     // reference centre of the single-reference filter for the pass whose rows are in flight, and the head of its sorted row:
@@ -738,7 +743,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             entry_t(tk_cur, pos_cur, dead_cur);
             load_rows(pos_cur, perm[pos_cur], xn, oln);
             if (tk_nx < T) { entry_t(tk_nx, pos_nx, dead_nx); pnext = perm[pos_nx]; }
-            if (tk_nx2 < T) ent_nx2 = list[(int64_t)tk_nx2 * 64 + lane];
+            if (tk_nx2 < T) ent_nx2 = list[tk_index(tk_nx2)];
             reference_ahead();
         }
     } else {
@@ -1194,7 +1199,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             if constexpr (LIST) {
                 pos_nx = (int64_t)(ent_nx2 < 0 ? ~ent_nx2 : ent_nx2);
                 dead_nx = ent_nx2 < 0 || (!DYN && base + 2 * stride + threadIdx.x >= M);
-                if (KM_HAS_NX3) ent_nx2 = list[DYN ? (int64_t)tk_nx3 * 64 + lane : slot(base + 3 * stride)];
+                if (KM_HAS_NX3) ent_nx2 = list[DYN ? tk_index(tk_nx3) : slot(base + 3 * stride)];
             } else {
                 entry(base + 2 * stride, pos_nx, dead_nx);
             }
@@ -1732,7 +1737,7 @@ __global__ void __launch_bounds__(1024) kmeans_average_kernel(int n, int k, cons
         for (int q = 0; q < 16; ++q) { t += sh_d[q]; b |= sh_bad[q]; }
         stats[0] = t;
         prm[2] = b ? 1.0 : 0.0;      // a non-finite centre (NaN / inf data): the candidate filter stands down
-        if (nlist) { nlist[0] = 0; nlist[1] = 0; }
+        if (nlist) { nlist[0] = 0; nlist[KM_NL_TICKET] = 0; nlist[KM_NL_FRONT] = 0; nlist[KM_NL_BACK] = 0; }
     }
     if (shiftc) {
         // the KM_BND_TOP largest shifts, whose centres they are, and the largest of the rest (kmeans_bounds_kernel): wave 0 picks them one
@@ -1839,7 +1844,7 @@ __global__ void __launch_bounds__(256) kmeans_mstep_kernel(KmMstep a, int phases
         int nparts = a.nparts;
         if (a.nlist_in) {
             // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
-            const int64_t passes = ((int64_t)a.nlist_in[0] + a.span - 1) / a.span;
+            const int64_t passes = ((int64_t)a.nlist_in[0] + a.nlist_in[KM_NL_FRONT] + a.nlist_in[KM_NL_BACK] + a.span - 1) / a.span;
             const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
             const int tables = a.nblocks * (int)(used > 1 ? used : 1);
             nparts = tables < nparts ? tables : nparts;
@@ -1948,7 +1953,7 @@ tail:
         a.stats[3] = (double)em;
         a.prm[3] = em > 0 ? 1.0 : 0.0;                  // hold: the queued E-step returns at once, the host relocates
         a.prm[2] = bad ? 1.0 : 0.0;                     // a non-finite centre (NaN / inf data): the candidate filter stands down
-        if (a.nlist) { a.nlist[0] = 0; a.nlist[1] = 0; }
+        if (a.nlist) { a.nlist[0] = 0; a.nlist[KM_NL_TICKET] = 0; a.nlist[KM_NL_FRONT] = 0; a.nlist[KM_NL_BACK] = 0; }
         if (a.hstats) {
             a.hstats[0] = tsum; a.hstats[1] = a.stats[1]; a.hstats[2] = a.stats[2]; a.hstats[3] = (double)em;
             __threadfence_system();
@@ -2156,12 +2161,15 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 // by index) -- the candidates of a wave whose reference centre is a are a PREFIX of row a of Nk (kmeans_assign_lds_kernel, single-
 // reference filter), and one 8-byte load per lane brings the distance to test and the centre to evaluate; for kp <= 1024 (the
 // range of the kernels that use it).  Bitonic sort in the LDS.
+#ifndef KM_WIDE_CAND
+#define KM_WIDE_CAND 128                 // a pass with this many candidates counts as expensive (kmeans_bounds_kernel: such tiles first)
+#endif
 #ifndef KM_BND_BETA
 #define KM_BND_BETA 0.06                 // the prefix of a pass that leaves bounds is cut at 2 (1 + beta) u instead of 2 u
 #endif
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf,
-                                                           const float* __restrict__ shiftc, float* __restrict__ mvd) {
+                                                           const float* __restrict__ shiftc, float* __restrict__ mvd, float* __restrict__ rw2) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
     if (mvd && threadIdx.x < KM_BND_TOP) {
@@ -2204,6 +2212,10 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
             __syncthreads();
         }
     for (int i = threadIdx.x; i < kp; i += 256) Nk[(int64_t)a * kp + i] = keys[i];
+    // (round 5) the squared radius from which a wave about this centre needs KM_WIDE_CAND candidates or more: kmeans_bounds_kernel puts
+    // the tiles that hold such samples in FRONT of its list, so that the expensive passes are not the last ones drawn (a hint, nothing more)
+    if (rw2 && threadIdx.x == 0)
+        rw2[a] = k > KM_WIDE_CAND ? __uint_as_float((unsigned)(keys[KM_WIDE_CAND] >> 16)) / (float)(4.004 * (1.0 + KM_BND_BETA) * (1.0 + KM_BND_BETA)) : __builtin_inff();
     if (!Pf) return;
     // the row once more as FLOAT PAIRS for the packed-fp32 screening (kmeans_assign_pk_kernel), in the frame of the row's own centre:
     // pair t = the row's candidates 2 t and 2 t + 1, one 128-byte record [d0_0 d1_0 d0_1 d1_1 ... | -h0 -h1 | pad], d = c - c_a (formed
@@ -2266,7 +2278,8 @@ static_assert(KM_BND_TILE % (4 * KM_BND_BT) == 0 && KM_BND_BT % 64 == 0 && KM_BN
 __global__ void __launch_bounds__(KM_BND_BT) kmeans_bounds_kernel(int64_t N, int k, const int* __restrict__ labels, float* __restrict__ ub, float* __restrict__ lb,
                                                             const float* __restrict__ shiftc /* [k + KM_BND_TAIL]: kmeans_average_kernel */,
                                                             const float* __restrict__ mvd /* [k][KM_BND_TOP]: kmeans_cdist_kernel */,
-                                                            const double* __restrict__ prm, int* __restrict__ list, int* __restrict__ nlist) {
+                                                            const double* __restrict__ prm, int* __restrict__ list, int* __restrict__ nlist,
+                                                            const float* __restrict__ rw2 /* [k] or nullptr: kmeans_cdist_kernel */, long long cap) {
     if (prm[3] != 0.0) return;                        // hold: an empty cluster waits for its relocation
     float mv_s[KM_BND_TOP];
     int mv_c[KM_BND_TOP];
@@ -2276,7 +2289,9 @@ __global__ void __launch_bounds__(KM_BND_BT) kmeans_bounds_kernel(int64_t N, int
     const bool poisoned = !(m_rest == m_rest);         // a NaN shift (kmeans_average_kernel sets them all): every sample is evaluated
     __shared__ int buf[KM_BND_TILE + 64];
     __shared__ int wcnt[KM_BND_BT / 64];
-    __shared__ int s_off;
+    __shared__ int s_off, s_wide;
+    if (threadIdx.x == 0) s_wide = 0;                 // (the round loop's barriers order it before its readers)
+    bool wide = false;
     const float margin = (float)prm[0] * 1.0001f + 1.0e-37f;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * KM_BND_TILE;
@@ -2327,6 +2342,7 @@ __global__ void __launch_bounds__(KM_BND_BT) kmeans_bounds_kernel(int64_t N, int
                 l = l > 0.0f ? l * 0.9999997f : l;
                 // (fminf / fmaxf drop a NaN operand: a sample without bounds, a poisoned shift must not slip through them)
                 if (!poisoned && l4[j] == l4[j] && u + margin < l) { active = false; u4[j] = u; l4[j] = l; }
+                else if (rw2) wide = wide || u * u >= rw2[a];
             }
             act |= active ? 1u << j : 0u;
         }
@@ -2358,7 +2374,17 @@ __global__ void __launch_bounds__(KM_BND_BT) kmeans_bounds_kernel(int64_t N, int
     if (count == 0) return;                           // (block-uniform)
     const int padded = (count + 63) & ~63;
     if ((int)threadIdx.x < padded - count) buf[count + threadIdx.x] = ~buf[count - 1];
-    if (threadIdx.x == 0) s_off = atomicAdd(nlist, padded);
+    if (wide) s_wide = 1;
+    __syncthreads();
+    // rw2: two regions -- the tiles with a sample beyond its centre's "expensive" radius from the front of the buffer, the others from its
+    // end (kmeans_assign_lds_kernel<LIST> draws its tickets front region first)
+    if (threadIdx.x == 0) {
+        if (rw2) {
+            s_off = s_wide ? atomicAdd(nlist + KM_NL_FRONT, padded) : (int)(cap - (long long)atomicAdd(nlist + KM_NL_BACK, padded) - padded);
+        } else {
+            s_off = atomicAdd(nlist, padded);
+        }
+    }
     __syncthreads();
     int* out = list + s_off;
     for (int e = threadIdx.x; e < padded; e += KM_BND_BT) out[e] = buf[e];
@@ -3303,7 +3329,8 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
         if (e_ != hipSuccess) return e_; \
         hipLaunchKernelGGL((kmeans_assign_lds_kernel<NS_, LIST_>), dim3(blocks), dim3(KM_THREADS), lds2, st, N, n, k, X, xstride, mean, c2, labels, partial, nep, \
                            block_inertia, block_changed, Dc, prm, d2out, perm, fix, Nk, Nk ? Pf : nullptr, \
-                           use_list ? bounds->list : nullptr, use_list ? bounds->nlist : nullptr, ubo, lbo, tscale); } while (0)
+                           use_list ? bounds->list : nullptr, use_list ? bounds->nlist : nullptr, ubo, lbo, tscale, \
+                           (long long)((KM_LIST_DYNAMIC && use_list && bounds->rw2) ? kmeans_bounds_list_words(N) : 0)); } while (0)
         if (use_list) { if (n == 12) KM2_LAUNCH(12, true); else KM2_LAUNCH(13, true); }
         else if (n == 12) KM2_LAUNCH(12, false); else if (n == 13) KM2_LAUNCH(13, false); else KM2_LAUNCH(0, false);
 #undef KM2_LAUNCH
@@ -3356,10 +3383,10 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
     return hipGetLastError();
 }
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf, const float* shiftc,
-                               float* mvd) {
+                               float* mvd, float* rw2) {
     if (Pf && (!Nk || n > KM_PK_NMAX)) return hipErrorInvalidValue;
     if (mvd && !shiftc) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd);
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2);
     return hipGetLastError();
 }
 int kmeans_bounds_tail() { return KM_BND_TAIL; }
@@ -3368,7 +3395,7 @@ hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* lab
     if (!b.ub || !b.lb || !b.shiftc || !b.mvd || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
     // (b.nlist was zeroed by the M-step's launch_kmeans_average)
     hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(KM_BND_BT), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
-                       b.mvd, prm, b.list, b.nlist);
+                       b.mvd, prm, b.list, b.nlist, KM_LIST_DYNAMIC ? b.rw2 : nullptr, (long long)kmeans_bounds_list_words(N));
     return hipGetLastError();
 }
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records) {
