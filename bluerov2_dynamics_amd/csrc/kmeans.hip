@@ -2266,12 +2266,16 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
 // centres: the 65th nearest centre of a cluster is hardly farther than its 2nd; tools/hamerly_probe.py.)  While ub' + margin < lb' the sample's
 // nearest centre is still a, by more than the rounding of the E-step's scores: its label -- the full scan's -- cannot change, it keeps
 // its bounds and is skipped.  Everything else goes to the list the next E-step walks: position p, in position order within a tile of
-// 4096 positions, every tile's piece padded to whole waves with ~p of its last entry (a lane that loads the same row and counts for
+// 2048 positions, every tile's piece padded to whole waves with ~p of its last entry (a lane that loads the same row and counts for
 // nothing), tiles in the order their blocks finish -- which no result depends on: labels are per sample, the member sums integers.
 // All float operations round away from "skip".  NaN anywhere (a fresh sample, a poisoned centre) fails the test.
-constexpr int KM_BND_TILE = 4096;
+#ifndef KM_BND_TILE_
+#define KM_BND_TILE_ 2048       // positions per block of kmeans_bounds_kernel = the unit its list is padded and classified in (4096 / 1024 threads:
+                                 // the same 54 us, but the "expensive" class is coarser: list-form launches 247 against 241 us; 8192: 66 us)
+#endif
+constexpr int KM_BND_TILE = KM_BND_TILE_;
 #ifndef KM_BND_THREADS
-#define KM_BND_THREADS 1024      // one round per block: 2 442 blocks of 256 threads were 1.2 waves of resident blocks (59.6 -> 49.7 us at 1e7 rows)
+#define KM_BND_THREADS 512       // one round per block (2 442 blocks of 256 threads and four rounds were 1.2 waves of resident blocks: 59.6 us)
 #endif
 constexpr int KM_BND_BT = KM_BND_THREADS;
 static_assert(KM_BND_TILE % (4 * KM_BND_BT) == 0 && KM_BND_BT % 64 == 0 && KM_BND_BT <= 1024, "a thread takes four consecutive positions per round");
