@@ -905,6 +905,50 @@ def test_lloyd_distance_bounds_change_nothing(eng, monkeypatch):
         c.close()
 
 
+def test_list_form_draws_its_passes_from_the_counter_at_scale(eng):
+    """The list-form E-step hands its passes out as tickets (csrc/kmeans.hip, round 5): every wave's first three are fixed, all later
+    ones are drawn from a device-wide counter in per-block batches, a block flushes its member sums after 256 tickets (an epoch) and
+    the tiles with expensive passes lie in front of the list.  With 256 blocks the draws begin beyond 786 432 listed samples and a
+    second epoch beyond 4.2 million -- sizes the other Lloyd tests never reach -- so: 8e6 device-resident rows, the list form from the
+    first sorted iteration (most bounds still fail: lists of several million entries), against the loop without bounds.  Centres
+    bit for bit, labels, iteration count."""
+    import ctypes
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from bluerov2_dynamics_amd.engine import _drows, _dptr
+    from bluerov2_dynamics_amd._lib import _hptr, as_f64
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(2025)
+    N, n, k = 8_000_000, 12, 256
+    X = torch.cumsum(torch.randn((N, n), generator=g, dtype=torch.float64, device=dev) * 0.02, 0)
+    X += 0.3 * torch.sin(torch.arange(N, device=dev, dtype=torch.float64)[:, None] * torch.linspace(1e-4, 1e-3, n, device=dev, dtype=torch.float64))
+    mean_h = as_f64(X.mean(dim=0).cpu().numpy())
+    rows = torch.from_numpy(np.random.default_rng(3).choice(N, k, replace=False)).to(dev)
+    C0 = (X[rows] - torch.from_numpy(mean_h).to(dev)).contiguous()
+    out = []
+    for variant, rate in ((0, 1.0), (0, 0.03), (4, 0.03)):
+        c = _lib.Context(0)
+        c.use_torch_stream()
+        c.set_kmeans_variant(variant)
+        c.set_kmeans_bounds_rate(rate)
+        C = C0.clone()
+        labels = torch.empty(N, dtype=torch.int32, device=dev)
+        inertia, n_iter = ctypes.c_double(0.0), ctypes.c_int(0)
+        torch.cuda.synchronize()
+        c.check(c.lib.edmdc_kmeans_lloyd_dev(c.h, N, n, k, _drows(X), X.stride(0), _hptr(mean_h), _dptr(C), 25, 0.0, labels.data_ptr(),
+                                            ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
+        info = c.kmeans_loop_info()
+        out.append((C.cpu().numpy(), labels.cpu().numpy(), n_iter.value, inertia.value, info))
+        c.close()
+    (Ca, la, na, ia, infa), (Cb, lb_, nb_, ib, infb), (Cc, lc, nc, ic, _) = out
+    assert infa["list_form_e_steps"] >= 15 and infb["list_form_e_steps"] > 0, (infa, infb)
+    assert na == nb_ == nc
+    assert np.array_equal(la, lc) and np.array_equal(lb_, lc), (int(np.sum(la != lc)), int(np.sum(lb_ != lc)))
+    assert np.array_equal(Ca, Cc) and np.array_equal(Cb, Cc)
+    assert abs(ia - ic) <= 1e-10 * abs(ic) and abs(ib - ic) <= 1e-10 * abs(ic)
+
+
 def test_fit_twice_gives_the_same_bits(eng):
     """Two consecutive KoopmanEDMDc.fit() calls on the same data return bit-identical centres, A and B (round 3: the member
     sums of the Lloyd loop were fp64 atomics in arrival order, so the centres -- and with them A, B -- moved in their last bits)."""
