@@ -39,7 +39,7 @@ ROLLOUT_FLOP_PER_STEP = 3.1e3        # fp64 flop per RK4 step per trajectory (re
 # fp64 VALU instructions the shipped kernel (rollout_pair_kernel: body wave + thrust wave) executes per 64 trajectories and
 # step: static count of the two time loops (tools/isa_loops.py) minus the rarely executed blocks;
 # tests/test_cabi_cpu.py re-derives them from the compiler's listing, profiles/r02_rollout_pmc.txt has the counter view
-ROLLOUT_EXEC_FP64_INSTR = {"rk4": 725, "euler": 248}
+ROLLOUT_EXEC_FP64_INSTR = {"rk4": 713, "euler": 248}      # (rk4: 725 before the half-step stages' shorter sin / cos kernels, round 5)
 ROLLOUT_BYTES_PER_STEP = 160.0       # 64 B controls in + 96 B state out (store-all)
 EDMDC_FLOP_PER_SAMPLE = 1.1236e6     # 2 p^2 + 2 p d, p = 532, d = 524
 EDMDC_BYTES_PER_SAMPLE = 256.0
