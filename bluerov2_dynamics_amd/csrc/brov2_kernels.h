@@ -170,7 +170,8 @@ struct KmMstepArgs {
     float* shiftc = nullptr;
     float* mvd = nullptr;
     double* scratch = nullptr;          // [kmeans_mstep_scratch_doubles(k)], zeroed once before the loop (its ticket word)
-    double* hstats = nullptr;           // pinned, device-mapped [4] or nullptr
+    double* hstats = nullptr;           // pinned, device-mapped [5] or nullptr: four statistics, then `seq`
+    double seq = 0.0;
 };
 size_t kmeans_mstep_scratch_doubles(int k);
 hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& a, int phases);

@@ -1829,7 +1829,8 @@ struct KmMstep {
     double* shift2;                 // [k] scratch: squared shift of every centre
     int* flags;                     // [k] scratch: bit 0 empty, bit 1 not finite
     unsigned* ticket;               // device-wide arrival counter (zero between launches)
-    double* hstats;                 // pinned, device-mapped [4], or nullptr
+    double* hstats;                 // pinned, device-mapped [5], or nullptr
+    double seq;                     // what the tail stores behind the four statistics: the host waits for THIS M-step by polling it
 };
 __global__ void __launch_bounds__(256) kmeans_mstep_kernel(KmMstep a, int phases) {
     const int n = a.n, k = a.k, np1 = n + 1;
@@ -1957,6 +1958,7 @@ tail:
         if (a.hstats) {
             a.hstats[0] = tsum; a.hstats[1] = a.stats[1]; a.hstats[2] = a.stats[2]; a.hstats[3] = (double)em;
             __threadfence_system();
+            __hip_atomic_store(a.hstats + 4, a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // (no event in the stream: an event record cost the next kernel 6 us)
         }
     }
     if (a.shiftc) {
@@ -2039,7 +2041,7 @@ hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& h, int phases)
     a.delta = h.delta; a.nlist_in = h.delta ? h.nlist : nullptr; a.span = h.nblocks * KM_THREADS;
     a.fix = h.fix; a.Cold = h.Cold; a.Cnew = h.Cnew; a.Ct = h.Ct; a.stats = h.stats; a.prm = h.prm; a.shiftc = h.shiftc; a.mvd = h.mvd;
     a.nlist = h.nlist; a.shift2 = h.scratch; a.flags = reinterpret_cast<int*>(h.scratch + h.k); a.ticket = reinterpret_cast<unsigned*>(h.scratch + h.k) + h.k;
-    a.hstats = h.hstats;
+    a.hstats = h.hstats; a.seq = h.seq;
     if (phases & 3) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(h.k), dim3(256), 0, st, a, phases & 3);
     if (phases & 2) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(1), dim3(256), 0, st, a, 4);
     return hipGetLastError();
