@@ -2080,7 +2080,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     const bool pk_lds = nbr && sorting && !pk && (c->kmeans_variant & KMV_NO_SCREENING) == 0 && kmeans_pk_supported(n, k) && kmeans_reads_through_perm(n, k, scalar_records);
     // distance bounds (kmeans.hip: kmeans_bounds_kernel): once few labels change per iteration, an E-step visits only the samples whose
     // bounds fail and the M-step adds their CHANGES to the totals it keeps; + 256 in the k-means variant (or BROV2_KM_BOUNDS=0) switches it off
-    const bool bnd = pk_lds && (c->kmeans_variant & KMV_NO_BOUNDS) == 0;
+    const bool bnd = pk_lds && (c->kmeans_variant & KMV_NO_BOUNDS) == 0 && kmeans_bounds_list_words(N) < ((size_t)1 << 31);      // (32-bit offsets into the list)
     const size_t lwords = bnd ? kmeans_bounds_list_words(N) : 0;
     const int nb_pk = pk ? kmeans_pk_blocks(N, n, k) : 0;
     const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N, n, k) : 0;

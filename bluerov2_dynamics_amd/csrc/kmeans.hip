@@ -3399,6 +3399,7 @@ int kmeans_bounds_tail() { return KM_BND_TAIL; }
 size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
     if (!b.ub || !b.lb || !b.shiftc || !b.mvd || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
+    if (kmeans_bounds_list_words(N) >= ((size_t)1 << 31)) return hipErrorInvalidValue;      // (offsets into the list are 32-bit)
     // (b.nlist was zeroed by the M-step's launch_kmeans_average)
     hipLaunchKernelGGL(kmeans_bounds_kernel, dim3((unsigned)((N + KM_BND_TILE - 1) / KM_BND_TILE)), dim3(KM_BND_BT), 0, st, N, k, labels, b.ub, b.lb, b.shiftc,
                        b.mvd, prm, b.list, b.nlist, KM_LIST_DYNAMIC ? b.rw2 : nullptr, (long long)kmeans_bounds_list_words(N));
