@@ -140,8 +140,9 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr,
-                               const float* shiftc = nullptr, float* mvd = nullptr, float* rw2 = nullptr);
+                               const float* shiftc = nullptr, float* mvd = nullptr, float* rw2 = nullptr, int pf_pairs = 0);
 int kmeans_bounds_tail();
+int kmeans_lds_pf_pairs();          // pair records per row the LDS / DPP kernel's screening can reach (pf_pairs of launch_kmeans_cdist when it is Pf's only reader)
 // E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
 int kmeans_pk_blocks(int64_t N, int n, int k);
 int kmeans_pk_epochs(int64_t N, int n, int k);

@@ -2082,6 +2082,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     // bounds fail and the M-step adds their CHANGES to the totals it keeps; + 256 in the k-means variant (or BROV2_KM_BOUNDS=0) switches it off
     const bool bnd = pk_lds && (c->kmeans_variant & KMV_NO_BOUNDS) == 0 && kmeans_bounds_list_words(N) < ((size_t)1 << 31);      // (32-bit offsets into the list)
     const size_t lwords = bnd ? kmeans_bounds_list_words(N) : 0;
+    const int pf_pairs = (pk_lds && !pk) ? kmeans_lds_pf_pairs() : 0;      // pair records per row worth building (0: all of them)
     const int nb_pk = pk ? kmeans_pk_blocks(N, n, k) : 0;
     const int nparts_pk = pk ? nb_pk * kmeans_pk_epochs(N, n, k) : 0;
     const size_t pwords_pk = (size_t)nparts_pk * k * (n + 1);
@@ -2273,7 +2274,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                 HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCK(c, hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
             }
-            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr, rw2));
+            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr, rw2, pf_pairs));
             if (beside) {
                 HIPCK(c, hipEventRecord(c->ev_join[0], c->side[0]));
                 cdist_forked = true;
@@ -2289,7 +2290,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
-            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2));
+            if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2, pf_pairs));
             bounds_valid = false;                       // relocated centres jumped: a full E-step, whose sums start the totals afresh
             HIPCK(c, e_step(true));
         }

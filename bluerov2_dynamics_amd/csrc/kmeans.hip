@@ -2171,7 +2171,8 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 #endif
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf,
-                                                           const float* __restrict__ shiftc, float* __restrict__ mvd, float* __restrict__ rw2) {
+                                                           const float* __restrict__ shiftc, float* __restrict__ mvd, float* __restrict__ rw2,
+                                                           int pf_pairs /* > 0: only that many pair records per row are ever read */) {
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
     if (mvd && threadIdx.x < KM_BND_TOP) {
@@ -2211,7 +2212,7 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
                 const unsigned long long x = keys[lo], y = keys[hi];
                 if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
             }
-            __syncthreads();
+            __syncthreads();                          // (round 5: wave-level ordering for the stages with strides up to 64 -- 6 workgroup barriers instead of 45 -- changed nothing: 25.8 us either way)
         }
     for (int i = threadIdx.x; i < kp; i += 256) Nk[(int64_t)a * kp + i] = keys[i];
     // (round 5) the squared radius from which a wave about this centre needs KM_WIDE_CAND candidates or more: kmeans_bounds_kernel puts
@@ -2227,8 +2228,10 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
     // (one thread per candidate of the row forms its half of a record in the LDS -- twelve differences and their norm --, then the
     // block writes the records out as 16-byte pieces: entry by entry, with two of 32 threads walking the norm, this took 40 us)
     __shared__ float recs[256 * 32];                  // 256 pairs at a time (kp = 1024: two rounds)
-    for (int p0 = 0; p0 < (kp >> 1); p0 += 256) {
-        const int np = min(256, (kp >> 1) - p0);
+    // (the LDS / DPP kernel's screening reads the pairs of a prefix of at most KM2_NBR_MAX candidates: 128 of the 256 at k = 512)
+    const int npb = pf_pairs > 0 ? min(kp >> 1, pf_pairs) : (kp >> 1);
+    for (int p0 = 0; p0 < npb; p0 += 256) {
+        const int np = min(256, npb - p0);
         __syncthreads();
         for (int e = threadIdx.x; e < np * 32; e += 256) recs[e] = 0.0f;
         __syncthreads();
@@ -3389,13 +3392,14 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
     return hipGetLastError();
 }
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf, const float* shiftc,
-                               float* mvd, float* rw2) {
+                               float* mvd, float* rw2, int pf_pairs) {
     if (Pf && (!Nk || n > KM_PK_NMAX)) return hipErrorInvalidValue;
     if (mvd && !shiftc) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2);
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2, pf_pairs);
     return hipGetLastError();
 }
 int kmeans_bounds_tail() { return KM_BND_TAIL; }
+int kmeans_lds_pf_pairs() { return KM2_NBR_MAX / 2; }
 size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {
     if (!b.ub || !b.lb || !b.shiftc || !b.mvd || !b.list || !b.nlist || N >= ((int64_t)1 << 31)) return hipErrorInvalidValue;
