@@ -139,8 +139,10 @@ hipError_t launch_kmeans_assign(hipStream_t st, int64_t N, int n, int k, const d
                                 const unsigned long long* Nk = nullptr, const float* Pf = nullptr, const KmBounds* bounds = nullptr);
 // Dc [k][kp] (kp = k rounded up to 256); Nk (optional, kp <= 512): every row once more sorted, as keys (distance bits << 16 | centre index)
 // Pf (optional, with Nk; n <= 13): the sorted rows once more as float pair records [k][kp / 2][32] for kmeans_assign_pk_kernel
+struct KmMstepArgs;
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk = nullptr, float* Pf = nullptr,
-                               const float* shiftc = nullptr, float* mvd = nullptr, float* rw2 = nullptr, int pf_pairs = 0);
+                               const float* shiftc = nullptr, float* mvd = nullptr, float* rw2 = nullptr, int pf_pairs = 0,
+                               const KmMstepArgs* tail = nullptr);
 int kmeans_bounds_tail();
 int kmeans_lds_pf_pairs();          // pair records per row the LDS / DPP kernel's screening can reach (pf_pairs of launch_kmeans_cdist when it is Pf's only reader)
 // E-step with packed-fp32 screening of the candidates (kmeans.hip, third form): labels, scores and member sums as the other kernels'
@@ -173,6 +175,8 @@ struct KmMstepArgs {
     double* scratch = nullptr;          // [kmeans_mstep_scratch_doubles(k)], zeroed once before the loop (its ticket word)
     double* hstats = nullptr;           // pinned, device-mapped [5] or nullptr: four statistics, then `seq`
     double seq = 0.0;
+    bool tail_deferred = false;         // the one-block global part (sum of shifts, empty clusters, movers, the host's statistics) is not launched here:
+                                        // the caller hands these arguments to the launch_kmeans_cdist that follows (`tail`), which runs it as one more block
 };
 size_t kmeans_mstep_scratch_doubles(int k);
 hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& a, int phases);

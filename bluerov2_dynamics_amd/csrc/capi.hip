@@ -2239,6 +2239,9 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         ma.red = red; ma.tot = tot; ma.delta = e_list ? 1 : 0; ma.nlist = nlist; ma.fix = fix; ma.Cold = Cb[cc]; ma.Cnew = Cb[cc ^ 1]; ma.Ct = c2;
         ma.stats = stats; ma.prm = prm; ma.shiftc = shiftc; ma.mvd = mvd; ma.scratch = ms_scratch; ma.hstats = c->d_stats_map;
         ma.seq = (c->km_seq += 1.0);                  // (never repeats within a context: a stale block cannot pass for this iteration's)
+        // the M-step's one-block global part rides on the centre-distance launch that follows (one launch less per iteration); not when
+        // that launch goes to the side stream, where the bounds pass would not wait for it
+        ma.tail_deferred = filter && !cdist_beside;
         if (c->km_allreduce) {
             HIPCK(c, launch_kmeans_mstep(c->stream, ma, 1));
             if (c->km_allreduce(c->km_allreduce_user, red, (int64_t)rwords, 0) != 0) return fail(c, BROV_ERR_COMM, "edmdc_kmeans_lloyd: all-reduce (sum) failed");
@@ -2274,7 +2277,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
                 HIPCK(c, hipEventRecord(c->ev_fork, c->stream));
                 HIPCK(c, hipStreamWaitEvent(c->side[0], c->ev_fork, 0));
             }
-            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr, rw2, pf_pairs));
+            HIPCK(c, launch_kmeans_cdist(cs_, n, k, c2, Dc, Nk, Pf, nullptr, nullptr, rw2, pf_pairs, ma.tail_deferred ? &ma : nullptr));
             if (beside) {
                 HIPCK(c, hipEventRecord(c->ev_join[0], c->side[0]));
                 cdist_forked = true;

@@ -1832,95 +1832,13 @@ struct KmMstep {
     double* hstats;                 // pinned, device-mapped [5], or nullptr
     double seq;                     // what the tail stores behind the four statistics: the host waits for THIS M-step by polling it
 };
-__global__ void __launch_bounds__(256) kmeans_mstep_kernel(KmMstep a, int phases) {
+// ---- the iteration's global part: a launch of its own, one block (phases = 4).  (First built as the tail of the same launch, run by
+// the last block to take a device-wide ticket: 61 us per M-step against 38 for the two kernels of round 4 -- a release / acquire
+// between blocks on different XCDs means L2 write-backs and invalidations, which a kernel boundary does once.)
+// (round 5: where the centre distances are built next, the block runs as one more block of kmeans_cdist_kernel -- a launch of 12 us less
+// per iteration; `tail_deferred` of launch_kmeans_mstep / `tail` of launch_kmeans_cdist)
+__device__ __forceinline__ void km_mstep_tail(const KmMstep& a) {
     const int n = a.n, k = a.k, np1 = n + 1;
-    const int c = blockIdx.x;
-    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
-    __shared__ long long part[16][17][2];
-    __shared__ double s_cc[KM_NMAX];
-    __shared__ long long s_cw[2];
-    __int128 t = 0;
-    if (phases == 4) goto tail;
-    if (phases & 1) {
-        int nparts = a.nparts;
-        if (a.nlist_in) {
-            // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
-            const int64_t passes = ((int64_t)a.nlist_in[0] + a.nlist_in[KM_NL_FRONT] + a.nlist_in[KM_NL_BACK] + a.span - 1) / a.span;
-            const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
-            const int tables = a.nblocks * (int)(used > 1 ? used : 1);
-            nparts = tables < nparts ? tables : nparts;
-        }
-        __int128 s = 0;
-        if (j <= n) {
-            for (int b0 = sr; b0 < nparts; b0 += 16 * 8) {
-                long long v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nparts ? (long long)a.partial[((int64_t)b * k + c) * np1 + j] : 0ll; }
-#pragma unroll
-                for (int q = 0; q < 8; ++q) s += (__int128)v[q];
-            }
-        }
-        part[sr][j][0] = (long long)(s >> 64);
-        part[sr][j][1] = (long long)(u64)s;
-        __syncthreads();
-        if ((int)threadIdx.x <= n) {
-            for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
-            if (a.tot) {
-                if (a.delta) t += km_load128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2);
-                km_store128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2, t);
-            }
-            km_store128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
-        }
-        if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
-            const int l = threadIdx.x & 63;
-            double in = 0.0;
-            long long ch = 0;
-            for (int b = l; b < a.nblocks; b += 64) { in += a.block_inertia[b]; ch += a.block_changed[b]; }
-            for (int off = 32; off > 0; off >>= 1) {
-                in += __shfl_down(in, off);
-                ch += __shfl_down(ch, off);
-            }
-            if (l == 0) { a.stats[1] = in; a.red[(int64_t)k * np1 * 2] = ch; a.red[(int64_t)k * np1 * 2 + 1] = 0; }
-        }
-    }
-    if (!(phases & 2)) return;
-    // ---- this centre: kmeans_average_kernel's pass 1 and pass 3 (mode 0)
-    if (!(phases & 1) && (int)threadIdx.x <= n) t = km_load128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2);     // (sharded: the all-reduced totals)
-    if ((int)threadIdx.x == n) { s_cw[0] = (long long)(t >> 64); s_cw[1] = (long long)(u64)t; }
-    __syncthreads();
-    {
-        const __int128 cw = ((__int128)s_cw[0] << 64) + (__int128)(u64)s_cw[1];
-        const long long cnt = (long long)(cw & (KM_POISON - 1));
-        const bool poisoned = (cw >> 40) != 0;
-        const bool empty = !(cnt > 0 || poisoned);
-        if ((int)threadIdx.x < n) {
-            const int jj = threadIdx.x;
-            double v;
-            if (!empty) v = poisoned ? __builtin_nan("") : (km_to_double(t) * a.fix[16 + jj]) / (double)cnt;
-            else v = a.Cold[(int64_t)c * n + jj];          // an empty cluster keeps its old centre for now (the host relocates)
-            a.Cnew[(int64_t)c * n + jj] = v;
-            s_cc[jj] = v;
-        } else if (threadIdx.x < KM_NMAX) {
-            s_cc[threadIdx.x] = 0.0;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            double cc[KM_NMAX];
-            for (int q = 0; q < KM_NMAX; ++q) cc[q] = s_cc[q];
-            double sh = 0.0;
-            for (int q = 0; q < n; ++q) { const double dd = cc[q] - a.Cold[(int64_t)c * n + q]; sh = fma(dd, dd, sh); }
-            a.shift2[c] = sh;
-            // >= the true shift: sh carries n roundings of 2^-53; NaN (a poisoned centre) stays NaN and fails every bound test
-            if (a.shiftc) a.shiftc[c] = (float)sqrt(sh) * 1.000001f + 1.0e-37f;
-            const double qn = km_pack_centre(n, cc, a.Ct + (int64_t)c * 16);
-            a.flags[c] = (empty ? 1 : 0) | (!(qn - qn == 0.0) ? 2 : 0);
-        }
-    }
-    return;
-    // ---- the iteration's global part: a launch of its own, one block (phases = 4).  (First built as the tail of the same launch, run by
-    // the last block to take a device-wide ticket: 61 us per M-step against 38 for the two kernels of round 4 -- a release / acquire
-    // between blocks on different XCDs means L2 write-backs and invalidations, which a kernel boundary does once.)
-tail:
     __shared__ double sh_d[16];
     __shared__ int sh_em[4], sh_bad[4], sh_nan[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -2034,7 +1952,95 @@ tail:
         }
     }
 }
-hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& h, int phases) {
+__global__ void __launch_bounds__(256) kmeans_mstep_kernel(KmMstep a, int phases) {
+    const int n = a.n, k = a.k, np1 = n + 1;
+    const int c = blockIdx.x;
+    const int j = threadIdx.x & 15, sr = threadIdx.x >> 4;
+    __shared__ long long part[16][17][2];
+    __shared__ double s_cc[KM_NMAX];
+    __shared__ long long s_cw[2];
+    __int128 t = 0;
+    if (phases == 4) goto tail;
+    if (phases & 1) {
+        int nparts = a.nparts;
+        if (a.nlist_in) {
+            // a list-form E-step (span = its blocks x threads) fills and zeroes only the epochs its longest-running block reaches
+            const int64_t passes = ((int64_t)a.nlist_in[0] + a.nlist_in[KM_NL_FRONT] + a.nlist_in[KM_NL_BACK] + a.span - 1) / a.span;
+            const int64_t used = (passes + KM_EPOCH_PASSES - 1) / KM_EPOCH_PASSES;
+            const int tables = a.nblocks * (int)(used > 1 ? used : 1);
+            nparts = tables < nparts ? tables : nparts;
+        }
+        __int128 s = 0;
+        if (j <= n) {
+            for (int b0 = sr; b0 < nparts; b0 += 16 * 8) {
+                long long v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int b = b0 + 16 * q; v[q] = b < nparts ? (long long)a.partial[((int64_t)b * k + c) * np1 + j] : 0ll; }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) s += (__int128)v[q];
+            }
+        }
+        part[sr][j][0] = (long long)(s >> 64);
+        part[sr][j][1] = (long long)(u64)s;
+        __syncthreads();
+        if ((int)threadIdx.x <= n) {
+            for (int q = 0; q < 16; ++q) t += ((__int128)part[q][threadIdx.x][0] << 64) + (__int128)(u64)part[q][threadIdx.x][1];
+            if (a.tot) {
+                if (a.delta) t += km_load128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2);
+                km_store128(a.tot + ((int64_t)c * np1 + threadIdx.x) * 2, t);
+            }
+            km_store128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2, t);
+        }
+        if (blockIdx.x == 0 && (threadIdx.x >> 6) == 1) {
+            const int l = threadIdx.x & 63;
+            double in = 0.0;
+            long long ch = 0;
+            for (int b = l; b < a.nblocks; b += 64) { in += a.block_inertia[b]; ch += a.block_changed[b]; }
+            for (int off = 32; off > 0; off >>= 1) {
+                in += __shfl_down(in, off);
+                ch += __shfl_down(ch, off);
+            }
+            if (l == 0) { a.stats[1] = in; a.red[(int64_t)k * np1 * 2] = ch; a.red[(int64_t)k * np1 * 2 + 1] = 0; }
+        }
+    }
+    if (!(phases & 2)) return;
+    // ---- this centre: kmeans_average_kernel's pass 1 and pass 3 (mode 0)
+    if (!(phases & 1) && (int)threadIdx.x <= n) t = km_load128(a.red + ((int64_t)c * np1 + threadIdx.x) * 2);     // (sharded: the all-reduced totals)
+    if ((int)threadIdx.x == n) { s_cw[0] = (long long)(t >> 64); s_cw[1] = (long long)(u64)t; }
+    __syncthreads();
+    {
+        const __int128 cw = ((__int128)s_cw[0] << 64) + (__int128)(u64)s_cw[1];
+        const long long cnt = (long long)(cw & (KM_POISON - 1));
+        const bool poisoned = (cw >> 40) != 0;
+        const bool empty = !(cnt > 0 || poisoned);
+        if ((int)threadIdx.x < n) {
+            const int jj = threadIdx.x;
+            double v;
+            if (!empty) v = poisoned ? __builtin_nan("") : (km_to_double(t) * a.fix[16 + jj]) / (double)cnt;
+            else v = a.Cold[(int64_t)c * n + jj];          // an empty cluster keeps its old centre for now (the host relocates)
+            a.Cnew[(int64_t)c * n + jj] = v;
+            s_cc[jj] = v;
+        } else if (threadIdx.x < KM_NMAX) {
+            s_cc[threadIdx.x] = 0.0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double cc[KM_NMAX];
+            for (int q = 0; q < KM_NMAX; ++q) cc[q] = s_cc[q];
+            double sh = 0.0;
+            for (int q = 0; q < n; ++q) { const double dd = cc[q] - a.Cold[(int64_t)c * n + q]; sh = fma(dd, dd, sh); }
+            a.shift2[c] = sh;
+            // >= the true shift: sh carries n roundings of 2^-53; NaN (a poisoned centre) stays NaN and fails every bound test
+            if (a.shiftc) a.shiftc[c] = (float)sqrt(sh) * 1.000001f + 1.0e-37f;
+            const double qn = km_pack_centre(n, cc, a.Ct + (int64_t)c * 16);
+            a.flags[c] = (empty ? 1 : 0) | (!(qn - qn == 0.0) ? 2 : 0);
+        }
+    }
+    return;
+tail:
+    km_mstep_tail(a);
+}
+static KmMstep km_mstep_args(const KmMstepArgs& h) {
     KmMstep a;
     a.nparts = h.nparts; a.nblocks = h.nblocks; a.n = h.n; a.k = h.k;
     a.partial = h.partial; a.block_inertia = h.block_inertia; a.block_changed = h.block_changed; a.red = h.red; a.tot = h.tot;
@@ -2042,8 +2048,12 @@ hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& h, int phases)
     a.fix = h.fix; a.Cold = h.Cold; a.Cnew = h.Cnew; a.Ct = h.Ct; a.stats = h.stats; a.prm = h.prm; a.shiftc = h.shiftc; a.mvd = h.mvd;
     a.nlist = h.nlist; a.shift2 = h.scratch; a.flags = reinterpret_cast<int*>(h.scratch + h.k); a.ticket = reinterpret_cast<unsigned*>(h.scratch + h.k) + h.k;
     a.hstats = h.hstats; a.seq = h.seq;
+    return a;
+}
+hipError_t launch_kmeans_mstep(hipStream_t st, const KmMstepArgs& h, int phases) {
+    const KmMstep a = km_mstep_args(h);
     if (phases & 3) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(h.k), dim3(256), 0, st, a, phases & 3);
-    if (phases & 2) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(1), dim3(256), 0, st, a, 4);
+    if ((phases & 2) && !h.tail_deferred) hipLaunchKernelGGL(kmeans_mstep_kernel, dim3(1), dim3(256), 0, st, a, 4);
     return hipGetLastError();
 }
 size_t kmeans_mstep_scratch_doubles(int k) { return (size_t)k + ((size_t)k + 2) / 2 + 2; }
@@ -2172,7 +2182,12 @@ __global__ void __launch_bounds__(256) kmeans_reloc_dist_kernel(int64_t N, int n
 __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const double* __restrict__ Ct, float* __restrict__ Dc,
                                                            unsigned long long* __restrict__ Nk, float* __restrict__ Pf,
                                                            const float* __restrict__ shiftc, float* __restrict__ mvd, float* __restrict__ rw2,
-                                                           int pf_pairs /* > 0: only that many pair records per row are ever read */) {
+                                                           int pf_pairs /* > 0: only that many pair records per row are ever read */,
+                                                           KmMstep tail, int has_tail) {
+    if ((int)blockIdx.x == k) {                       // (has_tail: the grid has this one block more) the M-step's global part, see km_mstep_tail
+        if (has_tail) km_mstep_tail(tail);
+        return;
+    }
     const int a = blockIdx.x;
     const int kp = (k + 255) & ~255;
     if (mvd && threadIdx.x < KM_BND_TOP) {
@@ -3392,10 +3407,13 @@ hipError_t launch_kmeans_assign_pk(hipStream_t st, int64_t N, int n, int k, cons
     return hipGetLastError();
 }
 hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, float* Dc, unsigned long long* Nk, float* Pf, const float* shiftc,
-                               float* mvd, float* rw2, int pf_pairs) {
+                               float* mvd, float* rw2, int pf_pairs, const KmMstepArgs* tail) {
     if (Pf && (!Nk || n > KM_PK_NMAX)) return hipErrorInvalidValue;
     if (mvd && !shiftc) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2, pf_pairs);
+    if (tail && tail->k != k) return hipErrorInvalidValue;
+    KmMstep ta{};
+    if (tail) ta = km_mstep_args(*tail);
+    hipLaunchKernelGGL(kmeans_cdist_kernel, dim3(k + (tail ? 1 : 0)), dim3(256), 0, st, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2, pf_pairs, ta, tail ? 1 : 0);
     return hipGetLastError();
 }
 int kmeans_bounds_tail() { return KM_BND_TAIL; }
