@@ -1974,29 +1974,54 @@ def test_config4_shard_rollouts_and_gram(eng, fc):
     assert np.linalg.norm(Ys.cpu().numpy() - Yo) / np.linalg.norm(Yo) < 1e-12
 
 
-def test_bench_prints_one_json_line_with_the_contract_fields():
-    """bench.py at toy sizes: ONE JSON line on stdout with every field of the driver's contract, the roofline object
-    of the dominant kernel and the CPU baseline (kind "port" = the C oracle on the host cores)."""
+def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
+    """bench.py at toy sizes with the driver's flags (--steps 20 --warmup 5): ONE compact JSON line on stdout (<= 4096 bytes: round 5's
+    25 KB line came back from the driver unparsed) with every field of the driver's contract, the roofline object of the dominant
+    kernel, the CPU baseline (kind "port" = the C oracle on the host cores) and a flat summary of the other legs; the full record
+    of every leg goes to the --details file."""
     import json
     import os
     import subprocess
     import sys
     from conftest import REPO
-    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "1024", "--horizon", "40",
+    det = str(tmp_path / "details.json")
+    cmd = [sys.executable, os.path.join(REPO, "bench.py"), "--steps", "20", "--warmup", "5", "--batch", "1024", "--horizon", "40",
            "--edmdc-samples", "40000", "--edmdc-steps", "1", "--kmeans-iters", "2", "--cpu-seconds", "0.3",
-           "--cfg4-rollouts", "4096", "--cfg4-horizon", "50"]
+           "--cfg4-rollouts", "4096", "--cfg4-horizon", "50", "--details", det]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    assert len(lines[0]) <= 4096, len(lines[0])
+    c = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "summary", "details"):
+        assert k in c, k
+    assert c["metric"] == "rk4_rollout_steps_per_s" and c["unit"] == "steps/s" and c["n_gpus"] == 1 and c["steps"] == 20 and c["warmup"] == 5
+    assert c["higher_is_better"] is True and c["scaling"] == "weak" and c["vs_baseline"] is None and c["dtype"] == "f64" and c["data"] == "synthetic"
+    assert "workload" in c["config"] and "model" not in c["config"]
+    assert abs(c["value"] - 1024 * 40 * 20 / (c["ms_per_step"] * 20e-3)) / c["value"] < 1e-6
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"):
+        assert k in c["roofline"], k
+    assert abs(c["roofline"]["frac"] - c["roofline"]["achieved"] / c["roofline"]["peak"]) < 1e-5 and 0 < c["roofline"]["frac"] <= 1
+    for k in ("value", "unit", "cores", "kind", "sample", "budget_s"):
+        assert k in c["cpu_baseline"], k
+    assert c["cpu_baseline"]["kind"] == "port" and c["cpu_baseline"]["budget_s"] == 0.3
+    assert c["verified"]["ok"] is True
+    sm = c["summary"]
+    for k in ("gram_samples_per_s", "gram_mfma_frac", "fit_samples_per_s", "fit_multi_samples_per_s", "cfg4_rollout_ms", "cfg4_gram_samples_per_s",
+              "cfg4_rccl_ranks", "cfg4_per_rank_ms", "cfg4_rollout_hbm_frac", "cfg4_fill_hbm_frac", "recorded_cpu_fit_s"):
+        assert k in sm, k
+    assert all(not isinstance(v, (dict,)) for v in sm.values())          # flat
+    d = json.load(open(det))
+    assert d["steps"] == 20 and abs(d["value"] - c["value"]) / d["value"] < 1e-9
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["metric"] == "rk4_rollout_steps_per_s" and d["unit"] == "steps/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["metric"] == "rk4_rollout_steps_per_s" and d["unit"] == "steps/s" and d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 5
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f64" and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
-    assert abs(d["value"] - 1024 * 40 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-6
+    assert abs(d["value"] - 1024 * 40 * 20 / (d["ms_per_step"] * 20e-3)) / d["value"] < 1e-6
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in d["roofline"] and k in d["edmdc"]["roofline"], k
     assert d["edmdc"]["roofline"]["bound"] == "mfma"

@@ -3,7 +3,9 @@ stand-alone ThrusterLag filter, the ridge solve, argument checking, sharding ari
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+import os
+
+from conftest import REPO, load_golden, rel_err
 
 
 def test_quaternion_helpers_match_reference_fixture():
@@ -213,3 +215,48 @@ def test_bag_table_native_helper_equals_the_python_walk():
             maker()
     with pytest.raises(ValueError):
         engine.BagTable([np.zeros((5, 12))], [np.zeros((3, 8))], 12, 8)
+
+
+def _parse_like_the_driver(stdout):
+    """what the driver does with bench.py's stdout: the last non-empty line is ONE JSON object"""
+    import json
+    lines = [l for l in stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    assert len(lines[0]) <= 4096, len(lines[0])
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("record", ["r05_bench.json", "r06_bench_details.json"])
+def test_bench_compact_line_of_a_recorded_run_fits_the_driver(record):
+    """bench.compact_line on the full record of a real run (profiles/): <= 4096 bytes with the contract fields, `roofline`, `cpu_baseline`
+    and a flat summary -- also when eight ranks report (per-rank times in the summary) -- and it parses as the driver parses it."""
+    import json
+    import bench
+    path = os.path.join(REPO, "profiles", record)
+    if not os.path.exists(path):
+        pytest.skip(f"{record} not recorded yet")
+    full = json.load(open(path))
+    full.setdefault("cpu_seconds_budget_per_leg", 3.0)
+    for ranks in (1, 8):
+        d = json.loads(json.dumps(full))
+        d["n_gpus"] = ranks
+        if "config4" in d:
+            d["config4"]["per_rank_ms"] = [7126.156140999228 / ranks + i for i in range(ranks)]
+            d["config4"]["rccl_ranks"] = ranks
+        c = _parse_like_the_driver(json.dumps(bench.compact_line(d, "bench_details.json"), separators=(",", ":")) + "\n")
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                  "data", "config", "roofline", "cpu_baseline", "verified", "summary", "details"):
+            assert k in c, k
+        assert c["n_gpus"] == ranks and c["metric"] == "rk4_rollout_steps_per_s" and c["dtype"] == "f64" and "workload" in c["config"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in c["roofline"], k
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in c["cpu_baseline"], k
+        assert abs(c["value"] - full["value"]) / full["value"] < 1e-9 and abs(c["ms_per_step"] - full["ms_per_step"]) / full["ms_per_step"] < 1e-9
+        assert all(not isinstance(v, dict) for v in c["summary"].values())
+        assert len(c["summary"].get("cfg4_per_rank_ms", [0] * ranks)) == ranks
+    # a record too long for the line loses summary entries, never a contract field
+    d = json.loads(json.dumps(full))
+    d["config"]["workload"] = d["config"]["workload"] + " x" * 3000
+    c = bench.compact_line(d, "bench_details.json")
+    assert len(json.dumps(c, separators=(",", ":"))) <= 4096 and "roofline" in c and "cpu_baseline" in c
