@@ -11,8 +11,9 @@ What runs where:
     to rounding, tested.  `kmeans="sklearn"` calls scikit-learn for the whole thing instead;
   * lift phi(x) = [x, exp(-gamma(|x|^2+|c|^2-2x.c))] and the G^T[G|Y] normal-equation blocks:
     HIP kernels (csrc/edmdc.hip, fp64 MFMA);
-  * the p x p ridge solve: on the host, a symmetric eigendecomposition with numpy.linalg.pinv's cut-off (pinv="host": numpy's pinv
-    itself; measured against the reference's scores in tests/test_gpu_parity.py::test_fit_keeps_the_references_own_product_order).
+  * the p x p ridge solve: on the host, numpy.linalg.pinv like the reference -- replaced by a symmetric eigendecomposition with the same
+    cut-off only when the matrix is comfortably conditioned (pinv="auto", engine._host_pinv; measured against the reference's scores in
+    tests/test_gpu_parity.py::test_fit_keeps_the_references_own_product_order and ::test_fit_at_class_defaults_with_a_wide_kernel).
     fit_multi associates M = pinv(G^T G + ridge I) (G^T Y) (:147) and so
     does fit_multi here; fit() evaluates (pinv G^T) Y left to right (:97) and so does fit() here (two more MFMA passes:
     rows of W = G P^T, then W^T Y).  The two differ by the conditioning of the Gram -- 1e-6 in the H = 100 RMSE at the
@@ -61,8 +62,9 @@ class KoopmanEDMDc:
     B_: np.ndarray = None
     lift_dim_: int = None
     kmeans: str = "hip"                 # "hip" (k-means++ seeding and Lloyd on the GPU) or "sklearn"
-    pinv: str = "eigh"                  # the p x p solve: "eigh" = symmetric eigendecomposition on the host with numpy.linalg.pinv's cut-off (default: the
-                                        # same matrix to rounding, half the time); "host" = numpy.linalg.pinv itself like the reference (:97); "device" = on the GPU
+    pinv: str = "auto"                  # the p x p solve (engine._host_pinv): "auto" = numpy.linalg.pinv like the reference (:97) unless G^T G + ridge I
+                                        # is comfortably conditioned (then a symmetric eigendecomposition: same scores to 1e-10, half the time);
+                                        # "host" = numpy.linalg.pinv always; "eigh" = the eigendecomposition always (speed, opt-in)
 
     # ------------------------------------------------------------------ fitting
     def fit(self, X, U, centers=None) -> None:

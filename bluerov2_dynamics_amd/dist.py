@@ -95,7 +95,7 @@ def _device_apply(X, U, C, gamma, nbags, L, xs, us, P):
 
 
 def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, deterministic=False, order="fit_multi", apply_fn=None,
-                allreduce=None, pinv="eigh"):
+                allreduce=None, pinv="auto"):
     """EDMDc fit over trajectories sharded across ranks.
 
     X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);

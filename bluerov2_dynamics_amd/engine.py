@@ -596,22 +596,44 @@ def pinv_sym_device(G, ridge, rcond=1e-15):
     return (Q * winv) @ Q.T
 
 
-def pinv_sym_host(G, ridge, rcond=1e-15):
+def pinv_sym_host(G, ridge, rcond=1e-15, safe=None):
     """pinv(G + ridge I) of the symmetric p x p Gram on the HOST through a symmetric eigendecomposition (LAPACK syevd) with
-    numpy.linalg.pinv's cut-off: for a symmetric matrix the singular values are |eigenvalues| and V diag(1/s) U^T = Q diag(1/w) Q^T, so
-    this is the same matrix as the reference's `pinv(...)` (Koopman/koopmanEDMDc.py:97,147) up to the rounding of two different
-    LAPACK drivers (6e-12 .. 5e-10 relative on the bench shapes, tools/time_pinv_options.py) at 13 ms instead of 29 ms for p = 520."""
+    numpy.linalg.pinv's cut-off, Q diag(1/w) Q^T: 13 ms instead of 29 ms at p = 520.  In exact arithmetic this is the reference's
+    `pinv(...)` (Koopman/koopmanEDMDc.py:97,147); in floating point the two routes agree only while the matrix is comfortably
+    conditioned: with the smallest computed eigenvalue above 1e-10 of the largest the scores agree to <= 1e-10, at 1e-12 they differ by
+    1e-7 .. 1e-4, and at the class default ridge = 1e-8 with a wide kernel (cond ~ 1e14) the advisor of round 5 measured a 5 x worse
+    training RMSE for this route than for numpy's SVD.  `safe`: return None instead of a matrix when the smallest eigenvalue is not above
+    safe x the largest (pinv="auto" then calls numpy.linalg.pinv)."""
     A = G + ridge * np.eye(G.shape[0])
     w, Q = np.linalg.eigh(0.5 * (A + A.T))
     aw = np.abs(w)
+    if safe is not None and not (w[0] > safe * aw.max()):
+        return None
     keep = aw > rcond * aw.max()
     winv = np.zeros_like(w)
     winv[keep] = 1.0 / w[keep]
     return (Q * winv) @ Q.T
 
 
+PINV_AUTO_SAFE = 1e-10        # pinv="auto": smallest / largest eigenvalue of G^T G + ridge I above which the eigendecomposition route is taken
+
+
+def _host_pinv(G, ridge, pinv):
+    """The p x p solve of the normal equations on the host.  "host": numpy.linalg.pinv, the reference's call (Koopman/koopmanEDMDc.py:97,147).
+    "auto" (default): the symmetric eigendecomposition when the matrix is comfortably conditioned (PINV_AUTO_SAFE), numpy.linalg.pinv
+    otherwise -- the reference's own route wherever the route matters.  "eigh": the eigendecomposition unconditionally (speed; opt-in)."""
+    if pinv == "host":
+        return np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
+    if pinv == "auto":
+        P = pinv_sym_host(G, ridge, safe=PINV_AUTO_SAFE)
+        return P if P is not None else np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
+    if pinv in ("eigh", "device"):          # (the device form is fit_dev's; the host-list paths take the host's eigendecomposition)
+        return pinv_sym_host(G, ridge)
+    raise ValueError("pinv must be 'auto', 'host', 'eigh' or 'device'")
+
+
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
-            timings=None, lift_cache=False, pinv="eigh", bag_offsets=None):
+            timings=None, lift_cache=False, pinv="auto", bag_offsets=None):
     """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
     states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
@@ -620,12 +642,11 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     the stopping rule fired before max_iter.  lift_cache=True: keep the lifted rows of the Gram pass in HBM for the apply pass
     when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
     45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
-    so it pays for repeated fits in one process, not for a single one; off by default.  pinv: how the p x p solve is done -- "eigh"
-    (default since round 5): pinv_sym_host, a symmetric eigendecomposition on the host with numpy.linalg.pinv's cut-off (the same matrix
-    as the reference's pinv up to the rounding of another LAPACK driver: |dRMSE| <= 4e-10 / 9e-11 / 3.2e-8 against the reference's own
-    scores on the three fixture cases, where the reference's call itself gives 4e-10 / 2e-11 / 6.5e-9; 13 instead of 29 ms at p = 520);
-    "host": numpy.linalg.pinv itself (:97/:147); "device": pinv_sym_device (torch.linalg.eigh: 12 ms, but its first call in a process
-    costs 0.2 s).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
+    so it pays for repeated fits in one process, not for a single one; off by default.  pinv: how the p x p solve is done (_host_pinv) --
+    "auto" (default): a symmetric eigendecomposition on the host when G^T G + ridge I is comfortably conditioned (13 instead of 29 ms at
+    p = 520), numpy.linalg.pinv -- the reference's call, :97/:147 -- otherwise; "host": numpy.linalg.pinv always; "eigh": the
+    eigendecomposition always (not the reference's scores once cond reaches ~1e12); "device": pinv_sym_device (torch.linalg.eigh:
+    12 ms, first call in a process 0.2 s; torch tensors only).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
     of nbags bags of L pairs -- X [rows, n] the stacked states, U [rows, r] row-aligned with X (upload_bags); nbags / L are ignored."""
     import time
     import torch
@@ -676,13 +697,13 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
         if pinv == "device":
             t2 = tick()
             P = pinv_sym_device(GtG, ridge).cpu().numpy()
-        elif pinv in ("host", "eigh"):
+        elif pinv in ("auto", "host", "eigh"):
             Gh = GtG.cpu().numpy()
             t2 = tick()
             with _blas_threads(p):
-                P = np.linalg.pinv(Gh + ridge * np.eye(p)) if pinv == "host" else pinv_sym_host(Gh, ridge)
+                P = _host_pinv(Gh, ridge, pinv)
         else:
-            raise ValueError("pinv must be 'host', 'eigh' or 'device'")
+            raise ValueError("pinv must be 'auto', 'host', 'eigh' or 'device'")
         t3 = time.perf_counter()
         if order == "fit":
             M = torch.empty((p, d), dtype=torch.float64, device=X.device)
@@ -758,15 +779,7 @@ class _blas_threads:
         return False
 
 
-def _host_pinv(G, ridge, pinv):
-    if pinv == "host":
-        return np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
-    if pinv in ("eigh", "device"):          # (the device form is fit_dev's; the host-list paths take the host's eigendecomposition)
-        return pinv_sym_host(G, ridge)
-    raise ValueError("pinv must be 'host', 'eigh' or 'device'")
-
-
-def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="eigh"):
+def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="auto"):
     """(A, B) exactly as KoopmanEDMDc.fit associates the product (Koopman/koopmanEDMDc.py:97-101):
     M = (pinv(G^T G + ridge I) @ G.T) @ Y, the pinv on the host (numpy, like the reference), the two large products on
     the GPU.  Better conditioned than fit_multi's pinv(.) @ (G^T Y): at the class defaults (k = 200, ridge = 1e-8) the two
@@ -777,7 +790,7 @@ def solve_AB_fit_order(X_list, U_list, C, gamma, GtG, ridge, d, ctx=None, pinv="
     return np.ascontiguousarray(M[:, :d]), np.ascontiguousarray(M[:, d:])
 
 
-def solve_AB(GtG, GtY, ridge, d, pinv="eigh"):
+def solve_AB(GtG, GtY, ridge, d, pinv="auto"):
     """Host solve of the ridge normal equations exactly as the reference does it
     (Koopman/koopmanEDMDc.py:147-151): M = pinv(G^T G + ridge I) (G^T Y); A = M^T[:, :d]; B = M^T[:, d:]."""
     with _blas_threads(GtG.shape[0]):

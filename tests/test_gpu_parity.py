@@ -1622,12 +1622,42 @@ def test_fit_keeps_the_references_own_product_order(eng):
             ("def", X[:ntr], U[:ntr], Xt, Ut, int(g["def_k"]), float(g["def_gamma"]), float(g["def_ridge"]), g["def_centers"], g["def_ms_rmse"]),
             ("tank", X[:ntr], U[:ntr], Xt, Ut, int(g["tank_k"]), float(g["tank_gamma"]), float(g["tank_ridge"]), g["tank_centers"], g["tank_ms_rmse"]),
             ("small", Xs[:ns], Us[:ns], Xs[ns:], Us[ns:], 200, 1.0, 1e-8, g["small_centers"], g["small_ms_rmse"])):
-        for how in ("device", "eigh", "host"):
+        for how in ("device", "eigh", "host", "auto"):
             md = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=kk, gamma=gg, ridge=rr, pinv=how)
             md.fit(Xa, Ua, centers=cc)
             errd = np.abs(np.array([md.multistep_rmse(Xb, Ub, H) for H in (1, 10, 100)]) - ref)
             print(f"pinv = {how}, {tag}: |dRMSE| H=1/10/100 =", errd)
             assert np.max(errd) < 1e-6, (tag, how, errd)
+
+
+def test_fit_at_class_defaults_with_a_wide_kernel(eng):
+    """the p x p solve at the class-default ridge 1e-8 with near-duplicate RBF columns (gamma 0.05: the smallest computed
+    eigenvalue of G^T G + ridge I is 2.7e-12 of the largest).  There the symmetric-eigendecomposition route is NOT the reference's
+    numpy.linalg.pinv to rounding, so pinv="auto" (the default) must take numpy's pinv -- bit for bit the result of pinv="host" -- and land
+    on the reference's own scores (tests/golden/edmdc_illcond.npz, generated by importing the reference) as closely as a 1e-16 relative
+    perturbation of the Gram moves them (measured: 3e-5 at H = 100 on a score of 8.0); at gamma 0.2 (2.5e-9) the eigendecomposition is
+    taken and agrees to 1e-8.  The unconditional pinv="eigh" is printed beside them."""
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    e, z = load_golden("edmdc_fit.npz"), load_golden("edmdc_illcond.npz")
+    X, U, ntr = e["X"], e["U"], int(e["n_train"])
+    Xt, Ut = X[ntr:], U[ntr:]
+    for tag, tol in (("g005", 2e-4), ("g02", 1e-8)):
+        gamma, C = float(z[f"{tag}_gamma"]), z[f"{tag}_centers"]
+        assert float(z[f"{tag}_ridge"]) == KoopmanEDMDc(12, 8).ridge == 1e-8 and int(z[f"{tag}_k"]) == KoopmanEDMDc(12, 8).n_rbfs
+        got = {}
+        for how in ("auto", "host", "eigh"):
+            m = KoopmanEDMDc(state_dim=12, input_dim=8, gamma=gamma, pinv=how)
+            m.fit(X[:ntr], U[:ntr], centers=C)
+            sc = np.array([m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)] + [m.multistep_rmse(X[:ntr], U[:ntr], H) for H in (1, 10, 100)])
+            ref = np.concatenate([z[f"{tag}_ms_rmse"], z[f"{tag}_train_ms_rmse"]])
+            got[how] = (m.A_.copy(), m.B_.copy(), np.abs(sc - ref) / np.maximum(1.0, ref))
+            print(f"{tag} pinv={how}: |dRMSE| / max(1, RMSE) test H=1/10/100, train H=1/10/100 =", got[how][2])
+        assert np.max(got["auto"][2]) < tol and np.max(got["host"][2]) < tol, (tag, got["auto"][2], got["host"][2])
+        assert abs(np.linalg.norm(got["auto"][0]) / float(z[f"{tag}_A_fro"]) - 1) < (1e-3 if tag == "g005" else 1e-7)
+        if tag == "g005":          # below the threshold: "auto" IS numpy.linalg.pinv
+            assert np.array_equal(got["auto"][0], got["host"][0]) and np.array_equal(got["auto"][1], got["host"][1])
+        else:                      # above it: "auto" IS the eigendecomposition
+            assert np.array_equal(got["auto"][0], got["eigh"][0]) and np.array_equal(got["auto"][1], got["eigh"][1])
 
 
 def test_apply_kernels_agree_and_device_fit_matches_host_fit(eng):
@@ -1844,7 +1874,7 @@ def test_koopman_options_sklearn_backend_and_solve_options():
     Xl, Ul = [X[a:b] for a, b in cuts], [np.vstack([U[a:b], np.ones((3, 8))]) for a, b in cuts]         # three extra input rows per bag
     ref = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge, pinv="host")
     ref.fit_multi(Xl, [U[a:b] for a, b in cuts])
-    for opts in (dict(kmeans="sklearn"), dict(pinv="eigh"), dict(pinv="device"), dict(kmeans="sklearn", pinv="host")):
+    for opts in (dict(kmeans="sklearn"), dict(pinv="eigh"), dict(pinv="auto"), dict(pinv="device"), dict(kmeans="sklearn", pinv="host")):
         m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=k, gamma=gamma, ridge=ridge, **opts)
         m.fit_multi(Xl, Ul)
         assert rel_err(m.centers_, ref.centers_) < 1e-9, opts

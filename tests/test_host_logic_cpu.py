@@ -260,3 +260,29 @@ def test_bench_compact_line_of_a_recorded_run_fits_the_driver(record):
     d["config"]["workload"] = d["config"]["workload"] + " x" * 3000
     c = bench.compact_line(d, "bench_details.json")
     assert len(json.dumps(c, separators=(",", ":"))) <= 4096 and "roofline" in c and "cpu_baseline" in c
+
+
+def test_default_solve_is_numpy_pinv_wherever_the_route_matters():
+    """engine._host_pinv("auto") -- the class default -- on the NumPy oracle's Gram of the ill-conditioned fixture (class-default ridge 1e-8,
+    gamma 0.05: smallest eigenvalue 2.7e-12 of the largest): bit for bit numpy.linalg.pinv, the reference's call
+    (Koopman/koopmanEDMDc.py:97), and the reference's scores follow; at gamma 0.2 (2.5e-9) the symmetric eigendecomposition is taken
+    and gives the same scores to 1e-9.  The unconditional "eigh" route at gamma 0.05 is measurably off (that was round 5's default)."""
+    from oracle import edmdc_numpy as ek
+    from bluerov2_dynamics_amd import engine
+    e, z = load_golden("edmdc_fit.npz"), load_golden("edmdc_illcond.npz")
+    X, U, ntr = e["X"], e["U"], int(e["n_train"])
+    for tag, takes_pinv in (("g005", True), ("g02", False)):
+        gamma, C, ridge = float(z[f"{tag}_gamma"]), z[f"{tag}_centers"], 1e-8
+        Z, Zp = ek.lift(X[:ntr - 1], C, gamma), ek.lift(X[1:ntr], C, gamma)
+        G = np.hstack([Z, U[:ntr - 1]])
+        GtG = G.T @ G
+        ratio = float(z[f"{tag}_eig_min_over_max"])
+        assert (ratio < engine.PINV_AUTO_SAFE) == takes_pinv
+        Pa, Ph, Pe = (engine._host_pinv(GtG, ridge, how) for how in ("auto", "host", "eigh"))
+        assert np.array_equal(Pa, Ph if takes_pinv else Pe)
+        M = (Pa @ G.T @ Zp).T
+        A, B = M[:, :Z.shape[1]], M[:, Z.shape[1]:]
+        sc = np.array([ek.multistep_rmse(X[ntr:], U[ntr:], C, gamma, A, B, H) for H in (1, 10, 100)])
+        assert np.max(np.abs(sc - z[f"{tag}_ms_rmse"]) / np.maximum(1.0, z[f"{tag}_ms_rmse"])) < 1e-9, tag
+    with pytest.raises(ValueError):
+        engine._host_pinv(np.eye(3), 0.1, "svd")

@@ -15,6 +15,7 @@ Fixtures (all float64):
   edmdc.npz             KoopmanEDMDc fit / fit_multi / evaluate / multistep_rmse / simulate
   edmdc_fit.npz         KoopmanEDMDc.fit at the class defaults (k=200, ridge=1e-8) and the tank script's settings (k=500, gamma=3,
                         ridge=0.1) on 10 000 samples: the cases where fit()'s own product order matters
+  edmdc_illcond.npz     KoopmanEDMDc.fit at the class defaults with a wide kernel (gamma 0.05 / 0.2) on edmdc_fit.npz's rows: cond ~ 1e14
   di.npz                learned double-integrator baseline (gains, rollouts, windowed RMSE)
   torch_rhs.npz         fossen/bluerov_torch.py bluerov_compute / ssa on random batches
   simscript.npz         training/train_sim_brov2_koopmanEDMDc.py's data loop + scores (numpy global RNG, seed 42), shortened
@@ -366,6 +367,29 @@ def gen_edmdc_fit():
     np.savez(os.path.join(OUT, "edmdc_fit.npz"), **out)
 
 
+def gen_edmdc_illcond():
+    """KoopmanEDMDc.fit at the class defaults (n_rbfs=200, ridge=1e-8, Koopman/koopmanEDMDc.py:56-61) with a WIDE kernel (gamma 0.05:
+    near-duplicate RBF columns), on the training rows of edmdc_fit.npz (no new data stored): cond(G^T G + ridge I) ~ 1e14, the regime
+    where the route of the p x p solve (numpy.linalg.pinv's SVD, :97, against a symmetric eigendecomposition) shows in the scores."""
+    e = np.load(os.path.join(OUT, "edmdc_fit.npz"))
+    X, U, ntr = e["X"], e["U"], int(e["n_train"])
+    Xt, Ut = X[ntr:], U[ntr:]
+    out = {}
+    for tag, gamma in (("g005", 0.05), ("g02", 0.2)):
+        m = RefKoopman(state_dim=12, input_dim=8, n_rbfs=200, gamma=gamma)
+        m.fit(X[:ntr], U[:ntr])
+        Z = m._lift(X[:ntr - 1])
+        G = np.hstack([Z, U[:ntr - 1]])
+        w = np.linalg.eigvalsh(G.T @ G + m.ridge * np.eye(G.shape[1]))
+        out.update({f"{tag}_gamma": np.float64(gamma), f"{tag}_ridge": np.float64(m.ridge), f"{tag}_k": np.int64(200), f"{tag}_centers": m.centers_,
+                    f"{tag}_eig_min_over_max": np.float64(w.min() / w.max()), f"{tag}_eig_max": np.float64(w.max()),
+                    f"{tag}_A_fro": np.float64(np.linalg.norm(m.A_)), f"{tag}_B_fro": np.float64(np.linalg.norm(m.B_)),
+                    f"{tag}_train_ms_rmse": np.array([m.multistep_rmse(X[:ntr], U[:ntr], H) for H in (1, 10, 100)]),
+                    f"{tag}_ms_rmse": np.array([m.multistep_rmse(Xt, Ut, H) for H in (1, 10, 100)])})
+    out["versions"] = versions()
+    np.savez(os.path.join(OUT, "edmdc_illcond.npz"), **out)
+
+
 # --------------------------------------------------------------------------- double integrator
 def gen_di():
     """Learned double-integrator baseline of the comparison scripts: estimate_di_gains,
@@ -576,7 +600,7 @@ def gen_kmeans_empty():
     np.savez_compressed(os.path.join(OUT, "kmeans_empty.npz"), versions=versions(), **out)
 
 
-GENS = dict(kmeans_empty=gen_kmeans_empty, cfg5_pinc=gen_cfg5_pinc, torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
+GENS = dict(edmdc_illcond=gen_edmdc_illcond, kmeans_empty=gen_kmeans_empty, cfg5_pinc=gen_cfg5_pinc, torchrhs=gen_torchrhs, cfg5w=gen_cfg5w, simscript=gen_simscript, cfg5=gen_cfg5, di=gen_di, constants=gen_constants, rhs=gen_rhs_kat, rollouts=gen_rollouts, windows=gen_windows, edmdc=gen_edmdc, edmdc_fit=gen_edmdc_fit)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
