@@ -317,6 +317,9 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
                                       "source": "training/best_results.txt:761,798; BASELINE.md sections 1-2"}}
     child = os.path.join(REPO, "tools", "bench_fit_child.py")
     tmpd = tempfile.mkdtemp(prefix="brov2_bench_")
+    # the three ways a process can hold the library (bluerov2_dynamics_amd/_lib.py: _one_hip_runtime): the default -- torch is not
+    # imported, device memory through the C ABI --, the same on /opt/rocm's HIP runtime, and the torch-tensor path of rounds 1-5
+    modes = (("torch_free", "auto", "native"), ("torch_free_rocm_runtime", "0", "native"), ("torch_tensors", "1", "torch"))
     try:
         runs = {}
         for tag, rows in (("N45823", N), ("train36658", int(0.8 * N))):
@@ -325,12 +328,13 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
             if tag == "N45823":
                 kw.update(Xq=Xq[:rows], Uq=Uq[:rows])
             np.savez(path, **kw)
-            for pinv in (("eigh", "host", "device") if tag == "N45823" else ("eigh",)):
+            for mode, env_torch, arrays in (modes if tag == "N45823" else modes[:1]):
                 t0 = time.perf_counter()
-                pr = subprocess.run([sys.executable, child, "gpu", path, pinv], capture_output=True, text=True, timeout=600)
+                pr = subprocess.run([sys.executable, child, "gpu", path, "auto", arrays], capture_output=True, text=True, timeout=600,
+                                    env=dict(os.environ, BROV2_TORCH=env_torch))
                 wall = time.perf_counter() - t0
                 if pr.returncode != 0:
-                    runs[f"{tag}_pinv_{pinv}"] = {"error": pr.stderr[-400:]}
+                    runs[f"{tag}_{mode}"] = {"error": pr.stderr[-400:]}
                     continue
                 r_ = json.loads(pr.stdout.strip().splitlines()[-1])
                 r_["child_wall_s"] = wall
@@ -342,7 +346,7 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
                         r_[c_]["warm_call_median_s"] = float(np.median(f_[1:]))
                         r_[c_]["samples_per_s_warm"] = (r_[c_]["rows"] - 1) / min(f_[1:])
                         r_[c_]["samples_per_s_first_call"] = (r_[c_]["rows"] - 1) / f_[0]
-                runs[f"{tag}_pinv_{pinv}"] = r_
+                runs[f"{tag}_{mode}"] = r_
             if want_cpu and tag == "N45823":
                 env = dict(os.environ, OMP_NUM_THREADS="4", LOKY_MAX_CPU_COUNT="8")
                 t0 = time.perf_counter()
@@ -359,23 +363,23 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
                 else:
                     leg["cpu_baseline"] = {"error": pr.stderr[-400:]}
         leg["runs"] = runs
-        h = runs.get("N45823_pinv_eigh", {}).get("thruster_12_8")          # the shipped default
-        ref_ = runs.get("N45823_pinv_host", {}).get("thruster_12_8")        # numpy.linalg.pinv itself: the reference's call
-        if ref_:
-            opts = {}
-            for how in ("eigh", "host", "device"):
-                o_ = runs.get(f"N45823_pinv_{how}", {}).get("thruster_12_8")
-                if o_:
-                    opts[how] = {"first_call_s": o_["first_call_s"], "warm_call_s": o_["warm_call_s"], "warm_call_median_s": o_["warm_call_median_s"],
-                                 "max_abs_drmse_H1_10_100_vs_numpy_pinv": float(np.max(np.abs(np.array(o_["multistep_rmse_H1_10_100"]) - np.array(ref_["multistep_rmse_H1_10_100"]))))}
-            leg["pinv_options"] = {**opts, "default": "eigh",
-                                   "note": "same data, same centres (the device k-means is bit-reproducible): the scores differ by the p x p solve alone; "
-                                           "'eigh' = symmetric eigendecomposition on the host with numpy.linalg.pinv's cut-off (default), 'host' = "
-                                           "numpy.linalg.pinv (the reference's call), 'device' = torch.linalg.eigh on the GPU (first call +0.2 s)"}
+        first = {}
+        for mode, _, _ in modes:
+            run = runs.get(f"N45823_{mode}", {})
+            h_ = run.get("thruster_12_8")
+            if h_:
+                first[mode] = {"first_call_s": h_["first_call_s"], "warm_call_s": h_["warm_call_s"], "warm_call_median_s": h_["warm_call_median_s"],
+                               "process_start_to_first_fit_done_s": h_["process_start_to_first_fit_done_s"], "torch_imported": run.get("torch_imported"),
+                               "hip_runtime": run.get("hip_runtime"), "first_fit_AB_sha256": run.get("first_fit_AB_sha256"),
+                               "multistep_rmse_H1_10_100": h_["multistep_rmse_H1_10_100"]}
+        leg["first_calls"] = first
+        shas = {v["first_fit_AB_sha256"] for v in first.values()}
+        leg["AB_bit_equal_across_modes"] = bool(len(first) == len(modes) and len(shas) == 1)
+        h = runs.get("N45823_torch_free", {}).get("thruster_12_8")          # the shipped default
         if h:
             leg["value"] = h["samples_per_s_warm"]
             leg["unit"] = "samples/s"
-            leg["metric"] = "KoopmanEDMDc.fit samples/s at the reference's logged size (host arrays, fastest of six warm calls; median and first call beside it)"
+            leg["metric"] = "KoopmanEDMDc.fit samples/s at the reference's logged size (host arrays, torch-free process, fastest of six warm calls; median and first call beside it)"
             leg["vs_reference_logs"] = {"first_call_vs_authors_2.302s": 2.302 / h["first_call_s"], "warm_call_vs_authors_2.302s": 2.302 / h["warm_call_s"],
                                         "first_call_vs_survey_container_5.34s": 5.34 / h["first_call_s"],
                                         "note": "other hardware: orientation only (BASELINE.json publishes no number for this metric)"}

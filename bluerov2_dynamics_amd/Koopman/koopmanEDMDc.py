@@ -21,6 +21,9 @@ What runs where:
   * evaluate / multistep_rmse / simulate: H-step propagation Z <- Z A^T + U B^T as fp64 MFMA GEMMs
     (csrc/propagate.hip).
 Unlike the reference, importing this module does not set OMP_NUM_THREADS / LOKY_MAX_CPU_COUNT.
+Like the reference's module (numpy + scikit-learn only, Koopman/koopmanEDMDc.py:17,26-30), this one needs no torch: the library is
+bound through ctypes and device memory comes from its own C ABI (engine.DevArray); torch is imported only if the caller asks for
+arrays="torch" / pinv="device" or has imported it already (see _lib._one_hip_runtime).
 """
 from dataclasses import dataclass
 
@@ -65,6 +68,8 @@ class KoopmanEDMDc:
     pinv: str = "auto"                  # the p x p solve (engine._host_pinv): "auto" = numpy.linalg.pinv like the reference (:97) unless G^T G + ridge I
                                         # is comfortably conditioned (then a symmetric eigendecomposition: same scores to 1e-10, half the time);
                                         # "host" = numpy.linalg.pinv always; "eigh" = the eigendecomposition always (speed, opt-in)
+    arrays: str = "native"              # device-resident operands of fit / fit_multi: "native" = engine.DevArray through the C ABI (no torch),
+                                        # "torch" = torch CUDA tensors (same launches, same bits)
 
     # ------------------------------------------------------------------ fitting
     def fit(self, X, U, centers=None) -> None:
@@ -79,16 +84,26 @@ class KoopmanEDMDc:
             self._solve([X], [U], fit_order=True)
             return
         # one upload of the samples; centres, Gram and the two products of (P G^T) Y all read them where they lie in HBM
-        # (round 2 uploaded X three times and went through three host entry points)
-        import torch
-        dev = torch.device("cuda", engine.default_context().device)
-        Xd = torch.from_numpy(np.ascontiguousarray(X)).to(dev)
-        Ud = torch.from_numpy(np.ascontiguousarray(U[:N - 1])).to(dev)
-        Cd = None if centers is None else torch.from_numpy(np.ascontiguousarray(np.asarray(centers, dtype=float))).to(dev)
+        # (round 2 uploaded X three times and went through three host entry points).  No torch on this path (round 6): the
+        # buffers are brov_malloc'ed, the copies and launches go through the C ABI on the ctx's own stream.
+        ctx = engine.default_context()
+        ns = self._arrays(ctx)
+        Xd = ns.upload(X)
+        Ud = ns.upload(U[:N - 1])
+        Cd = None if centers is None else ns.upload(np.asarray(centers, dtype=float))
         k = self.n_rbfs if centers is None else Cd.shape[0]
-        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=engine.default_context(), pinv=self.pinv)
-        self.centers_ = C.cpu().numpy() if centers is None else np.asarray(centers, dtype=float)
+        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=ctx, pinv=self.pinv)
+        self.centers_ = ns.download(C) if centers is None else np.asarray(centers, dtype=float)
         self.lift_dim_ = self.state_dim + self.centers_.shape[0]
+
+    def _arrays(self, ctx):
+        """where fit / fit_multi keep their device-resident operands: engine.DevArray (default; no torch anywhere) or torch CUDA tensors
+        (arrays="torch", and always for pinv="device", which is torch.linalg.eigh) -- the same kernels with the same arguments."""
+        if self.arrays == "torch" or self.pinv == "device":
+            return engine._TorchArrays(ctx)
+        if self.arrays != "native":
+            raise ValueError("arrays must be 'native' or 'torch'")
+        return engine._NativeArrays(ctx)
 
     def fit_multi(self, X_list, U_list, centers=None) -> None:
         """Fit from several independent trajectories without cross-bag transitions (reference :113-152).  The list may be ragged
@@ -100,19 +115,19 @@ class KoopmanEDMDc:
         for X, U in zip(X_list, U_list):
             assert X.shape[1] == n and U.shape[1] == r
         ctx = engine.default_context()
-        Xd, Ud, off = engine.upload_bags(X_list, U_list, n, r, ctx=ctx)
+        ns = self._arrays(ctx)
+        Xd, Ud, off = engine.upload_bags(X_list, U_list, n, r, ctx=ctx, arrays=ns.kind)
         lens = np.diff(off)
         if off[-1] == 0 or not (lens >= 2).any():
             # np.vstack of an empty list (reference :125 when every bag is empty, :140 when no bag holds a pair)
             raise ValueError("need at least one array to concatenate")
         if centers is None and self.kmeans == "sklearn":
-            centers = _kmeans_centers(Xd.cpu().numpy(), self.n_rbfs, "sklearn")
-        import torch
-        Cd = None if centers is None else torch.from_numpy(np.ascontiguousarray(np.asarray(centers, dtype=float))).to(Xd.device)
+            centers = _kmeans_centers(ns.download(Xd), self.n_rbfs, "sklearn")
+        Cd = None if centers is None else ns.upload(np.asarray(centers, dtype=float))
         k = self.n_rbfs if centers is None else Cd.shape[0]
         self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 0, 0, k, self.gamma, self.ridge, order="fit_multi", centers=Cd, ctx=ctx, pinv=self.pinv,
                                              bag_offsets=off)
-        self.centers_ = C.cpu().numpy() if centers is None else np.asarray(centers, dtype=float)
+        self.centers_ = ns.download(C) if centers is None else np.asarray(centers, dtype=float)
         self.lift_dim_ = self.state_dim + self.centers_.shape[0]
 
     def _solve(self, X_list, U_list, fit_order=False):

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.environ.get("BROV2_LIBRARY") or os.path.join(PKG, "libbrov2.so")     # override: A/B runs of experimental builds
-SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "kmeans.hip", "sortperm.hip", "controls.hip", "comm.hip"]
+SOURCES = ["capi.hip", "rollout.hip", "edmdc.hip", "propagate.hip", "kmeans.hip", "sortperm.hip", "controls.hip", "comm.hip", "colstats.hip"]
 HEADERS = ["brov2_device.h", "brov2_fast.h", "brov2_kernels.h", os.path.join("..", "..", "include", "brov2.h")]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-DBROV2_BUILDING=1"]
 LDFLAGS = ["--offload-arch=gfx950", "-shared", "-fPIC", "-ldl"]      # dl: librccl is bound at run time (comm.hip)

@@ -93,6 +93,8 @@ SIGNATURES = {
     "brov_memcpy_h2d": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "brov_memcpy_d2h": (ctypes.c_int, [c_void_p, c_void_p, c_void_p, ctypes.c_size_t]),
     "brov_memset": (ctypes.c_int, [c_void_p, c_void_p, ctypes.c_int, ctypes.c_size_t]),
+    "brov_mem_info": (ctypes.c_int, [c_void_p, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
+    "edmdc_col_stats_dev": (ctypes.c_int, [c_void_p, i64, ctypes.c_int, c_void_p, i64, c_void_p, c_void_p]),
     "brov_rhs": (ctypes.c_int, [c_void_p, ctypes.c_int, i64, c_void_p, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
     "brov_thruster_forces": (ctypes.c_int, [c_void_p, i64, c_void_p, ctypes.c_double, c_void_p, c_void_p]),
     "brov_rollout": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, i64, i64,
@@ -168,9 +170,53 @@ def library_path():
     return _build.LIB
 
 
+hip_runtime = None        # how load_library() settled the HIP runtime question (diagnostics; see _one_hip_runtime)
+
+
+def _one_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (SONAME libamdhip64.so.7, like /opt/rocm's) and links
+    it by the unversioned name: if libbrov2.so has pulled in /opt/rocm's copy first, a later `import torch` loads its own as a SECOND
+    runtime and finds no GPU.  The drop-in classes themselves need no torch (north_star: torch only on the PINc path), and importing it
+    costs ~0.8 s of a script's first second, so by default torch is NOT imported here:
+      * torch already imported by the caller (the reference's PINc scripts import it at the top): nothing to do, its runtime serves both;
+      * BROV2_TORCH=auto (default), torch installed but not imported: only torch's libamdhip64.so is loaded (the very file torch would
+        load -- the loader recognises it by inode), so a later `import torch` still shares the runtime.  Caveat, measured with
+        tools/time_late_torch.py: once the runtime has been INITIALISED (a Context exists), HIP registers torch's code objects eagerly and
+        that later import takes ~10 s instead of ~0.8 s -- a script that wants torch should import it before its first use of this package;
+      * BROV2_TORCH=1: import torch here, first (the behaviour up to round 5);
+      * BROV2_TORCH=0: never look for torch; libbrov2.so binds /opt/rocm's runtime (a later `import torch` in the same process would then
+        not see the GPU)."""
+    import sys
+    if "torch" in sys.modules:
+        return "torch (imported by the caller)"
+    mode = os.environ.get("BROV2_TORCH", "auto").strip().lower()
+    if mode in ("1", "import", "yes", "true"):
+        try:
+            import torch  # noqa: F401
+            return "torch (imported by load_library: BROV2_TORCH=1)"
+        except ImportError:
+            return "system (BROV2_TORCH=1 but torch is not installed)"
+    if mode in ("0", "no", "never", "false"):
+        return "system (BROV2_TORCH=0)"
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")          # locates the package; imports nothing
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+                return "torch's libamdhip64.so preloaded (torch itself not imported)"
+            except OSError:
+                pass
+    return "system"
+
+
 def load_library():
     """dlopen libbrov2.so (needs libamdhip64; no GPU needed just to load) and bind every symbol."""
-    global _lib
+    global _lib, hip_runtime
     with _lib_lock:
         if _lib is not None:
             return _lib
@@ -179,15 +225,7 @@ def load_library():
             raise BrovError(
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
-        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 (same SONAME as /opt/rocm's).  Whichever is
-        # loaded first serves both; with /opt/rocm's first, torch later finds no GPU.  So torch, when installed, goes first.
-        # (Pre-loading only torch's libamdhip64 and leaving `import torch` to whoever needs it was measured and dropped:
-        # once the runtime is initialised, a later `import torch` registers its code objects eagerly and takes 10.4 s instead
-        # of 0.76 s -- tools/time_late_torch.py.)
-        try:
-            import torch  # noqa: F401
-        except ImportError:
-            pass
+        hip_runtime = _one_hip_runtime()
         lib = ctypes.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)   # AttributeError = ABI mismatch, fail loudly

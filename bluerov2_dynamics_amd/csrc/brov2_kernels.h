@@ -103,6 +103,15 @@ hipError_t launch_useq_t(hipStream_t st, const PropShape& s, int64_t T, const do
 int window_scan_chunk();
 hipError_t launch_sum(hipStream_t st, int64_t n, const double* v, double* out);
 
+// ---- column statistics (colstats.hip) -------------------------------------------------------
+// partial [colstats_blocks(N)][16]: per-block sums of x (squares = false) or of (x - d_shift)^2 (squares = true) per column
+int colstats_blocks(int64_t N);
+hipError_t launch_colstats(hipStream_t st, int64_t N, int n, const double* X, int64_t xstride, const double* d_shift, bool squares,
+                           double* d_partial);
+
+// copy by the shader cores, 16-byte words (both pointers 16-byte aligned, bytes a multiple of 16); src or dst may be pinned host memory
+hipError_t launch_copy_bytes(hipStream_t st, void* dst, const void* src, size_t bytes);
+
 // ---- k-means (kmeans.hip) ------------------------------------------------------------------
 int kmeans_blocks(int64_t N, int n, int k, bool scalar_records);
 int kmeans_epochs(int64_t N, int n, int k, bool scalar_records);

@@ -11,6 +11,8 @@
 #include <string>
 #include <ctime>
 #include <thread>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/brov2.h"
@@ -67,6 +69,9 @@ struct brov_ctx {
     double* h_io = nullptr;           // pinned, device-mapped staging of the per-call entry points (brov_rhs / brov_thruster_forces with a
     double* d_io = nullptr;           // handful of vehicles): the kernel reads and writes host memory, no copy calls; d_io = its device alias
     unsigned long long io_seq = 0;    // sequence number of the last per-call launch (completion flags at the end of the staging block)
+    std::vector<std::pair<void*, size_t>> pool;   // freed brov_malloc blocks kept for the next request (brov_malloc / brov_free)
+    std::unordered_map<void*, size_t> live;       // blocks handed out by brov_malloc: their sizes
+    size_t pool_bytes = 0;
     char* h_stage[2] = {nullptr, nullptr};        // pinned staging blocks of brov_upload_bags (created on first use)
     hipEvent_t ev_stage[2] = {nullptr, nullptr};  // "the DMA that read block i has finished"
     int upload_threads = 0;                       // host threads packing a block (0 = not probed yet)
@@ -108,6 +113,11 @@ enum : int {
     KMV_ACCEPTED = KMV_PUBLIC,
 #endif
 };
+
+// host <-> device copies of the ctx (defined with the device memory helpers below): through the ctx's pinned blocks, never by
+// handing pageable memory to the runtime in the size range it would pin in place
+static hipError_t h2d_copy(brov_ctx* c, void* dst, const void* src, size_t bytes);
+static hipError_t d2h_copy(brov_ctx* c, void* dst, const void* src, size_t bytes);
 
 namespace {
 
@@ -397,7 +407,7 @@ int get_dp(brov_ctx* c, double dt, const DevParams** out) {
         derive_fast(c->params, c->dp, c->fp);
         if (!c->d_fp) HIPCK(c, hipMalloc((void**)&c->d_fp, sizeof(FastParams)));
         // stream ordered: kernels already queued keep the old constants; c->fp outlives the copy (sync below)
-        HIPCK(c, hipMemcpyAsync(c->d_fp, &c->fp, sizeof(FastParams), hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, h2d_copy(c, c->d_fp, &c->fp, sizeof(FastParams)));
         HIPCK(c, hipStreamSynchronize(c->stream));
         c->dp_dt = dt;
         c->dp_valid = true;
@@ -508,10 +518,13 @@ int brov_create(int device_id, brov_ctx** out) {
     return BROV_OK;
 }
 
+static void pool_release(brov_ctx* c);
+
 void brov_destroy(brov_ctx* c) {
     if (!c) return;
     DeviceGuard g(c);
     (void)hipStreamSynchronize(c->stream);
+    pool_release(c);
     if (c->scratch) (void)hipFree(c->scratch);
     for (int m = 0; m < 3; ++m) if (c->d_tasks[m]) (void)hipFree(c->d_tasks[m]);
     if (c->d_fp) (void)hipFree(c->d_fp);
@@ -615,33 +628,141 @@ int brov_discretise_lag(const brov_params* p, double dt, double Ad[9], double Bd
 }
 
 // ---- device memory helpers ------------------------------------------------------------------
+// brov_malloc / brov_free keep freed blocks in a small per-ctx pool (like any caching allocator): a fit() of the drop-in class
+// allocates and releases the same handful of buffers on every call (hipMalloc + hipFree of 4 MB: 0.3 ms a pair, six pairs per fit at
+// the recorded size; a pooled pair: 0.02 ms).  A request takes the smallest pooled block of at least its size and at most twice its
+// size (+ 1 MB); blocks above POOL_BLOCK_MAX or beyond POOL_TOTAL_MAX in total go back to the driver at once.
+constexpr size_t POOL_BLOCK_MAX = (size_t)256 << 20;
+constexpr size_t POOL_TOTAL_MAX = (size_t)1 << 30;
+
+static void pool_release(brov_ctx* c) {
+    for (auto& b : c->pool) (void)hipFree(b.first);
+    c->pool.clear();
+    c->pool_bytes = 0;
+}
+
 int brov_malloc(brov_ctx* c, size_t bytes, void** dptr) {
     if (!c || !dptr) return BROV_ERR_ARG;
     DeviceGuard g(c);
     *dptr = nullptr;
     if (bytes == 0) return BROV_OK;
-    HIPCK(c, hipMalloc(dptr, bytes));
+    const size_t want = (bytes + 255) & ~(size_t)255;
+    int best = -1;
+    for (int i = 0; i < (int)c->pool.size(); ++i)
+        if (c->pool[i].second >= want && c->pool[i].second <= 2 * want + ((size_t)1 << 20) && (best < 0 || c->pool[i].second < c->pool[best].second)) best = i;
+    if (best >= 0) {
+        *dptr = c->pool[best].first;
+        c->live[*dptr] = c->pool[best].second;
+        c->pool_bytes -= c->pool[best].second;
+        c->pool.erase(c->pool.begin() + best);
+        return BROV_OK;
+    }
+    hipError_t e = hipMalloc(dptr, want);
+    if (e == hipErrorOutOfMemory && !c->pool.empty()) {        // give the pooled blocks back and try once more
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(c->stream);
+        pool_release(c);
+        e = hipMalloc(dptr, want);
+    }
+    if (e != hipSuccess) { *dptr = nullptr; return hip_fail(c, e, "hipMalloc"); }
+    c->live[*dptr] = want;
     return BROV_OK;
 }
 int brov_free(brov_ctx* c, void* dptr) {
     if (!c) return BROV_ERR_ARG;
     DeviceGuard g(c);
     lift_cache_touch(c, dptr);
-    if (dptr) HIPCK(c, hipFree(dptr));
+    if (!dptr) return BROV_OK;
+    auto it = c->live.find(dptr);
+    if (it == c->live.end()) { HIPCK(c, hipFree(dptr)); return BROV_OK; }        // not one of ours (never handed out by brov_malloc)
+    const size_t sz = it->second;
+    c->live.erase(it);
+    // whoever frees a block may still have work queued on it: the next owner's work is ordered behind it only on the same stream
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    if (sz <= POOL_BLOCK_MAX && c->pool_bytes + sz <= POOL_TOTAL_MAX) {
+        c->pool.emplace_back(dptr, sz);
+        c->pool_bytes += sz;
+        return BROV_OK;
+    }
+    HIPCK(c, hipFree(dptr));
     return BROV_OK;
 }
+// ---- host <-> device copies through the ctx's own pinned blocks -----------------------------------------------------------------
+// A hipMemcpyAsync from / to PAGEABLE host memory of more than a few pages is served by registering that memory with the driver (a
+// "userptr" mapping) for the DMA.  When the memory is released shortly afterwards -- a NumPy temporary, a std::vector of this file --
+// its unmapping invalidates the registration, and the kernel driver reacts by EVICTING every queue of the process and restoring them
+// some milliseconds later: the next kernel or DMA of the process, whatever it is, waits 12-28 ms (tools/time_first_fit.py,
+// profiles/r06_fit_time.txt: a third of a warm KoopmanEDMDc.fit() at the reference's recorded size; gone with single-threaded BLAS only
+// because the allocator then stops unmapping; not an SDMA, allocation or CPU-quota effect -- each was ruled out by experiment).
+// So no pageable pointer of this size range reaches the runtime: copies between 64 KB and 16 MB go through the two pinned blocks the
+// ctx keeps anyway (created once, on first use) -- pack + one DMA, or DMA + unpack.  Smaller ones take the runtime's own small-copy
+// buffer; larger uploads are left to the runtime (pinned in place: 55 GB/s measured), larger downloads stream through the two blocks
+// alternately.
+constexpr size_t STAGE_BLOCK = (size_t)32 << 20;        // bytes per pinned staging block (== UPLOAD_BLOCK below)
+constexpr size_t STAGE_MIN = (size_t)64 << 10;
+constexpr size_t STAGE_DIRECT_UP = (size_t)16 << 20;
+
+static hipError_t ensure_stage(brov_ctx* c) {
+    for (int i = 0; i < 2; ++i) {
+        if (!c->h_stage[i]) { hipError_t e = hipHostMalloc((void**)&c->h_stage[i], STAGE_BLOCK, hipHostMallocDefault); if (e != hipSuccess) return e; }
+        if (!c->ev_stage[i]) { hipError_t e = hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming); if (e != hipSuccess) return e; }
+    }
+    return hipSuccess;
+}
+
+// memcpy with a few threads once it is worth starting them (>= 4 MB); a process that cannot start threads copies alone
+static void par_memcpy(brov_ctx* c, char* dst, const char* src, size_t bytes);
+
+#define HIPTRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return e__; } while (0)
+// Host -> device on the ctx stream.  Staged sizes are in place on return; the others are queued like a plain hipMemcpyAsync from pageable
+// memory (the runtime has consumed the source when the call returns).
+static hipError_t h2d_copy(brov_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes < STAGE_MIN || bytes >= STAGE_DIRECT_UP) return hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream);
+    HIPTRY(ensure_stage(c));
+    par_memcpy(c, c->h_stage[0], static_cast<const char*>(src), bytes);          // bytes < 16 MB: one block
+    HIPTRY(hipMemcpyAsync(dst, c->h_stage[0], bytes, hipMemcpyHostToDevice, c->stream));
+    return hipStreamSynchronize(c->stream);                                       // the block is free again
+}
+// Device -> host on the ctx stream.  Staged sizes are on the host on return; small ones are queued (the caller synchronises, as before).
+static hipError_t d2h_copy(brov_ctx* c, void* dst, const void* src, size_t bytes) {
+    if (bytes == 0) return hipSuccess;
+    if (bytes < STAGE_MIN) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+    HIPTRY(ensure_stage(c));
+    // block i is filled by the DMA engine while block i - 1 is unpacked: at most two copies in flight
+    size_t off = 0, out = 0, len[2] = {0, 0};
+    int nissued = 0, nunpacked = 0;
+    while (out < bytes) {
+        while (off < bytes && nissued - nunpacked < 2) {
+            const int s_ = nissued & 1;
+            len[s_] = std::min(STAGE_BLOCK, bytes - off);
+            HIPTRY(hipMemcpyAsync(c->h_stage[s_], static_cast<const char*>(src) + off, len[s_], hipMemcpyDeviceToHost, c->stream));
+            HIPTRY(hipEventRecord(c->ev_stage[s_], c->stream));
+            off += len[s_];
+            ++nissued;
+        }
+        const int s_ = nunpacked & 1;
+        HIPTRY(hipEventSynchronize(c->ev_stage[s_]));
+        par_memcpy(c, static_cast<char*>(dst) + out, c->h_stage[s_], len[s_]);
+        out += len[s_];
+        ++nunpacked;
+    }
+    return hipSuccess;
+}
+#undef HIPTRY
+
 int brov_memcpy_h2d(brov_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return BROV_ERR_ARG;
     DeviceGuard g(c);
     lift_cache_touch(c, dst);
-    HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dst, src, bytes));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
 int brov_memcpy_d2h(brov_ctx* c, void* dst, const void* src, size_t bytes) {
     if (!c || (bytes && (!dst || !src))) return BROV_ERR_ARG;
     DeviceGuard g(c);
-    HIPCK(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, dst, src, bytes));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -653,11 +774,18 @@ int brov_memset(brov_ctx* c, void* dst, int value, size_t bytes) {
     return BROV_OK;
 }
 
+int brov_mem_info(brov_ctx* c, size_t* free_bytes, size_t* total_bytes) {
+    if (!c || !free_bytes || !total_bytes) return BROV_ERR_ARG;
+    DeviceGuard g(c);
+    HIPCK(c, hipMemGetInfo(free_bytes, total_bytes));
+    return BROV_OK;
+}
+
 // ---- a list of host arrays into one device buffer (fit_multi's X_list / U_list) ------------------------------------------------
 // The reference stacks its trajectory list on the host (np.vstack, Koopman/koopmanEDMDc.py:125,140-142).  Here every bag goes
 // straight to its place in ONE device buffer: a few host threads pack the bags into a pinned block while the DMA engine moves the
 // block before it (two blocks in flight), so the list costs about one pass of host memcpy instead of a stack + a pageable upload.
-constexpr size_t UPLOAD_BLOCK = (size_t)32 << 20;       // bytes per pinned staging block
+constexpr size_t UPLOAD_BLOCK = STAGE_BLOCK;            // bytes per pinned staging block
 constexpr size_t UPLOAD_GAP_MAX = 4096;                 // a hole of at most this many bytes between two bags' destinations is zero-filled
 constexpr size_t UPLOAD_DIRECT_MIN = (size_t)16 << 20;  // a contiguous run this long skips the staging block (the runtime pins it in place)
 
@@ -676,6 +804,27 @@ static int upload_thread_count() {
     }
     if (n > 6) n = 6;                                   // the copy is memory-bound: more threads add nothing
     return n < 1 ? 1 : n;
+}
+
+static void par_memcpy(brov_ctx* c, char* dst, const char* src, size_t bytes) {
+    if (c->upload_threads == 0) c->upload_threads = upload_thread_count();
+    const int nt = (bytes >= ((size_t)4 << 20)) ? c->upload_threads : 1;
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes + nt - 1) / nt + 63) & ~(size_t)63;
+    size_t started = per;
+    try {
+        for (int t = 1; t < nt; ++t) {
+            const size_t lo = std::min(bytes, per * t), hi = std::min(bytes, per * (t + 1));
+            th.emplace_back([=]() { if (hi > lo) std::memcpy(dst + lo, src + lo, hi - lo); });
+            started = hi;
+        }
+    } catch (...) {
+        c->upload_threads = 1;
+    }
+    std::memcpy(dst, src, std::min(bytes, per));
+    if (started < bytes) std::memcpy(dst + started, src + started, bytes - started);
+    for (auto& t : th) t.join();
 }
 
 int brov_upload_bags(brov_ctx* c, int64_t nbags, const double* const* bag_ptrs, const int64_t* bag_rows, const int64_t* dst_rows,
@@ -701,10 +850,7 @@ int brov_upload_bags(brov_ctx* c, int64_t nbags, const double* const* bag_ptrs, 
     if (pieces.empty()) return BROV_OK;
     DeviceGuard g(c);
     lift_cache_touch(c, d_dst);
-    for (int i = 0; i < 2; ++i) {
-        if (!c->h_stage[i]) HIPCK(c, hipHostMalloc((void**)&c->h_stage[i], UPLOAD_BLOCK, hipHostMallocDefault));
-        if (!c->ev_stage[i]) HIPCK(c, hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
-    }
+    HIPCK(c, ensure_stage(c));
     if (c->upload_threads == 0) c->upload_threads = upload_thread_count();
     // a block = consecutive (parts of) pieces whose destinations are contiguous up to small holes: one DMA per block
     struct Part { const char* src; size_t bytes; size_t at; };          // at = offset in the staging block; src == nullptr: zeros
@@ -899,15 +1045,15 @@ int brov_rhs(brov_ctx* c, int model, int64_t B, const double* x, const double* u
     double* du = a.take<double>(B * nu);
     double* dxd = a.take<double>(B * nx);
     double* dl = lag ? a.take<double>(B * 24) : nullptr;
-    HIPCK(c, hipMemcpyAsync(dx, x, B * nx * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(du, u, B * nu * 8, hipMemcpyHostToDevice, c->stream));
-    if (lag) HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dx, x, B * nx * 8));
+    HIPCK(c, h2d_copy(c, du, u, B * nu * 8));
+    if (lag) HIPCK(c, h2d_copy(c, dl, lag_io, B * 24 * 8));
     {
         CallTimer t(c);
         HIPCK(c, launch_rhs(c->stream, *dp, model, B, dx, du, dl, dxd));
     }
-    HIPCK(c, hipMemcpyAsync(xdot, dxd, B * nx * 8, hipMemcpyDeviceToHost, c->stream));
-    if (lag) HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, xdot, dxd, B * nx * 8));
+    if (lag) HIPCK(c, d2h_copy(c, lag_io, dl, B * 24 * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -944,14 +1090,14 @@ int brov_thruster_forces(brov_ctx* c, int64_t B, const double* u, double dt, dou
     double* du = a.take<double>(B * 8);
     double* dl = a.take<double>(B * 24);
     double* dt_ = a.take<double>(B * 6);
-    HIPCK(c, hipMemcpyAsync(du, u, B * 8 * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, du, u, B * 8 * 8));
+    HIPCK(c, h2d_copy(c, dl, lag_io, B * 24 * 8));
     {
         CallTimer t(c);
         HIPCK(c, launch_thruster_forces(c->stream, *dp, B, du, dl, dt_));
     }
-    HIPCK(c, hipMemcpyAsync(tau, dt_, B * 6 * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, tau, dt_, B * 6 * 8));
+    HIPCK(c, d2h_copy(c, lag_io, dl, B * 24 * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -976,7 +1122,7 @@ int brov_set_di_gains(brov_ctx* c, int nu, const double* K_lin, const double* K_
     for (int i = 0; i < nu; ++i)
         for (int k = 0; k < 3; ++k) { f.Tm[k][i] = K_lin[3 * i + k]; f.Tm[3 + k][i] = K_ang[3 * i + k]; }
     if (!c->d_fp_di) HIPCK(c, hipMalloc((void**)&c->d_fp_di, sizeof(FastParams)));
-    HIPCK(c, hipMemcpyAsync(c->d_fp_di, &f, sizeof f, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, c->d_fp_di, &f, sizeof f));
     HIPCK(c, hipStreamSynchronize(c->stream));
     c->di_set = true;
     return BROV_OK;
@@ -1025,14 +1171,14 @@ int brov_rollout(brov_ctx* c, int model, int integ, int lag_mode, int layout, in
     double* dxT = a.take<double>(B * nx);
     double* dl = lag ? a.take<double>(B * 24) : nullptr;
     double* dtr = traj ? a.take<double>((size_t)B * rows * nxw) : nullptr;
-    HIPCK(c, hipMemcpyAsync(dx0, x0, B * nx * 8, hipMemcpyHostToDevice, c->stream));
-    if (T) HIPCK(c, hipMemcpyAsync(dU, U, (size_t)B * T * nuw * 8, hipMemcpyHostToDevice, c->stream));
-    if (lag) HIPCK(c, hipMemcpyAsync(dl, lag_io, B * 24 * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dx0, x0, B * nx * 8));
+    if (T) HIPCK(c, h2d_copy(c, dU, U, (size_t)B * T * nuw * 8));
+    if (lag) HIPCK(c, h2d_copy(c, dl, lag_io, B * 24 * 8));
     rc = brov_rollout_dev(c, model, integ, lag_mode, layout, B, T, dt, dx0, dU, dl, dtr, stride, dxT);
     if (rc) return rc;
-    if (xT) HIPCK(c, hipMemcpyAsync(xT, dxT, B * nx * 8, hipMemcpyDeviceToHost, c->stream));
-    if (lag) HIPCK(c, hipMemcpyAsync(lag_io, dl, B * 24 * 8, hipMemcpyDeviceToHost, c->stream));
-    if (traj) HIPCK(c, hipMemcpyAsync(traj, dtr, (size_t)B * rows * nxw * 8, hipMemcpyDeviceToHost, c->stream));
+    if (xT) HIPCK(c, d2h_copy(c, xT, dxT, B * nx * 8));
+    if (lag) HIPCK(c, d2h_copy(c, lag_io, dl, B * 24 * 8));
+    if (traj) HIPCK(c, d2h_copy(c, traj, dtr, (size_t)B * rows * nxw * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1065,7 +1211,7 @@ static int window_dev_impl(brov_ctx* c, int model, int integ, int64_t N, int64_t
         const int64_t spw = H * (integ == BROV_RK4 ? 4 : 1);
         lag_window_phi(*dp, spw, Phi);
         lag_window_phi(*dp, spw * window_scan_chunk(), Phi + 9);
-        HIPCK(c, hipMemcpyAsync(d_phi, Phi, sizeof Phi, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, h2d_copy(c, d_phi, Phi, sizeof Phi));
         HIPCK(c, hipStreamSynchronize(c->stream));   // Phi is a stack temporary
     }
     if (model_is_di_h(model) && !c->di_set) return fail(c, BROV_ERR_ARG, "double-integrator model: call brov_set_di_gains first");
@@ -1106,12 +1252,12 @@ int brov_window_endpoint_se(brov_ctx* c, int model, int integ, int64_t N, int64_
     double* dU = a.take<double>(N * nu);
     double* dse = a.take<double>(nwin);
     double* dtot = a.take<double>(8);
-    HIPCK(c, hipMemcpyAsync(dX, X, N * nx * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(dU, U, N * nu * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dX, X, N * nx * 8));
+    HIPCK(c, h2d_copy(c, dU, U, N * nu * 8));
     rc = window_dev_impl(c, model, integ, N, H, dt, dX, dU, carry_lag, dtot, dse, a);
     if (rc) return rc;
-    HIPCK(c, hipMemcpyAsync(se_total, dtot, 8, hipMemcpyDeviceToHost, c->stream));
-    if (per_window) HIPCK(c, hipMemcpyAsync(per_window, dse, nwin * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, se_total, dtot, 8));
+    if (per_window) HIPCK(c, d2h_copy(c, per_window, dse, nwin * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1161,13 +1307,13 @@ int edmdc_lift(brov_ctx* c, int64_t N, int n, int k, double gamma, const double*
     double* dX = a.take<double>(N * n);
     double* dC = a.take<double>((size_t)k * n);
     double* dZ = a.take<double>((size_t)N * (n + k));
-    HIPCK(c, hipMemcpyAsync(dX, X, N * n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dX, X, N * n * 8));
+    HIPCK(c, h2d_copy(c, dC, C, (size_t)k * n * 8));
     {
         CallTimer t(c);
         HIPCK(c, launch_lift_ref(c->stream, N, n, k, gamma, dX, dC, dZ));
     }
-    HIPCK(c, hipMemcpyAsync(Z, dZ, (size_t)N * (n + k) * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, Z, dZ, (size_t)N * (n + k) * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1250,7 +1396,7 @@ static int bag_pairflags(brov_ctx* c, Arena& a, const BagLayout& bl, const unsig
     if (!bl.ragged()) return BROV_OK;
     int64_t* d_off = a.take<int64_t>((size_t)bl.nbags + 1);
     unsigned char* pf = a.take<unsigned char>((size_t)bl.total_rows + 16);
-    HIPCK(c, hipMemcpyAsync(d_off, bl.offsets_host, (size_t)(bl.nbags + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, d_off, bl.offsets_host, (size_t)(bl.nbags + 1) * 8));
     HIPCK(c, launch_bag_pairflags(c->stream, bl.nbags, d_off, bl.total_rows, pf));
     HIPCK(c, hipStreamSynchronize(c->stream));  // the offsets are the caller's (host) array: it may go away when the call returns
     *out = pf;
@@ -1478,7 +1624,7 @@ static int apply_core(brov_ctx* c, int n, int r, int k, double gamma, const doub
                 if (rj >= 0) h[(size_t)f * W + j] = P_host[(size_t)rj * p + rf];
             }
         }
-        HIPCK(c, hipMemcpyAsync(dPt, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, h2d_copy(c, dPt, h.data(), h.size() * 8));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     HIPCK(c, hipMemsetAsync(dWr, 0, (size_t)(chunk + 8) * W * 8, c->stream));   // the Gram kernel prefetches up to 8 rows past the chunk
@@ -1542,13 +1688,13 @@ static int apply_host(brov_ctx* c, int n, int r, int k, double gamma, const doub
     HIPCK_CLEAN(hipMalloc((void**)&dU, (size_t)(urows > 0 ? urows : 1) * (r > 0 ? r : 1) * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dM, (size_t)p * d * 8));
-    if (xrows) HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)xrows * n * 8, hipMemcpyHostToDevice, c->stream));
-    if (urows && r) HIPCK_CLEAN(hipMemcpyAsync(dU, U, (size_t)urows * r * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK_CLEAN(hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (xrows) HIPCK_CLEAN(h2d_copy(c, dX, X, (size_t)xrows * n * 8));
+    if (urows && r) HIPCK_CLEAN(h2d_copy(c, dU, U, (size_t)urows * r * 8));
+    HIPCK_CLEAN(h2d_copy(c, dC, C, (size_t)k * n * 8));
     HIPCK_CLEAN(hipMemsetAsync(dM, 0, (size_t)p * d * 8, c->stream));
     int rc = apply_core(c, n, r, k, gamma, dC, bl, dX, dU, P, dM);
     if (rc) { cleanup(); return rc; }
-    HIPCK_CLEAN(hipMemcpyAsync(M, dM, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(d2h_copy(c, M, dM, (size_t)p * d * 8));
     HIPCK_CLEAN(hipStreamSynchronize(c->stream));
     cleanup();
     return BROV_OK;
@@ -1591,20 +1737,20 @@ static int gram_host(brov_ctx* c, int n, int r, int k, double gamma, const doubl
     HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dG, (size_t)p * p * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dY, (size_t)p * d * 8));
-    if (xrows) HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)xrows * n * 8, hipMemcpyHostToDevice, c->stream));
-    if (urows && r) HIPCK_CLEAN(hipMemcpyAsync(dU, U, (size_t)urows * r * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK_CLEAN(hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    if (xrows) HIPCK_CLEAN(h2d_copy(c, dX, X, (size_t)xrows * n * 8));
+    if (urows && r) HIPCK_CLEAN(h2d_copy(c, dU, U, (size_t)urows * r * 8));
+    HIPCK_CLEAN(h2d_copy(c, dC, C, (size_t)k * n * 8));
     if (accumulate) {
-        HIPCK_CLEAN(hipMemcpyAsync(dG, GtG, (size_t)p * p * 8, hipMemcpyHostToDevice, c->stream));
-        HIPCK_CLEAN(hipMemcpyAsync(dY, GtY, (size_t)p * d * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK_CLEAN(h2d_copy(c, dG, GtG, (size_t)p * p * 8));
+        HIPCK_CLEAN(h2d_copy(c, dY, GtY, (size_t)p * d * 8));
     } else {
         HIPCK_CLEAN(hipMemsetAsync(dG, 0, (size_t)p * p * 8, c->stream));
         HIPCK_CLEAN(hipMemsetAsync(dY, 0, (size_t)p * d * 8, c->stream));
     }
     int rc = gram_core(c, n, r, k, gamma, dC, bl, dX, dU, accumulate, dG, dY);
     if (rc) { cleanup(); return rc; }
-    HIPCK_CLEAN(hipMemcpyAsync(GtG, dG, (size_t)p * p * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCK_CLEAN(hipMemcpyAsync(GtY, dY, (size_t)p * d * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(d2h_copy(c, GtG, dG, (size_t)p * p * 8));
+    HIPCK_CLEAN(d2h_copy(c, GtY, dY, (size_t)p * d * 8));
     HIPCK_CLEAN(hipStreamSynchronize(c->stream));
     cleanup();
     return BROV_OK;
@@ -1641,7 +1787,7 @@ static int upload_ABt(brov_ctx* c, const PropShape& s, const double* A, const do
         for (int j = 0; j < s.d; ++j) h[(size_t)j * s.dpad + i] = A[(size_t)i * s.d + j];
         for (int j = 0; j < s.r; ++j) h[(size_t)(s.d + j) * s.dpad + i] = B[(size_t)i * s.r + j];
     }
-    HIPCK(c, hipMemcpyAsync(dABt, h.data(), h.size() * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dABt, h.data(), h.size() * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1671,15 +1817,15 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     double* dse = a.take<double>(nw);
     double* dxh = a.take<double>(nw * n);
     double* dtot = a.take<double>(8);
-    HIPCK(c, hipMemcpyAsync(dX, X, N * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dX, X, N * n * 8));
     // the windows read input rows 0 .. N-2 only (window k, step t uses U[k+t], k+t <= N-2): like the reference's
     // multistep_rmse / evaluate, accept a U with N-1 rows and never touch row N-1 of the caller's buffer
     const int64_t urows = N - 1;
     if (r) {
         HIPCK(c, hipMemsetAsync(dU + urows * r, 0, (size_t)r * 8, c->stream));
-        if (urows > 0) HIPCK(c, hipMemcpyAsync(dU, U, urows * r * 8, hipMemcpyHostToDevice, c->stream));
+        if (urows > 0) HIPCK(c, h2d_copy(c, dU, U, urows * r * 8));
     }
-    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dC, C, (size_t)k * n * 8));
     rc = upload_ABt(c, s, A, B, dABt);
     if (rc) return rc;
     HIPCK(c, hipMemsetAsync(dUt, 0, (size_t)rpad * NUt * 8, c->stream));
@@ -1729,8 +1875,8 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
         HIPCK(c, launch_endpoint_se(c->stream, s, n, dX + H * n, zin, dse, xhat_end ? dxh : nullptr));
         HIPCK(c, launch_sum(c->stream, nw, dse, dtot));
     }
-    HIPCK(c, hipMemcpyAsync(se_total, dtot, 8, hipMemcpyDeviceToHost, c->stream));
-    if (xhat_end) HIPCK(c, hipMemcpyAsync(xhat_end, dxh, nw * n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, se_total, dtot, 8));
+    if (xhat_end) HIPCK(c, d2h_copy(c, xhat_end, dxh, nw * n * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1758,9 +1904,9 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
     double* dZ1 = a.take<double>((size_t)s.zrows * s.nwp);
     double* dUst = a.take<double>((size_t)(ust_rows + rpad) * s.nwp);
     double* dXp = a.take<double>((size_t)nb * (T + 1) * n);
-    HIPCK(c, hipMemcpyAsync(dx0, x0, nb * n * 8, hipMemcpyHostToDevice, c->stream));
-    if (T && r) HIPCK(c, hipMemcpyAsync(dUs, U_seq, (size_t)nb * T * r * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK(c, hipMemcpyAsync(dC, C, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK(c, h2d_copy(c, dx0, x0, nb * n * 8));
+    if (T && r) HIPCK(c, h2d_copy(c, dUs, U_seq, (size_t)nb * T * r * 8));
+    HIPCK(c, h2d_copy(c, dC, C, (size_t)k * n * 8));
     rc = upload_ABt(c, s, A, B, dABt);
     if (rc) return rc;
     HIPCK(c, hipMemsetAsync(dUst, 0, (size_t)(ust_rows + rpad) * s.nwp * 8, c->stream));
@@ -1779,7 +1925,7 @@ int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double*
             HIPCK(c, launch_extract_state(c->stream, s, T + 1, t + 1, zin, dXp));
         }
     }
-    HIPCK(c, hipMemcpyAsync(X_pred, dXp, (size_t)nb * (T + 1) * n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(c, d2h_copy(c, X_pred, dXp, (size_t)nb * (T + 1) * n * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));
     return BROV_OK;
 }
@@ -1925,10 +2071,10 @@ static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d
     std::vector<int> lab((size_t)N);
     std::vector<long long> hred(kmeans_red_words(n, k));
     double hfix[32];
-    HIPCK_R(hipMemcpyAsync(dist.data(), d_dist, (size_t)N * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCK_R(hipMemcpyAsync(lab.data(), d_lab, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCK_R(hipMemcpyAsync(hred.data(), red, hred.size() * 8, hipMemcpyDeviceToHost, c->stream));
-    HIPCK_R(hipMemcpyAsync(hfix, fix, sizeof hfix, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_R(d2h_copy(c, dist.data(), d_dist, (size_t)N * 8));
+    HIPCK_R(d2h_copy(c, lab.data(), d_lab, (size_t)N * 4));
+    HIPCK_R(d2h_copy(c, hred.data(), red, hred.size() * 8));
+    HIPCK_R(d2h_copy(c, hfix, fix, sizeof hfix));
     HIPCK_R(hipStreamSynchronize(c->stream));
     const int np1 = n + 1;
     auto load = [&](int q, int j) { return ((__int128)hred[((size_t)q * np1 + j) * 2] << 42) + (__int128)hred[((size_t)q * np1 + j) * 2 + 1]; };
@@ -1939,9 +2085,9 @@ static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d
     // words through the ranks (device buffer in, device buffer out: the callback's contract), synchronous: this path is rare
     auto exchange = [&](long long* w, int count, int op) -> int {
         if (!c->km_allreduce) return BROV_OK;
-        if (hipMemcpyAsync(d_words, w, (size_t)count * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return BROV_ERR_HIP;
+        if (h2d_copy(c, d_words, w, (size_t)count * 8) != hipSuccess) return BROV_ERR_HIP;
         if (c->km_allreduce(c->km_allreduce_user, d_words, count, op) != 0) return BROV_ERR_COMM;
-        if (hipMemcpyAsync(w, d_words, (size_t)count * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return BROV_ERR_HIP;
+        if (d2h_copy(c, w, d_words, (size_t)count * 8) != hipSuccess) return BROV_ERR_HIP;
         return hipStreamSynchronize(c->stream) == hipSuccess ? BROV_OK : BROV_ERR_HIP;
     };
 #define EXCH(w, count, op) do { int rc__ = exchange((w), (count), (op)); if (rc__) { cleanup(); return fail(c, rc__, "edmdc_kmeans_lloyd: exchange of the relocation failed"); } } while (0)
@@ -2008,7 +2154,7 @@ static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d
                 bool ok = hipMemsetAsync(d_all, 0, (size_t)Ng * 8, c->stream) == hipSuccess &&
                           hipMemcpyAsync(d_all + c->km_row_offset, d_dist, (size_t)N * 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
                 const int arc = ok ? c->km_allreduce(c->km_allreduce_user, d_all, Ng, 0) : 1;
-                ok = ok && arc == 0 && hipMemcpyAsync(gdist.data(), d_all, (size_t)Ng * 8, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                ok = ok && arc == 0 && d2h_copy(c, gdist.data(), d_all, (size_t)Ng * 8) == hipSuccess &&
                      hipStreamSynchronize(c->stream) == hipSuccess;
                 (void)hipFree(d_all);
                 if (!ok) { cleanup(); return fail(c, arc ? BROV_ERR_COMM : BROV_ERR_HIP, "edmdc_kmeans_lloyd: gathering the distances of the ranks failed"); }
@@ -2036,7 +2182,7 @@ static int kmeans_relocate(brov_ctx* c, int64_t N, int n, int k, const double* d
                 apply(new_ids[q], (int)msg[16], msg);
             }
         }
-        HIPCK_R(hipMemcpyAsync(red, hred.data(), hred.size() * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK_R(h2d_copy(c, red, hred.data(), hred.size() * 8));
         HIPCK_R(hipStreamSynchronize(c->stream));
         ++c->kmeans_relocations;
     }
@@ -2135,7 +2281,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         nlist = a.take<int>(64);
     }
     if (mean_host) {
-        HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
+        HIPCK(c, h2d_copy(c, dmean, mean_host, n * 8));
         HIPCK(c, hipStreamSynchronize(c->stream));
     }
     HIPCK(c, hipMemsetAsync(d_labels, 0xFF, N * sizeof(int32_t), c->stream));
@@ -2290,7 +2436,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             // empty clusters: relocate (the queued E-step did nothing), average again, and queue the E-step again
             rc = kmeans_relocate(c, N, n, k, d_X, xstride, mean_host, mp, fix, Cb[cc], Cb[cc ^ 1], c2, stats, prm, red, Lc, Pc);
             if (rc) return rc;
-            HIPCK(c, hipMemcpyAsync(c->h_stats, stats, sizeof hs, hipMemcpyDeviceToHost, c->stream));
+            HIPCK(c, d2h_copy(c, c->h_stats, stats, sizeof hs));
             HIPCK(c, hipStreamSynchronize(c->stream));
             hs[0] = c->h_stats[0];
             if (filter) HIPCK(c, launch_kmeans_cdist(c->stream, n, k, c2, Dc, Nk, Pf, shiftc, mvd, rw2, pf_pairs));
@@ -2337,7 +2483,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
     if (Pc) HIPCK(c, launch_kmeans_unpermute(c->stream, N, Pc, Lc, d_labels));      // labels back in the caller's order
     if (!strict) {   // labels / inertia consistent with the final centres: the E-step already queued
         std::vector<double> hb(e_nb);
-        HIPCK(c, hipMemcpyAsync(hb.data(), binert, e_nb * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, d2h_copy(c, hb.data(), binert, e_nb * 8));
         HIPCK(c, hipStreamSynchronize(c->stream));
         in = 0.0;
         for (double v : hb) in += v;
@@ -2379,8 +2525,8 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     float* Xf = screening ? a.take<float>((size_t)N * n) : nullptr;
     char* rowbuf = screening ? a.take<char>(kmeanspp_row_bytes(N, n)) : nullptr;      // row level of the screening (kmeans.hip: PPRows)
     double* dshard = a.take<double>(nshard);
-    if (mean_host) HIPCK(c, hipMemcpyAsync(dmean, mean_host, n * 8, hipMemcpyHostToDevice, c->stream));
-    if (k > 1) HIPCK(c, hipMemcpyAsync(du, uniforms_host, (size_t)(k - 1) * n_trials * 8, hipMemcpyHostToDevice, c->stream));
+    if (mean_host) HIPCK(c, h2d_copy(c, dmean, mean_host, n * 8));
+    if (k > 1) HIPCK(c, h2d_copy(c, du, uniforms_host, (size_t)(k - 1) * n_trials * 8));
     HIPCK(c, hipStreamSynchronize(c->stream));          // the host buffers may be temporaries of the caller
     {
         CallTimer t(c);
@@ -2399,9 +2545,42 @@ int edmdc_kmeanspp_dev(brov_ctx* c, int64_t N, int n, int k, const double* d_X, 
     }
     if (indices_host) {
         static_assert(sizeof(long long) == sizeof(int64_t), "index width");
-        HIPCK(c, hipMemcpyAsync(indices_host, dind, (size_t)k * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCK(c, d2h_copy(c, indices_host, dind, (size_t)k * 8));
     }
     HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
+int edmdc_col_stats_dev(brov_ctx* c, int64_t N, int n, const double* d_X, int64_t xstride, double* mean_host, double* var_host) {
+    if (!c || N < 1 || n < 1 || n > 16 || !d_X || xstride < n) return fail(c, BROV_ERR_ARG, "edmdc_col_stats_dev: bad argument (1 <= n <= 16, x_stride >= n)");
+    DeviceGuard g(c);
+    const int nb = colstats_blocks(N);
+    Arena a(c);
+    int rc = a.reserve((size_t)nb * 16 * 8 + 16 * 8 + 1024);
+    if (rc) return rc;
+    double* d_part = a.take<double>((size_t)nb * 16);
+    double* d_mean = a.take<double>(16);
+    std::vector<double> part((size_t)nb * 16);
+    double mean[16] = {0};
+    auto total = [&](double* out) {            // the partial rows in block order
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int b = 0; b < nb; ++b) s += part[(size_t)b * 16 + j];
+            out[j] = s / (double)N;
+        }
+    };
+    HIPCK(c, launch_colstats(c->stream, N, n, d_X, xstride, nullptr, false, d_part));
+    HIPCK(c, d2h_copy(c, part.data(), d_part, part.size() * 8));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    total(mean);
+    if (mean_host) std::memcpy(mean_host, mean, (size_t)n * 8);
+    if (var_host) {
+        HIPCK(c, h2d_copy(c, d_mean, mean, 16 * 8));
+        HIPCK(c, launch_colstats(c->stream, N, n, d_X, xstride, d_mean, true, d_part));
+        HIPCK(c, d2h_copy(c, part.data(), d_part, part.size() * 8));
+        HIPCK(c, hipStreamSynchronize(c->stream));
+        total(var_host);
+    }
     return BROV_OK;
 }
 
@@ -2415,12 +2594,12 @@ int edmdc_kmeans_lloyd(brov_ctx* c, int64_t N, int n, int k, const double* X, co
     HIPCK_CLEAN(hipMalloc((void**)&dX, (size_t)N * n * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dC, (size_t)k * n * 8));
     HIPCK_CLEAN(hipMalloc((void**)&dL, (size_t)N * 4));
-    HIPCK_CLEAN(hipMemcpyAsync(dX, X, (size_t)N * n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCK_CLEAN(hipMemcpyAsync(dC, C_io, (size_t)k * n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCK_CLEAN(h2d_copy(c, dX, X, (size_t)N * n * 8));
+    HIPCK_CLEAN(h2d_copy(c, dC, C_io, (size_t)k * n * 8));
     int rc = edmdc_kmeans_lloyd_dev(c, N, n, k, dX, n, mean, dC, max_iter, tol_abs, dL, inertia, n_iter);
     if (rc) { cleanup(); return rc; }
-    HIPCK_CLEAN(hipMemcpyAsync(C_io, dC, (size_t)k * n * 8, hipMemcpyDeviceToHost, c->stream));
-    if (labels) HIPCK_CLEAN(hipMemcpyAsync(labels, dL, (size_t)N * 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCK_CLEAN(d2h_copy(c, C_io, dC, (size_t)k * n * 8));
+    if (labels) HIPCK_CLEAN(d2h_copy(c, labels, dL, (size_t)N * 4));
     HIPCK_CLEAN(hipStreamSynchronize(c->stream));
     cleanup();
     return BROV_OK;

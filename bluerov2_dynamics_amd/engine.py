@@ -1,8 +1,10 @@
 """Batched API over libbrov2.so: RHS, rollouts, sliding-window endpoint RMSE, EDMDc lift / Gram.
 
 Host path  : NumPy arrays in / out (the library stages them through HBM).
-Device path: torch CUDA tensors (fp64, contiguous) -- only their data_ptr() and the current
-             torch stream cross the C ABI; results stay in HBM.
+Device path: device-resident arrays -- either DevArray (this module: brov_malloc'ed HBM, no torch anywhere; what the drop-in
+             classes use) or torch CUDA tensors (fp64, contiguous; the caller's own pipeline, bench.py, dist.py).  Only the device
+             address and the stream cross the C ABI; results stay in HBM.  The two kinds run the same launches with the same
+             arguments: results are bit-identical.
 """
 import ctypes
 import os
@@ -45,17 +47,195 @@ def _is_torch(x):
     return type(x).__module__.startswith("torch")
 
 
+class DevArray:
+    """A row-major array in HBM owned through the C ABI (brov_malloc / brov_free, copies on the ctx's stream): the device-resident
+    operand of the `_dev` entry points for callers without torch.  float64 unless said otherwise; `view` / `reshape` give
+    non-owning aliases that keep their base alive."""
+    __slots__ = ("ctx", "ptr", "shape", "dtype", "_base", "_owned")
+    is_cuda = True
+
+    def __init__(self, ctx, shape, dtype=np.float64, _ptr=None, _base=None):
+        self.ctx = ctx
+        self.shape = tuple(int(v) for v in (shape if isinstance(shape, (tuple, list)) else (shape,)))
+        self.dtype = np.dtype(dtype)
+        self._base = _base
+        self._owned = _ptr is None
+        if _ptr is None:
+            p_ = ctypes.c_void_p()
+            ctx.check(ctx.lib.brov_malloc(ctx.h, max(self.nbytes, 8), ctypes.byref(p_)), "brov_malloc")
+            _ptr = p_.value
+        self.ptr = _ptr
+
+    @property
+    def nbytes(self):
+        return int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    def numel(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def data_ptr(self):
+        return self.ptr
+
+    def dim(self):
+        return len(self.shape)
+
+    def stride(self, i):
+        return int(np.prod(self.shape[i + 1:], dtype=np.int64))
+
+    def is_contiguous(self):
+        return True
+
+    @classmethod
+    def from_host(cls, ctx, a, dtype=np.float64):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return cls(ctx, a.shape, dtype).copy_from_host(a)
+
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        assert a.nbytes == self.nbytes, "size mismatch"
+        if a.nbytes:
+            self.ctx.check(self.ctx.lib.brov_memcpy_h2d(self.ctx.h, self.ptr, a.ctypes.data, a.nbytes), "brov_memcpy_h2d")
+        return self
+
+    def numpy(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        if out.nbytes:
+            self.ctx.check(self.ctx.lib.brov_memcpy_d2h(self.ctx.h, out.ctypes.data, self.ptr, out.nbytes), "brov_memcpy_d2h")
+        return out
+
+    def zero_(self):
+        self.ctx.check(self.ctx.lib.brov_memset(self.ctx.h, self.ptr, 0, self.nbytes), "brov_memset")
+        return self
+
+    def view(self, *shape):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        shape = list(int(v) for v in shape)
+        total = self.numel()
+        if -1 in shape:
+            i = shape.index(-1)
+            rest = int(np.prod([v for v in shape if v != -1], dtype=np.int64))
+            shape[i] = total // rest if rest else 0
+        assert int(np.prod(shape, dtype=np.int64)) == total, f"cannot view {self.shape} as {tuple(shape)}"
+        return DevArray(self.ctx, tuple(shape), self.dtype, _ptr=self.ptr, _base=self)
+
+    reshape = view
+
+    def rows(self, a, b):
+        """alias of rows a .. b-1 (leading dimension)"""
+        a, b = int(a), int(b)
+        assert 0 <= a <= b <= self.shape[0]
+        return DevArray(self.ctx, (b - a,) + self.shape[1:], self.dtype, _ptr=self.ptr + a * self.stride(0) * self.dtype.itemsize, _base=self)
+
+    def free(self):
+        if self._owned and self.ptr:
+            p_, self.ptr = self.ptr, None
+            self.ctx.lib.brov_free(self.ctx.h, ctypes.c_void_p(p_))
+
+    def __del__(self):
+        try:
+            if self.ctx.h:
+                self.free()
+        except Exception:
+            pass
+
+
+class _NativeArrays:
+    """allocation / movement of DevArray operands (no torch); launches go to the ctx's own stream (the null stream)"""
+    kind = "native"
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def bind(self):
+        self.ctx.use_null_stream()
+
+    def empty(self, shape, dtype=np.float64):
+        return DevArray(self.ctx, shape, dtype)
+
+    def upload(self, a, dtype=np.float64):
+        return DevArray.from_host(self.ctx, a, dtype)
+
+    def download(self, d):
+        return d.numpy()
+
+    def sync(self):
+        self.ctx.sync()
+
+    def mem_free(self):
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        self.ctx.check(self.ctx.lib.brov_mem_info(self.ctx.h, ctypes.byref(f), ctypes.byref(t)), "brov_mem_info")
+        return int(f.value)
+
+
+class _TorchArrays:
+    """the same for torch CUDA tensors; launches go to torch's current stream"""
+    kind = "torch"
+
+    def __init__(self, ctx):
+        import torch
+        self.ctx, self.torch = ctx, torch
+        self.dev = torch.device("cuda", ctx.device)
+
+    def bind(self):
+        self.ctx.use_torch_stream()
+
+    def empty(self, shape, dtype=np.float64):
+        t = self.torch
+        return t.empty(shape, dtype={np.dtype(np.float64): t.float64, np.dtype(np.int32): t.int32, np.dtype(np.uint8): t.uint8}[np.dtype(dtype)], device=self.dev)
+
+    def upload(self, a, dtype=np.float64):
+        return self.torch.from_numpy(np.ascontiguousarray(a, dtype=dtype)).to(self.dev)
+
+    def download(self, d):
+        return d.cpu().numpy()
+
+    def sync(self):
+        self.torch.cuda.synchronize(self.dev)
+
+    def mem_free(self):
+        return int(self.torch.cuda.mem_get_info(self.dev)[0])
+
+
+def arrays_of(x, ctx):
+    """the array namespace an operand belongs to"""
+    return _TorchArrays(ctx) if _is_torch(x) else _NativeArrays(ctx)
+
+
+def _ctx_of(x, ctx):
+    if ctx is not None:
+        return ctx
+    return x.ctx if isinstance(x, DevArray) else default_context(x.device.index)
+
+
+def _bind(x, ctx):
+    """launch where the operand lives: DevArray -> the ctx's null stream, torch tensor -> torch's current stream"""
+    if isinstance(x, DevArray):
+        ctx.use_null_stream()
+    else:
+        ctx.use_torch_stream()
+
+
 def _dptr(t):
-    """device pointer of a contiguous fp64 CUDA tensor (or None)."""
+    """device pointer of a DevArray or of a contiguous fp64 CUDA tensor (or None)."""
     if t is None:
         return None
+    if isinstance(t, DevArray):
+        assert t.dtype == np.float64, "need a float64 DevArray"
+        return t.ptr
     import torch
     assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous(), "need a contiguous fp64 CUDA tensor"
     return t.data_ptr()
 
 
 def _drows(t):
-    """device pointer of a 2-D fp64 CUDA tensor whose ROWS are contiguous (any row stride: a column slice of a padded buffer)."""
+    """device pointer of a 2-D fp64 array whose ROWS are contiguous (any row stride: a column slice of a padded buffer)."""
+    if isinstance(t, DevArray):
+        assert t.dtype == np.float64 and t.ndim == 2
+        return t.ptr
     import torch
     assert t.is_cuda and t.dtype == torch.float64 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) >= t.shape[1], \
         "need a 2-D fp64 CUDA tensor with contiguous rows"
@@ -148,10 +328,10 @@ def window_rmse(model, integrator, X, U, H, dt, carry_lag=True, ctx=None):
 # ------------------------------------------------------------------------------------------ device path
 def rollout_dev(model, integrator, x0, U, dt, lag=None, traj=None, xT=None, lag_mode=LAG_PER_CALL, layout="tub", stride=1,
                 ctx=None):
-    """Asynchronous rollout on torch CUDA tensors (no copies).  Shapes as in rollout(); traj / xT / lag are
-    written in place when given."""
-    ctx = ctx or default_context(x0.device.index)
-    ctx.use_torch_stream()
+    """Asynchronous rollout on device-resident arrays (DevArray or torch CUDA tensors; no copies).  Shapes as in rollout();
+    traj / xT / lag are written in place when given."""
+    ctx = _ctx_of(x0, ctx)
+    _bind(x0, ctx)
     lay = LAYOUTS[layout]
     nu = NU[model]
     B, T, nu_ = _dims(tuple(U.shape), lay)
@@ -165,9 +345,9 @@ def rollout_dev(model, integrator, x0, U, dt, lag=None, traj=None, xT=None, lag_
 
 
 def fill_controls_dev(U, layout, dist="iid", seed=0x5EED, b0=0, T_total=None, scale=None, ctx=None):
-    """Fill a torch CUDA tensor U ([B,T,nu] or [T,nu,B]) with the synthetic control stream."""
-    ctx = ctx or default_context(U.device.index)
-    ctx.use_torch_stream()
+    """Fill a device-resident U ([B,T,nu] or [T,nu,B]; DevArray or torch CUDA tensor) with the synthetic control stream."""
+    ctx = _ctx_of(U, ctx)
+    _bind(U, ctx)
     lay = LAYOUTS[layout]
     B, T, nu = _dims(tuple(U.shape), lay)
     d = {"iid": DIST_IID_UNIFORM, "ar1": DIST_AR1}[dist]
@@ -177,8 +357,8 @@ def fill_controls_dev(U, layout, dist="iid", seed=0x5EED, b0=0, T_total=None, sc
 
 
 def window_endpoint_se_dev(model, integrator, X, U, H, dt, se_total, per_window, carry_lag=True, ctx=None):
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
     N = X.shape[0]
     ctx.check(ctx.lib.brov_window_endpoint_se_dev(ctx.h, model, INTEGRATORS[integrator], N, int(H), float(dt), _dptr(X), _dptr(U),
                                                   int(bool(carry_lag)), _dptr(se_total), _dptr(per_window)),
@@ -288,18 +468,18 @@ class BagTable:
                       "brov_upload_bags")
 
 
-def upload_bags(X_list, U_list, n, r, device=None, ctx=None):
-    """fit_multi's trajectory list in HBM, uploaded once: (Xd [rows, n], Ud [rows, r] row-aligned with Xd, offsets int64 [nbags + 1])
-    as torch CUDA tensors.  Xd is np.vstack(X_list) (Koopman/koopmanEDMDc.py:125); no stacked copy is formed on the host."""
-    import torch
+def upload_bags(X_list, U_list, n, r, device=None, ctx=None, arrays="native"):
+    """fit_multi's trajectory list in HBM, uploaded once: (Xd [rows, n], Ud [rows, r] row-aligned with Xd, offsets int64 [nbags + 1]).
+    Xd is np.vstack(X_list) (Koopman/koopmanEDMDc.py:125); no stacked copy is formed on the host.  arrays: "native" = DevArray (no torch),
+    "torch" = torch CUDA tensors."""
     ctx = ctx or default_context(device)
-    ctx.use_torch_stream()
-    dev = torch.device("cuda", ctx.device)
+    ns = _TorchArrays(ctx) if arrays == "torch" else _NativeArrays(ctx)
+    ns.bind()
     bt = BagTable(X_list, U_list, n, r)
     rows = bt.rows
-    Xd = torch.empty((rows, n), dtype=torch.float64, device=dev)
+    Xd = ns.empty((rows, n))
     # rows of U that no bag provides (len(U) == len(X) - 1) stay as allocated: the kernels never read the input next to a bag's last state
-    Ud = torch.empty((rows, r), dtype=torch.float64, device=dev)
+    Ud = ns.empty((rows, r))
     bt.upload_into(Xd.data_ptr(), Ud.data_ptr(), ctx)
     return Xd, Ud, bt.offsets
 
@@ -384,10 +564,10 @@ def gtg_decomposition(n, r, k):
 
 
 def gram_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, GtG, GtY, accumulate=False, ctx=None):
-    """Device Gram on torch tensors: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h).
+    """Device Gram on device-resident arrays: X [rows,n] states, U [rows,r] inputs in bag layout (see include/brov2.h).
     GtY=None: G^T G alone -- all KoopmanEDMDc.fit needs before its pinv (a third of the tile products)."""
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     ctx.check(ctx.lib.edmdc_gram_dev(ctx.h, n, r, k, float(gamma), _dptr(C), int(nbags), int(L), int(x_bag_stride), int(u_bag_stride),
                                      _dptr(X), _dptr(U), int(bool(accumulate)), _dptr(GtG), _dptr(GtY)), "edmdc_gram_dev")
@@ -402,8 +582,8 @@ def _offsets(bag_offsets):
 def gram_ragged_dev(X, U, C, gamma, bag_offsets, GtG, GtY, accumulate=False, ctx=None):
     """Device Gram over a RAGGED bag list (fit_multi): X [rows,n] the stacked states, U [rows,r] row-aligned with X, bag b = rows
     bag_offsets[b] .. bag_offsets[b+1]-1 (host int64 array) -- see edmdc_gram_ragged_dev in include/brov2.h.  GtY=None: G^T G alone."""
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
     off = _offsets(bag_offsets)
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     assert X.shape[0] == off[-1] and U.shape[0] == off[-1], "X / U rows must equal bag_offsets[-1]"
@@ -413,8 +593,8 @@ def gram_ragged_dev(X, U, C, gamma, bag_offsets, GtG, GtY, accumulate=False, ctx
 
 def pinv_apply_ragged_dev(X, U, C, gamma, bag_offsets, P, M, ctx=None):
     """pinv_apply_dev for the ragged bag list of gram_ragged_dev."""
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
     off = _offsets(bag_offsets)
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     P = as_f64(P)
@@ -469,24 +649,35 @@ def kmeanspp_draws(N, k, random_state=0):
 
 
 def kmeanspp_dev(X, k, mean=None, random_state=0, ctx=None, n_global=None):
-    """k-means++ seeding of a device-resident X (torch CUDA [N,n]) with scikit-learn's algorithm and random stream
-    (edmdc_kmeanspp_dev).  Returns (C0 CUDA [k,n] in the frame of X - mean, indices [k] int64 numpy).
+    """k-means++ seeding of a device-resident X ([N,n] DevArray or torch CUDA tensor) with scikit-learn's algorithm and random stream
+    (edmdc_kmeanspp_dev).  Returns (C0 [k,n] device array of X's kind, in the frame of X - mean; indices [k] int64 numpy).
     n_global: rows over all ranks when X is this rank's shard of a sharded seeding (dist.kmeanspp_sharded installs the exchange):
     the random numbers are drawn for that many rows, indices come back global."""
-    import torch
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    ns = arrays_of(X, ctx)
+    ns.bind()
     N, n = X.shape
     assert X.stride(1) == 1
     first, U, L = kmeanspp_draws(N if n_global is None else int(n_global), k, random_state)
-    C = torch.empty((k, n), dtype=torch.float64, device=X.device)
+    C = ns.empty((k, n))
     ind = np.empty(k, dtype=np.int64)
     m = None if mean is None else as_f64(mean).reshape(n)
     Uc = np.ascontiguousarray(U)
-    torch.cuda.current_stream(X.device).synchronize()
+    ns.sync()
     ctx.check(ctx.lib.edmdc_kmeanspp_dev(ctx.h, N, n, k, _drows(X), X.stride(0), _hptr(m), first, L, _hptr(Uc) if k > 1 else None,
                                          _dptr(C), ind.ctypes.data), "edmdc_kmeanspp_dev")
     return C, ind
+
+
+def col_stats_dev(X, ctx=None):
+    """(mean [n], var [n]) of the columns of a device-resident X [N,n] as host arrays (edmdc_col_stats_dev): scikit-learn's
+    `X.mean(axis=0)` / `np.var(X, axis=0)` before its Lloyd loop.  The same kernel and summation order for DevArray and torch operands."""
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
+    N, n = X.shape
+    mean, var = np.empty(n), np.empty(n)
+    ctx.check(ctx.lib.edmdc_col_stats_dev(ctx.h, N, n, _drows(X), X.stride(0), mean.ctypes.data, var.ctypes.data), "edmdc_col_stats_dev")
+    return mean, var
 
 
 def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", ctx=None):
@@ -494,27 +685,25 @@ def kmeans_centers(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", ctx
     Koopman/koopmanEDMDc.py:85): k-means++ seeding with scikit-learn's random stream, then Lloyd's E/M loop with
     scikit-learn's stopping rules, both on the GPU over the full data.  init="sklearn" seeds with
     sklearn.cluster.kmeans_plusplus on the host instead (same centres; kept for cross-checks).  X: host array [N,n]."""
-    import torch
     X = as_f64(X)
     ctx = ctx or default_context()
-    Xd = torch.from_numpy(X).to(torch.device("cuda", ctx.device))
+    Xd = DevArray.from_host(ctx, X)
     C, _, _ = kmeans_centers_dev(Xd, k, random_state=random_state, max_iter=max_iter, tol=tol, init=init, ctx=ctx)
-    return C.cpu().numpy()
+    return C.numpy()
 
 
 def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip", init_rows=None, ctx=None, timings=None):
-    """kmeans_centers for a device-resident X (torch CUDA tensor [N,n]).  Returns (centres CUDA tensor [k,n], inertia,
-    n_iter).  init_rows: seed on a seeded subsample of that many rows instead of all N (not what scikit-learn does;
+    """kmeans_centers for a device-resident X ([N,n] DevArray or torch CUDA tensor).  Returns (centres [k,n] device array of X's
+    kind, inertia, n_iter).  init_rows: seed on a seeded subsample of that many rows instead of all N (not what scikit-learn does;
     useful with init="sklearn", whose host seeding takes minutes at N = 1e7, and applied automatically -- 1.5e7 rows --
     beyond the 3e7 rows the device seeding accepts); the Lloyd iterations always run over all N rows.  timings: dict that receives
     kmeanspp_ms / lloyd_ms (kernel time, needs ctx.set_timing(True)) and host_draws_s."""
-    import torch
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    ctx = _ctx_of(X, ctx)
+    ns = arrays_of(X, ctx)
+    ns.bind()
     N, n = X.shape
-    mean = X.mean(dim=0)
-    mean_h = as_f64(mean.cpu().numpy())
-    tol_abs = float(X.var(dim=0, unbiased=False).mean().item() * tol)
+    mean_h, var_h = col_stats_dev(X, ctx=ctx)
+    tol_abs = float(var_h.mean() * tol)
     Xi = X
     if init_rows is None and N > KMEANSPP_MAX_ROWS:
         init_rows = KMEANSPP_MAX_ROWS // 2          # the device seeding holds its running-sum table in LDS: N <= 3e7 rows
@@ -523,27 +712,32 @@ def kmeans_centers_dev(X, k, random_state=0, max_iter=300, tol=1e-4, init="hip",
                       f"subsample of {init_rows} rows (scikit-learn would seed on all rows: the centres differ from its); the Lloyd "
                       "iterations run over all rows", RuntimeWarning, stacklevel=2)
     if init_rows is not None and N > init_rows:
-        idx = torch.from_numpy(np.random.RandomState(random_state).choice(N, init_rows, replace=False)).to(X.device)
-        Xi = X[idx].contiguous()
+        idx = np.random.RandomState(random_state).choice(N, init_rows, replace=False)
+        if ns.kind == "torch":
+            Xi = X[ns.torch.from_numpy(idx).to(X.device)].contiguous()
+        else:
+            Xi = ns.upload(ns.download(X)[idx])          # (a host round trip: the subsample path is a fallback beyond 3e7 rows)
     if init == "hip":
         C, _ = kmeanspp_dev(Xi, k, mean=mean_h, random_state=random_state, ctx=ctx)
         if timings is not None and getattr(ctx, "timing", False):
             timings["kmeanspp_ms"] = ctx.last_kernel_ms()
     elif init == "sklearn":
         from sklearn.cluster import kmeans_plusplus
-        C0, _ = kmeans_plusplus((Xi - mean).cpu().numpy(), k, random_state=np.random.RandomState(random_state))
-        C = torch.from_numpy(np.ascontiguousarray(C0)).to(X.device)
+        C0, _ = kmeans_plusplus(ns.download(Xi) - mean_h, k, random_state=np.random.RandomState(random_state))
+        C = ns.upload(C0)
     else:
         raise ValueError("init must be 'hip' or 'sklearn'")
-    labels = torch.empty(N, dtype=torch.int32, device=X.device)
+    labels = ns.empty((N,), np.int32)
     inertia = ctypes.c_double(0.0)
     n_iter = ctypes.c_int(0)
-    torch.cuda.current_stream(X.device).synchronize()
+    ns.sync()
     ctx.check(ctx.lib.edmdc_kmeans_lloyd_dev(ctx.h, N, n, k, _drows(X), X.stride(0), _hptr(mean_h), _dptr(C), int(max_iter), tol_abs,
                                              labels.data_ptr(), ctypes.byref(inertia), ctypes.byref(n_iter)), "edmdc_kmeans_lloyd_dev")
     if timings is not None and getattr(ctx, "timing", False):
         timings["lloyd_ms"] = ctx.last_kernel_ms()
-    return C + mean, inertia.value, n_iter.value
+    # back to the caller's frame: k x n values through the host (IEEE addition either way: the same bits as a device add)
+    Cf = ns.upload(ns.download(C) + mean_h)
+    return Cf, inertia.value, n_iter.value
 
 
 def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
@@ -570,10 +764,10 @@ def pinv_apply(X_list, U_list, C, gamma, P, ctx=None):
 
 
 def pinv_apply_dev(X, U, C, gamma, nbags, L, x_bag_stride, u_bag_stride, P, M, ctx=None):
-    """Device form of pinv_apply on torch tensors (bag layout as gram_dev): P [p,p] host array (the host's pinv), M [p,d]
-    CUDA tensor, overwritten with (P G^T) Y."""
-    ctx = ctx or default_context(X.device.index)
-    ctx.use_torch_stream()
+    """Device form of pinv_apply on device-resident arrays (bag layout as gram_dev): P [p,p] host array (the host's pinv), M [p,d]
+    device array, overwritten with (P G^T) Y."""
+    ctx = _ctx_of(X, ctx)
+    _bind(X, ctx)
     n, k, r = X.shape[-1], C.shape[0], U.shape[-1]
     P = as_f64(P)
     assert P.shape == (n + k + r, n + k + r) and tuple(M.shape) == (n + k + r, n + k)
@@ -634,11 +828,11 @@ def _host_pinv(G, ridge, pinv):
 
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,
             timings=None, lift_cache=False, pinv="auto", bag_offsets=None):
-    """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (torch CUDA tensors, bag layout: X [nbags*(L+1), n]
-    states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
+    """The whole of KoopmanEDMDc.fit / fit_multi on device-resident data (DevArray or torch CUDA tensors -- the same launches, the same
+    bits; bag layout: X [nbags*(L+1), n] states, U [nbags*L, r] inputs): centres with scikit-learn's KMeans stopping rule (Koopman/koopmanEDMDc.py:85: k-means++
     seeding, Lloyd up to max_iter 300, tol 1e-4) unless given, G^T[G|Y], the host pinv (:97/:147), and for order="fit" the
     two products of `(P G^T) Y` on the device (order="fit_multi": `P (G^T Y)` on the host).  Returns (A [d,d], B [d,r],
-    centres CUDA [k,n]); timings (dict) receives the stage wall times in seconds, the Lloyd iteration count and whether
+    centres [k,n] on the device); timings (dict) receives the stage wall times in seconds, the Lloyd iteration count and whether
     the stopping rule fired before max_iter.  lift_cache=True: keep the lifted rows of the Gram pass in HBM for the apply pass
     when they fit (edmdc_lift_cache; X, U, C are not touched in between): saves the second lift (11 ms per 1e7 pairs) for a
     45.7 GB block from torch's caching allocator -- whose FIRST allocation costs ~0.5 s (the driver hands out scrubbed memory),
@@ -649,14 +843,14 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     12 ms, first call in a process 0.2 s; torch tensors only).  bag_offsets (host int64 [nbags + 1]): a RAGGED trajectory list instead
     of nbags bags of L pairs -- X [rows, n] the stacked states, U [rows, r] row-aligned with X (upload_bags); nbags / L are ignored."""
     import time
-    import torch
-    ctx = ctx or default_context(X.device.index)
+    ctx = _ctx_of(X, ctx)
+    ns = arrays_of(X, ctx)
     n, r = X.shape[-1], U.shape[-1]
     d, p = n + k, n + k + r
     tm = {} if timings is None else timings
 
     def tick():
-        torch.cuda.synchronize(X.device)
+        ns.sync()
         return time.perf_counter()
 
     t0 = tick()
@@ -666,24 +860,28 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
     else:
         C = centers
     t1 = tick()
-    GG = torch.empty((p * p + p * d,), dtype=torch.float64, device=X.device)
-    GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+    GG = ns.empty((p * p + p * d,))
+    if ns.kind == "torch":
+        GtG, GtY = GG[: p * p].view(p, p), GG[p * p:].view(p, d)
+    else:
+        GtG, GtY = GG.rows(0, p * p).view(p, p), GG.rows(p * p, p * p + p * d).view(p, d)
     if order == "fit":
         GtY = None                  # fit() never forms G^T Y (Koopman/koopmanEDMDc.py:89-97): its Gram pass is G^T G alone
     if order not in ("fit", "fit_multi"):
         raise ValueError("order must be 'fit' or 'fit_multi'")
+    if pinv == "device" and ns.kind != "torch":
+        raise ValueError("pinv='device' is torch.linalg.eigh: it needs torch tensors (arrays='torch')")
     cache_buf = None
     if order == "fit" and lift_cache:
         # keep the lifted rows of the Gram pass for the apply pass when HBM has room (rows x padded width x 8 B + slack)
         W = (k + 15) // 16 * 16 + (n + r + 15) // 16 * 16
         need = int(X.shape[0] * 1.01 + (1 << 21)) * (W + 1) * 8
-        free_b, _ = torch.cuda.mem_get_info(X.device)
-        if free_b > need + (4 << 30):
+        if ns.mem_free() > need + (4 << 30):
             # torch's caching allocator owns the block: a second fit() gets it back without a trip to the driver (a raw
             # hipMalloc of 45 GB right after a hipFree of the same size was seen to take 2.4 s)
             try:
-                cache_buf = torch.empty(need, dtype=torch.uint8, device=X.device)
-            except RuntimeError:
+                cache_buf = ns.empty((need,), np.uint8)
+            except (RuntimeError, _lib.BrovError):
                 cache_buf = None
     try:
         if cache_buf is not None:
@@ -698,7 +896,7 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
             t2 = tick()
             P = pinv_sym_device(GtG, ridge).cpu().numpy()
         elif pinv in ("auto", "host", "eigh"):
-            Gh = GtG.cpu().numpy()
+            Gh = ns.download(GtG)
             t2 = tick()
             with _blas_threads(p):
                 P = _host_pinv(Gh, ridge, pinv)
@@ -706,18 +904,18 @@ def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter
             raise ValueError("pinv must be 'auto', 'host', 'eigh' or 'device'")
         t3 = time.perf_counter()
         if order == "fit":
-            M = torch.empty((p, d), dtype=torch.float64, device=X.device)
+            M = ns.empty((p, d))
             if bag_offsets is not None:
                 pinv_apply_ragged_dev(X, U, C, gamma, bag_offsets, P, M, ctx=ctx)
             else:
                 pinv_apply_dev(X, U, C, gamma, nbags, L, L + 1, L, P, M, ctx=ctx)
-            Mt = M.cpu().numpy().T
+            Mt = ns.download(M).T
         else:
             with _blas_threads(p):
-                Mt = (P @ GtY.cpu().numpy()).T
+                Mt = (P @ ns.download(GtY)).T
     finally:
         if cache_buf is not None:              # withdraw the buffer before it goes back to the allocator, whatever happened
-            torch.cuda.synchronize(X.device)
+            ns.sync()
             ctx.lift_cache(None)
             del cache_buf
     t4 = tick()

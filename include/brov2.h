@@ -128,6 +128,9 @@ BROV_API int brov_free(brov_ctx* ctx, void* dptr);
 BROV_API int brov_memcpy_h2d(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
 BROV_API int brov_memcpy_d2h(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
 BROV_API int brov_memset(brov_ctx* ctx, void* dst, int value, size_t bytes);
+/* Free and total bytes of the ctx's device (hipMemGetInfo): lets a caller without HIP / torch decide whether an optional buffer
+ * (edmdc_lift_cache) fits. */
+BROV_API int brov_mem_info(brov_ctx* ctx, size_t* free_bytes, size_t* total_bytes);
 /* A list of host arrays into ONE device buffer -- what KoopmanEDMDc.fit_multi's np.vstack of its trajectory list becomes
  * (Koopman/koopmanEDMDc.py:125,140-142).  Bag b = bag_rows[b] rows of `cols` contiguous doubles at bag_ptrs[b]; it is written to
  * d_dst + dst_rows[b] * cols.  The destinations must ascend without overlap (holes are allowed; small ones are zero-filled, larger ones
@@ -257,6 +260,14 @@ BROV_API int edmdc_kmeans_lloyd(brov_ctx* ctx, int64_t N, int n, int k, const do
 BROV_API int edmdc_kmeans_lloyd_dev(brov_ctx* ctx, int64_t N, int n, int k, const double* d_X, int64_t x_stride,
                                     const double* mean_host, double* d_C_io, int max_iter, double tol_abs,
                                     int32_t* d_labels, double* inertia, int* n_iter);
+
+/* Column means and (population) variances of d_X [N][n] (row stride x_stride doubles, n <= 16) into HOST arrays mean_host [n],
+ * var_host [n] (either may be NULL): what scikit-learn's KMeans takes from `X.mean(axis=0)` and `np.var(X, axis=0)` before the loop
+ * above (sklearn/cluster/_kmeans.py: centring and `_tolerance`; reached from Koopman/koopmanEDMDc.py:85,126) -- mean_host is
+ * edmdc_kmeans_lloyd_dev's `mean_host`, tol * mean(var_host) its tol_abs.  Two passes over X, fixed summation order: the values
+ * depend on (N, n, x_stride) only.  Synchronous (the results are on the host on return). */
+BROV_API int edmdc_col_stats_dev(brov_ctx* ctx, int64_t N, int n, const double* d_X, int64_t x_stride, double* mean_host,
+                                 double* var_host);
 
 /* k-means++ seeding on device: scikit-learn 1.7.2 `_kmeans_plusplus` with unit sample weights, i.e. the initialisation
  * of the KMeans(n_clusters, n_init="auto", random_state=0) that KoopmanEDMDc.fit constructs

@@ -363,3 +363,43 @@ def test_asynchronous_scalar_loads_are_left_alone_until_their_wait(tmp_path):
     bad2.write_text("\n".join(l2))
     r2 = subprocess.run([sys.executable, tool, str(bad2)], capture_output=True, text=True)
     assert r2.returncode == 1 and "overlaps the address pair" in r2.stdout, r2.stdout
+
+
+@pytest.mark.parametrize("mode", ["auto", "0", "1"])
+def test_loading_the_library_and_the_dropin_modules_does_not_import_torch(lib, mode):
+    """north_star: host code = Python over a thin ctypes C ABI, torch ONLY on the bluerov_torch / PINc path.  The reference's Koopman
+    module depends on numpy + scikit-learn alone (Koopman/koopmanEDMDc.py:17,26-30) and two of its scripts never import torch
+    (training/train_tank_brov2_koopmanEDMDc.py:12-17).  A fresh process that imports the drop-in modules and binds the library must not
+    have torch in sys.modules (BROV2_TORCH=auto / 0); BROV2_TORCH=1 restores the import-first behaviour of rounds 1-5; and with "auto" a
+    later `import torch` must still find ONE HIP runtime: the libamdhip64.so mapped into the process is torch's own file."""
+    import sys
+    code = r'''
+import sys, json
+from bluerov2_dynamics_amd import _lib
+from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+from bluerov2_dynamics_amd.fossen import BlueROV2, BlueROV2_thrust, BlueROV2_wrench
+_lib.load_library()
+m = KoopmanEDMDc(state_dim=12, input_dim=8)
+maps = [l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l]
+print(json.dumps({"torch": "torch" in sys.modules, "hip_runtime": _lib.hip_runtime, "amdhip": sorted(set(maps))}))
+'''
+    env = dict(os.environ, BROV2_TORCH=mode, PYTHONPATH=REPO)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert len(d["amdhip"]) == 1, d                        # one HIP runtime in the process
+    if mode == "1":
+        assert d["torch"] and "imported by load_library" in d["hip_runtime"]
+        return
+    assert d["torch"] is False, d
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except ImportError:
+        spec = None
+    torch_hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so") if spec else None
+    if mode == "auto" and torch_hip and os.path.exists(torch_hip):
+        assert "preloaded" in d["hip_runtime"] and os.path.samefile(d["amdhip"][0], torch_hip), d
+    else:
+        assert d["hip_runtime"].startswith("system") and (torch_hip is None or not os.path.samefile(d["amdhip"][0], torch_hip)), d

@@ -1463,7 +1463,7 @@ def test_fit_multi_ragged_2000_bags_one_upload(eng):
     Xs, Us, lens = _ragged_bags(rng, 2000, n, r, 2, 700)
     assert (lens < 2).sum() >= 30 and lens.max() >= 690
     ctx = _lib.default_context(0)
-    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx)
+    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx, arrays="torch")
     Xall = np.vstack([x for x in Xs if len(x)])
     assert np.array_equal(Xd.cpu().numpy(), Xall) and np.array_equal(Ud.cpu().numpy(), np.vstack([u for u in Us if len(u)]))
     assert np.array_equal(off, np.concatenate([[0], np.cumsum(lens)]))
@@ -1490,7 +1490,7 @@ def test_fit_multi_ragged_2000_bags_one_upload(eng):
     Xu = [x[:L + 1] for x in Xs if len(x) >= L + 1][:nb]
     Uu = [u[:L + 1] for u in Us if len(u) >= L + 1][:nb]
     assert len(Xu) == nb
-    Xud, Uud, offu = eng.upload_bags(Xu, Uu, n, r, ctx=ctx)
+    Xud, Uud, offu = eng.upload_bags(Xu, Uu, n, r, ctx=ctx, arrays="torch")
     Cd = torch.from_numpy(C).cuda()
     Ga, Ya, Gb, Yb = (torch.zeros(s_, dtype=torch.float64, device="cuda") for s_ in ((p, p), (p, d), (p, p), (p, d)))
     eng.gram_ragged_dev(Xud, Uud, Cd, gamma, offu, Ga, Ya, ctx=ctx)
@@ -1549,7 +1549,7 @@ def test_upload_bags_blocks_holes_and_views(eng):
     Xs[9] = Xs[9].astype(np.float32)                          # wrong dtype: converted, not reinterpreted
     Xs.insert(100, np.zeros((0, n)))
     Us = [rng.uniform(-1, 1, (max(len(x) - 1, 0), r)) for x in Xs]        # one row short: a hole of 64 bytes after every bag
-    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx)
+    Xd, Ud, off = eng.upload_bags(Xs, Us, n, r, ctx=ctx, arrays="torch")
     want = np.vstack([np.asarray(x, dtype=float) for x in Xs if len(x)])
     assert np.array_equal(Xd.cpu().numpy(), want)
     Uh = Ud.cpu().numpy()
@@ -1568,6 +1568,94 @@ def test_upload_bags_blocks_holes_and_views(eng):
     assert np.array_equal(h[5:15], A_) and np.array_equal(h[600:620], B_) and (h[:5] == 7).all() and (h[15:600] == 7).all() and (h[620:] == 7).all()
     at2 = np.array([5, 10], dtype=np.int64)
     assert ctx.lib.brov_upload_bags(ctx.h, 2, ptr.ctypes.data, rows.ctypes.data, at2.ctypes.data, 4, dst.data_ptr()) == -1
+
+
+def test_col_stats_match_numpy(eng):
+    """edmdc_col_stats_dev (csrc/colstats.hip): the column means and population variances scikit-learn's KMeans takes from NumPy before
+    its loop, for contiguous rows and for a strided column block, DevArray and torch operands giving the same bits."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(5)
+    for N, n in ((1, 3), (257, 12), (100_003, 13), (1_000_000, 16)):
+        X = rng.normal(2.0, 3.0, (N, n)) * np.linspace(0.1, 4.0, n)
+        mean, var = eng.col_stats_dev(eng.DevArray.from_host(ctx, X), ctx=ctx)
+        assert rel_err(mean, X.mean(0)) < 1e-13 and rel_err(var, X.var(0)) < 1e-12, (N, n)
+        mt, vt = eng.col_stats_dev(torch.from_numpy(X).cuda(), ctx=ctx)
+        assert np.array_equal(mt, mean) and np.array_equal(vt, var)
+    wide = torch.from_numpy(rng.normal(size=(5000, 40))).cuda()
+    ms, vs = eng.col_stats_dev(wide[:, 7:19], ctx=ctx)                       # rows 40 doubles apart
+    ref = wide[:, 7:19].cpu().numpy()
+    assert rel_err(ms, ref.mean(0)) < 1e-13 and rel_err(vs, ref.var(0)) < 1e-12
+    assert ctx.lib.edmdc_col_stats_dev(ctx.h, 10, 17, wide.data_ptr(), 40, None, None) == -1          # n > 16: BROV_ERR_ARG
+
+
+def test_native_and_torch_arrays_give_the_same_bits(eng):
+    """The drop-in classes keep their device-resident operands in engine.DevArray (brov_malloc through the C ABI, the ctx's own
+    stream; no torch); arrays="torch" is the torch-tensor path of rounds 1-5.  Same launches, same arguments: centres, A and B are
+    bit-identical, for fit (device k-means, given centres) and fit_multi (ragged list), and so is fit_dev called directly."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    g = load_golden("edmdc_fit.npz")
+    X, U = g["X"][:6000], g["U"][:6000]
+    res = {}
+    for arrays in ("native", "torch"):
+        m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=64, gamma=1.0, ridge=1e-3, arrays=arrays)
+        m.fit(X, U)
+        a = [m.centers_.copy(), m.A_.copy(), m.B_.copy()]
+        m.fit(X, U, centers=g["def_centers"][:40])
+        a += [m.A_.copy(), m.B_.copy()]
+        cuts = [(0, 900), (900, 901), (901, 901), (901, 4000), (4000, 6000)]
+        m.fit_multi([X[i:j] for i, j in cuts], [U[i:j] for i, j in cuts])
+        a += [m.centers_.copy(), m.A_.copy(), m.B_.copy()]
+        res[arrays] = a
+    for x, y in zip(res["native"], res["torch"]):
+        assert np.array_equal(x, y)
+    ctx = _lib.default_context()
+    outs = []
+    for mk in (lambda a: eng.DevArray.from_host(ctx, a), lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()):
+        A, B, C = eng.fit_dev(mk(X), mk(U[:-1]), 1, len(X) - 1, 48, 1.0, 1e-3, order="fit", ctx=ctx)
+        outs.append((A, B, C.numpy() if isinstance(C, eng.DevArray) else C.cpu().numpy()))
+    assert all(np.array_equal(x, y) for x, y in zip(*outs))
+    d = eng.DevArray.from_host(ctx, np.arange(24.0).reshape(6, 4))
+    assert np.array_equal(d.rows(2, 5).numpy(), np.arange(8.0, 20.0).reshape(3, 4)) and np.array_equal(d.view(-1, 8).numpy(), np.arange(24.0).reshape(3, 8))
+    with pytest.raises(ValueError):
+        KoopmanEDMDc(12, 8, arrays="cupy").fit(X, U)
+
+
+@pytest.mark.parametrize("mode", ["auto", "0"])
+def test_dropin_classes_in_a_process_that_never_imports_torch(tmp_path, mode):
+    """north_star: "host code stays Python calling HIP through a thin ctypes C-ABI (PyTorch-ROCm only for the existing bluerov_torch/PINC
+    path)".  tests/dropin_worker.py -- every method of the drop-in classes the reference's scripts call -- in a fresh process with
+    BROV2_TORCH=auto (torch's libamdhip64 preloaded, torch not imported) and BROV2_TORCH=0 (/opt/rocm's runtime): torch is never
+    imported, and every result equals, bit for bit, the run of the same worker on the torch-tensor path (BROV2_TORCH=1,
+    arrays="torch"); the results also match the reference's fixtures."""
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    worker = os.path.join(REPO, "tests", "dropin_worker.py")
+    runs = {}
+    for tag, env_mode, arrays in (("free", mode, "native"), ("torch", "1", "torch")):
+        out = str(tmp_path / f"{tag}.npz")
+        pr = subprocess.run([sys.executable, worker, out, arrays], capture_output=True, text=True, timeout=600, env=dict(os.environ, BROV2_TORCH=env_mode))
+        assert pr.returncode == 0, pr.stderr[-2000:]
+        runs[tag] = np.load(out)
+    free, tor = runs["free"], runs["torch"]
+    assert not bool(free["torch_imported"]) and bool(tor["torch_imported"]), (str(free["hip_runtime"]), str(tor["hip_runtime"]))
+    assert ("preloaded" in str(free["hip_runtime"])) if mode == "auto" else str(free["hip_runtime"]).startswith("system")
+    for key in free.files:
+        if key not in ("torch_imported", "hip_runtime"):
+            assert np.array_equal(free[key], tor[key]), key
+    g, kat, w = load_golden("edmdc.npz"), load_golden("fossen_rhs_kat.npz"), load_golden("windows.npz")
+    assert rel_err(free["refc_A"], g["A"]) < 1e-8 and rel_err(free["refc_B"], g["B"]) < 1e-8
+    assert np.max(np.abs(free["refc_ms"] - g["ms_rmse"])) < 1e-7 and rel_err(free["fit_centers"], g["centers"]) < 1e-9
+    assert rel_err(free["thr_xdot"], kat["thr_cur_XDOT"][:, 5]) < TOL_CALL and rel_err(free["thr_lag"], kat["thr_cur_LAG"][2, 5]) < TOL_CALL
+    assert rel_err(free["thr_tau"], kat["thr_TAU1"][5]) < TOL_CALL
+    assert rel_err(free["we_xdot"], kat["we_cur_XDOT"][5]) < TOL_CALL and rel_err(free["wq_xdot"], kat["wq_cur_XDOT"][5]) < TOL_CALL
+    Hs = [int(h) for h in w["H"]]
+    assert abs(free["window_rmse"][0] - w["thr_euler_rmse"][Hs.index(1)]) < 1e-9 and abs(free["window_rmse"][1] - w["thr_euler_rmse"][Hs.index(10)]) < 1e-9
 
 
 def test_fit_keeps_the_references_own_product_order(eng):
@@ -2040,7 +2128,8 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert c["verified"]["ok"] is True
     sm = c["summary"]
     for k in ("gram_samples_per_s", "gram_mfma_frac", "fit_samples_per_s", "fit_multi_samples_per_s", "cfg4_rollout_ms", "cfg4_gram_samples_per_s",
-              "cfg4_rccl_ranks", "cfg4_per_rank_ms", "cfg4_rollout_hbm_frac", "cfg4_fill_hbm_frac", "recorded_cpu_fit_s"):
+              "cfg4_rccl_ranks", "cfg4_per_rank_ms", "cfg4_rollout_hbm_frac", "cfg4_fill_hbm_frac", "recorded_cpu_fit_s",
+              "recorded_first_fit_s_torch_free", "recorded_first_fit_s_torch_tensors", "recorded_AB_bit_equal_across_modes"):
         assert k in sm, k
     assert all(not isinstance(v, (dict,)) for v in sm.values())          # flat
     d = json.load(open(det))
@@ -2084,9 +2173,12 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert hc["finite"] and hc["fit_multi"]["finite"] and hc["fit_multi"]["bags"] == 80 and hc["fit_multi"]["samples_per_s_second_call"] > 0
     rs = ef["recorded_shape"]
     assert rs["data_finite"] and rs["rows_logged_by_the_reference"] == 45823 and rs["value"] > 0 and rs["unit"] == "samples/s"
-    run = rs["runs"]["N45823_pinv_eigh"]
+    run = rs["runs"]["N45823_torch_free"]
     assert run["thruster_12_8"]["finite"] and run["quaternion_13_6"]["finite"] and run["thruster_12_8"]["first_call_s"] >= run["thruster_12_8"]["warm_call_s"] > 0
-    assert all(rs["pinv_options"][how]["max_abs_drmse_H1_10_100_vs_numpy_pinv"] < 1e-6 for how in ("eigh", "host", "device"))
+    # round 6: the same fit in a process that never imports torch (both HIP runtimes) and on the torch-tensor path: the same bits
+    fc_ = rs["first_calls"]
+    assert set(fc_) == {"torch_free", "torch_free_rocm_runtime", "torch_tensors"} and rs["AB_bit_equal_across_modes"] is True
+    assert fc_["torch_free"]["torch_imported"] is False and fc_["torch_free_rocm_runtime"]["torch_imported"] is False and fc_["torch_tensors"]["torch_imported"] is True
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in rs["cpu_baseline"], k
     assert rs["cpu_baseline"]["kind"] == "port" and rs["cpu_baseline"]["cores"] == 4

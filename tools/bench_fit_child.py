@@ -2,7 +2,8 @@
 (training/best_results.txt:761,798: N = 45 823 samples, n = 12, r = 8, 500 RBFs, gamma = 3, ridge = 0.1 -- the settings of
 training/train_tank_brov2_full_comparison.py:40-44) on HOST arrays, as the FIRST thing a fresh process does, then again (warm).
 
-    python tools/bench_fit_child.py gpu <data.npz> [pinv]     the drop-in class (libbrov2.so)
+    python tools/bench_fit_child.py gpu <data.npz> [pinv] [arrays]   the drop-in class (libbrov2.so); arrays = native (default: no torch in the
+                                                              process unless $BROV2_TORCH=1) or torch (the torch-tensor path of rounds 1-5)
     python tools/bench_fit_child.py cpu <data.npz>            the NumPy / scikit-learn restatement of the reference's fit() in its own
                                                               shape (oracle/edmdc_numpy.py; bench.py's cpu_baseline leg -- the parent
                                                               sets OMP_NUM_THREADS=4, the reference's import-time default,
@@ -29,21 +30,25 @@ def main():
     k, gamma, ridge = int(z["k"]), float(z["gamma"]), float(z["ridge"])
     Hs = (1, 10, 100)
     if mode == "gpu":
-        pinv = sys.argv[3] if len(sys.argv) > 3 else "host"
+        import hashlib
+        pinv = sys.argv[3] if len(sys.argv) > 3 else "auto"
+        arrays = sys.argv[4] if len(sys.argv) > 4 else "native"
+        out["data_loaded_s_since_start"] = time.perf_counter() - T_START
         t0 = time.perf_counter()
-        from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc     # imports torch, binds libbrov2.so lazily
+        from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc     # binds libbrov2.so lazily (first Context)
         out["import_s"] = time.perf_counter() - t0
-        out["pinv"] = pinv
+        out["pinv"], out["arrays"] = pinv, arrays
         for name, X, U in cases:
             n, r = X.shape[1], U.shape[1]
             calls, first_done = [], None
             for rep in range(7 if name == cases[0][0] else 4):
-                m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge, pinv=pinv)
+                m = KoopmanEDMDc(state_dim=n, input_dim=r, n_rbfs=k, gamma=gamma, ridge=ridge, pinv=pinv, arrays=arrays)
                 t0 = time.perf_counter()
                 m.fit(X, U)
                 calls.append(time.perf_counter() - t0)
                 if rep == 0 and name == cases[0][0]:
                     first_done = time.perf_counter() - T_START        # interpreter start -> imports -> data -> first fit() returned
+                    out["first_fit_AB_sha256"] = hashlib.sha256(m.A_.tobytes() + m.B_.tobytes() + m.centers_.tobytes()).hexdigest()[:16]
             t0 = time.perf_counter()
             scores = [m.multistep_rmse(X, U, H) for H in Hs]
             sc_s = time.perf_counter() - t0
@@ -55,6 +60,9 @@ def main():
                          "multistep_rmse_H1_10_100": scores, "multistep_rmse_three_calls_s": [sc_s, sc2_s],
                          "finite": bool(np.isfinite(m.A_).all() and np.isfinite(m.B_).all()),
                          "checksum": float(np.abs(m.A_).sum() + np.abs(m.B_).sum())}
+        from bluerov2_dynamics_amd import _lib
+        out["torch_imported"] = "torch" in sys.modules
+        out["hip_runtime"] = _lib.hip_runtime
         out["process_total_s"] = time.perf_counter() - T_START
     else:
         from sklearn.cluster import KMeans

@@ -48,7 +48,7 @@ del a_, b_
 for rep in range(2):
     t0 = time.perf_counter(); bt_ = engine.BagTable(X_list, U_list, n, r); print(f"BagTable (Python bookkeeping): {(time.perf_counter() - t0) * 1e3:.1f} ms")
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    Xd, Ud, off = engine.upload_bags(X_list, U_list, n, r, ctx=ctx)
+    Xd, Ud, off = engine.upload_bags(X_list, U_list, n, r, ctx=ctx, arrays="torch")
     torch.cuda.synchronize(); ub = time.perf_counter() - t0
     print(f"engine.upload_bags: {ub * 1e3:.1f} ms", flush=True)
 t0 = time.perf_counter(); vs = np.vstack(X_list); print(f"np.vstack(X_list) alone: {(time.perf_counter() - t0) * 1e3:.1f} ms"); del vs
