@@ -412,6 +412,11 @@ def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
         self_launch(a)                     # does not return
+    # stdout carries ONE line, the JSON at the end: whatever a library prints meanwhile (gloo announces its ranks on fd 1, for one)
+    # goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -1064,7 +1069,8 @@ def main():
         details = write_details(out, a.details)
         line = json.dumps(compact_line(out, details), separators=(",", ":"))
         assert len(line) <= MAX_LINE_BYTES, len(line)
-        print(line, flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (line + "\n").encode())
 
 
 MAX_LINE_BYTES = 4096        # the driver parses the ONE stdout line; round 5's 25 KB line came back unparsed (BENCH_r05.json: parsed null)

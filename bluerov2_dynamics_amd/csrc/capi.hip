@@ -2290,9 +2290,11 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
         std::memset(c->h_stats, 0, 8 * sizeof(double));
         HIPCK(c, hipHostGetDevicePointer((void**)&c->d_stats_map, c->h_stats, 0));      // the M-step stores the iteration's statistics there itself
     }
+#ifdef BROV2_EXPERIMENTS      // the side stream serves the cdist_beside experiment alone (BROV2_KM_CDIST_BESIDE below): nothing of it in the default build
     if (!c->side[0]) HIPCK(c, hipStreamCreateWithFlags(&c->side[0], hipStreamNonBlocking));
     if (!c->ev_fork) HIPCK(c, hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     if (!c->ev_join[0]) HIPCK(c, hipEventCreateWithFlags(&c->ev_join[0], hipEventDisableTiming));
+#endif
     HIPCK(c, hipMemsetAsync(ms_scratch, 0, kmeans_mstep_scratch_doubles(k) * 8, c->stream));
     CallTimer t(c);
     double* prm = stats + 4;

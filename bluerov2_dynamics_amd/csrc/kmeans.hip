@@ -651,7 +651,10 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     // enough for the whole list: if tickets were left, every block would have used all of its own.  No result depends on who takes
     // which ticket: labels and bounds are per position, the member sums integers.
     constexpr bool DYN = LIST && KM_LIST_DYNAMIC;
-    __shared__ unsigned long long s_tw;               // (first ticket of the block's batch << 8) | tickets handed out (16: none left)
+    __shared__ unsigned long long s_tw;               // (first ticket of the block's batch << 16) | tickets handed out (16: none left)
+    // the count field is 16 bits wide: every retry of a waiting wave adds one to it (at most 15 waves x 257 tries = 3 855 on top of the
+    // 16 of a spent batch), which must never carry into the ticket above it (round-5 review: an 8-bit field could, after 240 retries)
+    static_assert(16 + 15 * 257 < (1 << 16), "retries of the waiting waves must fit below the ticket bits");
     __shared__ int s_taken, s_more;
     const int T = (int)(M >> 6);                      // tickets; a value >= T is "none" (N < 2^31: 32 bits hold every ticket drawn)
     const int tk_dyn0 = (int)gridDim.x * (3 * (KM_THREADS / 64));
@@ -674,22 +677,22 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
             const int none = 0x7ffffff0;
             for (int tries = 0;; ++tries) {
                 const unsigned long long old = atomicAdd(&s_tw, 1ull);
-                const unsigned cnt = (unsigned)(old & 255ull);
-                if (cnt < (unsigned)TK_BATCH) { tk = (int)(old >> 8) + (int)cnt; break; }
+                const unsigned cnt = (unsigned)(old & 0xFFFFull);
+                if (cnt < (unsigned)TK_BATCH) { tk = (int)(old >> 16) + (int)cnt; break; }
                 if (cnt == (unsigned)TK_BATCH) {
                     if (atomicAdd(&s_taken, TK_BATCH) + TK_BATCH > TK_EPOCH) {      // this epoch's share is drawn: closed until the flush
-                        atomicExch(&s_tw, (unsigned long long)none << 8);
+                        atomicExch(&s_tw, (unsigned long long)none << 16);
                         tk = none;
                     } else {
                         tk = tk_dyn0 + atomicAdd(tctr, TK_BATCH);
-                        atomicExch(&s_tw, ((unsigned long long)tk << 8) | 1ull);
+                        atomicExch(&s_tw, ((unsigned long long)tk << 16) | 1ull);
                     }
                     break;
                 }
                 // another wave of the block is fetching the next batch: a few microseconds.  Bounded all the same -- a wave that gives up
                 // takes "none" and stops drawing; what it would have drawn stays in the counter for the others (never seen)
                 int spins = 0;
-                while ((*reinterpret_cast<volatile unsigned long long*>(&s_tw) & 255ull) >= (unsigned long long)TK_BATCH && ++spins < 4096) __builtin_amdgcn_s_sleep(2);
+                while ((*reinterpret_cast<volatile unsigned long long*>(&s_tw) & 0xFFFFull) >= (unsigned long long)TK_BATCH && ++spins < 4096) __builtin_amdgcn_s_sleep(2);
                 if (tries >= 256) { tk = none; break; }
             }
         }
@@ -1023,7 +1026,7 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
                 const float mf = (float)(8.0e-6 * u2_ref) * 1.001f + 1.0e-37f;
                 float fb = -3.0e38f, fs = -3.0e38f;
                 int bp = 0;
-                const int npairs2 = (((ncand_nbr + 1) >> 1) + 1) & ~1;
+                const int npairs2 = (((ncand_nbr + 1) >> 1) + 1) & ~1;       // <= kmeans_lds_pf_pairs() (static_assert there): the records cdist built
                 const cfp_ rows = (cfp_)(unsigned long long)Pf + (int64_t)a_ref * (kp >> 1) * 32;
                 // Two records per round trip, worked on together (two independent FMA chains: no wait states between them).  With
                 // four waves on a SIMD and a record that comes from the L2 (each pass walks another cluster's row: the scalar cache
@@ -3417,6 +3420,9 @@ hipError_t launch_kmeans_cdist(hipStream_t st, int n, int k, const double* c2, f
     return hipGetLastError();
 }
 int kmeans_bounds_tail() { return KM_BND_TAIL; }
+// The prefix contract of Pf (round-5 review): launch_kmeans_cdist builds only this many pair records per row when the LDS / DPP kernel is
+// their only reader, and that kernel's screening loop walks npairs2 = ((ceil(ncand / 2) + 1) & ~1) records with ncand <= KM2_NBR_MAX.
+static_assert((((((KM2_NBR_MAX + 1) >> 1) + 1) & ~1)) <= KM2_NBR_MAX / 2, "the screening loop would read pair records that were never built");
 int kmeans_lds_pf_pairs() { return KM2_NBR_MAX / 2; }
 size_t kmeans_bounds_list_words(int64_t N) { return (size_t)((N + KM_BND_TILE - 1) / KM_BND_TILE) * (KM_BND_TILE + 64); }
 hipError_t launch_kmeans_bounds(hipStream_t st, int64_t N, int k, const int* labels, const KmBounds& b, const double* prm) {

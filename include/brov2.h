@@ -122,7 +122,10 @@ BROV_API int brov_discretise_lag(const brov_params* p, double dt, double Ad[9], 
 BROV_API int brov_model_nx(int model);
 BROV_API int brov_model_nu(int model);
 
-/* ---- device memory helpers (so that callers need no HIP/torch of their own) ----------- */
+/* ---- device memory helpers (so that callers need no HIP/torch of their own) -----------
+ * brov_free keeps blocks of up to 256 MB (1 GB in total per ctx) for the next brov_malloc of a similar size; brov_destroy releases them.
+ * The copies are synchronous (done on return) and accept pageable host memory: between 64 KB and 16 MB they are staged through two
+ * pinned blocks owned by the ctx instead of handing the caller's pages to the runtime. */
 BROV_API int brov_malloc(brov_ctx* ctx, size_t bytes, void** dptr);
 BROV_API int brov_free(brov_ctx* ctx, void* dptr);
 BROV_API int brov_memcpy_h2d(brov_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -337,7 +340,9 @@ BROV_API int edmdc_set_apply_variant(brov_ctx* ctx, int variant);
  * A library built with -DBROV2_EXPERIMENTS=1 (tools/, A/B measurements; brov_experiments_build() = 1) accepts further bits that swap
  * single stages for their earlier forms (csrc/capi.hip: KMV_*) and reads its tuning knobs from the environment; the default build
  * refuses those bits and reads no environment variable except BROV2_QUIET (silences the one note brov_create may print about the XCD
- * placement probe) and BROV2_RCCL_LIBRARY (below). */
+ * placement probe) and BROV2_RCCL_LIBRARY (below).
+ * Changelog: up to round 4 `+ 4` selected the scalar-record kernel and `+ 8 .. + 256` were accepted by every build; since round 5 the
+ * bits mean what is listed above and a caller passing the old values to a default build gets BROV_ERR_ARG. */
 BROV_API int edmdc_set_kmeans_variant(brov_ctx* ctx, int variant);
 /* When the distance bounds take over: an E-step visits only the samples whose bounds fail once at most `rate` of all labels changed in
  * the iteration before (default 0.03; 1 = from the first sorted iteration on, 0 = never).  Speed only: labels and centres do not depend

@@ -13,12 +13,12 @@ import json
 import sys
 
 root = sys.argv[1]
-NAMES = {"rollout_pair_kernel<1, 2,": "rollout",     # thruster model, RK4, paired time-major layout: the benchmark kernel
+NAMES = {"rollout_pair_kernel<1, 2,": "rollout", "rollout_pair_kernel<1, 0,": "rollout_btu", "fill_ar1_btu_kernel": "fill_ar1_btu",     # thruster model, RK4, paired time-major layout: the benchmark kernel
           "gram_kernel": "gram", "lift_rows_kernel": "lift", "kmeans_assign_kernel": "kmeans_assign_scalar_records", "kmeans_assign_lds_kernel": "kmeans_assign",
          "propagate_kernel": "propagate", "pp_round_kernel": "kmeanspp_round", "pp_decide_kernel": "kmeanspp_decide", "lift_tail_kernel": "lift_tail",
          "gram_kernel<false>": "gram", "gram_kernel<true>": "wty_gram", "wrows_kernel": "wrows", "rows_times_pt_simple_kernel": "wrows_simple"}
 NAMES.pop("gram_kernel")
-pats = sys.argv[2:] or list(NAMES)
+pats = sys.argv[2:] or [p_ for p_ in NAMES if p_ not in ("rollout_pair_kernel<1, 0,", "fill_ar1_btu_kernel")]
 out = {p: {} for p in pats}
 for f in glob.glob(root + "/*/**/*counter_collection.csv", recursive=True):
     acc = {}
