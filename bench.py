@@ -70,7 +70,7 @@ def kernel_source_sha():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(parts, files=("r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
+def pmc_traffic(parts, files=("r06_pmc_summary.json", "r05_pmc_summary.json", "r04_pmc_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json", "r01_pmc_summary.json")):
     """HBM bytes from the committed PMC run (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command,
     FETCH_SIZE x2 per the gfx950 note of MI355X_MICROARCH.md).  parts: {kernel name in the summary: launches}; the figure is
     the sum over ALL of them (a fit = lift + tail + Gram per chunk).  PMC counters cannot be read from inside the timed
@@ -99,7 +99,7 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
     if rows != 10_020_000 or kk != 512 or not ms_per_step:
         return None
     cur = kernel_source_sha()
-    for name in ("r05_lloyd_pmc_summary.json", "r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
+    for name in ("r06_lloyd_pmc_summary.json", "r05_lloyd_pmc_summary.json", "r04_lloyd_pmc_summary.json", "r03_lloyd_pmc_summary.json"):
         try:
             full = json.load(open(os.path.join(REPO, "profiles", name)))
             d = full.get("kmeans_assign") or full["kmeans_assign_lds_kernel<12>"]      # (all launches of the E-step kernel of the recorded loop)
@@ -128,6 +128,27 @@ def lloyd_roofline(rows, kk, ms_per_step, iterations):
                                      "algorithmic = one 96-byte row, its permutation index and old label in, label and sort key out per sample"}
                             if "hbm_total_GB_per_launch" in d else None)}
     return None
+
+
+def cfg4_counter_terms(B, T, roll_ms, fill_ms):
+    """Config 4's two caller-layout kernels against the ceilings that bind them, from the recorded counter run of exactly those kernels
+    (tools/r06_cfg4_pmc.sh -> profiles/r06_cfg4_pmc_summary.json; times are this run's): the AR(1) fill is bound by fp64 VALU issue
+    (216 instructions per value: two splitmix64, log, sqrt, cospi), the stored rollout by how HBM serves 2 x 65 536 interleaved
+    192-byte streams (measured bytes, not algorithmic ones)."""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r06_cfg4_pmc_summary.json")))
+        if not (B == 1 << 20 and T == 500):
+            return {}
+        rb, fl = d["rollout_btu"], d["fill_ar1_btu"]
+        slots = SIMDS * CLOCK_HZ / 4.0                       # fp64-rate wave-instructions per second, whole chip
+        return {"fill_issue_frac": fl["SQ_INSTS_VALU"] / (fill_ms * 1e-3) / slots,
+                "fill_valu_instr_per_value": fl["SQ_INSTS_VALU"] / (B * T * 8 / 64.0),
+                "rollout_issue_frac": rb["SQ_INSTS_VALU"] / (roll_ms * 1e-3) / slots,
+                "rollout_hbm_measured_bytes": rb["hbm_total_GB_per_launch"] * 1e9,
+                "rollout_hbm_measured_frac": rb["hbm_total_GB_per_launch"] / (roll_ms * 1e-3) / PEAK_HBM_GBS,
+                "counters_source": "profiles/r06_cfg4_pmc_summary.json", "counters_stale": d.get("_kernel_source_sha") != kernel_source_sha()}
+    except Exception:
+        return {}
 
 
 def parse():
@@ -858,7 +879,7 @@ def main():
                                        "kernel_ms": apply_kernel_ms, "flop_per_sample": wrows_flop + wty_flop,
                                        "wrows_flop_per_sample": wrows_flop, "wty_flop_per_sample": wty_flop, "decomposition": dec,
                                        "note": "executed MFMA flop of the two passes of (P G^T) Y / time of the whole apply pass (any re-lift included)",
-                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r05_fit_pmc_summary.json", "r04_fit_pmc_summary.json", "r03_fit_pmc_summary.json")) if pairs == 10_000_000 else None,
+                                       "traffic": pmc_traffic({"wrows": chunks, "wty_gram": chunks}, files=("r06_fit_pmc_summary.json", "r05_fit_pmc_summary.json", "r04_fit_pmc_summary.json", "r03_fit_pmc_summary.json")) if pairs == 10_000_000 else None,
                                        "algorithmic": {"flop_per_sample": 2.0 * p * p + 2.0 * p * d, "unit": "TFLOP/s",
                                                        "achieved": pairs * (2.0 * p * p + 2.0 * p * d) / (apply_kernel_ms * 1e-3) / 1e12}}
                     leg["ratio_to_full_gram_ms"] = (tmf["total_s"] - tmf["centres_s"]) * 1e3 / (ewall / a.edmdc_steps * 1e3)
@@ -1042,6 +1063,7 @@ def main():
                 # caller-layout ([B][T][c]) kernels of this leg against HBM: 64 B in + 96 B out per step; 64 B written per step by the fill
                 "rollout_hbm_frac": Bl * T4 * 160.0 / (roll_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                 "fill_ar1_ms": fill_ms, "fill_hbm_frac": Bl * T4 * 64.0 / (fill_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                **cfg4_counter_terms(Bl, T4, roll_ms, fill_ms),
                 "gram_samples_per_s": pairs4 / (gram_max * 1e-3),
                 "pairs_total": pairs4,
                 "verified": {"GtG_xx_vs_torch_rel": e_gg, "GtY_xx_vs_torch_rel": e_gy, "ok": bool(e_gg < 1e-11 and e_gy < 1e-11),
@@ -1205,6 +1227,9 @@ def compact_line(out, details_path):
         put("cfg4_rollout_hbm_frac", "config4", "rollout_hbm_frac")
         put("cfg4_fill_ms", "config4", "fill_ar1_ms")
         put("cfg4_fill_hbm_frac", "config4", "fill_hbm_frac")
+        put("cfg4_fill_issue_frac", "config4", "fill_issue_frac")
+        put("cfg4_rollout_issue_frac", "config4", "rollout_issue_frac")
+        put("cfg4_rollout_hbm_measured_frac", "config4", "rollout_hbm_measured_frac")
         put("cfg4_gram_samples_per_s", "config4", "gram_samples_per_s")
         put("cfg4_verified", "config4", "verified", "ok")
         put("cfg4_gram_trace", "config4", "gram_fingerprint", "trace_GtG")

@@ -22,6 +22,14 @@ __device__ __forceinline__ double uniform01_at(uint64_t seed, uint64_t counter) 
     return (double)(splitmix64_at(seed, counter) >> 11) * 0x1.0p-53;
 }
 
+// Box-Muller normal of dist B from two uniforms of the counter stream: sqrt(-2 ln(1 - u1)) cos(2 pi u2) (oracle/controls.py).  1 - u1 is exact
+// (u1 is a multiple of 2^-53 below 1), so log(1 - u1) is the oracle's log1p(-u1) to an ulp, and cospi(2 u2) is cos(2 pi u2) without the
+// rounding of the product 2 pi u2 and without the large-argument branch of cos: the values agree with the NumPy oracle to ~6e-15 absolute
+// (tested at 1e-12) for 0.7 of the instructions (round 6: the fill kernels are bound by fp64 VALU issue, profiles/r06_cfg4_pmc_summary.json).
+__device__ __forceinline__ double box_muller(double u1, double u2) {
+    return sqrt(-2.0 * log(1.0 - u1)) * cospi(2.0 * u2);
+}
+
 struct Scale8 { double s[8]; };
 
 // one thread per (b, t); TUB stores are coalesced over b, BTU stores are one 8*nu-byte row per thread
@@ -53,7 +61,7 @@ __global__ void __launch_bounds__(256) fill_ar1_kernel(int64_t B, int64_t T, int
     for (int64_t t = 0; t < T; ++t) {
         const uint64_t c = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)t) * (uint64_t)nu + (uint64_t)j;
         const double u1 = uniform01_at(s2, 2ull * c), u2 = uniform01_at(s2, 2ull * c + 1ull);
-        const double xi = sqrt(-2.0 * log1p(-u1)) * cos(6.283185307179586476925286766559 * u2);
+        const double xi = box_muller(u1, u2);
         prev = fmin(fmax(fma(0.98, prev, 0.02 * xi), -1.0), 1.0);
         const double v = prev * sc.s[j];
         if constexpr (LAYOUT == LAYOUT_BTU) U[(b * T + t) * nu + j] = v;
@@ -86,7 +94,7 @@ __global__ void __launch_bounds__(256) fill_ar1_btu_kernel(int64_t B, int64_t T,
         for (int s = 0; s < ns; ++s) {
             const uint64_t c = ((uint64_t)(b0 + b) * (uint64_t)T_total + (uint64_t)(t0 + s)) * (uint64_t)NU + (uint64_t)j;
             const double u1 = uniform01_at(s2, 2ull * c), u2 = uniform01_at(s2, 2ull * c + 1ull);
-            const double xi = sqrt(-2.0 * log1p(-u1)) * cos(6.283185307179586476925286766559 * u2);
+            const double xi = box_muller(u1, u2);
             prev = fmin(fmax(fma(0.98, prev, 0.02 * xi), -1.0), 1.0);
             pk[s * SROW + lane] = prev * sc.s[j];
         }

@@ -311,6 +311,9 @@ __global__ void __launch_bounds__(256) rollout_kernel(const FastParams* __restri
 #ifndef BROV_PAIR_RING
 #define BROV_PAIR_RING 2         // exchange slots (the flag form can run the thrust wave further ahead)
 #endif
+#ifndef BROV_PAIR_STAGE
+#define BROV_PAIR_STAGE 1        // LAYOUT_BTU: stored states go through LDS and leave in contiguous runs (0: six 16-byte stores per lane and step)
+#endif
 #ifndef BROV_PAIR_PRIO
 #define BROV_PAIR_PRIO 0         // 1: s_setprio 3 for the body wave, 0 for the thrust wave
 #endif
@@ -330,6 +333,12 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
     constexpr int NS = (INTEG == INTEG_RK4) ? 4 : 1;          // dynamics() calls per step
     __shared__ double2 qt[4];
     __shared__ __attribute__((aligned(16))) double2 xch[BROV_PAIR_RING][4][NS * 3][64];     // [slot][pair][stage, channel pair][lane]
+    // LAYOUT_BTU, every state stored (round 6): a body wave parks STG_S consecutive states of its 64 trajectories in LDS (row q = trajectory
+    // q, STG_S x 96 bytes + 16 of padding: conflict-free both ways) and writes them out with lanes ALONG the trajectories -- a store
+    // instruction then covers 1 KB in runs of STG_S x 96 contiguous bytes (11 cache lines) instead of one 16-byte piece in each of 64 lines
+    constexpr bool STG = (LAYOUT == LAYOUT_BTU) && BROV_PAIR_STAGE;
+    constexpr int STG_S = 2, STG_ROW = STG_S * NXP + 1, STG_PER = STG_S * NXP;               // double2 per parked row; pieces per trajectory and tile
+    __shared__ __attribute__((aligned(16))) double2 stg[STG ? 4 * 64 * STG_ROW : 1];
 #if BROV_PAIR_EXP == 4
     __shared__ int pflag[2][4];                               // [produced | consumed][pair]: steps done so far
     if (threadIdx.x < 8) (&pflag[0][0])[threadIdx.x] = 0;
@@ -423,7 +432,63 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
             else if constexpr (LAYOUT == LAYOUT_TUB) { tp = traj + b; tstep = (int64_t)NX * B; }
             else { tp = traj + 2 * b; tstep = (int64_t)NXP * 2 * B; }
         }
+        // staged stores (LAYOUT_BTU, stride 1).  Write-out of a tile: STG_PER = 12 lanes per trajectory, five trajectories per instruction (lanes
+        // 60-63 idle), 13 instructions for the wave's 64 trajectories -- lane l always handles piece l % 12 of trajectory 5 it + l / 12, so
+        // its global offset and LDS index are one register each plus a wave-uniform term per instruction
+        const bool staged = STG && traj != nullptr && stride == 1 && (uint64_t)(T + 1) * (NX * 8) * 64 < (1ull << 32);
+        const int64_t bw = (int64_t)blockIdx.x * 256 + pair * 64;          // first trajectory of this wave
+        constexpr int STG_TPI = 64 / STG_PER, STG_NI = (64 + STG_TPI - 1) / STG_TPI;       // trajectories per instruction, instructions per tile
+        const int st_q = lane / STG_PER, st_c = lane - st_q * STG_PER;
+        const unsigned st_rb = (unsigned)((T + 1) * (NX * 8));             // bytes of one trajectory
+        const unsigned st_off = (unsigned)st_q * st_rb + (unsigned)st_c * 16u;
+        const int st_lds = st_q * STG_ROW + st_c;
+        const int st_live = (int)((B - bw) < 64 ? (B - bw) : 64);          // trajectories of this wave that exist (wave-uniform)
+        int st_fill = 0;
+        char* st_base = nullptr;                                          // wave-uniform: row `rows flushed so far` of the wave's first trajectory
+        double2* const st_wave = stg + (STG ? pair * 64 * STG_ROW : 0);
+        if constexpr (STG) {
+            if (staged) {
+                const uint64_t a = reinterpret_cast<uint64_t>(traj) + (uint64_t)bw * (uint64_t)st_rb;
+                st_base = reinterpret_cast<char*>(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                                                  (uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a & 0xFFFFFFFFull)));
+            }
+        }
+        auto st_flush = [&](int ns) {
+            if constexpr (STG) {
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (ns == STG_S) {
+#pragma unroll
+                    for (int it = 0; it < STG_NI; ++it) {
+                        if (lane < STG_TPI * STG_PER && it * STG_TPI + st_q < st_live) {
+                            const double2 v = st_wave[st_lds + it * STG_TPI * STG_ROW];
+                            *reinterpret_cast<double2*>(st_base + (uint64_t)(it * STG_TPI) * st_rb + st_off) = v;
+                        }
+                    }
+                } else {                                                  // the last, shorter tile of a trajectory with an odd number of rows
+                    const int per = ns * NXP;
+                    for (int i = lane; i < 64 * per; i += 64) {
+                        const int q = i / per, c = i - q * per;
+                        const double2 v = st_wave[q * STG_ROW + c];
+                        if (q < st_live) *reinterpret_cast<double2*>(st_base + (uint64_t)q * st_rb + (uint64_t)c * 16u) = v;
+                    }
+                }
+                st_base += (int64_t)ns * (NX * 8);
+                st_fill = 0;
+                __builtin_amdgcn_wave_barrier();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+        };
         auto store_state = [&]() {
+            if constexpr (STG) {
+                if (staged) {
+                    double2* row = st_wave + lane * STG_ROW + st_fill * NXP;
+#pragma unroll
+                    for (int j = 0; j < NXP; ++j) row[j] = make_double2(x[2 * j], x[2 * j + 1]);
+                    if (++st_fill == STG_S) st_flush(STG_S);
+                    return;
+                }
+            }
             if (live) {
                 if constexpr (LAYOUT == LAYOUT_BTU) store_row<NX>(tp, x);
                 else if constexpr (LAYOUT == LAYOUT_TUB) store_soa<NX>(tp, B, x);
@@ -479,6 +544,7 @@ __global__ void __launch_bounds__(512) rollout_pair_kernel(const FastParams* __r
             g_clock_stamps[blockIdx.x][2] = __builtin_amdgcn_s_memtime(); g_clock_stamps[blockIdx.x][3] = __builtin_amdgcn_s_memrealtime();
         }
 #endif
+        if constexpr (STG) { if (staged && st_fill > 0) st_flush(st_fill); }
         if (XT && live) store_row<NX>(XT + b * NX, x);
     }
 }
