@@ -144,13 +144,20 @@ class KoopmanEDMDc:
         """One-step RMSE in state space (reference :157-170)."""
         return self.multistep_rmse(X, U, H=1)
 
-    def multistep_rmse(self, X, U, H: int = 10) -> float:
-        """RMSE after H open-loop steps from every start index (reference :172-200)."""
+    def multistep_rmse(self, X, U, H: int = 10, method: str = "propagate") -> float:
+        """RMSE after H open-loop steps from every start index (reference :172-200).  method="propagate" (default): H lifted steps
+        Z <- Z A^T + U_t B^T like the reference; "linear" (opt-in): the same prediction through the explicit powers of A in one pass
+        over the windows (engine.multistep_se_linear) -- equal to rounding, ~40 x less arithmetic at H = 100."""
         X = np.asarray(X, dtype=float)
         n_start = len(X) - H
         if hasattr(self, "decoder_"):
             raise NotImplementedError("decoder_ is never set by the reference's fit(); not supported")
-        se, _ = engine.multistep_se(X, U, self.centers_, self.gamma, self.A_, self.B_, H)
+        if method == "propagate":
+            se, _ = engine.multistep_se(X, U, self.centers_, self.gamma, self.A_, self.B_, H)
+        elif method == "linear":
+            se, _ = engine.multistep_se_linear(X, U, self.centers_, self.gamma, self.A_, self.B_, H)
+        else:
+            raise ValueError("method must be 'propagate' or 'linear'")
         with np.errstate(invalid="ignore", divide="ignore"):
             return float(np.sqrt(np.float64(se) / (n_start * X.shape[1]))) if n_start > 0 else float("nan")
 

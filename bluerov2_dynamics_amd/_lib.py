@@ -132,6 +132,8 @@ SIGNATURES = {
                                           c_void_p, c_void_p]),
     "edmdc_multistep_se": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                           c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "edmdc_multistep_se_linear": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
+                                                 c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p, c_void_p]),
     "edmdc_simulate": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,
                                       c_void_p, c_void_p, i64, i64, c_void_p, c_void_p, c_void_p]),
     "edmdc_pinv_apply": (ctypes.c_int, [c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, c_void_p,

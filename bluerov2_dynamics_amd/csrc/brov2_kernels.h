@@ -49,6 +49,9 @@ inline EdmdcShape edmdc_shape(int n, int r, int k) {
 }
 // Reference-order lift Z[N][n+k] = [x, rbf]  (edmdc_lift C entry point)
 hipError_t launch_lift_ref(hipStream_t st, int64_t N, int n, int k, double gamma, const double* X, const double* C, double* Z);
+// multistep_rmse by linearity: se[w] = |X[w + H] - (RHt^T phi(x_w) + sum_t Gt[t]^T u_{w+t})|^2 for w < nw; RHt [n + k][n], Gt [H][r][n]; xhat [nw][n] optional
+hipError_t launch_linear_windows(hipStream_t st, int64_t nw, int n, int r, int k, int64_t H, double gamma, const double* X, const double* U,
+                                 const double* C, const double* RHt, const double* Gt, double* se, double* xhat);
 // Device-native lifted rows for `rows` consecutive state rows starting at global row `row0`
 // (bag structure: state row index = b * xs + t, t in [0, L]; input row = b * us + t, t < L).
 // Rows >= total_rows (and gap rows t > L) are written as zeros with weight 0.

@@ -1881,6 +1881,47 @@ int edmdc_multistep_se(brov_ctx* c, int n, int r, int k, double gamma, const dou
     return BROV_OK;
 }
 
+int edmdc_multistep_se_linear(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const double* RHt, const double* Gt,
+                              int64_t N, int64_t H, const double* X, const double* U, double* se_total, double* xhat_end) {
+    int rc = edmdc_shape_ok(c, n, r, k);
+    if (rc) return rc;
+    if (N < 0 || H < 0 || !C || !RHt || (H && r && !Gt) || !se_total || (N && (!X || (r && !U)))) return fail(c, BROV_ERR_ARG, "edmdc_multistep_se_linear: bad argument");
+    const int64_t nw = N - H;
+    if (nw <= 0) { *se_total = 0.0; return BROV_OK; }
+    DeviceGuard g(c);
+    const int d = n + k;
+    const int64_t urows = N - 1;                       // like edmdc_multistep_se: rows 0 .. N-2 of U are read, a shorter-by-one U is accepted
+    Arena a(c);
+    rc = a.reserve(Arena::al(N * n * 8) + Arena::al(N * (r ? r : 1) * 8) + Arena::al((size_t)k * n * 8) + Arena::al((size_t)d * n * 8) +
+                   Arena::al((size_t)(H ? H : 1) * (r ? r : 1) * n * 8) + Arena::al(nw * 8) + Arena::al(nw * n * 8) + 4096);
+    if (rc) return rc;
+    double* dX = a.take<double>(N * n);
+    double* dU = a.take<double>(N * (r ? r : 1));
+    double* dC = a.take<double>((size_t)k * n);
+    double* dR = a.take<double>((size_t)d * n);
+    double* dG = a.take<double>((size_t)(H ? H : 1) * (r ? r : 1) * n);
+    double* dse = a.take<double>(nw);
+    double* dxh = a.take<double>(nw * n);
+    double* dtot = a.take<double>(8);
+    HIPCK(c, h2d_copy(c, dX, X, N * n * 8));
+    if (r) {
+        HIPCK(c, hipMemsetAsync(dU + urows * r, 0, (size_t)r * 8, c->stream));
+        if (urows > 0) HIPCK(c, h2d_copy(c, dU, U, urows * r * 8));
+    }
+    HIPCK(c, h2d_copy(c, dC, C, (size_t)k * n * 8));
+    HIPCK(c, h2d_copy(c, dR, RHt, (size_t)d * n * 8));
+    if (H && r) HIPCK(c, h2d_copy(c, dG, Gt, (size_t)H * r * n * 8));
+    {
+        CallTimer t(c);
+        HIPCK(c, launch_linear_windows(c->stream, nw, n, r, k, H, gamma, dX, dU, dC, dR, dG, dse, xhat_end ? dxh : nullptr));
+        HIPCK(c, launch_sum(c->stream, nw, dse, dtot));
+    }
+    HIPCK(c, d2h_copy(c, se_total, dtot, 8));
+    if (xhat_end) HIPCK(c, d2h_copy(c, xhat_end, dxh, nw * n * 8));
+    HIPCK(c, hipStreamSynchronize(c->stream));
+    return BROV_OK;
+}
+
 int edmdc_simulate(brov_ctx* c, int n, int r, int k, double gamma, const double* C, const double* A, const double* B,
                    int64_t nb, int64_t T, const double* x0, const double* U_seq, double* X_pred) {
     int rc = edmdc_shape_ok(c, n, r, k);

@@ -20,7 +20,7 @@ from ._lib import (EULER, RK4, LAG_PER_CALL, LAG_PER_STEP, LAYOUT_BTU, LAYOUT_TU
                    WRENCH_QUAT, DIST_IID_UNIFORM, DIST_AR1, NX, NU, as_f64, _hptr, default_context)
 
 __all__ = ["rhs", "thruster_forces", "rollout", "window_endpoint_se", "window_rmse", "rollout_dev", "fill_controls_dev",
-           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "gram_ragged_dev", "pinv_apply_ragged_dev", "upload_bags", "BagTable", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "gtg_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "simulate_lifted"]
+           "window_endpoint_se_dev", "lift", "gram", "gram_dev", "gram_ragged_dev", "pinv_apply_ragged_dev", "upload_bags", "BagTable", "solve_AB", "solve_AB_fit_order", "pinv_apply", "pinv_apply_dev", "fit_dev", "apply_decomposition", "gtg_decomposition", "kmeans_lloyd", "kmeans_centers", "kmeans_centers_dev", "multistep_se", "multistep_se_linear", "simulate_lifted", "DevArray", "col_stats_dev"]
 
 INTEGRATORS = {"euler": EULER, "rk4": RK4, EULER: EULER, RK4: RK4}
 LAYOUTS = {"btu": LAYOUT_BTU, "tub": LAYOUT_TUB, "tpb": LAYOUT_TPB, LAYOUT_BTU: LAYOUT_BTU, LAYOUT_TUB: LAYOUT_TUB, LAYOUT_TPB: LAYOUT_TPB}
@@ -1015,6 +1015,39 @@ def multistep_se(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
     se = ctypes.c_double(0.0)
     ctx.check(ctx.lib.edmdc_multistep_se(ctx.h, n, r, k, float(gamma), _hptr(C), _hptr(A), _hptr(B), N, int(H), _hptr(X), _hptr(U),
                                          ctypes.addressof(se), _hptr(xhat)), "edmdc_multistep_se")
+    return se.value, xhat
+
+
+def linear_coefficients(A, B, n, H):
+    """(RHt [d, n], Gt [H, r, n]) of multistep_se_linear: RHt = (E A^H)^T, Gt[t] = (E A^(H-1-t) B)^T with E the first n rows of the identity --
+    H products of an n x d block by A on the host (NumPy)."""
+    A, B = as_f64(A), as_f64(B)
+    d, r = A.shape[0], B.shape[1]
+    R = np.zeros((n, d))
+    R[:, :n] = np.eye(n)
+    Gt = np.empty((H, r, n))
+    for j in range(H):                  # R = E A^j
+        Gt[H - 1 - j] = (R @ B).T
+        R = R @ A
+    return np.ascontiguousarray(R.T), Gt
+
+
+def multistep_se_linear(X, U, C, gamma, A, B, H, want_xhat=False, ctx=None):
+    """multistep_se by linearity (opt-in): x_hat[w] = (E A^H) phi(x_w) + sum_t (E A^(H-1-t) B) u_{w+t} in ONE pass over the windows
+    (edmdc_multistep_se_linear) instead of H lifted GEMM steps.  Same arguments and results as multistep_se up to the rounding of the
+    explicit powers of A."""
+    ctx = ctx or default_context()
+    ctx.use_null_stream()
+    X, U, C = as_f64(X), as_f64(U), as_f64(C)
+    N, n = X.shape
+    k, r = C.shape[0], U.shape[1]
+    ns = N - H
+    assert U.shape[0] >= N - 1, f"U has {U.shape[0]} rows, need at least len(X) - 1 = {N - 1}"
+    RHt, Gt = linear_coefficients(A, B, n, int(H))
+    xhat = np.empty((max(ns, 0), n)) if want_xhat else None
+    se = ctypes.c_double(0.0)
+    ctx.check(ctx.lib.edmdc_multistep_se_linear(ctx.h, n, r, k, float(gamma), _hptr(C), _hptr(RHt), _hptr(Gt) if H else None, N, int(H),
+                                                _hptr(X), _hptr(U), ctypes.addressof(se), _hptr(xhat)), "edmdc_multistep_se_linear")
     return se.value, xhat
 
 

@@ -1658,6 +1658,44 @@ def test_dropin_classes_in_a_process_that_never_imports_torch(tmp_path, mode):
     assert abs(free["window_rmse"][0] - w["thr_euler_rmse"][Hs.index(1)]) < 1e-9 and abs(free["window_rmse"][1] - w["thr_euler_rmse"][Hs.index(10)]) < 1e-9
 
 
+def test_multistep_rmse_by_linearity_equals_the_propagated_scores(eng):
+    """KoopmanEDMDc.multistep_rmse(..., method="linear") (opt-in; edmdc_multistep_se_linear: x_hat = (E A^H) phi(x) + sum_t (E A^(H-1-t) B) u in
+    one pass over the windows) against the default H-step propagation (the reference's loop, Koopman/koopmanEDMDc.py:172-200) and against
+    the reference's own scores: |dRMSE| <= 1e-9 at H = 1 / 10 / 100 on edmdc.npz (k = 48) and edmdc_fit.npz (class defaults k = 200 and the
+    tank settings k = 500, gamma = 3), endpoint predictions equal to 1e-9, inputs one row short accepted, H = 0 and H >= N handled alike."""
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    g = load_golden("edmdc.npz")
+    X, U, nt = g["X"], g["U"], int(g["n_train"])
+    m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=int(g["k"]), gamma=float(g["gamma"]), ridge=float(g["ridge"]))
+    m.centers_, m.A_, m.B_, m.lift_dim_ = g["centers"], g["A"], g["B"], 12 + int(g["k"])
+    Xt, Ut = X[nt:], U[nt:]
+    for i, H in enumerate((1, 10, 100)):
+        a, b = m.multistep_rmse(Xt, Ut, H), m.multistep_rmse(Xt, Ut, H, method="linear")
+        assert abs(a - b) < 1e-9 and abs(b - g["ms_rmse"][i]) < 1e-9, (H, a, b)
+        assert abs(m.multistep_rmse(Xt, Ut[:-1], H, method="linear") - b) == 0.0            # len(U) == len(X) - 1, like the reference accepts
+        sa, xa = eng.multistep_se(Xt, Ut, m.centers_, m.gamma, m.A_, m.B_, H, want_xhat=True)
+        sb, xb = eng.multistep_se_linear(Xt, Ut, m.centers_, m.gamma, m.A_, m.B_, H, want_xhat=True)
+        assert rel_err(xb, xa) < 1e-9 and abs(sa - sb) <= 1e-9 * max(1.0, sa)
+    assert m.multistep_rmse(Xt, Ut, 0, method="linear") == 0.0 and np.isnan(m.multistep_rmse(Xt[:5], Ut[:5], 10, method="linear"))
+    with pytest.raises(ValueError):
+        m.multistep_rmse(Xt, Ut, 3, method="fft")
+    f = load_golden("edmdc_fit.npz")
+    Xf, Uf, ntr = f["X"], f["U"], int(f["n_train"])
+    for tag in ("def", "tank"):
+        mm = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=int(f[f"{tag}_k"]), gamma=float(f[f"{tag}_gamma"]), ridge=float(f[f"{tag}_ridge"]))
+        mm.fit(Xf[:ntr], Uf[:ntr], centers=f[f"{tag}_centers"])
+        for H in (1, 10, 100):
+            a, b = mm.multistep_rmse(Xf[ntr:], Uf[ntr:], H), mm.multistep_rmse(Xf[ntr:], Uf[ntr:], H, method="linear")
+            assert abs(a - b) < 1e-9, (tag, H, a, b)
+    # quaternion shapes (n = 13, r = 6)
+    rng = np.random.default_rng(3)
+    Xq, Uq = np.cumsum(rng.normal(0, 0.02, (700, 13)), 0), rng.uniform(-1, 1, (700, 6))
+    mq = KoopmanEDMDc(state_dim=13, input_dim=6, n_rbfs=40, gamma=0.5, ridge=1e-2)
+    mq.fit(Xq[:500], Uq[:500])
+    for H in (1, 7, 60):
+        assert abs(mq.multistep_rmse(Xq[500:], Uq[500:], H) - mq.multistep_rmse(Xq[500:], Uq[500:], H, method="linear")) < 1e-9
+
+
 def test_fit_keeps_the_references_own_product_order(eng):
     """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
     (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
