@@ -3,8 +3,8 @@ the same inputs and against the committed golden vectors of the reference.  Need
 
 Tolerances (fp64): the north star asks for <= 1e-6 relative per step vs fossen/BlueROV2.py; the
 kernels differ from the reference only by operation order / FMA contraction / device libm, so the
-tests hold them to 1e-9 (whole 5000-step trajectories) and 1e-11..1e-12 (single calls), measured as
-max |a-b| / max(1,|b|)."""
+tests hold them to 1e-9 (whole 5000-step trajectories) and 1e-11..1e-12 (single calls), measured as the
+MIXED error max |a-b| / max(1,|b|) (absolute below 1, relative above; conftest.rel_err)."""
 import numpy as np
 import pytest
 

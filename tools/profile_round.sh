@@ -9,7 +9,7 @@ tag=${1:-r04}
 out=gpurun_out/prof_$tag
 mkdir -p $out
 root=$(pwd)
-python3 bench.py > $out/bench.json 2> $out/bench.err
+python3 bench.py --details $root/$out/bench_details.json > $out/bench.json 2> $out/bench.err
 echo "bench done"
 ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/trace -o run -- python3 $root/bench.py --no-cpu --no-variants > $root/$out/trace.log 2>&1 )
 cp $(find $out/trace -name "*kernel_stats.csv" | head -1) $out/kernel_stats.csv
