@@ -58,15 +58,20 @@ MEASURED_HBM_GBS = 6300.0
 
 
 def kernel_source_sha():
-    """sha256 (16 hex) over the kernel sources: recorded next to a PMC summary (tools/pmc_summary.py) so that a traffic
-    figure taken from an older build of the kernels is visible as stale."""
+    """sha256 (16 hex) over the kernel sources with comments and blank space taken out: recorded next to a PMC summary
+    (tools/pmc_summary.py) so that a traffic figure taken from an older build of the kernels is visible as stale -- and one that only
+    predates an edited comment is not."""
     import hashlib
+    import re
     h = hashlib.sha256()
     root = os.path.join(REPO, "bluerov2_dynamics_amd", "csrc")
     for f in sorted(os.listdir(root)):
         if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(root, f), encoding="utf-8", errors="replace").read()
+            txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)          # block comments
+            txt = re.sub(r"//[^\n]*", " ", txt)                         # line comments (no string of these sources holds "//")
             h.update(f.encode())
-            h.update(open(os.path.join(root, f), "rb").read())
+            h.update(" ".join(txt.split()).encode())
     return h.hexdigest()[:16]
 
 
@@ -340,7 +345,8 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
     tmpd = tempfile.mkdtemp(prefix="brov2_bench_")
     # the three ways a process can hold the library (bluerov2_dynamics_amd/_lib.py: _one_hip_runtime): the default -- torch is not
     # imported, device memory through the C ABI --, the same on /opt/rocm's HIP runtime, and the torch-tensor path of rounds 1-5
-    modes = (("torch_free", "auto", "native"), ("torch_free_rocm_runtime", "0", "native"), ("torch_tensors", "1", "torch"))
+    modes = (("torch_free", "auto", "native"), ("torch_free_rocm_runtime", "0", "native"), ("torch_tensors", "1", "torch"),
+             ("torch_free_warm_up", "auto", "native"))        # ... and with bluerov2_dynamics_amd.warm_up() called right after the imports
     try:
         runs = {}
         for tag, rows in (("N45823", N), ("train36658", int(0.8 * N))):
@@ -351,8 +357,8 @@ def recorded_shape_leg(engine, _lib, ctx, dev, dt, want_cpu):
             np.savez(path, **kw)
             for mode, env_torch, arrays in (modes if tag == "N45823" else modes[:1]):
                 t0 = time.perf_counter()
-                pr = subprocess.run([sys.executable, child, "gpu", path, "auto", arrays], capture_output=True, text=True, timeout=600,
-                                    env=dict(os.environ, BROV2_TORCH=env_torch))
+                pr = subprocess.run([sys.executable, child, "gpu", path, "auto", arrays] + (["warm_up"] if mode.endswith("warm_up") else []),
+                                    capture_output=True, text=True, timeout=600, env=dict(os.environ, BROV2_TORCH=env_torch))
                 wall = time.perf_counter() - t0
                 if pr.returncode != 0:
                     runs[f"{tag}_{mode}"] = {"error": pr.stderr[-400:]}

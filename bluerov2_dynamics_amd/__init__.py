@@ -9,7 +9,7 @@ Batched engine: bluerov2_dynamics_amd.engine; multi-GPU: bluerov2_dynamics_amd.d
 Everything computes in hand-written HIP kernels behind the C ABI of include/brov2.h;
 there is no CPU fallback.
 """
-from ._lib import (BrovError, BrovParams, Context, default_context, default_params, discretise_lag, load_library,
+from ._lib import (BrovError, BrovParams, Context, default_context, default_params, discretise_lag, load_library, warm_up,
                    THRUSTER_EULER, WRENCH_EULER, WRENCH_QUAT, EULER, RK4, LAG_PER_CALL, LAG_PER_STEP,
                    LAYOUT_BTU, LAYOUT_TUB, LAYOUT_TPB)
 

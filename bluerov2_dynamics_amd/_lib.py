@@ -183,7 +183,7 @@ def _one_hip_runtime():
       * torch already imported by the caller (the reference's PINc scripts import it at the top): nothing to do, its runtime serves both;
       * BROV2_TORCH=auto (default), torch installed but not imported: only torch's libamdhip64.so is loaded (the very file torch would
         load -- the loader recognises it by inode), so a later `import torch` still shares the runtime.  Caveat, measured with
-        tools/time_late_torch.py: once the runtime has been INITIALISED (a Context exists), HIP registers torch's code objects eagerly and
+        tools/attic/time_late_torch.py: once the runtime has been INITIALISED (a Context exists), HIP registers torch's code objects eagerly and
         that later import takes ~10 s instead of ~0.8 s -- a script that wants torch should import it before its first use of this package;
       * BROV2_TORCH=1: import torch here, first (the behaviour up to round 5);
       * BROV2_TORCH=0: never look for torch; libbrov2.so binds /opt/rocm's runtime (a later `import torch` in the same process would then
@@ -447,15 +447,38 @@ class Context:
 
 
 _default = {}
+_default_lock = threading.Lock()
 
 
 def default_context(device: int = None) -> Context:
     """Process-wide context per device (device defaults to $BROV2_DEVICE, then $LOCAL_RANK, then 0)."""
     if device is None:
         device = int(os.environ.get("BROV2_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-    if device not in _default:
-        _default[device] = Context(device)
-    return _default[device]
+    ctx = _default.get(device)
+    if ctx is None:
+        with _default_lock:                      # (a warm_up() thread may be creating it right now)
+            ctx = _default.get(device)
+            if ctx is None:
+                ctx = _default[device] = Context(device)
+    return ctx
+
+
+def warm_up(device: int = None, block: bool = False):
+    """Start creating the process-wide context NOW, in a background thread: binding the library and initialising the HIP runtime is
+    0.15-0.2 s of the first call of a fresh process (profiles/r06_fit_time.txt) and needs nothing from the caller -- a script that calls
+    this right after its imports overlaps it with its own start-up (pandas import, CSV parsing; the reference's scripts spend
+    seconds there before their first fit()).  The ctypes calls release the GIL.  Errors (no GPU) are left for the first real use to
+    raise.  Opt-in: nothing happens at import time.  block=True waits for the context (returns it)."""
+    def work():
+        try:
+            default_context(device)
+        except Exception:                        # reported by whoever needs the context
+            pass
+    if block:
+        return default_context(device)
+    t = threading.Thread(target=work, name="brov2-warm-up", daemon=True)
+    t.start()
+    return t
 
 
 class Comm:

@@ -128,7 +128,7 @@ hipError_t launch_kmeans_scale(hipStream_t st, int n, const unsigned long long* 
 // whose bounds fail go to `list` (tiles padded to whole waves with ~position), their number to nlist[0]
 // nlist: [0] the list's entries (one-region form) | [KM_NL_TICKET] tickets drawn by the E-step | [KM_NL_FRONT], [KM_NL_BACK] entries of the two
 // regions (two-region form; [0] stays 0) -- every counter in its own 64-byte line: atomics on one line are served one after the other
-// (83 per microsecond, tools/atomic_ticket_probe.hip), and 2 442 tiles reserving their piece of the list are 29 us of that
+// (83 per microsecond, tools/attic/atomic_ticket_probe.hip), and 2 442 tiles reserving their piece of the list are 29 us of that
 constexpr int KM_NL_TICKET = 16, KM_NL_FRONT = 32, KM_NL_BACK = 48;
 struct KmBounds {
     float* ub = nullptr;            // [N] >= distance to the own centre

@@ -2499,7 +2499,7 @@ int edmdc_kmeans_lloyd_dev(brov_ctx* c, int64_t N, int n, int k, const double* d
             // hs[2] = labels changed by the E-step before the one just queued.  Sort once 1 % of the samples have changed label since
             // the last sort (a fresh order costs ~55 candidates per wave, the caller's ~130; a sort costs less than half an E-step),
             // but not while more than 1 % still change per iteration -- such an order is stale at once.  Thresholds from scans at
-            // 10^7 x 12, k = 512 (tools/run_lloyd_variants.sh): 314 ms per 300 iterations; 0.02 / 0.01: 322 ms; 0.005 / 0.005: 331 ms;
+            // 10^7 x 12, k = 512 (tools/attic/run_lloyd_variants.sh): 314 ms per 300 iterations; 0.02 / 0.01: 322 ms; 0.005 / 0.005: 331 ms;
             // every iteration: 384 ms; the caller's order: 423 ms.  Round 4, single-reference filter (a moved label widens the wave's
             // radius a little instead of opening a second candidate set: the order decays more slowly): moved / rate 0.01 / 0.01: 305 ms;
             // 0.02 / 0.2: 290; 0.03 / 0.01: 294; 0.05 / 0.05: 288; 0.08 / 0.01: 299; 0.15 / 0.01: 314; 0.005 / 0.2: 326; never: 484

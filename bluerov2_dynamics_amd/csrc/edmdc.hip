@@ -220,7 +220,7 @@ hipError_t launch_linear_windows(hipStream_t st, int64_t nw, int n, int r, int k
 // paid once per four RBF values (40 instructions per value instead of 65 with two centres per lane), and a lane's
 // results are 32 contiguous bytes (two 16-byte stores, 2 KiB contiguous per wave).  History of the loop "fetch a row's state,
 // lift it, store it" per 2^20-row chunk (180 VALU instructions per row and wave = 0.8 ms of issue slots, the stores alone
-// 0.8 ms at 5.4 TB/s, tools/store_probe.hip): state through scalar loads 1.65 ms; the next row's state fetched while the
+// 0.8 ms at 5.4 TB/s, tools/attic/store_probe.hip): state through scalar loads 1.65 ms; the next row's state fetched while the
 // current one is lifted, tail blocks four rows at a time 1.48 ms; the block's 64 state rows staged in LDS once 1.26 ms; the
 // tail columns in a kernel of their own 1.07 + 0.09 ms.
 #ifndef LIFT_NC_

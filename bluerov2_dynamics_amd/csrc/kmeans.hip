@@ -161,7 +161,7 @@ __device__ __forceinline__ void km_zero_epochs(u64* __restrict__ partial, int ep
 }
 
 #ifndef KM_BLOCKTIME
-#define KM_BLOCKTIME 0           // experiment build: how evenly the list-form E-step's work falls on blocks and waves (tools/lloyd_balance.py)
+#define KM_BLOCKTIME 0           // experiment build: how evenly the list-form E-step's work falls on blocks and waves (tools/attic/lloyd_balance.py)
 #endif
 #if KM_BLOCKTIME
 __device__ unsigned long long km_blk[8];       // list form: [0] sum of block durations, [1] blocks, [2] sum of the waves' loop times, [3] waves (100 MHz ticks)
@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 }
 
 // ---- E-step, second form: centre records from the LDS through DPP ---------------------------------------------------------------
-// Phase timing of the kernel above on the config-3 data (tools/lloyd_phase_profile.py): the evaluation of the candidates is a
+// Phase timing of the kernel above on the config-3 data (tools/attic/lloyd_phase_profile.py): the evaluation of the candidates is a
 // third to a half of a wave's pass; the rest is waiting -- for the wave's own rows (HBM, nothing else to do meanwhile), for the
 // group centres' records (scalar loads, one after the other), for the rows of the distance table, and in the evaluation loop
 // for the scalar loads of the records (two in flight per wave: 52 scalar registers).  Eight waves per SIMD were there to hide
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(KM_THREADS) __attribute__((amdgpu_waves_per_eu
 //     CU, 4 waves per SIMD, 128 vector registers);
 //   * a centre record reaches a wave as ONE ds_read_b64 -- lane l gets double l & 15 of the record, so every DPP row of 16 lanes
 //     holds the whole record -- and the FMA takes its centre operand through `row_newbcast:j` (v_fmac_f64_dpp: the broadcast
-//     costs nothing; tools/dpp64_probe.hip checks rate and bits against the scalar-operand form).  A record in flight costs 2
+//     costs nothing; tools/attic/dpp64_probe.hip checks rate and bits against the scalar-operand form).  A record in flight costs 2
 //     vector registers instead of 26 scalar ones: KM2_DEPTH records are prefetched round the evaluation loop;
 //   * the candidates of all mask words form one list in the LDS (written by the lanes that hold the mask bits: mbcnt ranks), padded
 //     by repeating the last candidate (an equal score never replaces the best): the loop spends no scalar instructions on bit
@@ -498,7 +498,7 @@ __device__ __forceinline__ double score_bcast(double rec, const double (&x)[15])
     return sc;
 }
 // two records at once, their chains interleaved: a dependent fp64 FMA cannot issue back to back, so one chain per wave fills
-// half of the vector ALU's slots and it takes four waves in this loop at the same time to fill them all (tools/dpp64_probe.hip:
+// half of the vector ALU's slots and it takes four waves in this loop at the same time to fill them all (tools/attic/dpp64_probe.hip:
 // 80 / 51 / 45 ns per evaluation and SIMD with 1 / 2 / 4 waves) -- with passes as short as 60 candidates they rarely are
 #define KM2_SEED2 "s_nop 1\n\tv_mov_b64_dpp %0, %2 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\tv_mov_b64_dpp %1, %3 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
 #define KM2_G(j, op) "v_fmac_f64_dpp %0, %2, %" #op " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\tv_fmac_f64_dpp %1, %3, %" #op " row_newbcast:" #j " row_mask:0xf bank_mask:0xf\n\t"
@@ -639,12 +639,12 @@ kmeans_assign_lds_kernel(int64_t N, int n, int k, const double* __restrict__ X, 
     int oln = -1;
     int64_t base = (int64_t)blockIdx.x * KM_THREADS;
     // ---- LIST, dynamic assignment (round 5).  With a fixed share per block a launch lasted 306 us where its mean block was busy for 229
-    // and its mean wave for 193 (tools/lloyd_balance.py): a listed pass costs anything between 40 and 512 candidates, and the wide ones
+    // and its mean wave for 193 (tools/attic/lloyd_balance.py): a listed pass costs anything between 40 and 512 candidates, and the wide ones
     // come in runs.  Now a wave's pass is a TICKET = 64 consecutive list entries (the list is whole waves).  The first three tickets of
     // every wave are fixed -- (q blocks + block) 16 + wave, q = 0 .. 2: the depth of the prefetch chain --, all later ones are drawn from
     // the device-wide counter nlist[KM_NL_TICKET] (zeroed by the M-step) in BATCHES of 16 per block: a 64-bit LDS word holds (first ticket << 8 |
     // handed out); the wave that finds it empty draws the next batch (one global atomic per 1 024 entries: a single address serves
-    // 83 per microsecond, tools/atomic_ticket_probe.hip), the others wait on the LDS word for the few microseconds that takes.
+    // 83 per microsecond, tools/attic/atomic_ticket_probe.hip), the others wait on the LDS word for the few microseconds that takes.
     // The member sums still must not see more than KM_EPOCH_PASSES x KM_THREADS samples between two flushes: a block draws at most
     // that many entries per EPOCH, then all its waves run dry, meet at a barrier, flush and start the next epoch -- at most as many
     // epochs as the fixed shares would have used (kmeans_mstep_kernel derives that number from the list's length), which is capacity
@@ -2286,7 +2286,7 @@ __global__ void __launch_bounds__(256) kmeans_cdist_kernel(int n, int k, const d
 // the sample's own centre NOW, and then it is at least d(c_a, c_t) - ub' away whatever it did.  The largest shift is a single outlying cluster's on the config-3 data, 1.5 % of a cluster radius per iteration
 // at iteration 70 against a median of 0.2 %; restricting it to the K nearest centres of a -- the others held off by the triangle
 // inequality through c_a -- was probed for K = 8 ... 256, alone and all at once, and buys nothing in 12 dimensions with 512
-// centres: the 65th nearest centre of a cluster is hardly farther than its 2nd; tools/hamerly_probe.py.)  While ub' + margin < lb' the sample's
+// centres: the 65th nearest centre of a cluster is hardly farther than its 2nd; tools/attic/hamerly_probe.py.)  While ub' + margin < lb' the sample's
 // nearest centre is still a, by more than the rounding of the E-step's scores: its label -- the full scan's -- cannot change, it keeps
 // its bounds and is skipped.  Everything else goes to the list the next E-step walks: position p, in position order within a tile of
 // 2048 positions, every tile's piece padded to whole waves with ~p of its last entry (a lane that loads the same row and counts for
@@ -2554,7 +2554,7 @@ __device__ __forceinline__ double pp_dist(const double x[KM_NMAX], Row&& crow, d
 // per sample.  If for every point p of the round   |p - centre| - radius >= max sqrt(closest) (1 + 5e-6) + 2.5e-6 R   then no sample
 // of the row is in reach of any point: the owed update changes nothing, every min(closest, d) is closest, and the row contributes its
 // stored sum to every potential WITHOUT its samples being touched (not even closest[]).  From round ~100 on that certifies 85 % of the
-// rows of the config-3 data (tools/kmeanspp_ball_probe.py; the per-sample float test: 97 %), so a round reads ~15 instead of ~60 bytes
+// rows of the config-3 data (tools/attic/kmeanspp_ball_probe.py; the per-sample float test: 97 %), so a round reads ~15 instead of ~60 bytes
 // per sample.  Rows that fail go through the per-sample float screening and, where that fails too, the fp64 path, exactly as before.
 // The chunk sums are formed the same way on every path -- a fixed tree over the 16 lanes of a row, then a fixed order over the 256
 // rows of the chunk -- so that a certified row's stored sum IS what its samples would add: screened and unscreened runs agree bit

@@ -18,7 +18,7 @@ namespace brov {
 constexpr int TRIG_REFRESH = 64;   // steps between full sin/cos evaluations of the carried attitude trig (power of two)
 
 #if BROV_CLOCK_STAMPS
-// Diagnostic build only (tools/clock_probe.py; never in the shipped library): the body wave of every workgroup stamps the
+// Diagnostic build only (tools/attic/clock_probe.py; never in the shipped library): the body wave of every workgroup stamps the
 // shader clock (s_memtime) and the constant 100 MHz clock (s_memrealtime) around its time loop; the ratio is the clock the
 // chip holds under this launch.  The stamps go to a buffer of their own, no output value is computed from them.
 __device__ unsigned long long g_clock_stamps[4096][4];

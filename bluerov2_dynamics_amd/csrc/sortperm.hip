@@ -3,7 +3,7 @@
 // The candidate filter of the E-step (kmeans.hip) decides per WAVE: 64 consecutive samples share one union of candidate
 // centres, and a group's radius is the largest distance of its lanes to their centre.  In trajectory order a wave holds 4.5
 // label groups and evaluates 131 of 512 centres; with the samples ordered by (label, distance to the centre) a wave is one
-// group of homogeneous radius and evaluates 55 -- the per-sample need (tools/nbr_probe.py, tools/sort_probe.py).  The order
+// group of homogeneous radius and evaluates 55 -- the per-sample need (tools/attic/nbr_probe.py, tools/attic/sort_probe.py).  The order
 // decays as labels change (0.3-1.4 % of the samples per iteration: 57 -> 71 -> 80 -> 86 centres one to four iterations after a
 // sort early on, 55 -> 70 over six iterations late), so the loop re-sorts when enough labels have moved (capi.hip).
 //

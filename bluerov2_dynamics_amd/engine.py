@@ -779,7 +779,7 @@ def pinv_sym_device(G, ridge, rcond=1e-15):
     """pinv(G + ridge I) of the symmetric p x p Gram ON THE DEVICE: symmetric eigendecomposition (torch.linalg.eigh = the ROCm
     LAPACK library, a library primitive like a library GEMM) with numpy.linalg.pinv's cut-off -- eigenvalues (= singular values of
     a symmetric matrix, up to sign) not above rcond * the largest are dropped.  G: CUDA tensor [p, p]; returns a CUDA tensor.
-    Opt-in (fit_dev(pinv="device")): 13 ms against 31-93 ms for the host's LAPACK pinv at p = 532 (tools/time_pinv_device.py;
+    Opt-in (fit_dev(pinv="device")): 13 ms against 31-93 ms for the host's LAPACK pinv at p = 532 (tools/attic/time_pinv_device.py;
     the library's time is not monotone in p -- 87 ms at p = 520), P agrees with numpy's to 5e-12..2e-11 relative on the fixtures."""
     import torch
     A = G + ridge * torch.eye(G.shape[0], dtype=G.dtype, device=G.device)
@@ -819,8 +819,16 @@ def _host_pinv(G, ridge, pinv):
     if pinv == "host":
         return np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
     if pinv == "auto":
-        P = pinv_sym_host(G, ridge, safe=PINV_AUTO_SAFE)
-        return P if P is not None else np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
+        A = G + ridge * np.eye(G.shape[0])
+        # a 1 ms look before the 13 ms eigendecomposition: with A = L L^T, cond(A) >= (max L_ii / min L_ii)^2 -- when that alone puts the
+        # smallest eigenvalue below the threshold (or A is not numerically positive definite) the answer is numpy's pinv anyway
+        try:
+            dl = np.diag(np.linalg.cholesky(0.5 * (A + A.T)))
+            hopeless = (dl.min() / dl.max()) ** 2 < PINV_AUTO_SAFE
+        except np.linalg.LinAlgError:
+            hopeless = True
+        P = None if hopeless else pinv_sym_host(G, ridge, safe=PINV_AUTO_SAFE)
+        return P if P is not None else np.linalg.pinv(A)
     if pinv in ("eigh", "device"):          # (the device form is fit_dev's; the host-list paths take the host's eigendecomposition)
         return pinv_sym_host(G, ridge)
     raise ValueError("pinv must be 'auto', 'host', 'eigh' or 'device'")
@@ -950,7 +958,7 @@ class _blas_threads:
     """The host solve of the p x p normal matrix is the one BLAS/LAPACK call left on the fit path.  The reference caps its
     BLAS at 4 threads on import (Koopman/koopmanEDMDc.py:23-25); left alone, OpenBLAS starts one thread per VISIBLE CPU, and
     in a container that is granted fewer cores than it sees the solve takes 60-200 ms instead of 33 (p = 532).  Cap the pool for
-    the duration of the solve: two threads up to p = 700 (round 5, tools/time_eigh_threads.py on the GPU boxes' hosts: neither syevd
+    the duration of the solve: two threads up to p = 700 (round 5, tools/attic/time_eigh_threads.py on the GPU boxes' hosts: neither syevd
     nor gesdd at p ~ 520 gains from more -- eigh 18 / 14-17 / 17 / 18 ms, pinv 34 / 29-37 / 37 / 38 ms at 1 / 2 / 4 / 8 threads),
     the granted cores (at most 8) beyond; no-op when threadpoolctl is missing."""
     _cores = None

@@ -403,3 +403,26 @@ print(json.dumps({"torch": "torch" in sys.modules, "hip_runtime": _lib.hip_runti
         assert "preloaded" in d["hip_runtime"] and os.path.samefile(d["amdhip"][0], torch_hip), d
     else:
         assert d["hip_runtime"].startswith("system") and (torch_hip is None or not os.path.samefile(d["amdhip"][0], torch_hip)), d
+
+
+def test_warm_up_is_opt_in_and_never_raises_in_the_background(lib):
+    """bluerov2_dynamics_amd.warm_up(): context creation in a background thread (overlaps the 0.15-0.2 s of HIP start-up with the script's
+    own start-up).  Nothing happens at import time; on a box without a GPU the thread ends quietly and the first real use raises as
+    before; with a GPU the context it made is the process-wide one."""
+    import bluerov2_dynamics_amd as pkg
+    from bluerov2_dynamics_amd import _lib
+    have_gpu = True
+    try:
+        _lib.Context(0).close()
+    except _lib.BrovError:
+        have_gpu = False
+    before = dict(_lib._default)
+    t = pkg.warm_up()
+    t.join(60)
+    assert not t.is_alive()
+    if have_gpu:
+        assert 0 in _lib._default and pkg.warm_up(block=True) is _lib._default[0]
+    else:
+        assert _lib._default == before
+        with pytest.raises(_lib.BrovError):
+            _lib.default_context(0)

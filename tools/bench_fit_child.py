@@ -21,6 +21,11 @@ sys.path.insert(0, REPO)
 
 def main():
     mode, path = sys.argv[1], sys.argv[2]
+    if mode == "gpu" and len(sys.argv) > 5 and sys.argv[5] == "warm_up":
+        # what a script does that calls bluerov2_dynamics_amd.warm_up() right after its imports: the context is created in the background
+        # while the interpreter imports numpy and reads the data
+        import bluerov2_dynamics_amd
+        bluerov2_dynamics_amd.warm_up()
     import numpy as np
     z = np.load(path)
     out = {"mode": mode}

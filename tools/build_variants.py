@@ -3,7 +3,7 @@
 
     python tools/build_variants.py name1=-DA=1,-DB=1 name2=-DC=1 ...
 
-Run them on the GPU box with tools/run_variants.sh (BROV2_LIBRARY selects the copy)."""
+Run them on the GPU box with tools/attic/run_variants.sh (BROV2_LIBRARY selects the copy)."""
 import os
 import sys
 from concurrent.futures import ThreadPoolExecutor

@@ -1,5 +1,5 @@
 """KoopmanEDMDc.fit()'s device path on BASELINE config-3 data without the centres stage (centres = seeded sample rows): Gram,
-host pinv, edmdc_pinv_apply_dev.  Short enough for rocprofv3 --pmc passes (tools/r03_fit_pmc.sh).  Run on the GPU box.
+host pinv, edmdc_pinv_apply_dev.  Short enough for rocprofv3 --pmc passes (tools/attic/r03_fit_pmc.sh).  Run on the GPU box.
 
     python3 tools/time_fit.py [pairs] [reps] [simple]
 """
