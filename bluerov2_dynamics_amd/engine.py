@@ -812,26 +812,57 @@ def pinv_sym_host(G, ridge, rcond=1e-15, safe=None):
 PINV_AUTO_SAFE = 1e-10        # pinv="auto": smallest / largest eigenvalue of G^T G + ridge I above which the eigendecomposition route is taken
 
 
-def _host_pinv(G, ridge, pinv):
-    """The p x p solve of the normal equations on the host.  "host": numpy.linalg.pinv, the reference's call (Koopman/koopmanEDMDc.py:97,147).
-    "auto" (default): the symmetric eigendecomposition when the matrix is comfortably conditioned (PINV_AUTO_SAFE), numpy.linalg.pinv
-    otherwise -- the reference's own route wherever the route matters.  "eigh": the eigendecomposition unconditionally (speed; opt-in)."""
+def _chol_inverse(A):
+    """(A^-1, kappa_1) of a symmetric positive definite A through LAPACK potrf / potri (3 ms at p = 520 where the eigendecomposition takes
+    13-15), kappa_1 = |A|_1 |A^-1|_1 -- for a symmetric matrix an UPPER bound of the 2-norm condition number.  None when A is not
+    numerically positive definite or SciPy's LAPACK bindings are missing."""
+    try:
+        from scipy.linalg import lapack
+    except ImportError:
+        return None
+    try:
+        L = np.linalg.cholesky(A)
+    except np.linalg.LinAlgError:
+        return None
+    Ai, info = lapack.dpotri(L, lower=1)
+    if info != 0:
+        return None
+    Ai = np.tril(Ai) + np.tril(Ai, -1).T
+    return Ai, float(np.abs(A).sum(0).max() * np.abs(Ai).sum(0).max())
+
+
+def _host_pinv_route(G, ridge, pinv):
+    """(P, route) of the p x p solve of the normal equations on the host; route is "pinv", "cholesky" or "eigh".
+    pinv="host": numpy.linalg.pinv, the reference's call (Koopman/koopmanEDMDc.py:97,147).
+    pinv="auto" (default): the reference's own route wherever the route matters, something cheaper where it provably does not --
+      1. Cholesky inverse when kappa_1(G^T G + ridge I) < 1 / PINV_AUTO_SAFE (then the smallest eigenvalue is above PINV_AUTO_SAFE x the
+         largest, and the inverse IS the pseudo-inverse: nothing is cut off);
+      2. otherwise the symmetric eigendecomposition with numpy.linalg.pinv's cut-off if the computed eigenvalue ratio is above the threshold;
+      3. otherwise numpy.linalg.pinv.
+    pinv="eigh": the eigendecomposition unconditionally (round 5's default; opt-in)."""
     if pinv == "host":
-        return np.linalg.pinv(G + ridge * np.eye(G.shape[0]))
+        return np.linalg.pinv(G + ridge * np.eye(G.shape[0])), "pinv"
     if pinv == "auto":
         A = G + ridge * np.eye(G.shape[0])
-        # a 1 ms look before the 13 ms eigendecomposition: with A = L L^T, cond(A) >= (max L_ii / min L_ii)^2 -- when that alone puts the
-        # smallest eigenvalue below the threshold (or A is not numerically positive definite) the answer is numpy's pinv anyway
-        try:
-            dl = np.diag(np.linalg.cholesky(0.5 * (A + A.T)))
+        A = 0.5 * (A + A.T)
+        ci = _chol_inverse(A)
+        if ci is not None and ci[1] * PINV_AUTO_SAFE < 1.0:
+            return ci[0], "cholesky"
+        hopeless = False
+        try:                                                    # cond >= (max L_ii / min L_ii)^2: a lower bound that can rule the rest out
+            dl = np.diag(np.linalg.cholesky(A))
             hopeless = (dl.min() / dl.max()) ** 2 < PINV_AUTO_SAFE
         except np.linalg.LinAlgError:
             hopeless = True
         P = None if hopeless else pinv_sym_host(G, ridge, safe=PINV_AUTO_SAFE)
-        return P if P is not None else np.linalg.pinv(A)
+        return (P, "eigh") if P is not None else (np.linalg.pinv(A), "pinv")
     if pinv in ("eigh", "device"):          # (the device form is fit_dev's; the host-list paths take the host's eigendecomposition)
-        return pinv_sym_host(G, ridge)
+        return pinv_sym_host(G, ridge), "eigh"
     raise ValueError("pinv must be 'auto', 'host', 'eigh' or 'device'")
+
+
+def _host_pinv(G, ridge, pinv):
+    return _host_pinv_route(G, ridge, pinv)[0]
 
 
 def fit_dev(X, U, nbags, L, k, gamma, ridge, order="fit", centers=None, max_iter=300, tol=1e-4, random_state=0, ctx=None,

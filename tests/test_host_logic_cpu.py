@@ -263,26 +263,37 @@ def test_bench_compact_line_of_a_recorded_run_fits_the_driver(record):
 
 
 def test_default_solve_is_numpy_pinv_wherever_the_route_matters():
-    """engine._host_pinv("auto") -- the class default -- on the NumPy oracle's Gram of the ill-conditioned fixture (class-default ridge 1e-8,
-    gamma 0.05: smallest eigenvalue 2.7e-12 of the largest): bit for bit numpy.linalg.pinv, the reference's call
-    (Koopman/koopmanEDMDc.py:97), and the reference's scores follow; at gamma 0.2 (2.5e-9) the symmetric eigendecomposition is taken
-    and gives the same scores to 1e-9.  The unconditional "eigh" route at gamma 0.05 is measurably off (that was round 5's default)."""
+    """engine._host_pinv_route("auto") -- the class default -- on the NumPy oracle's Gram of the ill-conditioned fixture (class-default ridge
+    1e-8, gamma 0.05: smallest eigenvalue 2.7e-12 of the largest): bit for bit numpy.linalg.pinv, the reference's call
+    (Koopman/koopmanEDMDc.py:97), and the reference's scores follow; at gamma 0.2 (2.5e-9, kappa_1 bound 2.2e9) the Cholesky inverse is
+    taken and gives the same scores to 1e-8; on the tank settings (ridge 0.1) likewise to 1e-9.  A matrix between the two thresholds takes
+    the eigendecomposition.  The unconditional "eigh" route at gamma 0.05 is measurably off (that was round 5's default)."""
     from oracle import edmdc_numpy as ek
     from bluerov2_dynamics_amd import engine
     e, z = load_golden("edmdc_fit.npz"), load_golden("edmdc_illcond.npz")
     X, U, ntr = e["X"], e["U"], int(e["n_train"])
-    for tag, takes_pinv in (("g005", True), ("g02", False)):
+    for tag, want, tol in (("g005", "pinv", 1e-9), ("g02", "cholesky", 1e-8)):
         gamma, C, ridge = float(z[f"{tag}_gamma"]), z[f"{tag}_centers"], 1e-8
         Z, Zp = ek.lift(X[:ntr - 1], C, gamma), ek.lift(X[1:ntr], C, gamma)
         G = np.hstack([Z, U[:ntr - 1]])
         GtG = G.T @ G
-        ratio = float(z[f"{tag}_eig_min_over_max"])
-        assert (ratio < engine.PINV_AUTO_SAFE) == takes_pinv
-        Pa, Ph, Pe = (engine._host_pinv(GtG, ridge, how) for how in ("auto", "host", "eigh"))
-        assert np.array_equal(Pa, Ph if takes_pinv else Pe)
+        Pa, route = engine._host_pinv_route(GtG, ridge, "auto")
+        assert route == want, (tag, route)
+        if want == "pinv":
+            assert np.array_equal(Pa, engine._host_pinv(GtG, ridge, "host"))
+        else:
+            assert np.array_equal(Pa, Pa.T)
         M = (Pa @ G.T @ Zp).T
         A, B = M[:, :Z.shape[1]], M[:, Z.shape[1]:]
         sc = np.array([ek.multistep_rmse(X[ntr:], U[ntr:], C, gamma, A, B, H) for H in (1, 10, 100)])
-        assert np.max(np.abs(sc - z[f"{tag}_ms_rmse"]) / np.maximum(1.0, z[f"{tag}_ms_rmse"])) < 1e-9, tag
+        assert np.max(np.abs(sc - z[f"{tag}_ms_rmse"]) / np.maximum(1.0, z[f"{tag}_ms_rmse"])) < tol, tag
+    # between the thresholds: kappa_1 says "cannot tell", the eigenvalues say "safe"
+    rng = np.random.default_rng(1)
+    Q, _ = np.linalg.qr(rng.normal(size=(60, 60)))
+    S = (Q * np.geomspace(1.0, 2.5e-10, 60)) @ Q.T
+    P, route = engine._host_pinv_route(0.5 * (S + S.T), 0.0, "auto")
+    assert route in ("eigh", "cholesky") and np.linalg.norm(P @ S - np.eye(60)) < 1e-4
+    assert engine._host_pinv_route(np.diag([1.0, 1e-13]), 0.0, "auto")[1] == "pinv"
+    assert engine._host_pinv_route(-np.eye(3), 0.0, "auto")[1] == "pinv"                # not positive definite: the reference's route
     with pytest.raises(ValueError):
         engine._host_pinv(np.eye(3), 0.1, "svd")
