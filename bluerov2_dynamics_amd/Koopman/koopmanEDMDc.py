@@ -75,6 +75,8 @@ class KoopmanEDMDc:
     def fit(self, X, U, centers=None) -> None:
         """Learn (A, B) from one rollout X (N,n), U (N,r) (reference :72-103).
         `centers` (k,n) overrides the KMeans step (extension, used for parity runs)."""
+        if isinstance(X, engine.DevArray) or engine._is_torch(X):
+            return self._fit_resident(X, U, centers)
         X = np.asarray(X, dtype=float)
         U = np.asarray(U, dtype=float)
         N, n = X.shape
@@ -90,6 +92,19 @@ class KoopmanEDMDc:
         ns = self._arrays(ctx)
         Xd = ns.upload(X)
         Ud = ns.upload(U[:N - 1])
+        Cd = None if centers is None else ns.upload(np.asarray(centers, dtype=float))
+        k = self.n_rbfs if centers is None else Cd.shape[0]
+        self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=ctx, pinv=self.pinv)
+        self.centers_ = ns.download(C) if centers is None else np.asarray(centers, dtype=float)
+        self.lift_dim_ = self.state_dim + self.centers_.shape[0]
+
+    def _fit_resident(self, Xd, Ud, centers):
+        """fit() on samples that already live in HBM (engine.DevArray or torch CUDA tensors [N,n] / [N,r] or [N-1,r]: e.g.
+        data.load_dataset_dev, a simulated ensemble): the same pipeline without the upload; the inputs' last row is never read."""
+        N = Xd.shape[0]
+        assert Xd.shape[1] == self.state_dim and Ud.shape[1] == self.input_dim and Ud.shape[0] >= N - 1 and N >= 2
+        ctx = engine._ctx_of(Xd, None)
+        ns = engine.arrays_of(Xd, ctx)
         Cd = None if centers is None else ns.upload(np.asarray(centers, dtype=float))
         k = self.n_rbfs if centers is None else Cd.shape[0]
         self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=ctx, pinv=self.pinv)

@@ -58,6 +58,17 @@ def load_dataset(csv_path, input_cols=None, verbose=True, variant="thruster"):
     return X, U, dt
 
 
+def load_dataset_dev(csv_path, input_cols=None, verbose=True, variant="thruster", ctx=None):
+    """load_dataset with the samples left in HBM: (Xd [N,nx], Ud [N,nu] as engine.DevArray, dt, (X, U) host copies).  The device arrays go
+    straight into KoopmanEDMDc.fit / fit_multi (no second upload) and into the engine's `_dev` entry points (rollout_dev windows,
+    gram_dev, multistep).  SURVEY 8(f)4: "a loader feeding device buffers directly" -- the parsing itself stays pandas (45 823 rows: 0.1 s,
+    not on the hot path); what this saves is the staging of every later call."""
+    from . import engine
+    X, U, dt = load_dataset(csv_path, input_cols=input_cols, verbose=verbose, variant=variant)
+    ctx = ctx or engine.default_context()
+    return engine.DevArray.from_host(ctx, X), engine.DevArray.from_host(ctx, U), dt, (X, U)
+
+
 def write_dataset(csv_path, t, X, U, input_cols=None):
     """Write a CSV in the reference's schema (used by the examples / tests to make synthetic recordings)."""
     import pandas as pd

@@ -1696,6 +1696,63 @@ def test_multistep_rmse_by_linearity_equals_the_propagated_scores(eng):
         assert abs(mq.multistep_rmse(Xq[500:], Uq[500:], H) - mq.multistep_rmse(Xq[500:], Uq[500:], H, method="linear")) < 1e-9
 
 
+def test_loader_feeding_device_buffers_and_the_memory_pool(eng, tmp_path):
+    """data.load_dataset_dev leaves the recording in HBM (engine.DevArray) and KoopmanEDMDc.fit takes it from there -- the same
+    A, B, centres as the fit on the host arrays, bit for bit, on the reference-schema CSV of config 5; torch CUDA tensors likewise.
+    brov_malloc / brov_free: freed blocks are handed out again (same address for the same size), brov_mem_info answers, a block larger
+    than the pool's per-block limit goes back to the driver, and nothing is lost when hundreds of blocks cycle."""
+    import ctypes
+    import gzip
+    import shutil
+    import torch
+    from conftest import GOLDEN
+    from bluerov2_dynamics_amd import _lib, data
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    csv = tmp_path / "rec.csv"
+    with gzip.open(f"{GOLDEN}/cfg5_dataset.csv.gz", "rb") as f, open(csv, "wb") as out:
+        shutil.copyfileobj(f, out)
+    Xd, Ud, dt, (X, U) = data.load_dataset_dev(str(csv), verbose=False)
+    assert isinstance(Xd, eng.DevArray) and Xd.shape == X.shape and np.array_equal(Xd.numpy(), X) and np.array_equal(Ud.numpy(), U)
+    res = []
+    for Xa, Ua in ((X, U), (Xd, Ud), (torch.from_numpy(X).cuda(), torch.from_numpy(U).cuda())):
+        m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=40, gamma=1.0, ridge=1e-2)
+        m.fit(Xa, Ua)
+        res.append((m.centers_.copy(), m.A_.copy(), m.B_.copy()))
+    for other in res[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(res[0], other))
+    ctx = _lib.default_context()
+    lib = ctx.lib
+
+    def malloc(nbytes):
+        p_ = ctypes.c_void_p()
+        ctx.check(lib.brov_malloc(ctx.h, nbytes, ctypes.byref(p_)), "brov_malloc")
+        return p_.value
+
+    free0, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    ctx.check(lib.brov_mem_info(ctx.h, ctypes.byref(free0), ctypes.byref(tot)), "brov_mem_info")
+    assert 0 < free0.value <= tot.value and tot.value > 200 * (1 << 30)
+    a = malloc(3_000_000)
+    lib.brov_free(ctx.h, ctypes.c_void_p(a))
+    assert malloc(3_000_000) == a                                  # the pooled block again
+    lib.brov_free(ctx.h, ctypes.c_void_p(a))
+    big = malloc(300 << 20)                                        # above the pool's per-block limit: straight back to the driver
+    lib.brov_free(ctx.h, ctypes.c_void_p(big))
+    rng = np.random.default_rng(0)
+    live = {}
+    for it in range(600):
+        if live and (len(live) > 40 or rng.random() < 0.45):
+            key = list(live)[int(rng.integers(len(live)))]
+            arr, want = live.pop(key)
+            assert np.array_equal(arr.numpy(), want)               # nobody else was handed this block meanwhile
+            arr.free()
+        else:
+            want = rng.normal(size=int(rng.integers(1, 200_000)))
+            live[it] = (eng.DevArray.from_host(ctx, want), want)
+    for arr, want in live.values():
+        assert np.array_equal(arr.numpy(), want)
+    assert lib.brov_free(ctx.h, None) == 0 and lib.brov_malloc(ctx.h, 16, None) == -1
+
+
 def test_fit_keeps_the_references_own_product_order(eng):
     """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
     (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
