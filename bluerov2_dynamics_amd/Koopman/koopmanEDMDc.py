@@ -101,6 +101,8 @@ class KoopmanEDMDc:
     def _fit_resident(self, Xd, Ud, centers):
         """fit() on samples that already live in HBM (engine.DevArray or torch CUDA tensors [N,n] / [N,r] or [N-1,r]: e.g.
         data.load_dataset_dev, a simulated ensemble): the same pipeline without the upload; the inputs' last row is never read."""
+        if engine._is_torch(Xd):                    # (a tensor made from a Fortran-ordered array -- pandas' to_numpy -- has strided rows)
+            Xd, Ud = Xd.contiguous(), Ud.contiguous()
         N = Xd.shape[0]
         assert Xd.shape[1] == self.state_dim and Ud.shape[1] == self.input_dim and Ud.shape[0] >= N - 1 and N >= 2
         ctx = engine._ctx_of(Xd, None)

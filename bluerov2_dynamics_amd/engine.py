@@ -813,21 +813,17 @@ PINV_AUTO_SAFE = 1e-10        # pinv="auto": smallest / largest eigenvalue of G^
 
 
 def _chol_inverse(A):
-    """(A^-1, kappa_1) of a symmetric positive definite A through LAPACK potrf / potri (3 ms at p = 520 where the eigendecomposition takes
-    13-15), kappa_1 = |A|_1 |A^-1|_1 -- for a symmetric matrix an UPPER bound of the 2-norm condition number.  None when A is not
-    numerically positive definite or SciPy's LAPACK bindings are missing."""
+    """(A^-1, kappa_1) of a symmetric positive definite A: a Cholesky factorisation as the test of definiteness, then LAPACK's inverse
+    (numpy.linalg.inv; 5 ms at p = 520 where the eigendecomposition takes 13-15), symmetrised; kappa_1 = |A|_1 |A^-1|_1 -- for a symmetric
+    matrix an UPPER bound of the 2-norm condition number.  None when A is not numerically positive definite.  NumPy only: SciPy's potri
+    would halve the arithmetic, but importing scipy.linalg costs the first call of a process 0.1 s and starts a second, uncapped BLAS
+    thread pool (measured: 2.8 s of CPU-quota throttling in the first fit())."""
     try:
-        from scipy.linalg import lapack
-    except ImportError:
-        return None
-    try:
-        L = np.linalg.cholesky(A)
+        np.linalg.cholesky(A)
+        Ai = np.linalg.inv(A)
     except np.linalg.LinAlgError:
         return None
-    Ai, info = lapack.dpotri(L, lower=1)
-    if info != 0:
-        return None
-    Ai = np.tril(Ai) + np.tril(Ai, -1).T
+    Ai = 0.5 * (Ai + Ai.T)
     return Ai, float(np.abs(A).sum(0).max() * np.abs(Ai).sum(0).max())
 
 
@@ -835,7 +831,7 @@ def _host_pinv_route(G, ridge, pinv):
     """(P, route) of the p x p solve of the normal equations on the host; route is "pinv", "cholesky" or "eigh".
     pinv="host": numpy.linalg.pinv, the reference's call (Koopman/koopmanEDMDc.py:97,147).
     pinv="auto" (default): the reference's own route wherever the route matters, something cheaper where it provably does not --
-      1. Cholesky inverse when kappa_1(G^T G + ridge I) < 1 / PINV_AUTO_SAFE (then the smallest eigenvalue is above PINV_AUTO_SAFE x the
+      1. the plain inverse (positive definite by Cholesky) when kappa_1(G^T G + ridge I) < 1 / PINV_AUTO_SAFE (then the smallest eigenvalue is above PINV_AUTO_SAFE x the
          largest, and the inverse IS the pseudo-inverse: nothing is cut off);
       2. otherwise the symmetric eigendecomposition with numpy.linalg.pinv's cut-off if the computed eigenvalue ratio is above the threshold;
       3. otherwise numpy.linalg.pinv.

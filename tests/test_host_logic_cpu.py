@@ -297,3 +297,22 @@ def test_default_solve_is_numpy_pinv_wherever_the_route_matters():
     assert engine._host_pinv_route(-np.eye(3), 0.0, "auto")[1] == "pinv"                # not positive definite: the reference's route
     with pytest.raises(ValueError):
         engine._host_pinv(np.eye(3), 0.1, "svd")
+
+
+def test_two_rank_rehearsal_line_parses_like_the_drivers_scaling_run():
+    """profiles/r06_rehearsal_2ranks_shared_gpu.json = the stdout of `bench.py --gpus 2 --steps 20 --warmup 5` with two ranks sharing the one
+    GPU of the development box over gloo (BROV2_BENCH_SHARE_GPU=1 BROV2_BENCH_BACKEND=gloo; RCCL refuses two ranks per device): the first
+    real multi-GPU run must not be the first time that code path prints.  Parsed the way the driver parses: ONE line, <= 4 096 bytes."""
+    path = os.path.join(REPO, "profiles", "r06_rehearsal_2ranks_shared_gpu.json")
+    if not os.path.exists(path):
+        pytest.skip("rehearsal not recorded yet")
+    c = _parse_like_the_driver(open(path).read())
+    assert c["n_gpus"] == 2 and c["steps"] == 20 and c["warmup"] == 5 and c["scaling"] == "weak" and c["metric"] == "rk4_rollout_steps_per_s"
+    assert abs(c["value"] - 2 * 65536 * 5000 * 20 / (c["ms_per_step"] * 20e-3)) / c["value"] < 1e-6          # whole-job aggregate over both ranks
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in c["roofline"], k
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c["cpu_baseline"], k
+    sm = c["summary"]
+    assert sm["cfg4_rccl_ranks"] == 2 and len(sm["cfg4_per_rank_ms"]) == 2 and sm["cfg4_verified"] is True and sm["cfg4_total_rollouts"] == 1 << 20
+    assert sm["fit_sharded_identical_on_all_ranks"] is True and sm["fit_sharded_samples_per_s"] > 0 and c["verified"]["ok"] is True
