@@ -107,6 +107,8 @@ class KoopmanEDMDc:
         assert Xd.shape[1] == self.state_dim and Ud.shape[1] == self.input_dim and Ud.shape[0] >= N - 1 and N >= 2
         ctx = engine._ctx_of(Xd, None)
         ns = engine.arrays_of(Xd, ctx)
+        if centers is None and self.kmeans == "sklearn":          # scikit-learn picks the centres on the host, the device does the rest
+            centers = _kmeans_centers(ns.download(Xd), self.n_rbfs, "sklearn")
         Cd = None if centers is None else ns.upload(np.asarray(centers, dtype=float))
         k = self.n_rbfs if centers is None else Cd.shape[0]
         self.A_, self.B_, C = engine.fit_dev(Xd, Ud, 1, N - 1, k, self.gamma, self.ridge, order="fit", centers=Cd, ctx=ctx, pinv=self.pinv)
