@@ -2273,7 +2273,9 @@ def test_bench_prints_one_json_line_with_the_contract_fields(tmp_path):
     assert run["thruster_12_8"]["finite"] and run["quaternion_13_6"]["finite"] and run["thruster_12_8"]["first_call_s"] >= run["thruster_12_8"]["warm_call_s"] > 0
     # round 6: the same fit in a process that never imports torch (both HIP runtimes) and on the torch-tensor path: the same bits
     fc_ = rs["first_calls"]
-    assert set(fc_) == {"torch_free", "torch_free_rocm_runtime", "torch_tensors", "torch_free_warm_up"} and rs["AB_bit_equal_across_modes"] is True
+    assert set(fc_) == {"torch_free", "torch_free_rocm_runtime", "torch_tensors"} and rs["AB_bit_equal_across_modes"] is True
+    cs_ = rs["csv_script_start"]
+    assert cs_["plain"]["finite"] and cs_["warm_up"]["finite"] and cs_["warm_up"]["warm_up"] is True and not cs_["plain"]["torch_imported"]
     assert fc_["torch_free"]["torch_imported"] is False and fc_["torch_free_rocm_runtime"]["torch_imported"] is False and fc_["torch_tensors"]["torch_imported"] is True
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in rs["cpu_baseline"], k

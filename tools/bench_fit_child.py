@@ -4,6 +4,9 @@ training/train_tank_brov2_full_comparison.py:40-44) on HOST arrays, as the FIRST
 
     python tools/bench_fit_child.py gpu <data.npz> [pinv] [arrays]   the drop-in class (libbrov2.so); arrays = native (default: no torch in the
                                                               process unless $BROV2_TORCH=1) or torch (the torch-tensor path of rounds 1-5)
+    python tools/bench_fit_child.py csv <recording.csv> <k> <gamma> <ridge> [warm_up]   what the reference's tank scripts do: parse the 50 Hz CSV
+                                                              (data.load_dataset = their load_dataset), then fit -- optionally with
+                                                              bluerov2_dynamics_amd.warm_up() right after the imports
     python tools/bench_fit_child.py cpu <data.npz>            the NumPy / scikit-learn restatement of the reference's fit() in its own
                                                               shape (oracle/edmdc_numpy.py; bench.py's cpu_baseline leg -- the parent
                                                               sets OMP_NUM_THREADS=4, the reference's import-time default,
@@ -19,13 +22,31 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 
 
+def csv_script(path, k, gamma, ridge, warm):
+    """imports -> [warm_up()] -> load_dataset(csv) -> KoopmanEDMDc.fit: the shape of training/train_tank_brov2_koopmanEDMDc.py's start"""
+    import bluerov2_dynamics_amd
+    from bluerov2_dynamics_amd import _lib, data
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    t_imp = time.perf_counter() - T_START
+    if warm:
+        bluerov2_dynamics_amd.warm_up()
+    t0 = time.perf_counter()
+    X, U, dt = data.load_dataset(path, verbose=False)
+    t_load = time.perf_counter() - t0
+    m = KoopmanEDMDc(state_dim=X.shape[1], input_dim=U.shape[1], n_rbfs=k, gamma=gamma, ridge=ridge)
+    t0 = time.perf_counter()
+    m.fit(X, U)
+    t_fit = time.perf_counter() - t0
+    import numpy as np
+    print(json.dumps({"mode": "csv", "warm_up": bool(warm), "rows": int(X.shape[0]), "imports_s": t_imp, "load_dataset_s": t_load, "first_fit_s": t_fit,
+                      "process_start_to_first_fit_done_s": time.perf_counter() - T_START, "torch_imported": "torch" in sys.modules,
+                      "finite": bool(np.isfinite(m.A_).all()), "hip_runtime": _lib.hip_runtime}), flush=True)
+
+
 def main():
     mode, path = sys.argv[1], sys.argv[2]
-    if mode == "gpu" and len(sys.argv) > 5 and sys.argv[5] == "warm_up":
-        # what a script does that calls bluerov2_dynamics_amd.warm_up() right after its imports: the context is created in the background
-        # while the interpreter imports numpy and reads the data
-        import bluerov2_dynamics_amd
-        bluerov2_dynamics_amd.warm_up()
+    if mode == "csv":
+        return csv_script(path, int(sys.argv[3]), float(sys.argv[4]), float(sys.argv[5]), len(sys.argv) > 6 and sys.argv[6] == "warm_up")
     import numpy as np
     z = np.load(path)
     out = {"mode": mode}

@@ -8,10 +8,10 @@
 #   1. tests/test_cabi_cpu.py and tests/test_host_logic_cpu.py (every symbol bound, struct layout, no-GPU failure paths, ...);
 #   2. tools/sanitize_sweep.py: the decomposition / DP entry points and the host-only numerics over a sweep of (n, r, k), dt and
 #      parameter sets, and every entry point's argument validation with a NULL context.
-# Usage: tools/sanitize_host.sh [logfile]      (default profiles/r05_host_sanitizer.txt)
+# Usage: tools/sanitize_host.sh [logfile]      (default profiles/r06_host_sanitizer.txt)
 set -u -o pipefail
 cd "$(dirname "$0")/.."
-LOG=${1:-profiles/r05_host_sanitizer.txt}
+LOG=${1:-profiles/r06_host_sanitizer.txt}
 SAN="-fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g"
 RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 LIB=$(python - <<PY
