@@ -837,7 +837,7 @@ def main():
             host_call.update(samples=int(Xh_.shape[0] - 1), samples_per_s_second_call=(Xh_.shape[0] - 1) / host_call["second_call_s"],
                              finite=bool(np.isfinite(mk.A_).all() and np.isfinite(mk.B_).all()),
                              note="KoopmanEDMDc.fit(X, U) with NumPy arrays: H2D upload of 1.6 GB, k-means with scikit-learn's stopping rule, "
-                                  "G^T G, host solve (pinv="auto": numpy.linalg.pinv unless provably well conditioned), (P G^T) Y with a second lift (lift_cache off), "
+                                  "G^T G, host solve (pinv='auto': numpy.linalg.pinv unless provably well conditioned), (P G^T) Y with a second lift (lift_cache off), "
                                   "download of A, B.  The process is warm by now (rollouts, Gram, k-means have run): a true first call in a fresh "
                                   "process is the recorded_shape leg's")
             # ... and fit_multi(X_list, U_list) on config 3 as the reference would hold it: a Python list of 20 000 separately allocated
