@@ -1753,6 +1753,25 @@ def test_loader_feeding_device_buffers_and_the_memory_pool(eng, tmp_path):
     assert lib.brov_free(ctx.h, None) == 0 and lib.brov_malloc(ctx.h, 16, None) == -1
 
 
+def test_kmeans_centers_subsampled_seeding_both_array_kinds(eng):
+    """kmeans_centers_dev(init_rows=...) -- the fallback that seeds on a seeded subsample (applied by itself beyond the 3e7 rows the device
+    seeding accepts) -- for DevArray and torch operands: the same subsample, the same centres bit for bit; and the host-array entry
+    kmeans_centers equals the device entry on an uploaded copy."""
+    import torch
+    from bluerov2_dynamics_amd import _lib
+    ctx = _lib.default_context()
+    rng = np.random.default_rng(12)
+    X = np.cumsum(rng.normal(0, 0.05, (30000, 12)), 0)
+    outs = []
+    for Xd in (eng.DevArray.from_host(ctx, X), torch.from_numpy(X).cuda()):
+        C, inertia, it = eng.kmeans_centers_dev(Xd, 24, init_rows=5000, max_iter=20, ctx=ctx)
+        outs.append((C.numpy() if isinstance(C, eng.DevArray) else C.cpu().numpy(), inertia, it))
+    assert np.array_equal(outs[0][0], outs[1][0]) and outs[0][1:] == outs[1][1:]
+    Ch = eng.kmeans_centers(X, 24, max_iter=20, ctx=ctx)
+    Cd, _, _ = eng.kmeans_centers_dev(eng.DevArray.from_host(ctx, X), 24, max_iter=20, ctx=ctx)
+    assert np.array_equal(Ch, Cd.numpy())
+
+
 def test_fit_keeps_the_references_own_product_order(eng):
     """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
     (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
