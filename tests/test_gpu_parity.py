@@ -1731,9 +1731,9 @@ def test_loader_feeding_device_buffers_and_the_memory_pool(eng, tmp_path):
     free0, tot = ctypes.c_size_t(0), ctypes.c_size_t(0)
     ctx.check(lib.brov_mem_info(ctx.h, ctypes.byref(free0), ctypes.byref(tot)), "brov_mem_info")
     assert 0 < free0.value <= tot.value and tot.value > 200 * (1 << 30)
-    a = malloc(3_000_000)
+    a = malloc(3_141_593)                                          # (a size no other test uses: the best fit is this very block)
     lib.brov_free(ctx.h, ctypes.c_void_p(a))
-    assert malloc(3_000_000) == a                                  # the pooled block again
+    assert malloc(3_141_593) == a                                  # the pooled block again
     lib.brov_free(ctx.h, ctypes.c_void_p(a))
     big = malloc(300 << 20)                                        # above the pool's per-block limit: straight back to the driver
     lib.brov_free(ctx.h, ctypes.c_void_p(big))
