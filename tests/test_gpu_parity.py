@@ -1772,6 +1772,29 @@ def test_kmeans_centers_subsampled_seeding_both_array_kinds(eng):
     assert np.array_equal(Ch, Cd.numpy())
 
 
+def test_linear_multistep_at_the_recorded_size_equals_the_propagation(eng):
+    """The reference's recorded size (45 823 samples, 500 RBFs, gamma = 3, ridge = 0.1; training/best_results.txt:3,801) on schema-true
+    synthetic data: multistep_rmse by linearity against the H-step propagation at H = 1 / 10 / 100 / 400 -- a property at full size
+    (no reference score exists for synthetic data): |dRMSE| <= 1e-9 max(1, RMSE), endpoint predictions to 1e-8."""
+    from bluerov2_dynamics_amd import _lib
+    from bluerov2_dynamics_amd.Koopman.koopmanEDMDc import KoopmanEDMDc
+    from oracle import controls
+    N = 45823
+    U = controls.controls_ar1(0x7A2C, 0, 1, N)[0]
+    x0 = np.zeros((1, 12))
+    x0[0, 2] = 5.0
+    X = eng.rollout(_lib.THRUSTER_EULER, "euler", x0, U[None], 0.02)["traj"][0][:N]
+    X = X + np.random.default_rng(45823).normal(size=X.shape) * np.array([5e-4] * 3 + [1e-3] * 3 + [5e-4] * 3 + [1e-3] * 3)
+    m = KoopmanEDMDc(state_dim=12, input_dim=8, n_rbfs=500, gamma=3.0, ridge=0.1)
+    m.fit(X, U)
+    for H in (1, 10, 100, 400):
+        a, b = m.multistep_rmse(X, U, H), m.multistep_rmse(X, U, H, method="linear")
+        assert np.isfinite(a) and abs(a - b) <= 1e-9 * max(1.0, a), (H, a, b)
+    sa, xa = eng.multistep_se(X, U, m.centers_, m.gamma, m.A_, m.B_, 100, want_xhat=True)
+    sb, xb = eng.multistep_se_linear(X, U, m.centers_, m.gamma, m.A_, m.B_, 100, want_xhat=True)
+    assert rel_err(xb, xa) < 1e-8 and xa.shape == (N - 100, 12)
+
+
 def test_fit_keeps_the_references_own_product_order(eng):
     """KoopmanEDMDc.fit evaluates (pinv G^T) Y left to right (Koopman/koopmanEDMDc.py:97), fit_multi pinv (G^T Y) (:147).
     (1) edmdc_pinv_apply against NumPy in that order; (2) fit() against the reference's A, B and H = 1/10/100 RMSE at the class
