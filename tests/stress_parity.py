@@ -3,7 +3,7 @@
 strides, bag structures and chunk sizes through the C ABI against the oracle.  Prints the worst relative error per family
 and exits non-zero on the first violation.
 
-    python tests/stress_parity.py [seconds per family = 40] [seed = 0] [families, comma separated: applies,lloyds,rollouts,windows,grams,multistep,kmeanspp]
+    python tests/stress_parity.py [seconds per family = 40] [seed = 0] [families, comma separated: copies,linear_multistep,applies,lloyds,lloyds_list,rollouts,windows,grams,multistep,kmeanspp]
 
 Lives under tests/ because it checks against oracle/ (test infrastructure); tests/test_gpu_parity.py runs a short sweep."""
 import os, sys, time
@@ -281,6 +281,71 @@ def lloyds():
     print(f"Lloyd      : {n} cases, candidate filter == full scan (labels, iterations, centres bit for bit), {ties} excused", flush=True)
 
 
+def copies():
+    """Round 6: host <-> device copies of the C ABI (staged through the ctx's pinned blocks between 64 KB and 16 MB, the runtime's own paths
+    outside; downloads above one block stream through both) and the pooled brov_malloc -- random sizes around every boundary, odd byte
+    counts, several live blocks, round trips bit for bit; DevArray views."""
+    import ctypes
+    ctx = _lib.default_context(0)
+    lib = ctx.lib
+    edges = [1, 7, 8, 4096, (64 << 10) - 8, 64 << 10, (64 << 10) + 8, (4 << 20) - 16, 4 << 20, (4 << 20) + 24, (16 << 20) - 8, 16 << 20, (16 << 20) + 8,
+             (32 << 20) - 8, 32 << 20, (32 << 20) + 8, (64 << 20) + 40, 70_000_001]
+    n, t0 = 0, time.time()
+    live = []
+    while time.time() - t0 < budget:
+        nbytes = int(rng.choice(edges)) if rng.random() < 0.5 else int(rng.integers(1, 40 << 20))
+        src = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        p_ = ctypes.c_void_p()
+        ctx.check(lib.brov_malloc(ctx.h, nbytes, ctypes.byref(p_)), "brov_malloc")
+        ctx.check(lib.brov_memcpy_h2d(ctx.h, p_, src.ctypes.data, nbytes), "h2d")
+        live.append((p_, src))
+        if len(live) > 6 or rng.random() < 0.5:
+            q_, want = live.pop(int(rng.integers(len(live))))
+            out = np.empty_like(want)
+            ctx.check(lib.brov_memcpy_d2h(ctx.h, out.ctypes.data, q_, want.nbytes), "d2h")
+            assert np.array_equal(out, want), ("copy round trip", want.nbytes)
+            ctx.check(lib.brov_free(ctx.h, q_), "brov_free")
+        n += 1
+    for q_, want in live:
+        out = np.empty_like(want)
+        ctx.check(lib.brov_memcpy_d2h(ctx.h, out.ctypes.data, q_, want.nbytes), "d2h")
+        assert np.array_equal(out, want), ("copy round trip", want.nbytes)
+        ctx.check(lib.brov_free(ctx.h, q_), "brov_free")
+    a = rng.normal(size=(int(rng.integers(2, 3000)), 13))
+    d = engine.DevArray.from_host(ctx, a)
+    i, j = sorted(int(v) for v in rng.integers(0, len(a) + 1, 2))
+    assert np.array_equal(d.rows(i, j).numpy(), a[i:j]) and np.array_equal(d.view(-1).numpy(), a.ravel())
+    print(f"copies     : {n} cases (1 B .. 70 MB), every round trip bit for bit", flush=True)
+
+
+def linear_multistep():
+    """Round 6: multistep_se_linear (one pass, explicit powers of A) == multistep_se (H propagated steps) on random shapes."""
+    worst, n, t0 = 0.0, 0, time.time()
+    while time.time() - t0 < budget:
+        n_ = int(rng.choice([3, 12, 13, 16]))
+        r = int(rng.choice([1, 6, 8]))
+        k = int(rng.choice([1, 17, 48, 200, 512]))
+        N = int(rng.choice([2, 50, 257, 3000]))
+        H = int(rng.choice([0, 1, 2, 9, 40, 130]))
+        X = np.cumsum(rng.normal(0, 0.05, (N, n_)), 0)
+        U = rng.uniform(-1, 1, (N, r))
+        C = X[rng.choice(N, k, replace=True)] + rng.normal(0, 0.01, (k, n_))
+        d = n_ + k
+        A = rng.normal(0, 0.6 / np.sqrt(d), (d, d))               # spectral radius ~0.6: the powers stay tame
+        B = rng.normal(0, 0.3, (d, r))
+        g = float(rng.choice([0.3, 1.0, 3.0]))
+        sa, xa = engine.multistep_se(X, U, C, g, A, B, H, want_xhat=True)
+        sb, xb = engine.multistep_se_linear(X, U, C, g, A, B, H, want_xhat=True)
+        if N - H > 0:
+            e = float(np.max(np.abs(xa - xb)) / max(1.0, np.max(np.abs(xa))))
+            assert e < 1e-10 and abs(sa - sb) <= 1e-9 * max(1.0, sa), ("linear multistep", n_, r, k, N, H, e)
+            worst = max(worst, e)
+        else:
+            assert sa == sb == 0.0
+        n += 1
+    print(f"linear mstp: {n} cases, worst rel err {worst:.2e}", flush=True)
+
+
 LIST_FORM = False
 
 
@@ -294,7 +359,7 @@ def lloyds_list():
 
 
 if __name__ == "__main__":
-    fams = dict(applies=applies, lloyds=lloyds, lloyds_list=lloyds_list, rollouts=rollouts, windows=windows, grams=grams, multistep=multistep, kmeanspp=kmeanspp)
+    fams = dict(copies=copies, linear_multistep=linear_multistep, applies=applies, lloyds=lloyds, lloyds_list=lloyds_list, rollouts=rollouts, windows=windows, grams=grams, multistep=multistep, kmeanspp=kmeanspp)
     for name in (sys.argv[3].split(",") if len(sys.argv) > 3 else list(fams)):
         fams[name]()
     print("stress parity: ok")
