@@ -511,11 +511,16 @@ class Comm:
         return bytes(buf)
 
     def allreduce_gram_(self, GtG, GtY, stream_handle=None):
-        """In-place sum over ranks of two fp64 CUDA tensors, one grouped RCCL call on torch's current stream."""
-        import torch
-        assert GtG.is_cuda and GtY.is_cuda and GtG.dtype == torch.float64 and GtY.dtype == torch.float64
-        assert GtG.is_contiguous() and GtY.is_contiguous()
-        st = torch.cuda.current_stream(GtG.device).cuda_stream if stream_handle is None else stream_handle
+        """In-place sum over ranks of two fp64 device arrays, one grouped RCCL call: torch CUDA tensors (on torch's current stream) or
+        engine.DevArray (on the null stream their ctx launches on) -- the torch-free form of the path's only collective."""
+        if type(GtG).__module__.startswith("torch"):
+            import torch
+            assert GtG.is_cuda and GtY.is_cuda and GtG.dtype == torch.float64 and GtY.dtype == torch.float64
+            assert GtG.is_contiguous() and GtY.is_contiguous()
+            st = torch.cuda.current_stream(GtG.device).cuda_stream if stream_handle is None else stream_handle
+        else:
+            assert GtG.dtype == np.float64 and GtY.dtype == np.float64
+            st = 0 if stream_handle is None else stream_handle
         rc = self.lib.edmdc_gram_allreduce_dev(self.h, GtG.data_ptr(), GtG.numel(), GtY.data_ptr(), GtY.numel(), c_void_p(st or 0))
         if rc != 0:
             raise BrovError(f"edmdc_gram_allreduce_dev: {STATUS.get(rc, rc)}: {self.lib.brov_comm_last_error(self.h).decode()}")

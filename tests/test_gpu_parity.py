@@ -2013,6 +2013,13 @@ def test_rccl_entry_points_single_rank():
     comm.allreduce_gram_(G, Y)
     torch.cuda.synchronize()
     assert torch.equal(G, G0) and torch.equal(Y, Y0)
+    # the torch-free operands of the same call (engine.DevArray on the ctx's null stream)
+    from bluerov2_dynamics_amd import engine
+    ctx = _lib.default_context(0)
+    Gd, Yd = engine.DevArray.from_host(ctx, G0.cpu().numpy()), engine.DevArray.from_host(ctx, Y0.cpu().numpy())
+    comm.allreduce_gram_(Gd, Yd)
+    ctx.sync()
+    assert np.array_equal(Gd.numpy(), G0.cpu().numpy()) and np.array_equal(Yd.numpy(), Y0.cpu().numpy())
     comm.close()
 
 
