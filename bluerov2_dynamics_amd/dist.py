@@ -61,35 +61,46 @@ def broadcast_centers_(C, src=0, group=None):
     return C
 
 
-def _device_gram(X, U, C, gamma, nbags, L, xs, us):
-    """Local Gram on this rank's GPU (X, U, C: CUDA fp64 tensors) -> (GtG, GtY) CUDA tensors."""
+def _host(t):
+    """host copy of a device array of either kind (engine.DevArray or torch tensor)"""
+    from . import engine
+    return t.numpy() if isinstance(t, engine.DevArray) else t.cpu().numpy()
+
+
+def _zeros(X, shape):
+    """zero-filled fp64 device array of X's kind (engine.DevArray or torch CUDA tensor)"""
+    from . import engine
+    if isinstance(X, engine.DevArray):
+        return engine.DevArray(X.ctx, shape).zero_()
     import torch
+    return torch.zeros(shape, dtype=torch.float64, device=X.device)
+
+
+def _device_gram(X, U, C, gamma, nbags, L, xs, us):
+    """Local Gram on this rank's GPU (X, U, C: fp64 device arrays -- torch CUDA tensors or engine.DevArray) -> (GtG, GtY) of the same kind."""
     from . import engine
     n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
     p, d = n + k + r, n + k
-    GtG = torch.zeros((p, p), dtype=torch.float64, device=X.device)
-    GtY = torch.zeros((p, d), dtype=torch.float64, device=X.device)
+    GtG, GtY = _zeros(X, (p, p)), _zeros(X, (p, d))
     engine.gram_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, GtG, GtY)
     return GtG, GtY
 
 
 def _device_gtg(X, U, C, gamma, nbags, L, xs, us):
-    """Local G^T G alone (fit()'s own order never forms G^T Y) -> (GtG, a one-element placeholder) CUDA tensors."""
-    import torch
+    """Local G^T G alone (fit()'s own order never forms G^T Y) -> (GtG, a one-element placeholder)."""
     from . import engine
     n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
     p = n + k + r
-    GtG = torch.zeros((p, p), dtype=torch.float64, device=X.device)
+    GtG = _zeros(X, (p, p))
     engine.gram_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, GtG, None)
-    return GtG, GtG.new_zeros(1)
+    return GtG, _zeros(X, (1,))
 
 
 def _device_apply(X, U, C, gamma, nbags, L, xs, us, P):
-    """Local (P G^T) Y on this rank's GPU -> M [p, d] CUDA tensor."""
-    import torch
+    """Local (P G^T) Y on this rank's GPU -> M [p, d] device array."""
     from . import engine
     n, r, k = X.shape[-1], U.shape[-1], C.shape[0]
-    M = torch.empty((n + k + r, n + k), dtype=torch.float64, device=X.device)
+    M = _zeros(X, (n + k + r, n + k))
     engine.pinv_apply_dev(X.reshape(-1, n), U.reshape(-1, r), C, gamma, nbags, L, xs, us, P, M)
     return M
 
@@ -98,7 +109,8 @@ def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, det
                 allreduce=None, pinv="auto"):
     """EDMDc fit over trajectories sharded across ranks.
 
-    X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors);
+    X_local [nb_local, L+1, n], U_local [nb_local, L, r]: this rank's bags (torch tensors, or engine.DevArray together with
+    allreduce=_lib.Comm(...).allreduce_gram_ -- a sharded fit with no torch in the process);
     C [k, n] centres (identical on all ranks -- broadcast them first).
     gram_fn(X, U, C, gamma, nbags, L, xs, us) -> (GtG, GtY) defaults to the HIP path; tests on CPU
     inject a host implementation to exercise the collective + solve plumbing under gloo.
@@ -120,15 +132,15 @@ def fit_sharded(X_local, U_local, C, gamma, ridge, gram_fn=None, group=None, det
     allreduce(GtG, GtY)
     d = n + C.shape[0]
     if order == "fit_multi":
-        return engine.solve_AB(GtG.cpu().numpy(), GtY.cpu().numpy(), ridge, d, pinv=pinv)
+        return engine.solve_AB(_host(GtG), _host(GtY), ridge, d, pinv=pinv)
     if order != "fit":
         raise ValueError("order must be 'fit' or 'fit_multi'")
     with engine._blas_threads():
-        P = engine._host_pinv(GtG.cpu().numpy(), ridge, pinv)
+        P = engine._host_pinv(_host(GtG), ridge, pinv)
     M = (apply_fn or _device_apply)(X_local, U_local, C, gamma, nb, L, L + 1, L, P)
-    pad = M.new_zeros(1)                                   # the collective takes two tensors; the second one is a dummy
+    pad = _zeros(M, (1,))                                  # the collective takes two arrays; the second one is a dummy
     allreduce(M, pad)
-    Mt = M.cpu().numpy().T
+    Mt = _host(M).T
     return np.ascontiguousarray(Mt[:, :d]), np.ascontiguousarray(Mt[:, d:])
 
 

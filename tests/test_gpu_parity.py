@@ -2023,6 +2023,30 @@ def test_rccl_entry_points_single_rank():
     comm.close()
 
 
+def test_sharded_fit_without_torch_one_rank():
+    """dist.fit_sharded on engine.DevArray shards with the collective through the C ABI's own communicator (_lib.Comm.allreduce_gram_:
+    RCCL, no torch.distributed, no torch tensors) -- one rank is all this box has: the same A, B, bit for bit, as the torch-tensor form
+    with torch.distributed's (absent) group, for both product orders."""
+    import torch
+    from bluerov2_dynamics_amd import _lib, dist as bdist, engine
+    if not _lib.Comm.available():
+        pytest.skip("librccl not loadable")
+    g = load_golden("edmdc.npz")
+    X, U = g["X"][:1800].reshape(6, 300, 12), g["U"][:1800].reshape(6, 300, 8)[:, :299]
+    C, gamma, ridge = g["centers"], float(g["gamma"]), 1e-2
+    ctx = _lib.default_context(0)
+    comm = _lib.Comm(0, _lib.Comm.unique_id(), 1, 0)
+    try:
+        for order in ("fit_multi", "fit"):
+            Xd, Ud, Cd = (engine.DevArray.from_host(ctx, a) for a in (X, U, C))
+            A1, B1 = bdist.fit_sharded(Xd, Ud, Cd, gamma, ridge, order=order, allreduce=comm.allreduce_gram_)
+            Xt, Ut, Ct = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (X, U, C))
+            A2, B2 = bdist.fit_sharded(Xt, Ut, Ct, gamma, ridge, order=order)
+            assert np.array_equal(A1, A2) and np.array_equal(B1, B2), order
+    finally:
+        comm.close()
+
+
 def test_timed_config2_launch_is_the_references_trajectories(eng, fc):
     """THE launch bench.py times -- rollout_kernel<THRUSTER, RK4, TPB, per-call lag, untracked, reference vehicle>,
     B = 65 536, T = 5 000, every state stored (52 GB) -- checked directly: lanes 0..7, every 50th state, against the states
